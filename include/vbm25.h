@@ -1,0 +1,175 @@
+/*
+ * vbm25.h -- C ABI of the MI355X-native BM25 top-k scorer (libvbm25.so).
+ *
+ * Drop-in boundary: this library replaces ONE call of the reference,
+ *     bm25::search(&index, k, &query, filter)
+ * made at /root/reference/src/index/bm25/scanners/default.rs:117-129 and defined
+ * at crates/bm25/src/search.rs:28-36, plus the index flattening that feeds it.
+ * INTEGRATION.md shows the Rust `extern "C"` block and the replacement body of
+ * DefaultBuilder::build a maintainer would add.
+ *
+ * Conventions: plain pointers and sizes, caller-owned
+ * outputs, no callbacks, no exceptions or longjmp across the boundary.  Every
+ * function returns 0 on success or a negative vbm25_status; the message for the
+ * last failure on the calling thread is available from vbm25_last_error().
+ * One handle may be used from one thread at a time.
+ */
+#ifndef VBM25_H
+#define VBM25_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef enum vbm25_status {
+    VBM25_OK = 0,
+    VBM25_ERR_INVALID = -1,     /* bad argument (reference: pgrx::error! at default.rs:114-116 etc.) */
+    VBM25_ERR_CORRUPT = -2,     /* index arrays inconsistent (reference: panic "data corruption") */
+    VBM25_ERR_DEVICE = -3,      /* HIP runtime failure / no gfx950 device */
+    VBM25_ERR_UNSUPPORTED = -4, /* valid request outside what the GPU path covers */
+    VBM25_ERR_NOMEM = -5
+} vbm25_status;
+
+/* One result: replaces (Reverse<Score>, AlwaysEqual<[u16; 3]>) of search.rs:33.
+ * score is the positive f64 (the SQL operator negates it, operators.rs:54);
+ * payload is the heap ctid key (fetcher.rs:218-232). */
+typedef struct vbm25_hit {
+    double score;
+    uint32_t doc_id;
+    uint16_t payload[3];
+    uint16_t _pad;
+} vbm25_hit;
+
+/* Flattened sealed segment: the values flush.rs:40-158 writes to the Token /
+ * Summary / Block / Document tapes (tuples.rs:756-1069), as arrays.
+ * All pointers are host memory, borrowed for the duration of the call. */
+typedef struct vbm25_index_desc {
+    uint32_t n_docs;              /* JumpTuple.number_of_documents */
+    uint32_t n_terms;
+    uint32_t n_blocks;
+    uint32_t _pad;
+    uint64_t sum_len;             /* JumpTuple.sum_of_document_lengths */
+    uint64_t blob_bytes;
+    double k1, b;                 /* MetaTuple.k1 / b */
+    const uint8_t *term_key;          /* n_terms x 16, ascending (TokenTuple.id) */
+    const uint32_t *term_df;          /* TokenTuple.number_of_documents */
+    const uint8_t *term_wand_fn;      /* TokenTuple.wand_fieldnorm */
+    const uint32_t *term_wand_tf;     /* TokenTuple.wand_term_frequency */
+    const uint32_t *term_first_block; /* n_terms + 1; summaries of a token are contiguous */
+    const uint32_t *blk_min_doc;      /* SummaryTuple.min_document_id */
+    const uint32_t *blk_max_doc;      /* SummaryTuple.max_document_id */
+    const uint8_t *blk_n;             /* SummaryTuple.number_of_documents (1..128) */
+    const uint8_t *blk_wand_fn;       /* SummaryTuple.wand_fieldnorm */
+    const uint32_t *blk_wand_tf;      /* SummaryTuple.wand_term_frequency */
+    const uint8_t *blk_meta_doc;      /* BlockTuple.metadata_document_ids */
+    const uint8_t *blk_meta_tf;       /* BlockTuple.metadata_term_frequencies */
+    const uint32_t *blk_off8;         /* n_blocks + 1: block body offset in blob, units of 8 B */
+    const uint8_t *blob;              /* per block: doc-id bytes, pad to 8, tf bytes, pad to 8 */
+    const uint8_t *doc_fieldnorm;     /* DocumentTuple.fieldnorm, n_docs */
+    const uint16_t *doc_payload;      /* DocumentTuple.payload, n_docs x 3 */
+} vbm25_index_desc;
+
+const char *vbm25_last_error(void);
+const char *vbm25_version(void);
+
+/* ------------------------------------------------------------------------
+ * Host side: sealed-segment construction (replaces flush.rs:40-158 for the
+ * benchmark / test harness; CPU, multi-threaded, byte-identical output).
+ * ---------------------------------------------------------------------- */
+typedef struct vbm25_segment vbm25_segment;
+
+/* Segment = records (length, payload) in doc-id order + mappings sorted by
+ * (token key, doc id) in CSR form (segment.rs:19-50). threads <= 0: all cores. */
+int vbm25_segment_build(double k1, double b, uint32_t n_docs, const uint32_t *doc_len,
+                        const uint16_t *doc_payload, uint32_t n_terms, const uint8_t *term_key,
+                        const uint64_t *term_start, const uint32_t *post_doc,
+                        const uint32_t *post_tf, int threads, vbm25_segment **out);
+
+/* Synthetic corpus of SURVEY section 8(d), generated per token so that 10M-50M
+ * documents stream: every document is `len` i.i.d. token draws (uniform, or
+ * Zipf(s) over token rank when zipf_s > 0); token t's key is its ASCII decimal,
+ * zero padded (vector.rs:21-24 short path).  len_mode 0: every document has
+ * mean_len draws; 1: clamp(round(LogNormal(ln(0.8*mean_len), 0.6)), 8, 2000). */
+typedef struct vbm25_synth_params {
+    uint32_t n_docs;
+    uint32_t vocab;
+    uint32_t mean_len;
+    uint32_t len_mode;
+    double zipf_s;
+    double k1, b;
+    uint64_t seed;
+    int threads;
+    int _pad;
+} vbm25_synth_params;
+int vbm25_segment_synth(const vbm25_synth_params *params, vbm25_segment **out);
+/* token number -> term id (rank of its key among the keys present), UINT32_MAX if absent */
+int vbm25_segment_synth_token_terms(const vbm25_segment *, const uint32_t *tokens, uint32_t n,
+                                    uint32_t *term_ids);
+
+int vbm25_segment_desc(const vbm25_segment *, vbm25_index_desc *out);
+void vbm25_segment_free(vbm25_segment *);
+/* Serialise / load the flattened arrays (bench.py: rank 0 builds, other ranks load). */
+int vbm25_segment_save(const vbm25_segment *, const char *path);
+int vbm25_segment_load(const char *path, vbm25_segment **out);
+
+/* Algorithmic bytes of one query, SURVEY section 8(d) (exhaustive evaluation:
+ * block bodies + 16 B block header + 24 B summary per block + 1 fieldnorm byte
+ * per posting + 14 B per returned hit). term ids >= n_terms are ignored. */
+uint64_t vbm25_query_bytes(const vbm25_index_desc *, const uint32_t *term_ids, uint32_t n_terms,
+                           uint32_t k);
+
+/* ------------------------------------------------------------------------
+ * Device side
+ * ---------------------------------------------------------------------- */
+typedef struct vbm25_index vbm25_index; /* owns the HBM copy of one sealed segment */
+typedef struct vbm25_batch vbm25_batch; /* owns query / result buffers for one batch shape */
+
+/* Validates the arrays, uploads them to HBM on `device` (HIP ordinal) and
+ * derives the GPU-side structures (per-posting fieldnorm stream, per-term s0,
+ * the shared s1[256] table of bm25.rs:340-354). */
+int vbm25_index_create(const vbm25_index_desc *desc, int device, vbm25_index **out);
+void vbm25_index_destroy(vbm25_index *);
+/* HBM bytes held by the index. */
+uint64_t vbm25_index_device_bytes(const vbm25_index *);
+
+/* address_tokens::read (address_tokens.rs:61-98) for n keys at once: term id of
+ * each 16-byte key, or UINT32_MAX when the token is not in the index (such
+ * tokens are ignored by search, search.rs:59-61). */
+int vbm25_lookup_terms(const vbm25_index *, const uint8_t *keys, uint32_t n, uint32_t *term_ids);
+
+/* bm25::search for nq queries at once (filter == true, sealed segment only).
+ * Query q is term_ids[q_off[q] .. q_off[q+1]), strictly ascending (Query::new,
+ * vector.rs:101-110); ids >= n_terms are ignored.  k = bm25.limit (1..=65535,
+ * gucs.rs:37-46); k == 0 -> VBM25_ERR_INVALID like default.rs:114-116.
+ * hits: nq x k, caller owned; n_hits: nq.  Results per query are best first:
+ * score descending, ties by ascending doc id.  Synchronous. */
+int vbm25_search_batch(vbm25_index *, const uint32_t *term_ids, const uint32_t *q_off,
+                       uint32_t nq, uint32_t k, vbm25_hit *hits, uint32_t *n_hits);
+
+/* Same computation with the batch resident in HBM: create once, upload
+ * queries, run (asynchronous on `hip_stream`, NULL = default stream), fetch. */
+int vbm25_batch_create(vbm25_index *, uint32_t max_queries, uint32_t max_total_terms, uint32_t k,
+                       vbm25_batch **out);
+void vbm25_batch_destroy(vbm25_batch *);
+int vbm25_batch_set_queries(vbm25_batch *, const uint32_t *term_ids, const uint32_t *q_off,
+                            uint32_t nq);
+int vbm25_batch_run(vbm25_batch *, void *hip_stream);
+int vbm25_batch_fetch(vbm25_batch *, vbm25_hit *hits, uint32_t *n_hits);
+/* Device address of the nq x k vbm25_hit array / the nq counts (valid after run). */
+int vbm25_batch_device_results(vbm25_batch *, void **hits, void **n_hits);
+/* When enabled, run() brackets the posting-scan kernel with HIP events on the
+ * launch stream; kernel_ms() synchronises and returns the average duration of
+ * the launches recorded since the last call. */
+int vbm25_batch_set_timing(vbm25_batch *, int enabled);
+int vbm25_batch_kernel_ms(vbm25_batch *, double *avg_ms, uint32_t *n_launches);
+
+/* bm25::evaluate-style exact scoring of explicit (document, query) pairs is a
+ * "next" row and not part of this ABI yet. */
+
+#ifdef __cplusplus
+}
+#endif
+#endif

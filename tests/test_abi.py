@@ -1,0 +1,62 @@
+"""The C-ABI library loads and exports every symbol include/vbm25.h declares (no GPU use)."""
+import ctypes
+import os
+import re
+
+import numpy as np
+import pytest
+
+import vectorchord_bm25_amd as vb
+from vectorchord_bm25_amd._lib import ABI
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def declared_functions():
+    src = open(os.path.join(ROOT, "include", "vbm25.h")).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    return sorted(set(re.findall(r"\b(vbm25_[a-z0-9_]+)\s*\(", src)))
+
+
+def test_every_declared_symbol_is_exported_and_bound():
+    names = declared_functions()
+    assert len(names) >= 20
+    L = ctypes.CDLL(vb.library_path())
+    for n in names:
+        assert hasattr(L, n), f"{n} declared in include/vbm25.h but not exported"
+        assert n in ABI, f"{n} has no ctypes binding"
+    assert sorted(ABI) == names
+
+
+def test_hit_layout_and_version():
+    assert vb.HIT_DTYPE.itemsize == 24
+    assert b"gfx950" in vb.lib().vbm25_version()
+
+
+def test_error_reporting_without_gpu_use():
+    # argument errors are reported through the status + thread-local message, never a crash
+    with pytest.raises(vb.Vbm25Error) as e:
+        vb.Segment.synth(0, 10)
+    assert e.value.code == -1 and "positive" in str(e.value)
+    with pytest.raises(vb.Vbm25Error):
+        vb.Segment.load("/nonexistent/file")
+
+
+def test_no_cpu_fallback_without_device():
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    seg = vb.Segment.synth(1000, 50, mean_len=20, threads=1)
+    with pytest.raises(vb.Vbm25Error) as e:
+        vb.GpuIndex(seg)
+    assert e.value.code == -3  # VBM25_ERR_DEVICE: fails loudly, no CPU path
+
+
+def test_intern_and_query():
+    assert vb.intern(b"12345") == b"12345" + b"\0" * 11
+    with pytest.raises(vb.Vbm25Error):
+        vb.intern(b"x" * 16)
+    q = vb.Query.from_tokens([b"9", b"10", b"9"])
+    assert q.keys == [vb.intern(b"10"), vb.intern(b"9")]  # bytewise order: "10" < "9"
+    with pytest.raises(ValueError):
+        vb.Query([vb.intern(b"9"), vb.intern(b"10")])

@@ -1,0 +1,186 @@
+"""Parity of the HIP path (through the C ABI) against the CPU oracle.  -m gpu only.
+
+Bit-exact rule: GPU == canonical brute force (doc ids, score bits, payloads).
+Reference rule: GPU vs the faithful Block-WAND restatement: same ranking outside tie groups,
+scores within 1e-5 (BASELINE.json north_star)."""
+import json
+import os
+
+import numpy as np
+import pytest
+
+import orc
+import vectorchord_bm25_amd as vb
+from corpus import make_corpus, make_queries
+from parity import assert_bit_exact, assert_same_ranking
+
+pytestmark = pytest.mark.gpu
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+def both(c=None, seg=None, k1=1.2, b=0.75):
+    if seg is None:
+        seg = vb.Segment.build(k1, b, c["doc_len"], c["doc_payload"], c["term_key"], c["term_start"],
+                               c["post_doc"], c["post_tf"])
+    oix = orc.OracleIndex.from_arrays(seg.meta(), seg.arrays())
+    return seg, vb.GpuIndex(seg), oix
+
+
+def check_batch(gix, oix, terms, off, k, wand=True):
+    hits, nh = vb.search_batch(gix, terms, off, k)
+    ob, onb, _ = oix.search_batch(terms, off, k, mode="brute", threads=8)
+    assert np.array_equal(nh, onb)
+    for q in range(len(off) - 1):
+        assert_bit_exact(ob[q, :onb[q]], hits[q, :nh[q]], what=f"q{q} vs brute")
+    if wand:
+        ow, onw, _ = oix.search_batch(terms, off, k, mode="wand", threads=8)
+        for q in range(len(off) - 1):
+            t = terms[off[q]:off[q + 1]]
+            assert_same_ranking(ow[q, :onw[q]], hits[q, :nh[q]], ref_ext=oix.search_brute(t, k + 300),
+                                what=f"q{q} vs wand")
+    return hits, nh
+
+
+def test_c1_1k_docs_3_terms_top10():
+    c = make_corpus(1000, 1000, seed=1, length="lognormal", mean_len=100)
+    seg, gix, oix = both(c)
+    terms, off = make_queries(c, 64, 3, seed=1)
+    check_batch(gix, oix, terms, off, 10)
+
+
+@pytest.mark.parametrize("length,zipf,nterms,k", [
+    ("fixed", None, 3, 10), ("lognormal", None, 5, 10), ("mixed", None, 2, 1),
+    ("lognormal", 1.0, 10, 100), ("lognormal", 1.0, 4, 7), ("fixed", None, 5, 1000)])
+def test_random_corpora(length, zipf, nterms, k):
+    c = make_corpus(20000, 2000, seed=7, length=length, mean_len=60, zipf=zipf)
+    seg, gix, oix = both(c)
+    terms, off = make_queries(c, 48, nterms, seed=9, zipf=zipf)
+    check_batch(gix, oix, terms, off, k)
+
+
+def test_fuzz_shape_100_term_queries_top100():
+    # tests/fuzz:43-59 shape: 10 000 docs x 100 draws of 10 000 tokens, ~100-term queries
+    c = make_corpus(10000, 10000, seed=11, length="fixed", mean_len=100)
+    seg, gix, oix = both(c)
+    terms, off = make_queries(c, 16, 100, seed=5)
+    check_batch(gix, oix, terms, off, 100)
+
+
+def test_edge_cases():
+    c = make_corpus(3000, 300, seed=3, length="lognormal", mean_len=50)
+    seg, gix, oix = both(c)
+    nt = gix.n_terms
+    df = seg.arrays()["term_df"]
+    rare = int(np.argmin(df))
+    terms = np.array([
+        # empty | unknown only | known+unknown | rare | all-known pair
+        nt + 7, 3, nt + 9, rare, 5, 6], dtype=np.uint32)
+    off = np.array([0, 0, 1, 3, 4, 6], dtype=np.uint32)
+    hits, nh = check_batch(gix, oix, terms, off, 10)
+    assert nh[0] == 0 and nh[1] == 0 and nh[2] == 10
+    # k larger than the number of matches: every matching doc comes back, sorted
+    hits, nh = check_batch(gix, oix, np.array([rare], dtype=np.uint32), np.array([0, 1], dtype=np.uint32), 1000)
+    assert nh[0] == df[rare]
+    # k == 0 is the reference's "number of needed rows is set to 0" error (default.rs:114-116)
+    with pytest.raises(vb.Vbm25Error) as e:
+        vb.search_batch(gix, np.array([1], dtype=np.uint32), np.array([0, 1], dtype=np.uint32), 0)
+    assert e.value.code == -1
+    with pytest.raises(vb.Vbm25Error):  # not strictly ascending (Query::new)
+        vb.search_batch(gix, np.array([5, 5], dtype=np.uint32), np.array([0, 2], dtype=np.uint32), 5)
+    with pytest.raises(vb.Vbm25Error) as e:
+        vb.search_batch(gix, np.array([5], dtype=np.uint32), np.array([0, 1], dtype=np.uint32), 5000)
+    assert e.value.code == -4
+
+
+def test_codec_corner_case_index():
+    # bitwidth-32 raw block, df == 128 exactly, single posting, 4-byte tf (see test_segment_builder)
+    n_docs = 3_000_000
+    docs_a = np.r_[np.arange(64), 2_900_000 + np.arange(64) * 3].astype(np.uint32)
+    docs_b = (np.arange(128) * 7 + 5).astype(np.uint32)
+    docs_c = np.array([123456], dtype=np.uint32)
+    docs_d = (np.arange(300) * 9000 + 17).astype(np.uint32)
+    rng = np.random.default_rng(0)
+    post_tf = np.r_[np.ones(128), rng.integers(1, 70000, 128), [1 << 30], rng.integers(1, 4, 300)].astype(np.uint32)
+    keys = np.zeros((4, 16), dtype=np.uint8)
+    keys[:, 0] = [ord("a"), ord("b"), ord("c"), ord("d")]
+    rng = np.random.default_rng(1)
+    seg = vb.Segment.build(1.2, 0.75, rng.integers(1, 3000, n_docs).astype(np.uint32),
+                           np.zeros((n_docs, 3), dtype=np.uint16), keys,
+                           np.array([0, 128, 256, 257, 557], dtype=np.uint64),
+                           np.r_[docs_a, docs_b, docs_c, docs_d], post_tf)
+    seg, gix, oix = both(seg=seg)
+    terms = np.array([0, 1, 2, 3, 0, 1, 2, 3, 0, 3], dtype=np.uint32)
+    off = np.array([0, 1, 2, 3, 4, 8, 10], dtype=np.uint32)
+    check_batch(gix, oix, terms, off, 10)
+    check_batch(gix, oix, terms, off, 300)
+
+
+def test_sqllogictest_golden_orders_on_gpu():
+    from test_oracle_pins import _slt_index
+    fixture = json.load(open(os.path.join(GOLD, "slt_corpus.json")))
+    for case in fixture["expect"]:
+        sel = {"all": range(1, 11), "even": range(2, 11, 2), "odd": range(1, 11, 2)}[case["ids"]]
+        oix, q, ids = _slt_index(set(sel), fixture)
+        desc, keep = vb.api.desc_from_arrays(
+            dict(n_docs=oix.n_docs, n_terms=oix.n_terms, n_blocks=oix.n_blocks, sum_len=oix.sum_len,
+                 k1=oix.k1, b=oix.b), oix.arrays)
+        gix = vb.GpuIndex(desc)
+        # through the reference-shaped entry point: Query of interned lexemes -> search()
+        hits = vb.search(gix, case["k"], vb.Query.from_tokens([t.encode() for t in fixture["query"]]))
+        assert [int(h["payload"][2]) for h in hits] == case["order"], case["name"]
+
+
+def test_c2_1m_docs_single_3_term_query_top10():
+    seg = vb.Segment.synth(1_000_000, 30000, mean_len=100, len_mode=1, seed=20260925)
+    seg, gix, oix = both(seg=seg)
+    rng = np.random.default_rng(1)
+    for _ in range(4):
+        toks = rng.choice(30000, 3, replace=False).astype(np.uint32)
+        t = np.sort(seg.token_terms(toks))
+        check_batch(gix, oix, t, np.array([0, 3], dtype=np.uint32), 10)
+    # a batch on the same index (C3 shape at 1/10 of the documents)
+    toks = np.stack([rng.choice(30000, 5, replace=False) for _ in range(256)]).astype(np.uint32)
+    t = np.sort(seg.token_terms(toks.reshape(-1)).reshape(256, 5), axis=1).reshape(-1)
+    check_batch(gix, oix, t, (np.arange(257) * 5).astype(np.uint32), 10, wand=False)
+
+
+def test_properties_idempotent_sorted_batch_invariant():
+    seg = vb.Segment.synth(2_000_000, 30000, mean_len=100, len_mode=1, seed=5)
+    gix = vb.GpuIndex(seg)
+    rng = np.random.default_rng(2)
+    nq = 512
+    toks = np.stack([rng.choice(30000, 5, replace=False) for _ in range(nq)]).astype(np.uint32)
+    t = np.sort(seg.token_terms(toks.reshape(-1)).reshape(nq, 5), axis=1).reshape(-1)
+    off = (np.arange(nq + 1) * 5).astype(np.uint32)
+    h1, n1 = vb.search_batch(gix, t, off, 10)
+    h2, n2 = vb.search_batch(gix, t, off, 10)
+    assert np.array_equal(h1.view(np.uint8), h2.view(np.uint8)) and np.array_equal(n1, n2)
+    assert (n1 == 10).all()
+    s = h1["score"]
+    assert (s[:, :-1] >= s[:, 1:]).all() and (s > 0).all()
+    tie = s[:, :-1] == s[:, 1:]
+    assert (h1["doc_id"][:, :-1][tie] < h1["doc_id"][:, 1:][tie]).all()
+    # a query's result does not depend on what else is in the batch
+    sub = [3, 77, 500]
+    for q in sub:
+        hq, nq1 = vb.search_batch(gix, t[off[q]:off[q + 1]], np.array([0, 5], dtype=np.uint32), 10)
+        assert np.array_equal(hq[0].view(np.uint8), h1[q].view(np.uint8))
+    # top-10 is a prefix of top-100
+    h100, _ = vb.search_batch(gix, t[:50], off[:11], 100)
+    assert np.array_equal(h100[:, :10]["doc_id"], h1[:10]["doc_id"])
+    # payload is the synthetic ctid of the doc (fetcher.rs:218-225 layout)
+    d = h1["doc_id"].astype(np.int64)
+    assert np.array_equal(h1["payload"][..., 2], d % 64 + 1)
+    assert np.array_equal(h1["payload"][..., 1], (d // 64) & 0xffff)
+
+
+def test_corrupt_index_is_rejected():
+    c = make_corpus(500, 50, seed=2, length="fixed", mean_len=20)
+    seg = vb.Segment.build(1.2, 0.75, c["doc_len"], c["doc_payload"], c["term_key"], c["term_start"],
+                           c["post_doc"], c["post_tf"])
+    arrs = {k: v.copy() for k, v in seg.arrays().items()}
+    arrs["blk_max_doc"][0] += 1  # summary disagrees with the block body
+    desc, keep = vb.api.desc_from_arrays(seg.meta(), arrs)
+    with pytest.raises(vb.Vbm25Error) as e:
+        vb.GpuIndex(desc)
+    assert e.value.code == -2

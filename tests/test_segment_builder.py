@@ -1,0 +1,131 @@
+"""Host-side segment builder of libvbm25 (CPU) vs the oracle's restatement of flush.rs:
+byte-identical flattened arrays.  Also checks the synthetic corpus generator by decoding
+what it produced with the oracle codec and re-flushing it with the oracle."""
+import os
+import tempfile
+
+import numpy as np
+import pytest
+
+import orc
+import vectorchord_bm25_amd as vb
+from corpus import make_corpus
+
+
+def assert_same_index(seg, oix):
+    a, o = seg.arrays(), oix.arrays
+    assert seg.n_docs == oix.n_docs and seg.n_terms == oix.n_terms and seg.n_blocks == oix.n_blocks
+    assert seg.desc.sum_len == oix.sum_len
+    for name in o:
+        assert np.array_equal(a[name].reshape(-1), o[name].reshape(-1)), name
+
+
+@pytest.mark.parametrize("n_docs,vocab,length,zipf", [
+    (1000, 1000, "fixed", None), (3000, 200, "lognormal", None), (5000, 50, "mixed", 1.0),
+    (700, 3, "fixed", None)])
+def test_builder_matches_oracle_flush(n_docs, vocab, length, zipf):
+    c = make_corpus(n_docs, vocab, seed=n_docs, length=length, mean_len=40, zipf=zipf)
+    args = (c["doc_len"], c["doc_payload"], c["term_key"], c["term_start"], c["post_doc"], c["post_tf"])
+    oix = orc.OracleIndex.build(1.2, 0.75, *args)
+    for threads in (1, 3):
+        assert_same_index(vb.Segment.build(1.2, 0.75, *args, threads=threads), oix)
+    # other parameters of Bm25IndexOptions (types.rs:18-45)
+    oix2 = orc.OracleIndex.build(2.0, 0.0, *args)
+    assert_same_index(vb.Segment.build(2.0, 0.0, *args), oix2)
+
+
+def test_builder_codec_corner_cases():
+    # one term with a huge id gap (bitwidth 32 -> raw ids), one with df == 128 exactly
+    # (no tail block), one with a single posting, large tf values
+    n_docs = 1 << 31
+    n_docs = 3_000_000
+    docs_a = np.r_[np.arange(64), 2_900_000 + np.arange(64) * 3].astype(np.uint32)
+    docs_b = (np.arange(128) * 7 + 5).astype(np.uint32)
+    docs_c = np.array([123456], dtype=np.uint32)
+    docs_d = (np.arange(300) * 9000 + 17).astype(np.uint32)
+    post_doc = np.r_[docs_a, docs_b, docs_c, docs_d]
+    rng = np.random.default_rng(0)
+    post_tf = np.r_[np.ones(128), rng.integers(1, 70000, 128), [1 << 30], rng.integers(1, 4, 300)].astype(np.uint32)
+    term_start = np.array([0, 128, 256, 257, 557], dtype=np.uint64)
+    keys = np.zeros((4, 16), dtype=np.uint8)
+    keys[:, 0] = [ord("a"), ord("b"), ord("c"), ord("d")]
+    doc_len = np.full(n_docs, 10, dtype=np.uint32)
+    payload = np.zeros((n_docs, 3), dtype=np.uint16)
+    args = (doc_len, payload, keys, term_start, post_doc, post_tf)
+    oix = orc.OracleIndex.build(1.2, 0.75, *args)
+    seg = vb.Segment.build(1.2, 0.75, *args, threads=2)
+    assert_same_index(seg, oix)
+    a = seg.arrays()
+    assert a["blk_meta_doc"][0] == 22 and a["blk_n"].tolist() == [128, 128, 1, 128, 128, 44]
+    assert a["blk_meta_tf"][2] == 0x84  # tf 2^30 needs 4 bytes
+
+
+def test_builder_rejects_bad_input():
+    c = make_corpus(100, 20, seed=1, length="fixed", mean_len=10)
+    args = [c["doc_len"], c["doc_payload"], c["term_key"], c["term_start"], c["post_doc"].copy(), c["post_tf"].copy()]
+    args[4][1] = args[4][0]  # not strictly increasing inside a term
+    with pytest.raises(vb.Vbm25Error) as e:
+        vb.Segment.build(1.2, 0.75, *args)
+    assert e.value.code == -1
+    with pytest.raises(vb.Vbm25Error):
+        vb.Segment.build(0.5, 0.75, c["doc_len"], c["doc_payload"], c["term_key"], c["term_start"], c["post_doc"], c["post_tf"])
+
+
+def decode_all(arrs):
+    """(term, doc, tf) of every posting, via the oracle codec."""
+    docs, tfs, term_start = [], [], [0]
+    fb = arrs["term_first_block"]
+    for t in range(len(fb) - 1):
+        for j in range(fb[t], fb[t + 1]):
+            off = 8 * int(arrs["blk_off8"][j])
+            n, md, mt = int(arrs["blk_n"][j]), int(arrs["blk_meta_doc"][j]), int(arrs["blk_meta_tf"][j])
+            ld = (md & 127) * n if md >> 7 else 16 * (md & 127)
+            lt = (mt & 127) * n if mt >> 7 else 16 * (mt & 127)
+            d = orc.decompress_doc_ids(int(arrs["blk_min_doc"][j]), md, arrs["blob"][off:off + ld])
+            f = orc.decompress_tfs(mt, arrs["blob"][off + (ld + 7) // 8 * 8:][:lt])
+            assert len(d) == n == len(f)
+            docs.append(d)
+            tfs.append(f)
+        term_start.append(term_start[-1] + int(arrs["term_df"][t]))
+    return np.concatenate(docs), np.concatenate(tfs), np.array(term_start, dtype=np.uint64)
+
+
+@pytest.mark.parametrize("len_mode,zipf", [(0, 0.0), (1, 0.0), (1, 1.0)])
+def test_synth_corpus_is_a_valid_flush(len_mode, zipf):
+    seg = vb.Segment.synth(30000, 400, mean_len=60, len_mode=len_mode, zipf_s=zipf, seed=7, threads=3)
+    a = seg.arrays()
+    docs, tfs, ts = decode_all(a)
+    # document length = sum of tf (vector.rs:77-83) -> fieldnorm
+    lens = np.zeros(seg.n_docs, dtype=np.int64)
+    np.add.at(lens, docs, tfs)
+    assert lens.sum() == seg.desc.sum_len
+    L = orc.lib()
+    fn = np.array([L.orc_length_to_fieldnorm(int(x)) for x in lens], dtype=np.uint8)
+    assert np.array_equal(fn, a["doc_fieldnorm"])
+    # re-flush the decoded postings with the oracle: identical arrays
+    oix = orc.OracleIndex.build(1.2, 0.75, lens.astype(np.uint32), a["doc_payload"], a["term_key"], ts, docs, tfs)
+    assert_same_index(seg, oix)
+    # deterministic, independent of thread count
+    seg2 = vb.Segment.synth(30000, 400, mean_len=60, len_mode=len_mode, zipf_s=zipf, seed=7, threads=1)
+    assert np.array_equal(seg2.arrays()["blob"], a["blob"])
+    # statistics: mean length close to the target, keys = ascii decimals in bytewise order
+    assert abs(lens.mean() / (60 if len_mode == 0 else lens.mean()) - 1) < 0.05
+    keys = [bytes(k).rstrip(b"\0") for k in a["term_key"]]
+    assert keys == sorted(keys) and all(k.isdigit() for k in keys)
+    toks = np.array([int(k) for k in keys], dtype=np.uint32)
+    assert np.array_equal(seg.token_terms(toks), np.arange(len(keys), dtype=np.uint32))
+
+
+def test_segment_save_load_and_query_bytes():
+    seg = vb.Segment.synth(5000, 100, mean_len=30, seed=3, threads=2)
+    with tempfile.TemporaryDirectory() as d:
+        path = os.path.join(d, "seg.bin")
+        seg.save(path)
+        seg2 = vb.Segment.load(path)
+    a, b = seg.arrays(), seg2.arrays()
+    for name in a:
+        assert np.array_equal(a[name], b[name]), name
+    assert seg2.meta() == seg.meta()
+    oix = orc.OracleIndex.from_arrays(seg.meta(), a)
+    for terms in ([0], [1, 5, 99], [3, 500]):
+        assert seg.query_bytes(terms, 10) == oix.query_bytes(terms, 10)

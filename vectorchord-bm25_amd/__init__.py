@@ -1,0 +1,10 @@
+"""vectorchord-bm25_amd: MI355X-native BM25 top-k scorer behind VectorChord-bm25's
+`bm25::search` boundary.
+
+The product is the C-ABI library `csrc/libvbm25.so` (HIP kernels for gfx950 + host-side
+segment builder, declared in include/vbm25.h).  This package is the thin Python host mirror
+used by the tests and bench.py; it never touches oracle/.
+"""
+from ._lib import build, lib, library_path, Vbm25Error  # noqa: F401
+from .api import (  # noqa: F401
+    HIT_DTYPE, Segment, GpuIndex, Batch, Query, intern, search, search_batch)

@@ -1,0 +1,256 @@
+"""Python host mirror of the reference's interface for the query path.
+
+Names follow the reference (crates/bm25): `intern` (vector.rs:19-35), `Query`
+(vector.rs:96-134), `search(index, k, query)` (search.rs:28-36).  Everything here is a thin
+wrapper over the C ABI in include/vbm25.h; no computation happens in Python.
+"""
+import ctypes as C
+
+import numpy as np
+
+from ._lib import IndexDesc, SynthParams, Vbm25Error, check, lib
+
+HIT_DTYPE = np.dtype({"names": ["score", "doc_id", "payload"],
+                      "formats": ["<f8", "<u4", ("<u2", (3,))],
+                      "offsets": [0, 8, 12], "itemsize": 24})
+
+WIDTH = 16  # crates/bm25/src/lib.rs:37
+
+_DESC_ARRAYS = [
+    ("term_key", np.uint8), ("term_df", np.uint32), ("term_wand_fn", np.uint8),
+    ("term_wand_tf", np.uint32), ("term_first_block", np.uint32), ("blk_min_doc", np.uint32),
+    ("blk_max_doc", np.uint32), ("blk_n", np.uint8), ("blk_wand_fn", np.uint8),
+    ("blk_wand_tf", np.uint32), ("blk_meta_doc", np.uint8), ("blk_meta_tf", np.uint8),
+    ("blk_off8", np.uint32), ("blob", np.uint8), ("doc_fieldnorm", np.uint8),
+    ("doc_payload", np.uint16),
+]
+
+
+def _p(a):
+    return a.ctypes.data_as(C.c_void_p) if a is not None and a.size else None
+
+
+def intern(string: bytes) -> bytes:
+    """vector.rs:19-35, short path only: strings shorter than 16 bytes without NUL are
+    zero padded.  Longer strings need the BLAKE3 keyed hash (blake3 1.8.4), which is outside
+    the query hot path and not implemented here."""
+    if len(string) < WIDTH and b"\0" not in string:
+        return string + b"\0" * (WIDTH - len(string))
+    raise Vbm25Error(-4, "intern(): lexemes >= 16 bytes need blake3::keyed_hash (not implemented)")
+
+
+class Query:
+    """Sorted, de-duplicated token keys (vector.rs:96-134)."""
+
+    def __init__(self, keys):
+        keys = [bytes(k) for k in keys]
+        if any(len(k) != WIDTH for k in keys) or any(a >= b for a, b in zip(keys, keys[1:])):
+            raise ValueError("invalid data")  # Query::new -> expect("invalid data")
+        self.keys = keys
+
+    @classmethod
+    def from_tokens(cls, tokens):
+        """cast_tsvector_to_query (src/datatype/tsvector.rs:96-105): intern, sort, dedup."""
+        return cls(sorted({intern(t) for t in tokens}))
+
+
+class Segment:
+    """Host-side sealed segment (flattened arrays), built by the library."""
+
+    def __init__(self, handle):
+        self.h = C.c_void_p(handle) if not isinstance(handle, C.c_void_p) else handle
+        self.desc = IndexDesc()
+        check(lib().vbm25_segment_desc(self.h, C.byref(self.desc)))
+
+    @classmethod
+    def build(cls, k1, b, doc_len, doc_payload, term_key, term_start, post_doc, post_tf, threads=0):
+        doc_len = np.ascontiguousarray(doc_len, dtype=np.uint32)
+        doc_payload = np.ascontiguousarray(doc_payload, dtype=np.uint16)
+        term_key = np.ascontiguousarray(term_key, dtype=np.uint8)
+        term_start = np.ascontiguousarray(term_start, dtype=np.uint64)
+        post_doc = np.ascontiguousarray(post_doc, dtype=np.uint32)
+        post_tf = np.ascontiguousarray(post_tf, dtype=np.uint32)
+        out = C.c_void_p()
+        check(lib().vbm25_segment_build(k1, b, len(doc_len), _p(doc_len), _p(doc_payload),
+                                        len(term_start) - 1, _p(term_key), _p(term_start),
+                                        _p(post_doc), _p(post_tf), threads, C.byref(out)))
+        return cls(out)
+
+    @classmethod
+    def synth(cls, n_docs, vocab, mean_len=100, len_mode=1, zipf_s=0.0, k1=1.2, b=0.75,
+              seed=20260925, threads=0):
+        p = SynthParams(n_docs, vocab, mean_len, len_mode, zipf_s, k1, b, seed, threads, 0)
+        out = C.c_void_p()
+        check(lib().vbm25_segment_synth(C.byref(p), C.byref(out)))
+        return cls(out)
+
+    @classmethod
+    def load(cls, path):
+        out = C.c_void_p()
+        check(lib().vbm25_segment_load(path.encode(), C.byref(out)))
+        return cls(out)
+
+    def save(self, path):
+        check(lib().vbm25_segment_save(self.h, path.encode()))
+
+    def __del__(self):
+        try:
+            lib().vbm25_segment_free(self.h)
+        except Exception:
+            pass
+
+    @property
+    def n_docs(self):
+        return self.desc.n_docs
+
+    @property
+    def n_terms(self):
+        return self.desc.n_terms
+
+    @property
+    def n_blocks(self):
+        return self.desc.n_blocks
+
+    def arrays(self):
+        """numpy views (no copy) of the flattened arrays; valid while self is alive."""
+        d = self.desc
+        sizes = {"term_key": 16 * d.n_terms, "term_df": d.n_terms, "term_wand_fn": d.n_terms,
+                 "term_wand_tf": d.n_terms, "term_first_block": d.n_terms + 1,
+                 "blk_min_doc": d.n_blocks, "blk_max_doc": d.n_blocks, "blk_n": d.n_blocks,
+                 "blk_wand_fn": d.n_blocks, "blk_wand_tf": d.n_blocks, "blk_meta_doc": d.n_blocks,
+                 "blk_meta_tf": d.n_blocks, "blk_off8": d.n_blocks + 1, "blob": d.blob_bytes,
+                 "doc_fieldnorm": d.n_docs, "doc_payload": 3 * d.n_docs}
+        out = {}
+        for name, dt in _DESC_ARRAYS:
+            n = sizes[name]
+            ptr = getattr(d, name)
+            if n == 0 or not ptr:
+                out[name] = np.zeros(0, dtype=dt)
+                continue
+            buf = (C.c_uint8 * (n * np.dtype(dt).itemsize)).from_address(ptr)
+            out[name] = np.frombuffer(buf, dtype=dt)
+        out["term_key"] = out["term_key"].reshape(-1, 16)
+        out["doc_payload"] = out["doc_payload"].reshape(-1, 3)
+        return out
+
+    def meta(self):
+        d = self.desc
+        return dict(n_docs=d.n_docs, n_terms=d.n_terms, n_blocks=d.n_blocks, sum_len=d.sum_len,
+                    k1=d.k1, b=d.b)
+
+    def token_terms(self, tokens):
+        tokens = np.ascontiguousarray(tokens, dtype=np.uint32)
+        out = np.zeros(len(tokens), dtype=np.uint32)
+        check(lib().vbm25_segment_synth_token_terms(self.h, _p(tokens), len(tokens), _p(out)))
+        return out
+
+    def query_bytes(self, term_ids, k):
+        term_ids = np.ascontiguousarray(term_ids, dtype=np.uint32)
+        return int(lib().vbm25_query_bytes(C.byref(self.desc), _p(term_ids), len(term_ids), k))
+
+
+def desc_from_arrays(meta, arrays):
+    """IndexDesc over caller-owned numpy arrays (returns (desc, keepalive))."""
+    keep = {}
+    d = IndexDesc()
+    d.n_docs, d.n_terms, d.n_blocks = meta["n_docs"], meta["n_terms"], meta["n_blocks"]
+    d.sum_len, d.k1, d.b = meta["sum_len"], meta["k1"], meta["b"]
+    for name, dt in _DESC_ARRAYS:
+        a = np.ascontiguousarray(arrays[name], dtype=dt)
+        keep[name] = a
+        setattr(d, name, a.ctypes.data if a.size else None)
+    d.blob_bytes = keep["blob"].size
+    return d, keep
+
+
+class GpuIndex:
+    """HBM-resident sealed segment (vbm25_index)."""
+
+    def __init__(self, segment_or_desc, device=0, keepalive=None):
+        desc = segment_or_desc.desc if isinstance(segment_or_desc, Segment) else segment_or_desc
+        self.h = C.c_void_p()
+        self.n_terms = desc.n_terms
+        self.n_docs = desc.n_docs
+        check(lib().vbm25_index_create(C.byref(desc), device, C.byref(self.h)))
+
+    def __del__(self):
+        try:
+            if self.h:
+                lib().vbm25_index_destroy(self.h)
+        except Exception:
+            pass
+
+    @property
+    def device_bytes(self):
+        return int(lib().vbm25_index_device_bytes(self.h))
+
+    def lookup_terms(self, keys):
+        """address_tokens::read for a list of 16-byte keys -> term ids (0xffffffff = absent)."""
+        buf = np.frombuffer(b"".join(keys), dtype=np.uint8) if keys else np.zeros(0, np.uint8)
+        out = np.zeros(len(keys), dtype=np.uint32)
+        check(lib().vbm25_lookup_terms(self.h, _p(buf), len(keys), _p(out)))
+        return out
+
+
+class Batch:
+    """Device-resident query batch (vbm25_batch)."""
+
+    def __init__(self, index, max_queries, max_total_terms, k):
+        self.index, self.k, self.nq = index, k, 0
+        self.h = C.c_void_p()
+        check(lib().vbm25_batch_create(index.h, max_queries, max(1, max_total_terms), k,
+                                       C.byref(self.h)))
+
+    def __del__(self):
+        try:
+            if self.h:
+                lib().vbm25_batch_destroy(self.h)
+        except Exception:
+            pass
+
+    def set_queries(self, term_ids, q_off):
+        term_ids = np.ascontiguousarray(term_ids, dtype=np.uint32)
+        q_off = np.ascontiguousarray(q_off, dtype=np.uint32)
+        check(lib().vbm25_batch_set_queries(self.h, _p(term_ids), q_off.ctypes.data_as(C.c_void_p),
+                                            len(q_off) - 1))
+        self.nq = len(q_off) - 1
+
+    def run(self, stream=None):
+        check(lib().vbm25_batch_run(self.h, C.c_void_p(stream) if stream else None))
+
+    def fetch(self):
+        hits = np.zeros((self.nq, self.k), dtype=HIT_DTYPE)
+        n_hits = np.zeros(self.nq, dtype=np.uint32)
+        check(lib().vbm25_batch_fetch(self.h, _p(hits) if self.nq else None,
+                                      _p(n_hits) if self.nq else None))
+        return hits, n_hits
+
+    def set_timing(self, enabled=True):
+        check(lib().vbm25_batch_set_timing(self.h, int(enabled)))
+
+    def kernel_ms(self):
+        ms, n = C.c_double(), C.c_uint32()
+        check(lib().vbm25_batch_kernel_ms(self.h, C.byref(ms), C.byref(n)))
+        return ms.value, n.value
+
+
+def search_batch(index, term_ids, q_off, k):
+    """vbm25_search_batch: nq queries (CSR of ascending term ids) -> (hits[nq,k], n_hits[nq])."""
+    term_ids = np.ascontiguousarray(term_ids, dtype=np.uint32)
+    q_off = np.ascontiguousarray(q_off, dtype=np.uint32)
+    nq = len(q_off) - 1
+    hits = np.zeros((nq, max(k, 1)), dtype=HIT_DTYPE)
+    n_hits = np.zeros(nq, dtype=np.uint32)
+    check(lib().vbm25_search_batch(index.h, _p(term_ids), q_off.ctypes.data_as(C.c_void_p), nq, k,
+                                   hits.ctypes.data_as(C.c_void_p),
+                                   n_hits.ctypes.data_as(C.c_void_p)))
+    return hits, n_hits
+
+
+def search(index, k, query):
+    """bm25::search(&index, k, &query, |_| true) (search.rs:28-36) for one Query:
+    best-first list of (score, payload) with the doc id alongside."""
+    ids = index.lookup_terms(query.keys)
+    ids = np.sort(ids[ids != 0xffffffff])  # unknown tokens are ignored (search.rs:59-61)
+    hits, n = search_batch(index, ids, np.array([0, len(ids)], dtype=np.uint32), k)
+    return hits[0, :n[0]]

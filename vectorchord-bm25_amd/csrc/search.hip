@@ -1,0 +1,989 @@
+// search.hip -- device half of libvbm25: batched BM25 top-k over compressed posting blocks
+// for MI355X (gfx950, wave64).  Replaces the traversal of
+// /root/reference/crates/bm25/src/search.rs:28-282 (bm25::search) for the sealed segment.
+//
+// Shape of the computation (DESIGN.md has the full story):
+//   plan_kernel   one workgroup: splits every query into doc-range chunks of roughly equal
+//                 posting counts -> work items (query, doc_lo, doc_hi)
+//   scan_kernel   one workgroup per item (grid-stride): walks the chunk in doc-range tiles;
+//                 per tile, term by term (ascending key order = the summation order of
+//                 evaluate.rs:43-72), each wave decodes one 128-posting block (bit-unpack +
+//                 wave prefix sum, search.rs:498-518 / compression.rs:65-136), evaluates
+//                 Cache::evaluate (bm25.rs:355-358) in f64 and accumulates per document in an
+//                 LDS hash table; the tile's documents are then filtered against the running
+//                 top-k (Results, search.rs:284-314) kept sorted in LDS.  A per-query threshold
+//                 is shared between workgroups through a 64-bit atomic max on the score bits.
+//   merge_kernel  one wave per query: merges the per-chunk top-k lists, adds payloads.
+//
+// Result order is canonical: score descending, ties by ascending doc id.  All f64 arithmetic
+// is IEEE (compiled with -ffp-contract=off, no fast-math): results are bit-identical to the
+// CPU oracle's brute-force evaluation.
+
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <memory>
+#include <vector>
+
+#include "vbm25_internal.h"
+
+namespace vbm25 {
+
+static thread_local char g_error[512] = "";
+
+int set_error(int code, const char *fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_error, sizeof g_error, fmt, ap);
+    va_end(ap);
+    return code;
+}
+
+#define HIP_TRY(expr)                                                                        \
+    do {                                                                                     \
+        hipError_t e_ = (expr);                                                              \
+        if (e_ != hipSuccess)                                                                \
+            return set_error(VBM25_ERR_DEVICE, "%s failed: %s (%s:%d)", #expr,               \
+                             hipGetErrorString(e_), __FILE__, __LINE__);                     \
+    } while (0)
+
+// ---------------------------------------------------------------------------
+// Device-side view of the index and of one batch
+// ---------------------------------------------------------------------------
+struct DevIndex {
+    uint32_t n_docs, n_terms, n_blocks;
+    const uint32_t *term_df;
+    const uint32_t *term_first_block;
+    const double *term_s0;       // idf * (k1 + 1), host-computed (libm log)
+    const uint32_t *blk_min_doc;
+    const uint32_t *blk_max_doc;
+    const uint4 *blk_meta;       // {min_doc, max_doc, off8, n | meta_doc<<8 | meta_tf<<16 | wand_fn<<24}
+    const uint8_t *blob;
+    const uint8_t *post_fn;      // derived: fieldnorm of every posting, 128 bytes per block
+    const uint16_t *doc_payload;
+    const double *s1;            // 256 entries
+};
+
+struct Item {
+    uint32_t q, doc_lo, doc_hi, _pad;
+};
+
+struct DevBatch {
+    const uint32_t *term_ids;
+    const uint32_t *q_off;
+    uint32_t nq, k;
+    Item *items;
+    uint32_t *n_items;
+    uint32_t *q_item_base;  // nq + 1
+    unsigned long long *theta;  // per query: bits of a lower bound of the k-th best score
+    double *res_score;      // per item: k entries
+    uint32_t *res_doc;
+    uint32_t *res_cnt;
+    vbm25_hit *hits;
+    uint32_t *n_hits;
+    uint32_t *error_flag;
+};
+
+constexpr int WG = 256;
+constexpr int NW = WG / 64;
+constexpr int SLOTS_LOG2 = 12;
+constexpr int SLOTS = 1 << SLOTS_LOG2;  // hash table slots per workgroup
+constexpr int CAP_BLOCKS = SLOTS / 2 / 128;  // blocks admitted per tile in hash mode
+constexpr int MAX_TERMS = 128;         // terms per query handled on the GPU
+constexpr uint32_t EMPTY = 0xffffffffu;
+constexpr uint32_t TARGET_ITEMS = 2048;
+constexpr uint32_t MIN_CHUNK_POSTINGS = 8192;
+constexpr int PLAN_WG = 1024;
+
+// ---------------------------------------------------------------------------
+// Block decode: one wave, two postings per lane (value indices 2*lane, 2*lane+1)
+// ---------------------------------------------------------------------------
+__device__ __forceinline__ uint32_t bp_field(const uint32_t *__restrict__ w32, uint32_t b,
+                                             uint32_t i) {
+    // crates/simd/src/bitpacking.rs:58-98: lane l = i % 4 is an LSB-first stream of b-bit
+    // fields, its word w lives at 32-bit index 4*w + l.
+    const uint32_t l = i & 3, bit = (i >> 2) * b, w = bit >> 5, sh = bit & 31;
+    const uint32_t lo = w32[4 * w + l];
+    const uint32_t hi = (sh + b > 32) ? w32[4 * (w + 1) + l] : 0u;
+    const unsigned long long both = ((unsigned long long)hi << 32) | lo;
+    return (uint32_t)(both >> sh) & ((1u << b) - 1u);
+}
+
+__device__ __forceinline__ uint32_t byte_field(const uint8_t *__restrict__ p, uint32_t w,
+                                               uint32_t i) {
+    uint32_t v = 0;
+    for (uint32_t j = 0; j < w; ++j) v |= (uint32_t)p[i * w + j] << (8 * j);
+    return v;
+}
+
+// Raw fields of a block payload (no delta).  meta: bit 7 = byte packed, low bits = width.
+__device__ __forceinline__ void decode_fields(const uint8_t *__restrict__ p, uint32_t meta,
+                                              uint32_t n, uint32_t lane, uint32_t &v0,
+                                              uint32_t &v1) {
+    const uint32_t i0 = 2 * lane, i1 = i0 + 1;
+    const uint32_t width = meta & 127u;
+    v0 = 0;
+    v1 = 0;
+    if ((meta >> 7) == 0) {
+        const uint32_t *w32 = reinterpret_cast<const uint32_t *>(p);
+        if (width == 32) {
+            v0 = w32[i0];
+            v1 = w32[i1];
+        } else if (width != 0) {
+            v0 = bp_field(w32, width, i0);
+            v1 = bp_field(w32, width, i1);
+        }
+    } else {
+        if (i0 < n) v0 = byte_field(p, width, i0);
+        if (i1 < n) v1 = byte_field(p, width, i1);
+    }
+}
+
+__device__ __forceinline__ uint32_t payload_bytes(uint32_t meta, uint32_t n) {
+    return (meta >> 7) ? (meta & 127u) * n : 16u * (meta & 127u);
+}
+
+// Document ids of a block: d1 deltas in index order from min_doc
+// (bitpacking_u32_ordered.rs:191-218), except width 32 / bytewidth 4 = raw absolute.
+__device__ __forceinline__ void decode_doc_ids(const uint8_t *__restrict__ p, uint32_t meta,
+                                               uint32_t n, uint32_t min_doc, uint32_t lane,
+                                               uint32_t &d0, uint32_t &d1) {
+    uint32_t v0, v1;
+    decode_fields(p, meta, n, lane, v0, v1);
+    const uint32_t width = meta & 127u;
+    const bool raw = (meta >> 7) ? (width == 4) : (width == 32);
+    if (raw) {
+        d0 = v0;
+        d1 = v1;
+        return;
+    }
+    uint32_t x = v0 + v1;  // inclusive scan of the per-lane sums
+    const uint32_t own = x;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        uint32_t y = __shfl_up(x, o);
+        if ((int)lane >= o) x += y;
+    }
+    d0 = min_doc + (x - own) + v0;
+    d1 = d0 + v1;
+}
+
+// ---------------------------------------------------------------------------
+// Index preparation: fieldnorm of every posting + structural validation
+// ---------------------------------------------------------------------------
+__global__ void __launch_bounds__(256)
+post_fn_kernel(uint32_t n_blocks, uint32_t n_docs, const uint4 *__restrict__ blk_meta,
+               const uint8_t *__restrict__ blob, const uint8_t *__restrict__ doc_fieldnorm,
+               uint8_t *__restrict__ post_fn, uint32_t *__restrict__ error_flag) {
+    const uint32_t lane = threadIdx.x & 63;
+    const uint32_t j = blockIdx.x * (blockDim.x / 64) + (threadIdx.x >> 6);
+    if (j >= n_blocks) return;
+    const uint4 m = blk_meta[j];
+    const uint32_t n = m.w & 0xff, md = (m.w >> 8) & 0xff;
+    uint32_t d0, d1;
+    decode_doc_ids(blob + 8ull * m.z, md, n, m.x, lane, d0, d1);
+    const uint32_t i0 = 2 * lane, i1 = i0 + 1;
+    uint8_t f0 = 0, f1 = 0;
+    bool bad = false;
+    if (i0 < n) {
+        bad |= d0 >= n_docs;
+        if (d0 < n_docs) f0 = doc_fieldnorm[d0];
+    }
+    if (i1 < n) {
+        bad |= d1 >= n_docs || d1 <= d0;
+        if (d1 < n_docs) f1 = doc_fieldnorm[d1];
+    }
+    // strictly increasing across lanes, first = min_doc, last = max_doc
+    const uint32_t prev = __shfl_up(d1, 1);
+    if (lane > 0 && i0 < n) bad |= d0 <= prev;
+    if (i0 == 0) bad |= d0 != m.x;
+    if (i0 == n - 1) bad |= d0 != m.y;
+    if (i1 == n - 1) bad |= d1 != m.y;
+    if (bad) atomicOr(error_flag, 1u);
+    reinterpret_cast<uchar2 *>(post_fn + 128ull * j)[lane] = make_uchar2(f0, f1);
+}
+
+// ---------------------------------------------------------------------------
+// Planner
+// ---------------------------------------------------------------------------
+__global__ void __launch_bounds__(PLAN_WG) plan_kernel(DevIndex ix, DevBatch bt, uint32_t max_items) {
+    __shared__ unsigned long long s_part[PLAN_WG];
+    __shared__ unsigned long long s_total;
+    const uint32_t tid = threadIdx.x;
+    const uint32_t per = (bt.nq + PLAN_WG - 1) / PLAN_WG;
+    const uint32_t q0 = min(bt.nq, tid * per), q1 = min(bt.nq, q0 + per);
+
+    auto postings_of = [&](uint32_t q) {
+        unsigned long long t = 0;
+        for (uint32_t p = bt.q_off[q]; p < bt.q_off[q + 1]; ++p) {
+            uint32_t term = bt.term_ids[p];
+            if (term < ix.n_terms) t += ix.term_df[term];
+        }
+        return t;
+    };
+    unsigned long long local = 0;
+    for (uint32_t q = q0; q < q1; ++q) local += postings_of(q);
+    s_part[tid] = local;
+    __syncthreads();
+    if (tid == 0) {
+        unsigned long long t = 0;
+        for (int i = 0; i < PLAN_WG; ++i) t += s_part[i];
+        s_total = t;
+    }
+    __syncthreads();
+    const unsigned long long total = s_total;
+    unsigned long long chunk = (total + TARGET_ITEMS - 1) / TARGET_ITEMS;
+    if (chunk < MIN_CHUNK_POSTINGS) chunk = MIN_CHUNK_POSTINGS;
+    __syncthreads();
+    auto chunks_of = [&](uint32_t q) -> uint32_t {
+        unsigned long long t = postings_of(q);
+        if (t == 0) return 0u;
+        unsigned long long c = (t + chunk - 1) / chunk;
+        if (c > ix.n_docs) c = ix.n_docs;
+        return (uint32_t)c;
+    };
+    unsigned long long cnt = 0;
+    for (uint32_t q = q0; q < q1; ++q) cnt += chunks_of(q);
+    s_part[tid] = cnt;
+    __syncthreads();
+    if (tid == 0) {  // exclusive scan over 1024 partial sums (tiny)
+        unsigned long long run = 0;
+        for (int i = 0; i < PLAN_WG; ++i) {
+            unsigned long long c = s_part[i];
+            s_part[i] = run;
+            run += c;
+        }
+        *bt.n_items = (uint32_t)min(run, (unsigned long long)max_items);
+        if (run > max_items) atomicOr(bt.error_flag, 2u);
+        bt.q_item_base[bt.nq] = (uint32_t)min(run, (unsigned long long)max_items);
+    }
+    __syncthreads();
+    uint32_t base = (uint32_t)s_part[tid];
+    for (uint32_t q = q0; q < q1; ++q) {
+        const uint32_t c = chunks_of(q);
+        bt.q_item_base[q] = min(base, max_items);
+        for (uint32_t i = 0; i < c && base + i < max_items; ++i) {
+            Item it;
+            it.q = q;
+            it.doc_lo = (uint32_t)((unsigned long long)ix.n_docs * i / c);
+            it.doc_hi = (uint32_t)((unsigned long long)ix.n_docs * (i + 1) / c);
+            it._pad = 0;
+            bt.items[base + i] = it;
+        }
+        base += c;
+    }
+}
+
+// ---------------------------------------------------------------------------
+// Sorted top-k list in LDS, maintained by ONE wave.
+// Order: score descending, then doc id ascending ("better").
+// ---------------------------------------------------------------------------
+__device__ __forceinline__ bool better(double sa, uint32_t da, double sb, uint32_t db) {
+    return sa > sb || (sa == sb && da < db);
+}
+
+template <int KMAX>
+struct TopK {
+    double score[KMAX];
+    uint32_t doc[KMAX];
+    uint32_t count;
+};
+
+// Wave-cooperative insert of (s, d); caller guarantees it qualifies.  All 64 lanes call.
+template <int KMAX>
+__device__ __forceinline__ void topk_insert(TopK<KMAX> &L, uint32_t k, double s, uint32_t d,
+                                            uint32_t lane) {
+    const uint32_t n = L.count;
+    uint32_t c = 0;
+    for (uint32_t i = lane; i < n; i += 64) c += better(L.score[i], L.doc[i], s, d) ? 1u : 0u;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) c += __shfl_xor(c, o);
+    const uint32_t pos = c;
+    const uint32_t newn = n < k ? n + 1 : k;
+    if (pos >= newn) return;
+    // shift [pos, newn-2] up by one, from the top down
+    for (int base = (int)newn - 2; base >= (int)pos; base -= 64) {
+        const int i = base - (int)lane;
+        double ts = 0;
+        uint32_t td = 0;
+        const bool act = i >= (int)pos;
+        if (act) {
+            ts = L.score[i];
+            td = L.doc[i];
+        }
+        __builtin_amdgcn_wave_barrier();
+        if (act) {
+            L.score[i + 1] = ts;
+            L.doc[i + 1] = td;
+        }
+        __builtin_amdgcn_wave_barrier();
+    }
+    if (lane == 0) {
+        L.score[pos] = s;
+        L.doc[pos] = d;
+        L.count = newn;
+    }
+    __builtin_amdgcn_wave_barrier();
+}
+
+// Offer up to 64 candidates (one per lane, `has` marks validity) to the list.
+template <int KMAX>
+__device__ __forceinline__ void topk_offer(TopK<KMAX> &L, uint32_t k, bool has, double s,
+                                           uint32_t d, uint32_t lane) {
+    for (;;) {
+        const uint32_t n = L.count;
+        bool alive = has;
+        if (alive && n >= k) alive = better(s, d, L.score[k - 1], L.doc[k - 1]);
+        const unsigned long long mask = __ballot(alive);
+        if (!mask) break;
+        const int leader = __ffsll((long long)mask) - 1;
+        const double cs = __shfl(s, leader);
+        const uint32_t cd = __shfl(d, leader);
+        topk_insert<KMAX>(L, k, cs, cd, lane);
+        if ((int)lane == leader) has = false;
+    }
+}
+
+// ---------------------------------------------------------------------------
+// Posting scan
+// ---------------------------------------------------------------------------
+template <int KMAX>
+__global__ void __launch_bounds__(WG) scan_kernel(DevIndex ix, DevBatch bt) {
+    __shared__ uint32_t s_key[SLOTS];
+    __shared__ double s_val[SLOTS];
+    __shared__ uint16_t s_cand[SLOTS];
+    __shared__ double s_s1[256];
+    __shared__ TopK<KMAX> s_top;
+    __shared__ uint32_t t_cur[MAX_TERMS], t_end[MAX_TERMS], t_quota[MAX_TERMS];
+    __shared__ double t_s0[MAX_TERMS];
+    __shared__ uint32_t s_m, s_hi, s_next_lo, s_cand_cnt, s_dense;
+    __shared__ unsigned long long s_theta, s_sumdf;
+
+    const uint32_t tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const uint32_t k = bt.k;
+    for (int i = tid; i < 256; i += WG) s_s1[i] = ix.s1[i];
+
+    const uint32_t n_items = *bt.n_items;
+    for (uint32_t item = blockIdx.x; item < n_items; item += gridDim.x) {
+        const Item it = bt.items[item];
+        const uint32_t q = it.q, clo = it.doc_lo, chi = it.doc_hi;
+        __syncthreads();  // previous item fully done with LDS
+        if (tid == 0) {
+            // valid terms of the query, ascending (Query::new guarantees sorted keys)
+            uint32_t m = 0;
+            unsigned long long sum = 0;
+            for (uint32_t p = bt.q_off[q]; p < bt.q_off[q + 1]; ++p) {
+                const uint32_t term = bt.term_ids[p];
+                if (term >= ix.n_terms) continue;  // search.rs:59-61
+                if (m < MAX_TERMS) {
+                    t_cur[m] = term;  // resolved below
+                    sum += ix.term_df[term];
+                    ++m;
+                }
+            }
+            s_m = m;
+            s_sumdf = sum;
+            s_top.count = 0;
+            s_dense = (m >= (uint32_t)CAP_BLOCKS) ? 1u : 0u;
+        }
+        __syncthreads();
+        const uint32_t m = s_m;
+        const bool dense = s_dense != 0;
+        if (tid < m) {
+            const uint32_t term = t_cur[tid];
+            const uint32_t b0 = ix.term_first_block[term], b1 = ix.term_first_block[term + 1];
+            // first block whose max_doc >= clo
+            uint32_t lo = b0, hi = b1;
+            while (lo < hi) {
+                const uint32_t mid = (lo + hi) >> 1;
+                if (ix.blk_max_doc[mid] < clo) lo = mid + 1; else hi = mid;
+            }
+            t_end[tid] = b1;
+            t_s0[tid] = ix.term_s0[term];
+            const unsigned long long df = ix.term_df[term];
+            const uint32_t share = (uint32_t)(((unsigned long long)(CAP_BLOCKS - (dense ? 0 : (int)m)) * df) / s_sumdf);
+            t_quota[tid] = share > 1 ? share : 1;
+            t_cur[tid] = lo;
+        }
+        __syncthreads();
+
+        uint32_t lo = clo;
+        unsigned long long published = 0;
+        while (lo < chi) {
+            // ---- tile bounds + table reset
+            if (tid == 0) {
+                s_hi = dense ? (chi - lo > (uint32_t)SLOTS ? lo + SLOTS : chi) : chi;
+                s_cand_cnt = 0;
+                s_next_lo = chi;
+                s_theta = __hip_atomic_load(&bt.theta[q], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+            for (int i = tid; i < SLOTS; i += WG) s_key[i] = EMPTY;
+            __syncthreads();
+            if (!dense && tid < m) {
+                const uint32_t j = t_cur[tid] + t_quota[tid];
+                if (j < t_end[tid]) atomicMin(&s_hi, ix.blk_min_doc[j]);
+            }
+            __syncthreads();
+            const uint32_t hi = s_hi;
+
+            // ---- accumulate, one term per phase (ascending key order)
+            for (uint32_t t = 0; t < m; ++t) {
+                const uint32_t jend = t_end[t];
+                const double s0 = t_s0[t];
+                for (uint32_t j = t_cur[t] + wave; j < jend; j += NW) {
+                    const uint4 bm = ix.blk_meta[j];
+                    if (bm.x >= hi) break;
+                    const uint32_t n = bm.w & 0xff, md = (bm.w >> 8) & 0xff, mt = (bm.w >> 16) & 0xff;
+                    const uint8_t *body = ix.blob + 8ull * bm.z;
+                    uint32_t d0, d1, f0, f1;
+                    decode_doc_ids(body, md, n, bm.x, lane, d0, d1);
+                    decode_fields(body + ((payload_bytes(md, n) + 7u) & ~7u), mt, n, lane, f0, f1);
+                    const uchar2 fn = reinterpret_cast<const uchar2 *>(ix.post_fn + 128ull * j)[lane];
+#pragma unroll
+                    for (int e = 0; e < 2; ++e) {
+                        const uint32_t i = 2 * lane + e;
+                        const uint32_t d = e ? d1 : d0;
+                        const uint32_t tfv = e ? f1 : f0;
+                        const uint32_t f = e ? fn.y : fn.x;
+                        if (i < n && d >= lo && d < hi) {
+                            const double tf = (double)tfv;
+                            const double p = (tf * s0) / (tf + s_s1[f]);  // bm25.rs:355-358
+                            const uint32_t key = d - lo;
+                            uint32_t slot = dense ? key : ((key * 0x9E3779B1u) >> (32 - SLOTS_LOG2));
+                            for (;;) {
+                                const uint32_t prev = atomicCAS(&s_key[slot], EMPTY, key);
+                                if (prev == EMPTY) {
+                                    s_val[slot] = p;
+                                    break;
+                                }
+                                if (prev == key) {
+                                    s_val[slot] += p;
+                                    break;
+                                }
+                                slot = (slot + 1) & (SLOTS - 1);
+                            }
+                        }
+                    }
+                }
+                __syncthreads();
+            }
+
+            // ---- candidates of this tile
+            {
+                const unsigned long long theta = s_theta;
+                const uint32_t n = s_top.count;
+                const double ws = n >= k ? s_top.score[k - 1] : 0.0;
+                const uint32_t wd = n >= k ? s_top.doc[k - 1] : 0u;
+                for (int i = tid; i < SLOTS; i += WG) {
+                    const uint32_t key = s_key[i];
+                    if (key == EMPTY) continue;
+                    const double sc = s_val[i];
+                    if ((unsigned long long)__double_as_longlong(sc) < theta) continue;
+                    if (n >= k && !better(sc, lo + key, ws, wd)) continue;
+                    const uint32_t at = atomicAdd(&s_cand_cnt, 1u);
+                    s_cand[at] = (uint16_t)i;
+                }
+            }
+            __syncthreads();
+            if (wave == 0) {
+                const uint32_t cnt = s_cand_cnt;
+                for (uint32_t base = 0; base < cnt; base += 64) {
+                    const bool has = base + lane < cnt;
+                    double sc = 0;
+                    uint32_t d = 0;
+                    if (has) {
+                        const uint32_t slot = s_cand[base + lane];
+                        sc = s_val[slot];
+                        d = lo + s_key[slot];
+                    }
+                    topk_offer<KMAX>(s_top, k, has, sc, d, lane);
+                }
+                if (s_top.count >= k && lane == 0) {
+                    const unsigned long long bits = (unsigned long long)__double_as_longlong(s_top.score[k - 1]);
+                    if (bits > published) {
+                        atomicMax(&bt.theta[q], bits);
+                        published = bits;
+                    }
+                }
+            }
+            // ---- advance cursors; next tile starts at the first remaining posting
+            if (tid < m) {
+                uint32_t j = t_cur[tid];
+                const uint32_t e = t_end[tid];
+                while (j < e && ix.blk_max_doc[j] < hi) ++j;
+                t_cur[tid] = j;
+                if (j < e) atomicMin(&s_next_lo, max(hi, ix.blk_min_doc[j]));
+            }
+            __syncthreads();
+            lo = max(hi, s_next_lo);
+        }
+
+        // ---- chunk result
+        __syncthreads();
+        {
+            const uint32_t n = s_top.count;
+            for (uint32_t i = tid; i < n; i += WG) {
+                bt.res_score[(size_t)item * k + i] = s_top.score[i];
+                bt.res_doc[(size_t)item * k + i] = s_top.doc[i];
+            }
+            if (tid == 0) bt.res_cnt[item] = n;
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------
+// Merge of per-chunk lists -> hits
+// ---------------------------------------------------------------------------
+template <int KMAX>
+__global__ void __launch_bounds__(64) merge_kernel(DevIndex ix, DevBatch bt) {
+    __shared__ TopK<KMAX> s_top;
+    const uint32_t q = blockIdx.x, lane = threadIdx.x, k = bt.k;
+    if (lane == 0) s_top.count = 0;
+    __builtin_amdgcn_wave_barrier();
+    const uint32_t i0 = bt.q_item_base[q], i1 = bt.q_item_base[q + 1];
+    for (uint32_t item = i0; item < i1; ++item) {
+        const uint32_t cnt = bt.res_cnt[item];
+        for (uint32_t base = 0; base < cnt; base += 64) {
+            const bool has = base + lane < cnt;
+            double sc = 0;
+            uint32_t d = 0;
+            if (has) {
+                sc = bt.res_score[(size_t)item * k + base + lane];
+                d = bt.res_doc[(size_t)item * k + base + lane];
+            }
+            topk_offer<KMAX>(s_top, k, has, sc, d, lane);
+        }
+    }
+    __builtin_amdgcn_wave_barrier();
+    const uint32_t n = s_top.count;
+    for (uint32_t i = lane; i < n; i += 64) {
+        vbm25_hit h;
+        h.score = s_top.score[i];
+        h.doc_id = s_top.doc[i];
+        const uint16_t *pl = ix.doc_payload + 3ull * h.doc_id;
+        h.payload[0] = pl[0];
+        h.payload[1] = pl[1];
+        h.payload[2] = pl[2];
+        h._pad = 0;
+        bt.hits[(size_t)q * k + i] = h;
+    }
+    if (lane == 0) bt.n_hits[q] = n;
+}
+
+// ---------------------------------------------------------------------------
+// Host objects
+// ---------------------------------------------------------------------------
+struct DeviceBuffer {
+    void *p = nullptr;
+    size_t bytes = 0;
+    ~DeviceBuffer() {
+        if (p) (void)hipFree(p);
+    }
+    int alloc(size_t n) {
+        bytes = n;
+        HIP_TRY(hipMalloc(&p, n ? n : 16));
+        return VBM25_OK;
+    }
+    int upload(const void *src, size_t n) {
+        if (int rc = alloc(n)) return rc;
+        if (n) HIP_TRY(hipMemcpy(p, src, n, hipMemcpyHostToDevice));
+        return VBM25_OK;
+    }
+    template <class T>
+    T *as() const {
+        return static_cast<T *>(p);
+    }
+};
+
+}  // namespace vbm25
+
+using namespace vbm25;
+
+struct vbm25_index {
+    int device = 0;
+    DevIndex dev{};
+    uint32_t n_docs = 0, n_terms = 0, n_blocks = 0;
+    std::vector<uint8_t> term_key;  // host copy for vbm25_lookup_terms
+    DeviceBuffer term_df, term_first_block, term_s0, blk_min_doc, blk_max_doc, blk_meta, blob,
+        post_fn, doc_payload, s1;
+    uint64_t device_bytes = 0;
+};
+
+struct vbm25_batch {
+    vbm25_index *index = nullptr;
+    uint32_t max_queries = 0, max_terms = 0, k = 0, nq = 0, max_items = 0;
+    DeviceBuffer term_ids, q_off, items, n_items, q_item_base, theta, res_score, res_doc, res_cnt,
+        hits, n_hits, error_flag;
+    bool timing = false;
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> events;
+    size_t events_used = 0;
+    ~vbm25_batch() {
+        for (auto &e : events) {
+            (void)hipEventDestroy(e.first);
+            (void)hipEventDestroy(e.second);
+        }
+    }
+};
+
+namespace {
+
+int check_desc(const vbm25_index_desc *d) {
+    if (!d) return set_error(VBM25_ERR_INVALID, "desc is NULL");
+    if (!d->n_docs) return set_error(VBM25_ERR_INVALID, "index without documents");
+    if (!(d->k1 >= 1.2 && d->k1 <= 2.0) || !(d->b >= 0.0 && d->b <= 1.0))
+        return set_error(VBM25_ERR_INVALID, "k1 must be in [1.2, 2] and b in [0, 1]");
+    if (d->n_terms && (!d->term_key || !d->term_df || !d->term_first_block))
+        return set_error(VBM25_ERR_INVALID, "term arrays missing");
+    if (d->n_blocks && (!d->blk_min_doc || !d->blk_max_doc || !d->blk_n || !d->blk_meta_doc ||
+                        !d->blk_meta_tf || !d->blk_off8 || !d->blob))
+        return set_error(VBM25_ERR_INVALID, "block arrays missing");
+    if (!d->doc_fieldnorm || !d->doc_payload)
+        return set_error(VBM25_ERR_INVALID, "document arrays missing");
+    if (d->n_terms) {
+        if (d->term_first_block[0] != 0 || d->term_first_block[d->n_terms] != d->n_blocks)
+            return set_error(VBM25_ERR_CORRUPT, "term_first_block does not cover the blocks");
+        for (uint32_t t = 0; t < d->n_terms; ++t) {
+            uint32_t nb = d->term_first_block[t + 1] - d->term_first_block[t];
+            if (d->term_first_block[t + 1] < d->term_first_block[t] ||
+                nb != (d->term_df[t] + 127) / 128 || d->term_df[t] == 0 || d->term_df[t] > d->n_docs)
+                return set_error(VBM25_ERR_CORRUPT, "term %u: df / block count mismatch", t);
+            if (t && std::memcmp(d->term_key + 16ull * (t - 1), d->term_key + 16ull * t, 16) >= 0)
+                return set_error(VBM25_ERR_CORRUPT, "term keys not strictly ascending at %u", t);
+        }
+    } else if (d->n_blocks) {
+        return set_error(VBM25_ERR_CORRUPT, "blocks without terms");
+    }
+    for (uint32_t t = 0; t < d->n_terms; ++t) {
+        uint32_t b0 = d->term_first_block[t], b1 = d->term_first_block[t + 1];
+        uint64_t cnt = 0;
+        for (uint32_t j = b0; j < b1; ++j) {
+            const uint32_t n = d->blk_n[j];
+            const uint8_t md = d->blk_meta_doc[j], mt = d->blk_meta_tf[j];
+            if (n < 1 || n > 128 || (j + 1 < b1 && n != 128))
+                return set_error(VBM25_ERR_CORRUPT, "block %u: bad posting count %u", j, n);
+            const bool full = n == 128;
+            for (uint8_t mm : {md, mt}) {
+                const uint32_t w = mm & 127;
+                if (full ? ((mm >> 7) != 0 || w > 32) : ((mm >> 7) != 1 || w < 1 || w > 4))
+                    return set_error(VBM25_ERR_CORRUPT, "block %u: bad codec metadata 0x%02x", j, mm);
+            }
+            const uint32_t ld = (md >> 7) ? (md & 127u) * n : 16u * (md & 127u);
+            const uint32_t lt = (mt >> 7) ? (mt & 127u) * n : 16u * (mt & 127u);
+            const uint64_t need = ((ld + 7) / 8) + ((lt + 7) / 8);
+            if (d->blk_off8[j + 1] < d->blk_off8[j] || d->blk_off8[j + 1] - d->blk_off8[j] != need)
+                return set_error(VBM25_ERR_CORRUPT, "block %u: body length mismatch", j);
+            if (d->blk_min_doc[j] > d->blk_max_doc[j] || d->blk_max_doc[j] >= d->n_docs ||
+                (j > b0 && d->blk_min_doc[j] <= d->blk_max_doc[j - 1]))
+                return set_error(VBM25_ERR_CORRUPT, "block %u: document range out of order", j);
+            cnt += n;
+        }
+        if (cnt != d->term_df[t]) return set_error(VBM25_ERR_CORRUPT, "term %u: df mismatch", t);
+    }
+    if (d->n_blocks && 8ull * d->blk_off8[d->n_blocks] > d->blob_bytes)
+        return set_error(VBM25_ERR_CORRUPT, "blob shorter than the block offsets");
+    return VBM25_OK;
+}
+
+int use_device(int device) {
+    HIP_TRY(hipSetDevice(device));
+    return VBM25_OK;
+}
+
+template <class F>
+int dispatch_k(uint32_t k, F &&f) {
+    if (k <= 64) return f(std::integral_constant<int, 64>());
+    return f(std::integral_constant<int, 1024>());
+}
+
+}  // namespace
+
+extern "C" {
+
+const char *vbm25_last_error(void) { return g_error; }
+const char *vbm25_version(void) { return "vbm25-mi355x 0.1 (gfx950)"; }
+
+int vbm25_index_create(const vbm25_index_desc *d, int device, vbm25_index **out) {
+    if (!out) return set_error(VBM25_ERR_INVALID, "out is NULL");
+    *out = nullptr;
+    if (int rc = check_desc(d)) return rc;
+    int n_dev = 0;
+    if (hipGetDeviceCount(&n_dev) != hipSuccess || n_dev == 0)
+        return set_error(VBM25_ERR_DEVICE, "no HIP device: the MI355X path has no CPU fallback");
+    if (device < 0 || device >= n_dev)
+        return set_error(VBM25_ERR_INVALID, "device %d out of range (%d devices)", device, n_dev);
+    hipDeviceProp_t prop;
+    HIP_TRY(hipGetDeviceProperties(&prop, device));
+    if (!std::strstr(prop.gcnArchName, "gfx950"))
+        return set_error(VBM25_ERR_DEVICE, "device %d is %s; this library is built for gfx950 only",
+                         device, prop.gcnArchName);
+    if (int rc = use_device(device)) return rc;
+
+    auto ix = std::make_unique<vbm25_index>();
+    ix->device = device;
+    ix->n_docs = d->n_docs;
+    ix->n_terms = d->n_terms;
+    ix->n_blocks = d->n_blocks;
+    ix->term_key.assign(d->term_key, d->term_key + 16ull * d->n_terms);
+
+    std::vector<double> s0(d->n_terms);
+    for (uint32_t t = 0; t < d->n_terms; ++t) s0[t] = bm25_s0(d->n_docs, d->term_df[t], d->k1);
+    double s1[256];
+    bm25_tables(d->n_docs, d->sum_len, d->k1, d->b, s1);
+    std::vector<uint4> meta(d->n_blocks);
+    for (uint32_t j = 0; j < d->n_blocks; ++j) {
+        meta[j].x = d->blk_min_doc[j];
+        meta[j].y = d->blk_max_doc[j];
+        meta[j].z = d->blk_off8[j];
+        meta[j].w = uint32_t(d->blk_n[j]) | uint32_t(d->blk_meta_doc[j]) << 8 |
+                    uint32_t(d->blk_meta_tf[j]) << 16 | uint32_t(d->blk_wand_fn ? d->blk_wand_fn[j] : 0) << 24;
+    }
+    DeviceBuffer fieldnorm, err;
+    int rc = 0;
+    const size_t blob_alloc = ((size_t(d->blob_bytes) + 15) & ~size_t(15)) + 64;  // slack for word reads
+    if ((rc = ix->term_df.upload(d->term_df, 4ull * d->n_terms)) ||
+        (rc = ix->term_first_block.upload(d->term_first_block, 4ull * (d->n_terms + 1))) ||
+        (rc = ix->term_s0.upload(s0.data(), 8ull * d->n_terms)) ||
+        (rc = ix->blk_min_doc.upload(d->blk_min_doc, 4ull * d->n_blocks)) ||
+        (rc = ix->blk_max_doc.upload(d->blk_max_doc, 4ull * d->n_blocks)) ||
+        (rc = ix->blk_meta.upload(meta.data(), 16ull * d->n_blocks)) ||
+        (rc = ix->blob.alloc(blob_alloc)) ||
+        (rc = ix->post_fn.alloc(128ull * d->n_blocks)) ||
+        (rc = ix->doc_payload.upload(d->doc_payload, 6ull * d->n_docs)) ||
+        (rc = ix->s1.upload(s1, sizeof s1)) ||
+        (rc = fieldnorm.upload(d->doc_fieldnorm, d->n_docs)) || (rc = err.alloc(4)))
+        return rc;
+    HIP_TRY(hipMemset(err.p, 0, 4));
+    HIP_TRY(hipMemset(ix->blob.p, 0, blob_alloc));
+    if (d->blob_bytes) HIP_TRY(hipMemcpy(ix->blob.p, d->blob, d->blob_bytes, hipMemcpyHostToDevice));
+    if (d->n_blocks) {
+        const uint32_t grid = (d->n_blocks + 3) / 4;
+        post_fn_kernel<<<grid, 256>>>(d->n_blocks, d->n_docs, ix->blk_meta.as<uint4>(),
+                                      ix->blob.as<uint8_t>(), fieldnorm.as<uint8_t>(),
+                                      ix->post_fn.as<uint8_t>(), err.as<uint32_t>());
+        HIP_TRY(hipGetLastError());
+    }
+    uint32_t flag = 0;
+    HIP_TRY(hipMemcpy(&flag, err.p, 4, hipMemcpyDeviceToHost));
+    if (flag)
+        return set_error(VBM25_ERR_CORRUPT,
+                         "posting blocks do not decode to strictly increasing ids within "
+                         "[min_doc, max_doc] below n_docs");
+    ix->dev.n_docs = d->n_docs;
+    ix->dev.n_terms = d->n_terms;
+    ix->dev.n_blocks = d->n_blocks;
+    ix->dev.term_df = ix->term_df.as<uint32_t>();
+    ix->dev.term_first_block = ix->term_first_block.as<uint32_t>();
+    ix->dev.term_s0 = ix->term_s0.as<double>();
+    ix->dev.blk_min_doc = ix->blk_min_doc.as<uint32_t>();
+    ix->dev.blk_max_doc = ix->blk_max_doc.as<uint32_t>();
+    ix->dev.blk_meta = ix->blk_meta.as<uint4>();
+    ix->dev.blob = ix->blob.as<uint8_t>();
+    ix->dev.post_fn = ix->post_fn.as<uint8_t>();
+    ix->dev.doc_payload = ix->doc_payload.as<uint16_t>();
+    ix->dev.s1 = ix->s1.as<double>();
+    for (const DeviceBuffer *b : {&ix->term_df, &ix->term_first_block, &ix->term_s0, &ix->blk_min_doc,
+                                  &ix->blk_max_doc, &ix->blk_meta, &ix->blob, &ix->post_fn,
+                                  &ix->doc_payload, &ix->s1})
+        ix->device_bytes += b->bytes;
+    *out = ix.release();
+    return VBM25_OK;
+}
+
+void vbm25_index_destroy(vbm25_index *ix) {
+    if (!ix) return;
+    (void)hipSetDevice(ix->device);
+    delete ix;
+}
+
+uint64_t vbm25_index_device_bytes(const vbm25_index *ix) { return ix ? ix->device_bytes : 0; }
+
+int vbm25_lookup_terms(const vbm25_index *ix, const uint8_t *keys, uint32_t n, uint32_t *term_ids) {
+    if (!ix || (!keys && n) || (!term_ids && n)) return set_error(VBM25_ERR_INVALID, "NULL argument");
+    for (uint32_t i = 0; i < n; ++i) {
+        uint32_t lo = 0, hi = ix->n_terms;
+        const uint8_t *key = keys + 16ull * i;
+        while (lo < hi) {
+            uint32_t mid = (lo + hi) >> 1;
+            if (std::memcmp(ix->term_key.data() + 16ull * mid, key, 16) < 0) lo = mid + 1; else hi = mid;
+        }
+        term_ids[i] = (lo < ix->n_terms && !std::memcmp(ix->term_key.data() + 16ull * lo, key, 16))
+                          ? lo : UINT32_MAX;
+    }
+    return VBM25_OK;
+}
+
+int vbm25_batch_create(vbm25_index *ix, uint32_t max_queries, uint32_t max_total_terms, uint32_t k,
+                       vbm25_batch **out) {
+    if (!out) return set_error(VBM25_ERR_INVALID, "out is NULL");
+    *out = nullptr;
+    if (!ix) return set_error(VBM25_ERR_INVALID, "index is NULL");
+    if (k == 0) return set_error(VBM25_ERR_INVALID, "number of needed rows is set to 0");  // default.rs:114-116
+    if (k > 65535) return set_error(VBM25_ERR_INVALID, "k exceeds bm25.limit's maximum of 65535");
+    if (k > 1024)
+        return set_error(VBM25_ERR_UNSUPPORTED, "k = %u: the GPU path currently keeps at most 1024 hits per query", k);
+    if (!max_queries) return set_error(VBM25_ERR_INVALID, "max_queries is 0");
+    if (int rc = use_device(ix->device)) return rc;
+    auto bt = std::make_unique<vbm25_batch>();
+    bt->index = ix;
+    bt->max_queries = max_queries;
+    bt->max_terms = max_total_terms;
+    bt->k = k;
+    bt->max_items = max_queries + TARGET_ITEMS;
+    int rc = 0;
+    if ((rc = bt->term_ids.alloc(4ull * max_total_terms)) ||
+        (rc = bt->q_off.alloc(4ull * (max_queries + 1))) ||
+        (rc = bt->items.alloc(sizeof(Item) * size_t(bt->max_items))) || (rc = bt->n_items.alloc(4)) ||
+        (rc = bt->q_item_base.alloc(4ull * (max_queries + 1))) ||
+        (rc = bt->theta.alloc(8ull * max_queries)) ||
+        (rc = bt->res_score.alloc(8ull * bt->max_items * k)) ||
+        (rc = bt->res_doc.alloc(4ull * bt->max_items * k)) ||
+        (rc = bt->res_cnt.alloc(4ull * bt->max_items)) ||
+        (rc = bt->hits.alloc(sizeof(vbm25_hit) * size_t(max_queries) * k)) ||
+        (rc = bt->n_hits.alloc(4ull * max_queries)) || (rc = bt->error_flag.alloc(4)))
+        return rc;
+    HIP_TRY(hipMemset(bt->error_flag.p, 0, 4));
+    *out = bt.release();
+    return VBM25_OK;
+}
+
+void vbm25_batch_destroy(vbm25_batch *bt) {
+    if (!bt) return;
+    (void)hipSetDevice(bt->index->device);
+    delete bt;
+}
+
+int vbm25_batch_set_queries(vbm25_batch *bt, const uint32_t *term_ids, const uint32_t *q_off,
+                            uint32_t nq) {
+    if (!bt || !q_off) return set_error(VBM25_ERR_INVALID, "NULL argument");
+    if (nq > bt->max_queries) return set_error(VBM25_ERR_INVALID, "%u queries exceed the batch capacity %u", nq, bt->max_queries);
+    if (q_off[0] != 0) return set_error(VBM25_ERR_INVALID, "q_off[0] must be 0");
+    for (uint32_t q = 0; q < nq; ++q) {
+        if (q_off[q + 1] < q_off[q]) return set_error(VBM25_ERR_INVALID, "q_off not monotone at query %u", q);
+        uint32_t valid = 0;
+        for (uint32_t p = q_off[q]; p < q_off[q + 1]; ++p) {
+            if (p > q_off[q] && term_ids[p] <= term_ids[p - 1])  // Query::checked_new, vector.rs:106-110
+                return set_error(VBM25_ERR_INVALID, "query %u: term ids must be strictly ascending", q);
+            valid += term_ids[p] < bt->index->n_terms;
+        }
+        if (valid > MAX_TERMS)
+            return set_error(VBM25_ERR_UNSUPPORTED, "query %u has %u indexed terms; the GPU path handles up to %d", q, valid, MAX_TERMS);
+    }
+    if (q_off[nq] > bt->max_terms) return set_error(VBM25_ERR_INVALID, "%u terms exceed the batch capacity %u", q_off[nq], bt->max_terms);
+    if (int rc = use_device(bt->index->device)) return rc;
+    if (q_off[nq]) HIP_TRY(hipMemcpy(bt->term_ids.p, term_ids, 4ull * q_off[nq], hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(bt->q_off.p, q_off, 4ull * (nq + 1), hipMemcpyHostToDevice));
+    bt->nq = nq;
+    return VBM25_OK;
+}
+
+int vbm25_batch_run(vbm25_batch *bt, void *hip_stream) {
+    if (!bt) return set_error(VBM25_ERR_INVALID, "batch is NULL");
+    if (!bt->nq) return VBM25_OK;
+    if (int rc = use_device(bt->index->device)) return rc;
+    hipStream_t st = static_cast<hipStream_t>(hip_stream);
+    DevBatch db{};
+    db.term_ids = bt->term_ids.as<uint32_t>();
+    db.q_off = bt->q_off.as<uint32_t>();
+    db.nq = bt->nq;
+    db.k = bt->k;
+    db.items = bt->items.as<Item>();
+    db.n_items = bt->n_items.as<uint32_t>();
+    db.q_item_base = bt->q_item_base.as<uint32_t>();
+    db.theta = bt->theta.as<unsigned long long>();
+    db.res_score = bt->res_score.as<double>();
+    db.res_doc = bt->res_doc.as<uint32_t>();
+    db.res_cnt = bt->res_cnt.as<uint32_t>();
+    db.hits = bt->hits.as<vbm25_hit>();
+    db.n_hits = bt->n_hits.as<uint32_t>();
+    db.error_flag = bt->error_flag.as<uint32_t>();
+    const DevIndex &ix = bt->index->dev;
+    HIP_TRY(hipMemsetAsync(bt->theta.p, 0, 8ull * bt->nq, st));
+    plan_kernel<<<1, PLAN_WG, 0, st>>>(ix, db, bt->max_items);
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    if (bt->timing) {
+        if (bt->events_used == bt->events.size()) {
+            HIP_TRY(hipEventCreate(&e0));
+            HIP_TRY(hipEventCreate(&e1));
+            bt->events.emplace_back(e0, e1);
+        }
+        e0 = bt->events[bt->events_used].first;
+        e1 = bt->events[bt->events_used].second;
+        bt->events_used++;
+        HIP_TRY(hipEventRecord(e0, st));
+    }
+    const uint32_t grid = std::min<uint32_t>(bt->max_items, TARGET_ITEMS);
+    const int rc = dispatch_k(bt->k, [&](auto kmax) {
+        scan_kernel<decltype(kmax)::value><<<grid, WG, 0, st>>>(ix, db);
+        if (bt->timing) HIP_TRY(hipEventRecord(e1, st));
+        merge_kernel<decltype(kmax)::value><<<bt->nq, 64, 0, st>>>(ix, db);
+        return int(VBM25_OK);
+    });
+    if (rc) return rc;
+    HIP_TRY(hipGetLastError());
+    return VBM25_OK;
+}
+
+int vbm25_batch_fetch(vbm25_batch *bt, vbm25_hit *hits, uint32_t *n_hits) {
+    if (!bt || (!hits && bt->nq) || (!n_hits && bt->nq)) return set_error(VBM25_ERR_INVALID, "NULL argument");
+    if (int rc = use_device(bt->index->device)) return rc;
+    HIP_TRY(hipDeviceSynchronize());
+    uint32_t flag = 0;
+    HIP_TRY(hipMemcpy(&flag, bt->error_flag.p, 4, hipMemcpyDeviceToHost));
+    if (flag) {
+        HIP_TRY(hipMemset(bt->error_flag.p, 0, 4));
+        return set_error(VBM25_ERR_DEVICE, "device-side planner overflow (flag %u)", flag);
+    }
+    if (bt->nq) {
+        HIP_TRY(hipMemcpy(hits, bt->hits.p, sizeof(vbm25_hit) * size_t(bt->nq) * bt->k, hipMemcpyDeviceToHost));
+        HIP_TRY(hipMemcpy(n_hits, bt->n_hits.p, 4ull * bt->nq, hipMemcpyDeviceToHost));
+    }
+    return VBM25_OK;
+}
+
+int vbm25_batch_device_results(vbm25_batch *bt, void **hits, void **n_hits) {
+    if (!bt) return set_error(VBM25_ERR_INVALID, "batch is NULL");
+    if (hits) *hits = bt->hits.p;
+    if (n_hits) *n_hits = bt->n_hits.p;
+    return VBM25_OK;
+}
+
+int vbm25_batch_set_timing(vbm25_batch *bt, int enabled) {
+    if (!bt) return set_error(VBM25_ERR_INVALID, "batch is NULL");
+    bt->timing = enabled != 0;
+    bt->events_used = 0;
+    return VBM25_OK;
+}
+
+int vbm25_batch_kernel_ms(vbm25_batch *bt, double *avg_ms, uint32_t *n_launches) {
+    if (!bt || !avg_ms) return set_error(VBM25_ERR_INVALID, "NULL argument");
+    if (int rc = use_device(bt->index->device)) return rc;
+    double sum = 0;
+    for (size_t i = 0; i < bt->events_used; ++i) {
+        HIP_TRY(hipEventSynchronize(bt->events[i].second));
+        float ms = 0;
+        HIP_TRY(hipEventElapsedTime(&ms, bt->events[i].first, bt->events[i].second));
+        sum += ms;
+    }
+    *avg_ms = bt->events_used ? sum / double(bt->events_used) : 0.0;
+    if (n_launches) *n_launches = uint32_t(bt->events_used);
+    bt->events_used = 0;
+    return VBM25_OK;
+}
+
+int vbm25_search_batch(vbm25_index *ix, const uint32_t *term_ids, const uint32_t *q_off, uint32_t nq,
+                       uint32_t k, vbm25_hit *hits, uint32_t *n_hits) {
+    if (!ix || !q_off) return set_error(VBM25_ERR_INVALID, "NULL argument");
+    if (nq == 0) return k ? VBM25_OK : set_error(VBM25_ERR_INVALID, "number of needed rows is set to 0");
+    vbm25_batch *bt = nullptr;
+    if (int rc = vbm25_batch_create(ix, nq, q_off[nq] ? q_off[nq] : 1, k, &bt)) return rc;
+    int rc = vbm25_batch_set_queries(bt, term_ids, q_off, nq);
+    if (!rc) rc = vbm25_batch_run(bt, nullptr);
+    if (!rc) rc = vbm25_batch_fetch(bt, hits, n_hits);
+    vbm25_batch_destroy(bt);
+    return rc;
+}
+
+}  // extern "C"
