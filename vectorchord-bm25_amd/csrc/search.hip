@@ -560,15 +560,13 @@ __global__ void __launch_bounds__(64) merge_kernel(DevIndex ix, DevBatch bt) {
     __builtin_amdgcn_wave_barrier();
     const uint32_t n = s_top.count;
     for (uint32_t i = lane; i < n; i += 64) {
-        vbm25_hit h;
-        h.score = s_top.score[i];
-        h.doc_id = s_top.doc[i];
-        const uint16_t *pl = ix.doc_payload + 3ull * h.doc_id;
-        h.payload[0] = pl[0];
-        h.payload[1] = pl[1];
-        h.payload[2] = pl[2];
-        h._pad = 0;
-        bt.hits[(size_t)q * k + i] = h;
+        // 24-byte record written as three 64-bit words so that padding bytes are zero
+        const uint32_t d = s_top.doc[i];
+        const uint16_t *pl = ix.doc_payload + 3ull * d;
+        unsigned long long *out = reinterpret_cast<unsigned long long *>(bt.hits + (size_t)q * k + i);
+        out[0] = (unsigned long long)__double_as_longlong(s_top.score[i]);
+        out[1] = (unsigned long long)d | (unsigned long long)pl[0] << 32 | (unsigned long long)pl[1] << 48;
+        out[2] = (unsigned long long)pl[2];
     }
     if (lane == 0) bt.n_hits[q] = n;
 }
