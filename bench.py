@@ -39,6 +39,21 @@ class _DevArray:
                                          "version": 2}
 
 
+def usable_cpus():
+    """CPUs this process may really use: affinity mask capped by the cgroup CPU quota."""
+    try:
+        n = len(os.sched_getaffinity(0))
+    except Exception:
+        n = os.cpu_count() or 1
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if quota != "max":
+            n = min(n, max(1, int(int(quota) / int(period))))
+    except Exception:
+        pass
+    return n
+
+
 def make_queries(seg, vocab, nq, nterms, seed, zipf_s):
     rng = np.random.default_rng(seed)
     if zipf_s > 0:
@@ -64,11 +79,7 @@ def cpu_baseline(seg, terms, off, k, budget_s=20.0):
     import orc
 
     oix = orc.OracleIndex.from_arrays(seg.meta(), seg.arrays())
-    cores = os.cpu_count() or 1
-    try:
-        cores = len(os.sched_getaffinity(0))
-    except Exception:
-        pass
+    cores = usable_cpus()
     nq = len(off) - 1
     probe = min(nq, 8)
     _, _, t_probe = oix.search_batch(terms[:off[probe]], off[:probe + 1], k, mode="wand", threads=1)
@@ -95,6 +106,7 @@ def main():
     ap.add_argument("--queries", type=int, default=0, help="override queries per GPU")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--build-threads", type=int, default=0)
+    ap.add_argument("--cache", default="", help="segment file: load if present, else build and save")
     args = ap.parse_args()
 
     import torch
@@ -118,10 +130,15 @@ def main():
     n_docs, vocab, mean_len, len_mode, zipf_s, nq, nterms, k = WORKLOADS[args.workload]
     if args.queries:
         nq = args.queries
-    threads = args.build_threads or max(1, (os.cpu_count() or 8) // world)
+    threads = args.build_threads or max(1, usable_cpus() // world)
     t0 = time.perf_counter()
-    seg = vb.Segment.synth(n_docs, vocab, mean_len=mean_len, len_mode=len_mode, zipf_s=zipf_s,
-                           seed=20260925, threads=threads)
+    if args.cache and os.path.exists(args.cache):
+        seg = vb.Segment.load(args.cache)
+    else:
+        seg = vb.Segment.synth(n_docs, vocab, mean_len=mean_len, len_mode=len_mode, zipf_s=zipf_s,
+                               seed=20260925, threads=threads)
+        if args.cache and rank == 0:
+            seg.save(args.cache)
     t_build = time.perf_counter() - t0
     t0 = time.perf_counter()
     gix = vb.GpuIndex(seg, device=local_rank)

@@ -68,7 +68,7 @@ struct DevIndex {
 };
 
 struct Item {
-    uint32_t q, doc_lo, doc_hi, _pad;
+    uint32_t q, doc_lo, doc_hi, m;  // m = number of indexed terms of query q
 };
 
 struct DevBatch {
@@ -97,6 +97,16 @@ constexpr uint32_t EMPTY = 0xffffffffu;
 constexpr uint32_t TARGET_ITEMS = 2048;
 constexpr uint32_t MIN_CHUNK_POSTINGS = 8192;
 constexpr int PLAN_WG = 1024;
+// chain kernel (scan_kernel) geometry
+constexpr int CWG = 512;                 // threads per workgroup
+constexpr int CNW = CWG / 64;
+constexpr int C_BLOCKS = 16;             // block slots of staging per workgroup
+constexpr int C_POSTINGS = C_BLOCKS * 128;
+constexpr int C_SLOTS_LOG2 = 12;
+constexpr int C_SLOTS = 1 << C_SLOTS_LOG2;
+constexpr int CHAIN_MAX_TERMS = C_BLOCKS;  // queries with more indexed terms use scan_many_kernel
+constexpr uint32_t NONE32 = 0xffffffffu;
+constexpr uint16_t NONE16 = 0xffffu;
 
 // ---------------------------------------------------------------------------
 // Block decode: one wave, two postings per lane (value indices 2*lane, 2*lane+1)
@@ -264,13 +274,15 @@ __global__ void __launch_bounds__(PLAN_WG) plan_kernel(DevIndex ix, DevBatch bt,
     uint32_t base = (uint32_t)s_part[tid];
     for (uint32_t q = q0; q < q1; ++q) {
         const uint32_t c = chunks_of(q);
+        uint32_t nterms = 0;
+        for (uint32_t p = bt.q_off[q]; p < bt.q_off[q + 1]; ++p) nterms += bt.term_ids[p] < ix.n_terms;
         bt.q_item_base[q] = min(base, max_items);
         for (uint32_t i = 0; i < c && base + i < max_items; ++i) {
             Item it;
             it.q = q;
             it.doc_lo = (uint32_t)((unsigned long long)ix.n_docs * i / c);
             it.doc_hi = (uint32_t)((unsigned long long)ix.n_docs * (i + 1) / c);
-            it._pad = 0;
+            it.m = nterms;
             bt.items[base + i] = it;
         }
         base += c;
@@ -351,7 +363,7 @@ __device__ __forceinline__ void topk_offer(TopK<KMAX> &L, uint32_t k, bool has, 
 // Posting scan
 // ---------------------------------------------------------------------------
 template <int KMAX>
-__global__ void __launch_bounds__(WG) scan_kernel(DevIndex ix, DevBatch bt) {
+__global__ void __launch_bounds__(WG) scan_many_kernel(DevIndex ix, DevBatch bt) {
     __shared__ uint32_t s_key[SLOTS];
     __shared__ double s_val[SLOTS];
     __shared__ uint16_t s_cand[SLOTS];
@@ -369,6 +381,7 @@ __global__ void __launch_bounds__(WG) scan_kernel(DevIndex ix, DevBatch bt) {
     const uint32_t n_items = *bt.n_items;
     for (uint32_t item = blockIdx.x; item < n_items; item += gridDim.x) {
         const Item it = bt.items[item];
+        if (it.m <= (uint32_t)CHAIN_MAX_TERMS) continue;  // handled by scan_kernel
         const uint32_t q = it.q, clo = it.doc_lo, chi = it.doc_hi;
         __syncthreads();  // previous item fully done with LDS
         if (tid == 0) {
@@ -535,6 +548,424 @@ __global__ void __launch_bounds__(WG) scan_kernel(DevIndex ix, DevBatch bt) {
 }
 
 // ---------------------------------------------------------------------------
+// Posting scan, chain formulation: queries with at most CHAIN_MAX_TERMS indexed terms.
+//
+// Per workgroup: C_BLOCKS block slots of staging in LDS (doc id, partial score, chain link
+// per posting), split into per-term regions in key order, so that a posting's staging index
+// orders postings by term.  Per doc-range tile [lo, hi):
+//   plan    hi = smallest min_doc of the first block that does not fit a term's region;
+//           entries = blocks still resident from the previous tile ("carried", not decoded
+//           again) + newly admitted blocks; block metadata comes from an LDS ring that is
+//           refilled one tile ahead
+//   pass A  one wave per entry: decode (unless carried), Cache::evaluate, then link every
+//           posting with lo <= doc < hi into the chain of its document (open-addressed LDS
+//           table of chain heads, lock-free CAS) -- no ordering between terms is needed here
+//   pass B  the head posting of each document walks its chain and adds the partial scores in
+//           ascending staging index = ascending key order (two addends commute; three or
+//           more are selected in order), resets the table slot, and offers the document to
+//           the top-k list if it can still make it
+// ---------------------------------------------------------------------------
+__device__ __forceinline__ uint32_t wave_incl_scan_u32(uint32_t x) {
+    // DPP row shifts inside 16-lane rows, then row broadcasts across rows (gfx9 wave64)
+    x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x111, 0xf, 0xf, false);  // row_shr:1
+    x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x112, 0xf, 0xf, false);  // row_shr:2
+    x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x114, 0xf, 0xf, false);  // row_shr:4
+    x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x118, 0xf, 0xf, false);  // row_shr:8
+    x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x142, 0xa, 0xf, false);  // row_bcast:15
+    x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x143, 0xc, 0xf, false);  // row_bcast:31
+    return x;
+}
+
+__device__ __forceinline__ void decode_doc_ids_dpp(const uint8_t *__restrict__ p, uint32_t meta,
+                                                   uint32_t n, uint32_t min_doc, uint32_t lane,
+                                                   uint32_t &d0, uint32_t &d1) {
+    uint32_t v0, v1;
+    decode_fields(p, meta, n, lane, v0, v1);
+    const uint32_t width = meta & 127u;
+    const bool raw = (meta >> 7) ? (width == 4) : (width == 32);
+    if (raw) {
+        d0 = v0;
+        d1 = v1;
+        return;
+    }
+    const uint32_t own = v0 + v1;
+    const uint32_t incl = wave_incl_scan_u32(own);
+    d0 = min_doc + (incl - own) + v0;
+    d1 = d0 + v1;
+}
+
+template <int KMAX>
+__global__ void __launch_bounds__(CWG, 6) scan_kernel(DevIndex ix, DevBatch bt) {
+    constexpr int T = CHAIN_MAX_TERMS;
+    constexpr int RING = 128;            // metadata ring entries (power-of-two ring per term)
+    constexpr int FAST_CAND = 64;        // candidates merged without stopping the workers
+    __shared__ uint32_t st_doc[C_POSTINGS];
+    __shared__ double st_p[C_POSTINGS];
+    __shared__ uint16_t st_next[C_POSTINGS];
+    __shared__ uint32_t s_slot[C_SLOTS];
+    __shared__ uint16_t s_cand[C_POSTINGS];
+    __shared__ double c_score[2][FAST_CAND];
+    __shared__ uint32_t c_doc[2][FAST_CAND];
+    __shared__ double s_s1[256];
+    __shared__ TopK<KMAX> s_top;
+    __shared__ uint4 s_ring[RING];
+    __shared__ uint4 e_meta[2][C_BLOCKS];
+    __shared__ uint32_t e_j[2][C_BLOCKS];
+    __shared__ uint16_t e_base[2][C_BLOCKS];  // staging base | 0x8000 if carried
+    __shared__ uint8_t e_t[2][C_BLOCKS];
+    __shared__ double t_s0[T];
+    __shared__ uint32_t i_rb[T], i_end[T], i_q[T], i_roff[T], i_rmask[T];  // chunk setup only
+    __shared__ uint32_t s_lo[2], s_hi[2], s_nent[2], s_cand_cnt[2], s_done[2];
+    __shared__ unsigned long long s_theta[2];
+
+    const uint32_t tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const uint32_t k = bt.k;
+    for (int i = tid; i < 256; i += CWG) s_s1[i] = ix.s1[i];
+    for (int i = tid; i < C_SLOTS; i += CWG) s_slot[i] = NONE32;
+
+    const uint32_t n_items = *bt.n_items;
+    for (uint32_t item = blockIdx.x; item < n_items; item += gridDim.x) {
+        const Item it = bt.items[item];
+        if (it.m > (uint32_t)T) continue;  // scan_many_kernel's
+        const uint32_t q = it.q, clo = it.doc_lo, chi = it.doc_hi;
+        __syncthreads();
+
+        // ---- planner state: lane t of wave 0 owns term t (registers, never spilled to LDS)
+        uint32_t p_rb = 0, p_re = 0, p_end = 0, p_q = 1, p_rmask = 0, p_roff = 0, p_base = 0,
+                 p_slot = 0;  // p_slot = region slot of block p_rb (p_rb mod p_q, kept incrementally)
+        uint32_t m = 0;
+        if (wave == 0) {
+            // indexed terms of the query in ascending key order (search.rs:53-79)
+            const uint32_t qb = bt.q_off[q], qe = bt.q_off[q + 1];
+            uint32_t term = NONE32;
+            unsigned long long df = 0;
+            {
+                // lane l looks at query position l, l+64, ...: positions are few (<= MAX_TERMS)
+                uint32_t rank = 0;
+                for (uint32_t p = qb; p < qe; ++p) {  // uniform loop, cheap: m <= 16 here
+                    const uint32_t tt = bt.term_ids[p];
+                    if (tt >= ix.n_terms) continue;  // search.rs:59-61
+                    if (rank == lane) term = tt;
+                    ++rank;
+                }
+                m = rank;
+            }
+            const bool act = lane < m;
+            if (act) df = ix.term_df[term];
+            unsigned long long sum = df;
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) sum += __shfl_xor(sum, o);
+            if (act) {
+                const uint32_t b0 = ix.term_first_block[term], b1 = ix.term_first_block[term + 1];
+                uint32_t lo_b = b0, hi_b = b1;  // first block whose max_doc >= clo
+                while (lo_b < hi_b) {
+                    const uint32_t mid = (lo_b + hi_b) >> 1;
+                    if (ix.blk_max_doc[mid] < clo) lo_b = mid + 1; else hi_b = mid;
+                }
+                p_rb = p_re = lo_b;
+                p_end = b1;
+                p_q = (uint32_t)(((unsigned long long)(C_BLOCKS - m) * df) / sum) + 1;
+                uint32_t rs = 2;  // ring holds blocks [rb, rb + 2q]
+                while (rs < 2 * p_q + 1) rs <<= 1;
+                p_rmask = rs - 1;
+                p_slot = 0;
+                t_s0[lane] = ix.term_s0[term];
+            }
+            // exclusive prefix sums over lanes for region bases and ring offsets
+            uint32_t xb = act ? 128 * p_q : 0, xr = act ? p_rmask + 1 : 0;
+            uint32_t ib = xb, ir = xr;
+#pragma unroll
+            for (int o = 1; o < 16; o <<= 1) {
+                const uint32_t yb = __shfl_up(ib, o), yr = __shfl_up(ir, o);
+                if ((int)lane >= o) {
+                    ib += yb;
+                    ir += yr;
+                }
+            }
+            p_base = ib - xb;
+            p_roff = ir - xr;
+            if (act) {
+                i_rb[lane] = p_rb;
+                i_end[lane] = p_end;
+                i_q[lane] = p_q;
+                i_roff[lane] = p_roff;
+                i_rmask[lane] = p_rmask;
+            }
+            if (lane == 0) {
+                s_top.count = 0;
+                s_cand_cnt[0] = 0;
+            }
+        }
+        __syncthreads();
+        // ---- fill the metadata rings: blocks [rb, rb + 2q] of every term (all threads)
+        if (tid < RING) {
+            const uint32_t mm = it.m;
+            uint32_t t = 0;
+            while (t + 1 < mm && i_roff[t + 1] <= tid) ++t;
+            if (t < mm) {
+                const uint32_t i = tid - i_roff[t];
+                const uint32_t j = i_rb[t] + i;
+                if (i <= 2 * i_q[t] && j < i_end[t]) s_ring[i_roff[t] + (j & i_rmask[t])] = ix.blk_meta[j];
+            }
+        }
+        __syncthreads();
+
+        // plan the tile that starts at `lo` into buffer nb; wave 0 only, all 64 lanes call
+        uint32_t p_hi = clo;  // end of the tile planned last (uniform in wave 0)
+        auto plan = [&](uint32_t nb) {
+            const bool act = lane < m;
+            const uint32_t hi_prev = p_hi;
+            // 1. drop blocks that end before the previous tile's end
+            uint32_t nrb = p_rb;
+            if (act) {
+                while (nrb < p_re && s_ring[p_roff + (nrb & p_rmask)].y < hi_prev) ++nrb;
+                uint32_t adv = nrb - p_rb;
+                p_slot += adv;
+                while (p_slot >= p_q) p_slot -= p_q;
+            }
+            // 2. start refilling the ring so that it covers [nrb, nrb + 2q] (needed next time)
+            uint4 pf0 = make_uint4(0, 0, 0, 0), pf1 = pf0;
+            uint32_t at0 = NONE32, at1 = NONE32;
+            if (act) {
+                uint32_t j2 = p_rb + 2 * p_q + 1;
+                const uint32_t last = min(nrb + 2 * p_q, p_end - 1);
+                if (j2 <= last) {
+                    pf0 = ix.blk_meta[j2];
+                    at0 = p_roff + (j2 & p_rmask);
+                    ++j2;
+                }
+                if (j2 <= last) {
+                    pf1 = ix.blk_meta[j2];
+                    at1 = p_roff + (j2 & p_rmask);
+                    ++j2;
+                }
+                for (; j2 <= last; ++j2) s_ring[p_roff + (j2 & p_rmask)] = ix.blk_meta[j2];
+                p_rb = nrb;
+            }
+            const unsigned long long theta =
+                __hip_atomic_load(&bt.theta[q], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            // 3. tile start: first posting that can still be there
+            uint32_t lo_c = chi, hi_c = chi;
+            if (act && p_rb < p_end) {
+                lo_c = max(hi_prev, s_ring[p_roff + (p_rb & p_rmask)].x);
+                if (p_rb + p_q < p_end) hi_c = s_ring[p_roff + ((p_rb + p_q) & p_rmask)].x;
+            }
+#pragma unroll
+            for (int o = 8; o > 0; o >>= 1) {
+                lo_c = min(lo_c, (uint32_t)__shfl_xor(lo_c, o));
+                hi_c = min(hi_c, (uint32_t)__shfl_xor(hi_c, o));
+            }
+            const uint32_t lo_n = __shfl(lo_c, 0), hi_n = min(chi, (uint32_t)__shfl(hi_c, 0));
+            // 4. entries: resident blocks, then newly admitted ones
+            uint32_t cnt = 0, re_old = p_re;
+            if (act && lo_n < chi) {
+                const uint32_t lim = min(p_rb + p_q, p_end);
+                uint32_t j = max(p_re, p_rb);
+                while (j < lim && s_ring[p_roff + (j & p_rmask)].x < hi_n) ++j;
+                cnt = j - p_rb;
+                re_old = max(p_re, p_rb);
+                p_re = j;
+            }
+            uint32_t incl = cnt;
+#pragma unroll
+            for (int o = 1; o < 16; o <<= 1) {
+                const uint32_t y = __shfl_up(incl, o);
+                if ((int)lane >= o) incl += y;
+            }
+            const uint32_t off = incl - cnt;
+            const uint32_t total = __shfl(incl, 15);
+            if (act) {
+                uint32_t slot = p_slot;
+                for (uint32_t i = 0; i < cnt; ++i) {
+                    const uint32_t j = p_rb + i, e = off + i;
+                    e_meta[nb][e] = s_ring[p_roff + (j & p_rmask)];
+                    e_j[nb][e] = j;
+                    e_base[nb][e] = (uint16_t)((p_base + slot * 128) | (j < re_old ? 0x8000u : 0u));
+                    e_t[nb][e] = (uint8_t)lane;
+                    if (++slot == p_q) slot = 0;
+                }
+            }
+            if (lane == 0) {
+                s_lo[nb] = lo_n;
+                s_hi[nb] = hi_n;
+                s_nent[nb] = total;
+                s_done[nb] = lo_n >= chi ? 1u : 0u;
+                s_cand_cnt[nb] = 0;
+                s_theta[nb] = theta;
+            }
+            if (at0 != NONE32) s_ring[at0] = pf0;
+            if (at1 != NONE32) s_ring[at1] = pf1;
+            p_hi = hi_n;
+        };
+
+        if (wave == 0) plan(0);
+        __syncthreads();
+
+        unsigned long long published = 0;
+        const uint32_t e_first = (wave + CNW - 1) & (CNW - 1);  // wave 0 takes the last entries
+        for (uint32_t par = 0;; par ^= 1) {
+            if (s_done[par]) break;
+            const uint32_t lo = s_lo[par], hi = s_hi[par], nent = s_nent[par];
+
+            // ---- pass A: decode (unless carried) and link postings of [lo, hi) into chains
+            uint32_t my_slot[2][2];
+#pragma unroll
+            for (int r = 0; r < 2; ++r) {
+                my_slot[r][0] = NONE32;
+                my_slot[r][1] = NONE32;
+                const uint32_t e = e_first + r * CNW;
+                if (e >= nent) continue;
+                const uint4 bm = e_meta[par][e];
+                const uint32_t eb = e_base[par][e];
+                const uint32_t i0 = (eb & 0x7fffu) + 2 * lane;
+                uint32_t d0, d1;
+                if (eb & 0x8000u) {
+                    const uint2 dd = *reinterpret_cast<const uint2 *>(&st_doc[i0]);
+                    d0 = dd.x;
+                    d1 = dd.y;
+                } else {
+                    const uint32_t j = e_j[par][e];
+                    const uint32_t n = bm.w & 0xff, md = (bm.w >> 8) & 0xff, mt = (bm.w >> 16) & 0xff;
+                    const uint8_t *body = ix.blob + 8ull * bm.z;
+                    uint32_t f0, f1;
+                    decode_doc_ids_dpp(body, md, n, bm.x, lane, d0, d1);
+                    decode_fields(body + ((payload_bytes(md, n) + 7u) & ~7u), mt, n, lane, f0, f1);
+                    const uchar2 fn = reinterpret_cast<const uchar2 *>(ix.post_fn + 128ull * j)[lane];
+                    const double s0 = t_s0[e_t[par][e]];
+                    const double tf0 = (double)f0, tf1 = (double)f1;
+                    double2 pp;
+                    pp.x = (tf0 * s0) / (tf0 + s_s1[fn.x]);  // bm25.rs:355-358
+                    pp.y = (tf1 * s0) / (tf1 + s_s1[fn.y]);
+                    if (2 * lane >= n) d0 = NONE32;
+                    if (2 * lane + 1 >= n) d1 = NONE32;
+                    *reinterpret_cast<uint2 *>(&st_doc[i0]) = make_uint2(d0, d1);
+                    *reinterpret_cast<double2 *>(&st_p[i0]) = pp;
+                }
+#pragma unroll
+                for (int h = 0; h < 2; ++h) {
+                    const uint32_t d = h ? d1 : d0;
+                    const uint32_t i = i0 + h;
+                    if (d >= lo && d < hi) {
+                        uint32_t slot = (d * 0x9E3779B1u) >> (32 - C_SLOTS_LOG2);
+                        for (;;) {
+                            uint32_t head = __hip_atomic_load(&s_slot[slot], __ATOMIC_RELAXED,
+                                                              __HIP_MEMORY_SCOPE_WORKGROUP);
+                            if (head == NONE32) {
+                                st_next[i] = NONE16;
+                                head = atomicCAS(&s_slot[slot], NONE32, i);
+                                if (head == NONE32) break;
+                            }
+                            if (__hip_atomic_load(&st_doc[head], __ATOMIC_RELAXED,
+                                                  __HIP_MEMORY_SCOPE_WORKGROUP) == d) {
+                                st_next[i] = (uint16_t)head;
+                                if (atomicCAS(&s_slot[slot], head, i) == head) break;
+                                continue;  // head moved: retry this slot
+                            }
+                            slot = (slot + 1) & (C_SLOTS - 1);
+                        }
+                        my_slot[r][h] = slot;
+                    }
+                }
+            }
+            if (wave == 0) plan(par ^ 1);  // runs ahead: depends on block metadata only
+            __syncthreads();
+
+            // ---- pass B: chain heads add up their document and offer it
+            {
+                const unsigned long long theta = s_theta[par];
+                const uint32_t ntop = s_top.count;
+                const double ws = ntop >= k ? s_top.score[k - 1] : 0.0;
+                const uint32_t wd = ntop >= k ? s_top.doc[k - 1] : 0u;
+#pragma unroll
+                for (int r = 0; r < 2; ++r) {
+                    const uint32_t e = e_first + r * CNW;
+                    if (e >= nent) continue;
+                    const uint32_t i0 = (e_base[par][e] & 0x7fffu) + 2 * lane;
+#pragma unroll
+                    for (int h = 0; h < 2; ++h) {
+                        const uint32_t slot = my_slot[r][h];
+                        const uint32_t i = i0 + h;
+                        if (slot == NONE32 || s_slot[slot] != i) continue;
+                        double score = st_p[i];
+                        const uint32_t j1 = st_next[i];
+                        if (j1 != NONE16) {
+                            const uint32_t j2 = st_next[j1];
+                            if (j2 == NONE16) {
+                                score = score + st_p[j1];  // two addends commute
+                            } else {  // three or more: ascending staging index = key order
+                                score = 0.0;
+                                int last = -1;
+                                for (;;) {
+                                    uint32_t best = NONE32;
+                                    for (uint32_t c = i; c != NONE16; c = st_next[c])
+                                        if ((int)c > last && c < best) best = c;
+                                    if (best == NONE32) break;
+                                    score += st_p[best];
+                                    last = (int)best;
+                                }
+                            }
+                        }
+                        s_slot[slot] = NONE32;
+                        if ((unsigned long long)__double_as_longlong(score) < theta) continue;
+                        const uint32_t d = st_doc[i];
+                        if (ntop >= k && !better(score, d, ws, wd)) continue;
+                        const uint32_t at = atomicAdd(&s_cand_cnt[par], 1u);
+                        st_p[i] = score;
+                        s_cand[at] = (uint16_t)i;
+                        if (at < (uint32_t)FAST_CAND) {
+                            c_score[par][at] = score;
+                            c_doc[par][at] = d;
+                        }
+                    }
+                }
+            }
+            __syncthreads();
+
+            // ---- merge the tile's candidates into the running top-k (wave 0).  Few candidates:
+            // merged from the copies while the other waves already run the next pass A.
+            const uint32_t cnt = s_cand_cnt[par];
+            if (wave == 0) {
+                for (uint32_t base = 0; base < cnt; base += 64) {
+                    const bool has = base + lane < cnt;
+                    double sc = 0;
+                    uint32_t d = 0;
+                    if (has) {
+                        if (cnt <= (uint32_t)FAST_CAND) {
+                            sc = c_score[par][base + lane];
+                            d = c_doc[par][base + lane];
+                        } else {
+                            const uint32_t i = s_cand[base + lane];
+                            sc = st_p[i];
+                            d = st_doc[i];
+                        }
+                    }
+                    topk_offer<KMAX>(s_top, k, has, sc, d, lane);
+                }
+                if (s_top.count >= k && lane == 0) {
+                    const unsigned long long bits =
+                        (unsigned long long)__double_as_longlong(s_top.score[k - 1]);
+                    if (bits > published) {
+                        atomicMax(&bt.theta[q], bits);
+                        published = bits;
+                    }
+                }
+            }
+            if (cnt > (uint32_t)FAST_CAND) __syncthreads();  // staging must survive the merge
+        }
+
+        __syncthreads();
+        {
+            const uint32_t n = s_top.count;
+            for (uint32_t i = tid; i < n; i += CWG) {
+                bt.res_score[(size_t)item * k + i] = s_top.score[i];
+                bt.res_doc[(size_t)item * k + i] = s_top.doc[i];
+            }
+            if (tid == 0) bt.res_cnt[item] = n;
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------
 // Merge of per-chunk lists -> hits
 // ---------------------------------------------------------------------------
 template <int KMAX>
@@ -616,6 +1047,7 @@ struct vbm25_batch {
     DeviceBuffer term_ids, q_off, items, n_items, q_item_base, theta, res_score, res_doc, res_cnt,
         hits, n_hits, error_flag;
     bool timing = false;
+    bool has_many_terms = false;  // some query has more than CHAIN_MAX_TERMS indexed terms
     std::vector<std::pair<hipEvent_t, hipEvent_t>> events;
     size_t events_used = 0;
     ~vbm25_batch() {
@@ -858,6 +1290,7 @@ int vbm25_batch_set_queries(vbm25_batch *bt, const uint32_t *term_ids, const uin
     if (!bt || !q_off) return set_error(VBM25_ERR_INVALID, "NULL argument");
     if (nq > bt->max_queries) return set_error(VBM25_ERR_INVALID, "%u queries exceed the batch capacity %u", nq, bt->max_queries);
     if (q_off[0] != 0) return set_error(VBM25_ERR_INVALID, "q_off[0] must be 0");
+    bool many = false;
     for (uint32_t q = 0; q < nq; ++q) {
         if (q_off[q + 1] < q_off[q]) return set_error(VBM25_ERR_INVALID, "q_off not monotone at query %u", q);
         uint32_t valid = 0;
@@ -866,6 +1299,7 @@ int vbm25_batch_set_queries(vbm25_batch *bt, const uint32_t *term_ids, const uin
                 return set_error(VBM25_ERR_INVALID, "query %u: term ids must be strictly ascending", q);
             valid += term_ids[p] < bt->index->n_terms;
         }
+        many |= valid > (uint32_t)CHAIN_MAX_TERMS;
         if (valid > MAX_TERMS)
             return set_error(VBM25_ERR_UNSUPPORTED, "query %u has %u indexed terms; the GPU path handles up to %d", q, valid, MAX_TERMS);
     }
@@ -874,6 +1308,7 @@ int vbm25_batch_set_queries(vbm25_batch *bt, const uint32_t *term_ids, const uin
     if (q_off[nq]) HIP_TRY(hipMemcpy(bt->term_ids.p, term_ids, 4ull * q_off[nq], hipMemcpyHostToDevice));
     HIP_TRY(hipMemcpy(bt->q_off.p, q_off, 4ull * (nq + 1), hipMemcpyHostToDevice));
     bt->nq = nq;
+    bt->has_many_terms = many;
     return VBM25_OK;
 }
 
@@ -914,8 +1349,9 @@ int vbm25_batch_run(vbm25_batch *bt, void *hip_stream) {
     }
     const uint32_t grid = std::min<uint32_t>(bt->max_items, TARGET_ITEMS);
     const int rc = dispatch_k(bt->k, [&](auto kmax) {
-        scan_kernel<decltype(kmax)::value><<<grid, WG, 0, st>>>(ix, db);
+        scan_kernel<decltype(kmax)::value><<<grid, CWG, 0, st>>>(ix, db);
         if (bt->timing) HIP_TRY(hipEventRecord(e1, st));
+        if (bt->has_many_terms) scan_many_kernel<decltype(kmax)::value><<<grid, WG, 0, st>>>(ix, db);
         merge_kernel<decltype(kmax)::value><<<bt->nq, 64, 0, st>>>(ix, db);
         return int(VBM25_OK);
     });
