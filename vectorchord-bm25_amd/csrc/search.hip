@@ -85,6 +85,7 @@ struct DevBatch {
     vbm25_hit *hits;
     uint32_t *n_hits;
     uint32_t *error_flag;
+    unsigned long long *prof;  // VBM25_PROFILE builds: 17 counters per workgroup
 };
 
 constexpr int WG = 256;
@@ -98,8 +99,8 @@ constexpr uint32_t TARGET_ITEMS = 2048;
 constexpr uint32_t MIN_CHUNK_POSTINGS = 8192;
 constexpr int PLAN_WG = 1024;
 // chain kernel (scan_kernel) geometry
-constexpr int CWG = 512;                 // threads per workgroup
-constexpr int CNW = CWG / 64;
+constexpr int CNW = 8;                   // worker waves per workgroup
+constexpr int CWG = (CNW + 1) * 64;      // + one planner / merger wave
 constexpr int C_BLOCKS = 16;             // block slots of staging per workgroup
 constexpr int C_POSTINGS = C_BLOCKS * 128;
 constexpr int C_SLOTS_LOG2 = 12;
@@ -547,6 +548,21 @@ __global__ void __launch_bounds__(WG) scan_many_kernel(DevIndex ix, DevBatch bt)
     }
 }
 
+// Workgroup barrier that orders LDS traffic only.  __syncthreads() also drains vmcnt, i.e. it
+// would wait for every global load in flight (the planner's metadata refills, the threshold
+// poll); all hand-offs inside the tile loop go through LDS.
+__device__ __forceinline__ void lds_barrier() {
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+}
+
+#ifdef VBM25_PROFILE
+#define PROF_T(var) const unsigned long long var = __builtin_readcyclecounter()
+#define PROF_ADD(slot, a, b) prof[slot] += (b) - (a)
+#else
+#define PROF_T(var)
+#define PROF_ADD(slot, a, b)
+#endif
+
 // ---------------------------------------------------------------------------
 // Posting scan, chain formulation: queries with at most CHAIN_MAX_TERMS indexed terms.
 //
@@ -595,10 +611,11 @@ __device__ __forceinline__ void decode_doc_ids_dpp(const uint8_t *__restrict__ p
 }
 
 template <int KMAX>
-__global__ void __launch_bounds__(CWG, 6) scan_kernel(DevIndex ix, DevBatch bt) {
+__global__ void __launch_bounds__(CWG) scan_kernel(DevIndex ix, DevBatch bt) {
     constexpr int T = CHAIN_MAX_TERMS;
     constexpr int RING = 128;            // metadata ring entries (power-of-two ring per term)
     constexpr int FAST_CAND = 64;        // candidates merged without stopping the workers
+    constexpr uint32_t PLANNER = CNW;    // the last wave plans and merges, waves 0..CNW-1 work
     __shared__ uint32_t st_doc[C_POSTINGS];
     __shared__ double st_p[C_POSTINGS];
     __shared__ uint16_t st_next[C_POSTINGS];
@@ -614,7 +631,6 @@ __global__ void __launch_bounds__(CWG, 6) scan_kernel(DevIndex ix, DevBatch bt) 
     __shared__ uint16_t e_base[2][C_BLOCKS];  // staging base | 0x8000 if carried
     __shared__ uint8_t e_t[2][C_BLOCKS];
     __shared__ double t_s0[T];
-    __shared__ uint32_t i_rb[T], i_end[T], i_q[T], i_roff[T], i_rmask[T];  // chunk setup only
     __shared__ uint32_t s_lo[2], s_hi[2], s_nent[2], s_cand_cnt[2], s_done[2];
     __shared__ unsigned long long s_theta[2];
 
@@ -623,6 +639,10 @@ __global__ void __launch_bounds__(CWG, 6) scan_kernel(DevIndex ix, DevBatch bt) 
     for (int i = tid; i < 256; i += CWG) s_s1[i] = ix.s1[i];
     for (int i = tid; i < C_SLOTS; i += CWG) s_slot[i] = NONE32;
 
+#ifdef VBM25_PROFILE
+    unsigned long long prof[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    const unsigned long long prof_t0 = __builtin_readcyclecounter();
+#endif
     const uint32_t n_items = *bt.n_items;
     for (uint32_t item = blockIdx.x; item < n_items; item += gridDim.x) {
         const Item it = bt.items[item];
@@ -630,301 +650,182 @@ __global__ void __launch_bounds__(CWG, 6) scan_kernel(DevIndex ix, DevBatch bt) 
         const uint32_t q = it.q, clo = it.doc_lo, chi = it.doc_hi;
         __syncthreads();
 
-        // ---- planner state: lane t of wave 0 owns term t (registers, never spilled to LDS)
-        uint32_t p_rb = 0, p_re = 0, p_end = 0, p_q = 1, p_rmask = 0, p_roff = 0, p_base = 0,
-                 p_slot = 0;  // p_slot = region slot of block p_rb (p_rb mod p_q, kept incrementally)
-        uint32_t m = 0;
-        if (wave == 0) {
-            // indexed terms of the query in ascending key order (search.rs:53-79)
-            const uint32_t qb = bt.q_off[q], qe = bt.q_off[q + 1];
-            uint32_t term = NONE32;
-            unsigned long long df = 0;
+        if (wave == PLANNER) {
+            // =====================================================================
+            // Planner wave: lane t owns term t.  Runs one tile ahead of the workers;
+            // everything it decides depends on block metadata only.
+            // =====================================================================
+            uint32_t p_rb = 0, p_re = 0, p_end = 0, p_q = 1, p_rmask = 0, p_roff = 0, p_base = 0,
+                     p_slot = 0;  // p_slot = region slot of block p_rb (p_rb mod p_q, incremental)
+            uint32_t m = 0;
             {
-                // lane l looks at query position l, l+64, ...: positions are few (<= MAX_TERMS)
-                uint32_t rank = 0;
-                for (uint32_t p = qb; p < qe; ++p) {  // uniform loop, cheap: m <= 16 here
+                const uint32_t qb = bt.q_off[q], qe = bt.q_off[q + 1];
+                uint32_t term = NONE32;
+                for (uint32_t p = qb; p < qe; ++p) {  // indexed terms in ascending key order
                     const uint32_t tt = bt.term_ids[p];
                     if (tt >= ix.n_terms) continue;  // search.rs:59-61
-                    if (rank == lane) term = tt;
-                    ++rank;
+                    if (m == lane) term = tt;
+                    ++m;
                 }
-                m = rank;
+                const bool act = lane < m;
+                unsigned long long df = act ? ix.term_df[term] : 0ull;
+                unsigned long long sum = df;
+#pragma unroll
+                for (int o = 32; o > 0; o >>= 1) sum += __shfl_xor(sum, o);
+                if (act) {
+                    const uint32_t b0 = ix.term_first_block[term], b1 = ix.term_first_block[term + 1];
+                    uint32_t lo_b = b0, hi_b = b1;  // first block whose max_doc >= clo
+                    while (lo_b < hi_b) {
+                        const uint32_t mid = (lo_b + hi_b) >> 1;
+                        if (ix.blk_max_doc[mid] < clo) lo_b = mid + 1; else hi_b = mid;
+                    }
+                    p_rb = p_re = lo_b;
+                    p_end = b1;
+                    p_q = (uint32_t)(((unsigned long long)(C_BLOCKS - m) * df) / sum) + 1;
+                    uint32_t rs = 2;  // ring holds blocks [rb, rb + 2q]
+                    while (rs < 2 * p_q + 1) rs <<= 1;
+                    p_rmask = rs - 1;
+                    t_s0[lane] = ix.term_s0[term];
+                }
+                const uint32_t xb = act ? 128 * p_q : 0, xr = act ? p_rmask + 1 : 0;
+                uint32_t ib = xb, ir = xr;
+#pragma unroll
+                for (int o = 1; o < 16; o <<= 1) {
+                    const uint32_t yb = __shfl_up(ib, o), yr = __shfl_up(ir, o);
+                    if ((int)lane >= o) {
+                        ib += yb;
+                        ir += yr;
+                    }
+                }
+                p_base = ib - xb;
+                p_roff = ir - xr;
+                if (act) {  // initial fill of the metadata ring: blocks [rb, rb + 2q]
+                    for (uint32_t i = 0; i <= 2 * p_q; ++i) {
+                        const uint32_t j = p_rb + i;
+                        if (j < p_end) s_ring[p_roff + (j & p_rmask)] = ix.blk_meta[j];
+                    }
+                }
+                if (lane == 0) {
+                    s_top.count = 0;
+                    s_cand_cnt[0] = 0;
+                }
             }
             const bool act = lane < m;
-            if (act) df = ix.term_df[term];
-            unsigned long long sum = df;
-#pragma unroll
-            for (int o = 32; o > 0; o >>= 1) sum += __shfl_xor(sum, o);
-            if (act) {
-                const uint32_t b0 = ix.term_first_block[term], b1 = ix.term_first_block[term + 1];
-                uint32_t lo_b = b0, hi_b = b1;  // first block whose max_doc >= clo
-                while (lo_b < hi_b) {
-                    const uint32_t mid = (lo_b + hi_b) >> 1;
-                    if (ix.blk_max_doc[mid] < clo) lo_b = mid + 1; else hi_b = mid;
-                }
-                p_rb = p_re = lo_b;
-                p_end = b1;
-                p_q = (uint32_t)(((unsigned long long)(C_BLOCKS - m) * df) / sum) + 1;
-                uint32_t rs = 2;  // ring holds blocks [rb, rb + 2q]
-                while (rs < 2 * p_q + 1) rs <<= 1;
-                p_rmask = rs - 1;
-                p_slot = 0;
-                t_s0[lane] = ix.term_s0[term];
-            }
-            // exclusive prefix sums over lanes for region bases and ring offsets
-            uint32_t xb = act ? 128 * p_q : 0, xr = act ? p_rmask + 1 : 0;
-            uint32_t ib = xb, ir = xr;
-#pragma unroll
-            for (int o = 1; o < 16; o <<= 1) {
-                const uint32_t yb = __shfl_up(ib, o), yr = __shfl_up(ir, o);
-                if ((int)lane >= o) {
-                    ib += yb;
-                    ir += yr;
-                }
-            }
-            p_base = ib - xb;
-            p_roff = ir - xr;
-            if (act) {
-                i_rb[lane] = p_rb;
-                i_end[lane] = p_end;
-                i_q[lane] = p_q;
-                i_roff[lane] = p_roff;
-                i_rmask[lane] = p_rmask;
-            }
-            if (lane == 0) {
-                s_top.count = 0;
-                s_cand_cnt[0] = 0;
-            }
-        }
-        __syncthreads();
-        // ---- fill the metadata rings: blocks [rb, rb + 2q] of every term (all threads)
-        if (tid < RING) {
-            const uint32_t mm = it.m;
-            uint32_t t = 0;
-            while (t + 1 < mm && i_roff[t + 1] <= tid) ++t;
-            if (t < mm) {
-                const uint32_t i = tid - i_roff[t];
-                const uint32_t j = i_rb[t] + i;
-                if (i <= 2 * i_q[t] && j < i_end[t]) s_ring[i_roff[t] + (j & i_rmask[t])] = ix.blk_meta[j];
-            }
-        }
-        __syncthreads();
-
-        // plan the tile that starts at `lo` into buffer nb; wave 0 only, all 64 lanes call
-        uint32_t p_hi = clo;  // end of the tile planned last (uniform in wave 0)
-        auto plan = [&](uint32_t nb) {
-            const bool act = lane < m;
-            const uint32_t hi_prev = p_hi;
-            // 1. drop blocks that end before the previous tile's end
-            uint32_t nrb = p_rb;
-            if (act) {
-                while (nrb < p_re && s_ring[p_roff + (nrb & p_rmask)].y < hi_prev) ++nrb;
-                uint32_t adv = nrb - p_rb;
-                p_slot += adv;
-                while (p_slot >= p_q) p_slot -= p_q;
-            }
-            // 2. start refilling the ring so that it covers [nrb, nrb + 2q] (needed next time)
+            uint32_t p_hi = clo;  // end of the tile planned last
             uint4 pf0 = make_uint4(0, 0, 0, 0), pf1 = pf0;
             uint32_t at0 = NONE32, at1 = NONE32;
-            if (act) {
-                uint32_t j2 = p_rb + 2 * p_q + 1;
-                const uint32_t last = min(nrb + 2 * p_q, p_end - 1);
-                if (j2 <= last) {
-                    pf0 = ix.blk_meta[j2];
-                    at0 = p_roff + (j2 & p_rmask);
-                    ++j2;
-                }
-                if (j2 <= last) {
-                    pf1 = ix.blk_meta[j2];
-                    at1 = p_roff + (j2 & p_rmask);
-                    ++j2;
-                }
-                for (; j2 <= last; ++j2) s_ring[p_roff + (j2 & p_rmask)] = ix.blk_meta[j2];
-                p_rb = nrb;
-            }
-            const unsigned long long theta =
-                __hip_atomic_load(&bt.theta[q], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            // 3. tile start: first posting that can still be there
-            uint32_t lo_c = chi, hi_c = chi;
-            if (act && p_rb < p_end) {
-                lo_c = max(hi_prev, s_ring[p_roff + (p_rb & p_rmask)].x);
-                if (p_rb + p_q < p_end) hi_c = s_ring[p_roff + ((p_rb + p_q) & p_rmask)].x;
-            }
-#pragma unroll
-            for (int o = 8; o > 0; o >>= 1) {
-                lo_c = min(lo_c, (uint32_t)__shfl_xor(lo_c, o));
-                hi_c = min(hi_c, (uint32_t)__shfl_xor(hi_c, o));
-            }
-            const uint32_t lo_n = __shfl(lo_c, 0), hi_n = min(chi, (uint32_t)__shfl(hi_c, 0));
-            // 4. entries: resident blocks, then newly admitted ones
-            uint32_t cnt = 0, re_old = p_re;
-            if (act && lo_n < chi) {
-                const uint32_t lim = min(p_rb + p_q, p_end);
-                uint32_t j = max(p_re, p_rb);
-                while (j < lim && s_ring[p_roff + (j & p_rmask)].x < hi_n) ++j;
-                cnt = j - p_rb;
-                re_old = max(p_re, p_rb);
-                p_re = j;
-            }
-            uint32_t incl = cnt;
-#pragma unroll
-            for (int o = 1; o < 16; o <<= 1) {
-                const uint32_t y = __shfl_up(incl, o);
-                if ((int)lane >= o) incl += y;
-            }
-            const uint32_t off = incl - cnt;
-            const uint32_t total = __shfl(incl, 15);
-            if (act) {
-                uint32_t slot = p_slot;
-                for (uint32_t i = 0; i < cnt; ++i) {
-                    const uint32_t j = p_rb + i, e = off + i;
-                    e_meta[nb][e] = s_ring[p_roff + (j & p_rmask)];
-                    e_j[nb][e] = j;
-                    e_base[nb][e] = (uint16_t)((p_base + slot * 128) | (j < re_old ? 0x8000u : 0u));
-                    e_t[nb][e] = (uint8_t)lane;
-                    if (++slot == p_q) slot = 0;
-                }
-            }
-            if (lane == 0) {
-                s_lo[nb] = lo_n;
-                s_hi[nb] = hi_n;
-                s_nent[nb] = total;
-                s_done[nb] = lo_n >= chi ? 1u : 0u;
-                s_cand_cnt[nb] = 0;
-                s_theta[nb] = theta;
-            }
-            if (at0 != NONE32) s_ring[at0] = pf0;
-            if (at1 != NONE32) s_ring[at1] = pf1;
-            p_hi = hi_n;
-        };
+            unsigned long long theta_next = 0;
 
-        if (wave == 0) plan(0);
-        __syncthreads();
-
-        unsigned long long published = 0;
-        const uint32_t e_first = (wave + CNW - 1) & (CNW - 1);  // wave 0 takes the last entries
-        for (uint32_t par = 0;; par ^= 1) {
-            if (s_done[par]) break;
-            const uint32_t lo = s_lo[par], hi = s_hi[par], nent = s_nent[par];
-
-            // ---- pass A: decode (unless carried) and link postings of [lo, hi) into chains
-            uint32_t my_slot[2][2];
-#pragma unroll
-            for (int r = 0; r < 2; ++r) {
-                my_slot[r][0] = NONE32;
-                my_slot[r][1] = NONE32;
-                const uint32_t e = e_first + r * CNW;
-                if (e >= nent) continue;
-                const uint4 bm = e_meta[par][e];
-                const uint32_t eb = e_base[par][e];
-                const uint32_t i0 = (eb & 0x7fffu) + 2 * lane;
-                uint32_t d0, d1;
-                if (eb & 0x8000u) {
-                    const uint2 dd = *reinterpret_cast<const uint2 *>(&st_doc[i0]);
-                    d0 = dd.x;
-                    d1 = dd.y;
-                } else {
-                    const uint32_t j = e_j[par][e];
-                    const uint32_t n = bm.w & 0xff, md = (bm.w >> 8) & 0xff, mt = (bm.w >> 16) & 0xff;
-                    const uint8_t *body = ix.blob + 8ull * bm.z;
-                    uint32_t f0, f1;
-                    decode_doc_ids_dpp(body, md, n, bm.x, lane, d0, d1);
-                    decode_fields(body + ((payload_bytes(md, n) + 7u) & ~7u), mt, n, lane, f0, f1);
-                    const uchar2 fn = reinterpret_cast<const uchar2 *>(ix.post_fn + 128ull * j)[lane];
-                    const double s0 = t_s0[e_t[par][e]];
-                    const double tf0 = (double)f0, tf1 = (double)f1;
-                    double2 pp;
-                    pp.x = (tf0 * s0) / (tf0 + s_s1[fn.x]);  // bm25.rs:355-358
-                    pp.y = (tf1 * s0) / (tf1 + s_s1[fn.y]);
-                    if (2 * lane >= n) d0 = NONE32;
-                    if (2 * lane + 1 >= n) d1 = NONE32;
-                    *reinterpret_cast<uint2 *>(&st_doc[i0]) = make_uint2(d0, d1);
-                    *reinterpret_cast<double2 *>(&st_p[i0]) = pp;
+            // plan the tile after [.., p_hi) into buffer nb; loads it starts are consumed by
+            // plan_finish(), which the caller runs after the next barrier
+            auto plan_start = [&](uint32_t nb) {
+                const uint32_t hi_prev = p_hi;
+                uint32_t nrb = p_rb;
+                if (act) {  // 1. drop blocks that end before the previous tile's end
+                    while (nrb < p_re && s_ring[p_roff + (nrb & p_rmask)].y < hi_prev) ++nrb;
+                    p_slot += nrb - p_rb;
+                    while (p_slot >= p_q) p_slot -= p_q;
+                }
+                at0 = at1 = NONE32;
+                if (act) {  // 2. refill the ring towards [nrb, nrb + 2q] (used one tile later)
+                    uint32_t j2 = p_rb + 2 * p_q + 1;
+                    const uint32_t last = min(nrb + 2 * p_q, p_end - 1);
+                    if (j2 <= last) {
+                        pf0 = ix.blk_meta[j2];
+                        at0 = p_roff + (j2 & p_rmask);
+                        ++j2;
+                    }
+                    if (j2 <= last) {
+                        pf1 = ix.blk_meta[j2];
+                        at1 = p_roff + (j2 & p_rmask);
+                        ++j2;
+                    }
+                    for (; j2 <= last; ++j2) s_ring[p_roff + (j2 & p_rmask)] = ix.blk_meta[j2];
+                    p_rb = nrb;
+                }
+                theta_next = __hip_atomic_load(&bt.theta[q], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                // 3. tile range
+                uint32_t lo_c = chi, hi_c = chi;
+                if (act && p_rb < p_end) {
+                    lo_c = max(hi_prev, s_ring[p_roff + (p_rb & p_rmask)].x);
+                    if (p_rb + p_q < p_end) hi_c = s_ring[p_roff + ((p_rb + p_q) & p_rmask)].x;
                 }
 #pragma unroll
-                for (int h = 0; h < 2; ++h) {
-                    const uint32_t d = h ? d1 : d0;
-                    const uint32_t i = i0 + h;
-                    if (d >= lo && d < hi) {
-                        uint32_t slot = (d * 0x9E3779B1u) >> (32 - C_SLOTS_LOG2);
-                        for (;;) {
-                            uint32_t head = __hip_atomic_load(&s_slot[slot], __ATOMIC_RELAXED,
-                                                              __HIP_MEMORY_SCOPE_WORKGROUP);
-                            if (head == NONE32) {
-                                st_next[i] = NONE16;
-                                head = atomicCAS(&s_slot[slot], NONE32, i);
-                                if (head == NONE32) break;
-                            }
-                            if (__hip_atomic_load(&st_doc[head], __ATOMIC_RELAXED,
-                                                  __HIP_MEMORY_SCOPE_WORKGROUP) == d) {
-                                st_next[i] = (uint16_t)head;
-                                if (atomicCAS(&s_slot[slot], head, i) == head) break;
-                                continue;  // head moved: retry this slot
-                            }
-                            slot = (slot + 1) & (C_SLOTS - 1);
-                        }
-                        my_slot[r][h] = slot;
+                for (int o = 8; o > 0; o >>= 1) {
+                    lo_c = min(lo_c, (uint32_t)__shfl_xor(lo_c, o));
+                    hi_c = min(hi_c, (uint32_t)__shfl_xor(hi_c, o));
+                }
+                const uint32_t lo_n = __shfl(lo_c, 0), hi_n = min(chi, (uint32_t)__shfl(hi_c, 0));
+                // 4. entries: resident blocks, then newly admitted ones
+                uint32_t cnt = 0, re_old = p_re;
+                if (act && lo_n < chi) {
+                    const uint32_t lim = min(p_rb + p_q, p_end);
+                    re_old = max(p_re, p_rb);
+                    uint32_t j = re_old;
+                    while (j < lim && s_ring[p_roff + (j & p_rmask)].x < hi_n) ++j;
+                    cnt = j - p_rb;
+                    p_re = j;
+                }
+                uint32_t incl = cnt;
+#pragma unroll
+                for (int o = 1; o < 16; o <<= 1) {
+                    const uint32_t y = __shfl_up(incl, o);
+                    if ((int)lane >= o) incl += y;
+                }
+                const uint32_t off = incl - cnt;
+                const uint32_t total = __shfl(incl, 15);
+                if (act) {
+                    uint32_t slot = p_slot;
+                    for (uint32_t i = 0; i < cnt; ++i) {
+                        const uint32_t j = p_rb + i, e = off + i;
+                        e_meta[nb][e] = s_ring[p_roff + (j & p_rmask)];
+                        e_j[nb][e] = j;
+                        e_base[nb][e] = (uint16_t)((p_base + slot * 128) | (j < re_old ? 0x8000u : 0u));
+                        e_t[nb][e] = (uint8_t)lane;
+                        if (++slot == p_q) slot = 0;
                     }
                 }
-            }
-            if (wave == 0) plan(par ^ 1);  // runs ahead: depends on block metadata only
-            __syncthreads();
-
-            // ---- pass B: chain heads add up their document and offer it
-            {
-                const unsigned long long theta = s_theta[par];
-                const uint32_t ntop = s_top.count;
-                const double ws = ntop >= k ? s_top.score[k - 1] : 0.0;
-                const uint32_t wd = ntop >= k ? s_top.doc[k - 1] : 0u;
-#pragma unroll
-                for (int r = 0; r < 2; ++r) {
-                    const uint32_t e = e_first + r * CNW;
-                    if (e >= nent) continue;
-                    const uint32_t i0 = (e_base[par][e] & 0x7fffu) + 2 * lane;
-#pragma unroll
-                    for (int h = 0; h < 2; ++h) {
-                        const uint32_t slot = my_slot[r][h];
-                        const uint32_t i = i0 + h;
-                        if (slot == NONE32 || s_slot[slot] != i) continue;
-                        double score = st_p[i];
-                        const uint32_t j1 = st_next[i];
-                        if (j1 != NONE16) {
-                            const uint32_t j2 = st_next[j1];
-                            if (j2 == NONE16) {
-                                score = score + st_p[j1];  // two addends commute
-                            } else {  // three or more: ascending staging index = key order
-                                score = 0.0;
-                                int last = -1;
-                                for (;;) {
-                                    uint32_t best = NONE32;
-                                    for (uint32_t c = i; c != NONE16; c = st_next[c])
-                                        if ((int)c > last && c < best) best = c;
-                                    if (best == NONE32) break;
-                                    score += st_p[best];
-                                    last = (int)best;
-                                }
-                            }
-                        }
-                        s_slot[slot] = NONE32;
-                        if ((unsigned long long)__double_as_longlong(score) < theta) continue;
-                        const uint32_t d = st_doc[i];
-                        if (ntop >= k && !better(score, d, ws, wd)) continue;
-                        const uint32_t at = atomicAdd(&s_cand_cnt[par], 1u);
-                        st_p[i] = score;
-                        s_cand[at] = (uint16_t)i;
-                        if (at < (uint32_t)FAST_CAND) {
-                            c_score[par][at] = score;
-                            c_doc[par][at] = d;
-                        }
-                    }
+                if (lane == 0) {
+                    s_lo[nb] = lo_n;
+                    s_hi[nb] = hi_n;
+                    s_nent[nb] = total;
+                    s_done[nb] = lo_n >= chi ? 1u : 0u;
+                    s_cand_cnt[nb] = 0;
                 }
-            }
-            __syncthreads();
+                p_hi = hi_n;
+                return lo_n >= chi;
+            };
+            auto plan_finish = [&](uint32_t nb) {
+                if (at0 != NONE32) s_ring[at0] = pf0;
+                if (at1 != NONE32) s_ring[at1] = pf1;
+                if (lane == 0) s_theta[nb] = theta_next;
+            };
 
-            // ---- merge the tile's candidates into the running top-k (wave 0).  Few candidates:
-            // merged from the copies while the other waves already run the next pass A.
-            const uint32_t cnt = s_cand_cnt[par];
-            if (wave == 0) {
+            PROF_T(ps0);
+            bool done = plan_start(0);
+            plan_finish(0);
+            PROF_T(ps1);
+            PROF_ADD(0, ps0, ps1);
+            lds_barrier();  // S
+            unsigned long long published = 0;
+            for (uint32_t par = 0; !done; par ^= 1) {
+                PROF_T(pa);
+                const bool next_done = plan_start(par ^ 1);
+                PROF_T(pb);
+                lds_barrier();  // X: pass A of this tile is finished
+                PROF_T(pc);
+                plan_finish(par ^ 1);
+                PROF_T(pd);
+                lds_barrier();  // Y: pass B of this tile is finished
+                PROF_T(pe);
+                PROF_ADD(1, pa, pb);
+                PROF_ADD(2, pb, pc);
+                PROF_ADD(3, pc, pd);
+                PROF_ADD(4, pd, pe);
+#ifdef VBM25_PROFILE
+                prof[7] += 1;
+#endif
+                const uint32_t cnt = s_cand_cnt[par];
                 for (uint32_t base = 0; base < cnt; base += 64) {
                     const bool has = base + lane < cnt;
                     double sc = 0;
@@ -949,8 +850,154 @@ __global__ void __launch_bounds__(CWG, 6) scan_kernel(DevIndex ix, DevBatch bt) 
                         published = bits;
                     }
                 }
+                if (cnt > (uint32_t)FAST_CAND) lds_barrier();  // Z: staging had to survive
+                PROF_T(pf);
+                PROF_ADD(5, pe, pf);
+                done = next_done;
             }
-            if (cnt > (uint32_t)FAST_CAND) __syncthreads();  // staging must survive the merge
+        } else {
+            // =====================================================================
+            // Worker waves
+            // =====================================================================
+            lds_barrier();  // S
+            for (uint32_t par = 0;; par ^= 1) {
+                if (s_done[par]) break;
+                const uint32_t lo = s_lo[par], hi = s_hi[par], nent = s_nent[par];
+                PROF_T(wa);
+
+                // ---- pass A.1: decode the new blocks of this wave's entries into staging
+                uint32_t dd[2][2];
+#pragma unroll
+                for (int r = 0; r < 2; ++r) {
+                    dd[r][0] = dd[r][1] = NONE32;
+                    const uint32_t e = wave + r * CNW;
+                    if (e >= nent) continue;
+                    const uint4 bm = e_meta[par][e];
+                    const uint32_t eb = e_base[par][e];
+                    const uint32_t i0 = (eb & 0x7fffu) + 2 * lane;
+                    if (eb & 0x8000u) {  // carried over from the previous tile: already staged
+                        const uint2 v = *reinterpret_cast<const uint2 *>(&st_doc[i0]);
+                        dd[r][0] = v.x;
+                        dd[r][1] = v.y;
+                    } else {
+                        const uint32_t j = e_j[par][e];
+                        const uint32_t n = bm.w & 0xff, md = (bm.w >> 8) & 0xff, mt = (bm.w >> 16) & 0xff;
+                        const uint8_t *body = ix.blob + 8ull * bm.z;
+                        uint32_t d0, d1, f0, f1;
+                        decode_doc_ids_dpp(body, md, n, bm.x, lane, d0, d1);
+                        decode_fields(body + ((payload_bytes(md, n) + 7u) & ~7u), mt, n, lane, f0, f1);
+                        const uchar2 fn = reinterpret_cast<const uchar2 *>(ix.post_fn + 128ull * j)[lane];
+                        const double s0 = t_s0[e_t[par][e]];
+                        const double tf0 = (double)f0, tf1 = (double)f1;
+                        double2 pp;
+                        pp.x = (tf0 * s0) / (tf0 + s_s1[fn.x]);  // bm25.rs:355-358
+                        pp.y = (tf1 * s0) / (tf1 + s_s1[fn.y]);
+                        if (2 * lane >= n) d0 = NONE32;
+                        if (2 * lane + 1 >= n) d1 = NONE32;
+                        *reinterpret_cast<uint2 *>(&st_doc[i0]) = make_uint2(d0, d1);
+                        *reinterpret_cast<double2 *>(&st_p[i0]) = pp;
+                        dd[r][0] = d0;
+                        dd[r][1] = d1;
+                    }
+                }
+                PROF_T(wb);
+                // ---- pass A.2: link postings of [lo, hi) into the chain of their document
+                uint32_t my_slot[2][2];
+#pragma unroll
+                for (int r = 0; r < 2; ++r) {
+                    const uint32_t e = wave + r * CNW;
+                    const uint32_t i0 = e < nent ? (e_base[par][e] & 0x7fffu) + 2 * lane : 0u;
+#pragma unroll
+                    for (int h = 0; h < 2; ++h) {
+                        const uint32_t d = dd[r][h];
+                        const uint32_t i = i0 + h;
+                        my_slot[r][h] = NONE32;
+                        if (d >= lo && d < hi) {  // NONE32 never is
+                            uint32_t slot = (d * 0x9E3779B1u) >> (32 - C_SLOTS_LOG2);
+                            st_next[i] = NONE16;
+                            uint32_t head = atomicCAS(&s_slot[slot], NONE32, i);
+                            while (head != NONE32) {
+                                if (__hip_atomic_load(&st_doc[head], __ATOMIC_RELAXED,
+                                                      __HIP_MEMORY_SCOPE_WORKGROUP) == d) {
+                                    st_next[i] = (uint16_t)head;  // same document: push in front
+                                    const uint32_t seen = atomicCAS(&s_slot[slot], head, i);
+                                    if (seen == head) break;
+                                    head = seen;  // head moved meanwhile (never back to empty)
+                                } else {
+                                    slot = (slot + 1) & (C_SLOTS - 1);
+                                    head = atomicCAS(&s_slot[slot], NONE32, i);
+                                }
+                            }
+                            my_slot[r][h] = slot;
+                        }
+                    }
+                }
+                PROF_T(wc);
+                lds_barrier();  // X
+                PROF_T(wd);
+
+                // ---- pass B: chain heads add up their document and offer it
+                {
+                    const unsigned long long theta = s_theta[par];
+                    const uint32_t ntop = s_top.count;
+                    const double ws = ntop >= k ? s_top.score[k - 1] : 0.0;
+                    const uint32_t wd = ntop >= k ? s_top.doc[k - 1] : 0u;
+#pragma unroll
+                    for (int r = 0; r < 2; ++r) {
+                        const uint32_t e = wave + r * CNW;
+                        if (e >= nent) continue;
+                        const uint32_t i0 = (e_base[par][e] & 0x7fffu) + 2 * lane;
+#pragma unroll
+                        for (int h = 0; h < 2; ++h) {
+                            const uint32_t slot = my_slot[r][h];
+                            const uint32_t i = i0 + h;
+                            if (slot == NONE32 || s_slot[slot] != i) continue;
+                            double score = st_p[i];
+                            const uint32_t j1 = st_next[i];
+                            if (j1 != NONE16) {
+                                const uint32_t j2 = st_next[j1];
+                                if (j2 == NONE16) {
+                                    score = score + st_p[j1];  // two addends commute
+                                } else {  // three or more: ascending staging index = key order
+                                    score = 0.0;
+                                    int last = -1;
+                                    for (;;) {
+                                        uint32_t best = NONE32;
+                                        for (uint32_t c = i; c != NONE16; c = st_next[c])
+                                            if ((int)c > last && c < best) best = c;
+                                        if (best == NONE32) break;
+                                        score += st_p[best];
+                                        last = (int)best;
+                                    }
+                                }
+                            }
+                            s_slot[slot] = NONE32;
+                            if ((unsigned long long)__double_as_longlong(score) < theta) continue;
+                            const uint32_t d = st_doc[i];
+                            if (ntop >= k && !better(score, d, ws, wd)) continue;
+                            const uint32_t at = atomicAdd(&s_cand_cnt[par], 1u);
+                            st_p[i] = score;
+                            s_cand[at] = (uint16_t)i;
+                            if (at < (uint32_t)FAST_CAND) {
+                                c_score[par][at] = score;
+                                c_doc[par][at] = d;
+                            }
+                        }
+                    }
+                }
+                PROF_T(we);
+                lds_barrier();  // Y
+                if (s_cand_cnt[par] > (uint32_t)FAST_CAND) lds_barrier();  // Z
+                PROF_T(wf);
+                PROF_ADD(0, wa, wb);
+                PROF_ADD(1, wb, wc);
+                PROF_ADD(2, wc, wd);
+                PROF_ADD(3, wd, we);
+                PROF_ADD(4, we, wf);
+#ifdef VBM25_PROFILE
+                prof[7] += nent;
+#endif
+            }
         }
 
         __syncthreads();
@@ -963,6 +1010,14 @@ __global__ void __launch_bounds__(CWG, 6) scan_kernel(DevIndex ix, DevBatch bt) 
             if (tid == 0) bt.res_cnt[item] = n;
         }
     }
+#ifdef VBM25_PROFILE
+    // per workgroup: 8 counters of worker wave 0, 8 of the planner wave, total cycles
+    if (bt.prof && lane == 0 && (wave == 0 || wave == PLANNER)) {
+        unsigned long long *o = bt.prof + (size_t)blockIdx.x * 17 + (wave == 0 ? 0 : 8);
+        for (int i = 0; i < 8; ++i) o[i] = prof[i];
+        if (wave == 0) bt.prof[(size_t)blockIdx.x * 17 + 16] = __builtin_readcyclecounter() - prof_t0;
+    }
+#endif
 }
 
 // ---------------------------------------------------------------------------
@@ -1045,7 +1100,7 @@ struct vbm25_batch {
     vbm25_index *index = nullptr;
     uint32_t max_queries = 0, max_terms = 0, k = 0, nq = 0, max_items = 0;
     DeviceBuffer term_ids, q_off, items, n_items, q_item_base, theta, res_score, res_doc, res_cnt,
-        hits, n_hits, error_flag;
+        hits, n_hits, error_flag, prof;
     bool timing = false;
     bool has_many_terms = false;  // some query has more than CHAIN_MAX_TERMS indexed terms
     std::vector<std::pair<hipEvent_t, hipEvent_t>> events;
@@ -1275,6 +1330,10 @@ int vbm25_batch_create(vbm25_index *ix, uint32_t max_queries, uint32_t max_total
         (rc = bt->n_hits.alloc(4ull * max_queries)) || (rc = bt->error_flag.alloc(4)))
         return rc;
     HIP_TRY(hipMemset(bt->error_flag.p, 0, 4));
+#ifdef VBM25_PROFILE
+    if (int rc2 = bt->prof.alloc(8ull * 17 * TARGET_ITEMS)) return rc2;
+    HIP_TRY(hipMemset(bt->prof.p, 0, 8ull * 17 * TARGET_ITEMS));
+#endif
     *out = bt.release();
     return VBM25_OK;
 }
@@ -1332,6 +1391,7 @@ int vbm25_batch_run(vbm25_batch *bt, void *hip_stream) {
     db.hits = bt->hits.as<vbm25_hit>();
     db.n_hits = bt->n_hits.as<uint32_t>();
     db.error_flag = bt->error_flag.as<uint32_t>();
+    db.prof = bt->prof.as<unsigned long long>();
     const DevIndex &ix = bt->index->dev;
     HIP_TRY(hipMemsetAsync(bt->theta.p, 0, 8ull * bt->nq, st));
     plan_kernel<<<1, PLAN_WG, 0, st>>>(ix, db, bt->max_items);
@@ -1406,6 +1466,15 @@ int vbm25_batch_kernel_ms(vbm25_batch *bt, double *avg_ms, uint32_t *n_launches)
     bt->events_used = 0;
     return VBM25_OK;
 }
+
+#ifdef VBM25_PROFILE
+// profiling builds only (not declared in include/vbm25.h): copy out the phase counters
+int vbm25_batch_profile(vbm25_batch *bt, unsigned long long *out, uint32_t n_workgroups) {
+    HIP_TRY(hipDeviceSynchronize());
+    HIP_TRY(hipMemcpy(out, bt->prof.p, 8ull * 17 * n_workgroups, hipMemcpyDeviceToHost));
+    return VBM25_OK;
+}
+#endif
 
 int vbm25_search_batch(vbm25_index *ix, const uint32_t *term_ids, const uint32_t *q_off, uint32_t nq,
                        uint32_t k, vbm25_hit *hits, uint32_t *n_hits) {
