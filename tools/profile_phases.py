@@ -33,6 +33,7 @@ b.set_queries(terms, off)
 b.run()
 b.fetch()
 L = vb.lib()
+print("occupancy API: workgroups per CU =", L.vbm25_scan_occupancy())
 NWG = 2048
 out = np.zeros((NWG, 17), dtype=np.uint64)
 L.vbm25_batch_profile.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32]

@@ -99,9 +99,9 @@ constexpr uint32_t TARGET_ITEMS = 2048;
 constexpr uint32_t MIN_CHUNK_POSTINGS = 8192;
 constexpr int PLAN_WG = 1024;
 // chain kernel (scan_kernel) geometry
-constexpr int CNW = 8;                   // worker waves per workgroup
+constexpr int CNW = 7;                   // worker waves per workgroup
 constexpr int CWG = (CNW + 1) * 64;      // + one planner / merger wave
-constexpr int C_BLOCKS = 16;             // block slots of staging per workgroup
+constexpr int C_BLOCKS = 2 * CNW;        // block slots of staging per workgroup (2 per worker)
 constexpr int C_POSTINGS = C_BLOCKS * 128;
 constexpr int C_SLOTS_LOG2 = 12;
 constexpr int C_SLOTS = 1 << C_SLOTS_LOG2;
@@ -548,9 +548,75 @@ __global__ void __launch_bounds__(WG) scan_many_kernel(DevIndex ix, DevBatch bt)
     }
 }
 
+
+// ---------------------------------------------------------------------------
+// Split decode used by scan_kernel: the two dwords that hold a field are fetched early
+// (possibly one tile ahead) and the field is extracted later.  One formula covers every
+// codec of compression.rs:65-136: bit-packed (lane stream words 16 bytes apart), width 32 /
+// bytewidth 4 (raw), byte-packed tails (unaligned little-endian bytes).
+// ---------------------------------------------------------------------------
+struct FieldAddr {
+    uint32_t off0, off1, sh, mask;
+};
+__device__ __forceinline__ FieldAddr field_addr(uint32_t meta, uint32_t n, uint32_t i) {
+    FieldAddr a;
+    const uint32_t width = meta & 127u;
+    if ((meta >> 7) == 0) {
+        if (width == 32) {
+            a.off0 = a.off1 = 4 * i;
+            a.sh = 0;
+            a.mask = 0xffffffffu;
+        } else {
+            const uint32_t l = i & 3, bit = (i >> 2) * width, w = bit >> 5;
+            a.sh = bit & 31;
+            a.off0 = 16 * w + 4 * l;
+            a.off1 = a.off0 + ((a.sh + width > 32) ? 16u : 0u);
+            a.mask = (1u << width) - 1u;  // width 0 -> mask 0 -> field 0
+        }
+    } else {
+        const uint32_t bo = (i < n ? i : 0u) * width;
+        a.off0 = bo & ~3u;
+        a.off1 = a.off0 + 4;
+        a.sh = 8 * (bo & 3u);
+        a.mask = width >= 4 ? 0xffffffffu : (1u << (8 * width)) - 1u;
+    }
+    return a;
+}
+__device__ __forceinline__ uint32_t field_val(uint32_t lo, uint32_t hi, const FieldAddr &a) {
+    const unsigned long long both = ((unsigned long long)hi << 32) | lo;
+    return (uint32_t)(both >> a.sh) & a.mask;
+}
+struct BlockFetch {  // raw dwords of one block for this lane: doc fields 0/1, tf fields 0/1
+    uint32_t dlo0, dhi0, dlo1, dhi1, tlo0, thi0, tlo1, thi1;
+    uint32_t fn;  // two fieldnorm bytes
+};
+__device__ __forceinline__ void block_fetch(const DevIndex &ix, const uint4 bm, uint32_t j,
+                                            uint32_t lane, BlockFetch &f) {
+    const uint32_t n = bm.w & 0xff, md = (bm.w >> 8) & 0xff, mt = (bm.w >> 16) & 0xff;
+    const uint8_t *body = ix.blob + 8ull * bm.z;
+    const uint8_t *tbody = body + ((payload_bytes(md, n) + 7u) & ~7u);
+    const FieldAddr a0 = field_addr(md, n, 2 * lane), a1 = field_addr(md, n, 2 * lane + 1);
+    const FieldAddr b0 = field_addr(mt, n, 2 * lane), b1 = field_addr(mt, n, 2 * lane + 1);
+    f.dlo0 = *reinterpret_cast<const uint32_t *>(body + a0.off0);
+    f.dhi0 = *reinterpret_cast<const uint32_t *>(body + a0.off1);
+    f.dlo1 = *reinterpret_cast<const uint32_t *>(body + a1.off0);
+    f.dhi1 = *reinterpret_cast<const uint32_t *>(body + a1.off1);
+    f.tlo0 = *reinterpret_cast<const uint32_t *>(tbody + b0.off0);
+    f.thi0 = *reinterpret_cast<const uint32_t *>(tbody + b0.off1);
+    f.tlo1 = *reinterpret_cast<const uint32_t *>(tbody + b1.off0);
+    f.thi1 = *reinterpret_cast<const uint32_t *>(tbody + b1.off1);
+    f.fn = reinterpret_cast<const uint16_t *>(ix.post_fn + 128ull * j)[lane];
+}
+
 // Workgroup barrier that orders LDS traffic only.  __syncthreads() also drains vmcnt, i.e. it
 // would wait for every global load in flight (the planner's metadata refills, the threshold
 // poll); all hand-offs inside the tile loop go through LDS.
+__device__ __forceinline__ uint32_t uni(uint32_t v) {  // value is wave-uniform: keep it in an SGPR
+    return (uint32_t)__builtin_amdgcn_readfirstlane((int)v);
+}
+__device__ __forceinline__ uint4 uni4(const uint4 v) {
+    return make_uint4(uni(v.x), uni(v.y), uni(v.z), uni(v.w));
+}
 __device__ __forceinline__ void lds_barrier() {
     asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
 }
@@ -611,7 +677,7 @@ __device__ __forceinline__ void decode_doc_ids_dpp(const uint8_t *__restrict__ p
 }
 
 template <int KMAX>
-__global__ void __launch_bounds__(CWG) scan_kernel(DevIndex ix, DevBatch bt) {
+__global__ void __launch_bounds__(CWG, 4) scan_kernel(DevIndex ix, DevBatch bt) {
     constexpr int T = CHAIN_MAX_TERMS;
     constexpr int RING = 128;            // metadata ring entries (power-of-two ring per term)
     constexpr int FAST_CAND = 64;        // candidates merged without stopping the workers
@@ -626,12 +692,12 @@ __global__ void __launch_bounds__(CWG) scan_kernel(DevIndex ix, DevBatch bt) {
     __shared__ double s_s1[256];
     __shared__ TopK<KMAX> s_top;
     __shared__ uint4 s_ring[RING];
-    __shared__ uint4 e_meta[2][C_BLOCKS];
+    __shared__ uint4 e_meta[2][C_BLOCKS];     // entries of a tile: new blocks first, then carried
     __shared__ uint32_t e_j[2][C_BLOCKS];
-    __shared__ uint16_t e_base[2][C_BLOCKS];  // staging base | 0x8000 if carried
+    __shared__ uint16_t e_base[2][C_BLOCKS];  // staging base of the block's region slot
     __shared__ uint8_t e_t[2][C_BLOCKS];
     __shared__ double t_s0[T];
-    __shared__ uint32_t s_lo[2], s_hi[2], s_nent[2], s_cand_cnt[2], s_done[2];
+    __shared__ uint32_t s_lo[2], s_hi[2], s_nent[2], s_nnew[2], s_cand_cnt[2], s_done[2];
     __shared__ unsigned long long s_theta[2];
 
     const uint32_t tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -655,6 +721,7 @@ __global__ void __launch_bounds__(CWG) scan_kernel(DevIndex ix, DevBatch bt) {
             // Planner wave: lane t owns term t.  Runs one tile ahead of the workers;
             // everything it decides depends on block metadata only.
             // =====================================================================
+            PROF_T(ps0);
             uint32_t p_rb = 0, p_re = 0, p_end = 0, p_q = 1, p_rmask = 0, p_roff = 0, p_base = 0,
                      p_slot = 0;  // p_slot = region slot of block p_rb (p_rb mod p_q, incremental)
             uint32_t m = 0;
@@ -716,7 +783,7 @@ __global__ void __launch_bounds__(CWG) scan_kernel(DevIndex ix, DevBatch bt) {
             uint32_t at0 = NONE32, at1 = NONE32;
             unsigned long long theta_next = 0;
 
-            // plan the tile after [.., p_hi) into buffer nb; loads it starts are consumed by
+            // plan the tile after [.., p_hi) into buffer nb; the loads it starts are consumed by
             // plan_finish(), which the caller runs after the next barrier
             auto plan_start = [&](uint32_t nb) {
                 const uint32_t hi_prev = p_hi;
@@ -756,31 +823,37 @@ __global__ void __launch_bounds__(CWG) scan_kernel(DevIndex ix, DevBatch bt) {
                     hi_c = min(hi_c, (uint32_t)__shfl_xor(hi_c, o));
                 }
                 const uint32_t lo_n = __shfl(lo_c, 0), hi_n = min(chi, (uint32_t)__shfl(hi_c, 0));
-                // 4. entries: resident blocks, then newly admitted ones
-                uint32_t cnt = 0, re_old = p_re;
+                // 4. entries: newly admitted blocks first (they cost a decode: spread them
+                //    over the waves), then the blocks still resident from earlier tiles
+                uint32_t n_car = 0, n_new = 0, re_old = p_re;
                 if (act && lo_n < chi) {
                     const uint32_t lim = min(p_rb + p_q, p_end);
                     re_old = max(p_re, p_rb);
                     uint32_t j = re_old;
                     while (j < lim && s_ring[p_roff + (j & p_rmask)].x < hi_n) ++j;
-                    cnt = j - p_rb;
+                    n_car = re_old - p_rb;
+                    n_new = j - re_old;
                     p_re = j;
                 }
-                uint32_t incl = cnt;
+                uint32_t inc_n = n_new, inc_c = n_car;
 #pragma unroll
                 for (int o = 1; o < 16; o <<= 1) {
-                    const uint32_t y = __shfl_up(incl, o);
-                    if ((int)lane >= o) incl += y;
+                    const uint32_t yn = __shfl_up(inc_n, o), yc = __shfl_up(inc_c, o);
+                    if ((int)lane >= o) {
+                        inc_n += yn;
+                        inc_c += yc;
+                    }
                 }
-                const uint32_t off = incl - cnt;
-                const uint32_t total = __shfl(incl, 15);
+                const uint32_t tot_new = __shfl(inc_n, 15), tot_car = __shfl(inc_c, 15);
                 if (act) {
                     uint32_t slot = p_slot;
-                    for (uint32_t i = 0; i < cnt; ++i) {
-                        const uint32_t j = p_rb + i, e = off + i;
+                    uint32_t e_c = tot_new + inc_c - n_car, e_n = inc_n - n_new;
+                    for (uint32_t i = 0; i < n_car + n_new; ++i) {
+                        const uint32_t j = p_rb + i;
+                        const uint32_t e = i < n_car ? e_c++ : e_n++;
                         e_meta[nb][e] = s_ring[p_roff + (j & p_rmask)];
                         e_j[nb][e] = j;
-                        e_base[nb][e] = (uint16_t)((p_base + slot * 128) | (j < re_old ? 0x8000u : 0u));
+                        e_base[nb][e] = (uint16_t)(p_base + slot * 128);
                         e_t[nb][e] = (uint8_t)lane;
                         if (++slot == p_q) slot = 0;
                     }
@@ -788,7 +861,8 @@ __global__ void __launch_bounds__(CWG) scan_kernel(DevIndex ix, DevBatch bt) {
                 if (lane == 0) {
                     s_lo[nb] = lo_n;
                     s_hi[nb] = hi_n;
-                    s_nent[nb] = total;
+                    s_nent[nb] = tot_new + tot_car;
+                    s_nnew[nb] = tot_new;
                     s_done[nb] = lo_n >= chi ? 1u : 0u;
                     s_cand_cnt[nb] = 0;
                 }
@@ -801,7 +875,6 @@ __global__ void __launch_bounds__(CWG) scan_kernel(DevIndex ix, DevBatch bt) {
                 if (lane == 0) s_theta[nb] = theta_next;
             };
 
-            PROF_T(ps0);
             bool done = plan_start(0);
             plan_finish(0);
             PROF_T(ps1);
@@ -842,7 +915,7 @@ __global__ void __launch_bounds__(CWG) scan_kernel(DevIndex ix, DevBatch bt) {
                     }
                     topk_offer<KMAX>(s_top, k, has, sc, d, lane);
                 }
-                if (s_top.count >= k && lane == 0) {
+                if (cnt && s_top.count >= k && lane == 0) {
                     const unsigned long long bits =
                         (unsigned long long)__double_as_longlong(s_top.score[k - 1]);
                     if (bits > published) {
@@ -857,131 +930,157 @@ __global__ void __launch_bounds__(CWG) scan_kernel(DevIndex ix, DevBatch bt) {
             }
         } else {
             // =====================================================================
-            // Worker waves
+            // Worker waves: entries wave, wave + CNW of every tile
             // =====================================================================
+            BlockFetch fetch[2];
+            bool fetched = false;  // fetch[] holds the raw words of this tile's new blocks
             lds_barrier();  // S
             for (uint32_t par = 0;; par ^= 1) {
-                if (s_done[par]) break;
-                const uint32_t lo = s_lo[par], hi = s_hi[par], nent = s_nent[par];
+                if (uni(s_done[par])) break;
+                const uint32_t lo = uni(s_lo[par]), hi = uni(s_hi[par]), nent = uni(s_nent[par]), nnew = uni(s_nnew[par]);
                 PROF_T(wa);
 
-                // ---- pass A.1: decode the new blocks of this wave's entries into staging
-                uint32_t dd[2][2];
+                // ---- pass A.1: decode this wave's new blocks into staging
+                uint32_t dd[4], ii[4];
 #pragma unroll
                 for (int r = 0; r < 2; ++r) {
-                    dd[r][0] = dd[r][1] = NONE32;
                     const uint32_t e = wave + r * CNW;
+                    dd[2 * r] = dd[2 * r + 1] = NONE32;
+                    ii[2 * r] = ii[2 * r + 1] = 0;
                     if (e >= nent) continue;
-                    const uint4 bm = e_meta[par][e];
-                    const uint32_t eb = e_base[par][e];
-                    const uint32_t i0 = (eb & 0x7fffu) + 2 * lane;
-                    if (eb & 0x8000u) {  // carried over from the previous tile: already staged
+                    const uint32_t i0 = uni(e_base[par][e]) + 2 * lane;
+                    ii[2 * r] = i0;
+                    ii[2 * r + 1] = i0 + 1;
+                    if (e >= nnew) {  // carried over from an earlier tile: already staged
                         const uint2 v = *reinterpret_cast<const uint2 *>(&st_doc[i0]);
-                        dd[r][0] = v.x;
-                        dd[r][1] = v.y;
-                    } else {
-                        const uint32_t j = e_j[par][e];
-                        const uint32_t n = bm.w & 0xff, md = (bm.w >> 8) & 0xff, mt = (bm.w >> 16) & 0xff;
-                        const uint8_t *body = ix.blob + 8ull * bm.z;
-                        uint32_t d0, d1, f0, f1;
-                        decode_doc_ids_dpp(body, md, n, bm.x, lane, d0, d1);
-                        decode_fields(body + ((payload_bytes(md, n) + 7u) & ~7u), mt, n, lane, f0, f1);
-                        const uchar2 fn = reinterpret_cast<const uchar2 *>(ix.post_fn + 128ull * j)[lane];
-                        const double s0 = t_s0[e_t[par][e]];
-                        const double tf0 = (double)f0, tf1 = (double)f1;
-                        double2 pp;
-                        pp.x = (tf0 * s0) / (tf0 + s_s1[fn.x]);  // bm25.rs:355-358
-                        pp.y = (tf1 * s0) / (tf1 + s_s1[fn.y]);
-                        if (2 * lane >= n) d0 = NONE32;
-                        if (2 * lane + 1 >= n) d1 = NONE32;
-                        *reinterpret_cast<uint2 *>(&st_doc[i0]) = make_uint2(d0, d1);
-                        *reinterpret_cast<double2 *>(&st_p[i0]) = pp;
-                        dd[r][0] = d0;
-                        dd[r][1] = d1;
+                        dd[2 * r] = v.x;
+                        dd[2 * r + 1] = v.y;
+                        continue;
                     }
+                    const uint4 bm = uni4(e_meta[par][e]);
+                    const uint32_t n = bm.w & 0xff, md = (bm.w >> 8) & 0xff, mt = (bm.w >> 16) & 0xff;
+                    if (!fetched) block_fetch(ix, bm, uni(e_j[par][e]), lane, fetch[r]);
+                    const BlockFetch &f = fetch[r];
+                    const uint32_t v0 = field_val(f.dlo0, f.dhi0, field_addr(md, n, 2 * lane));
+                    const uint32_t v1 = field_val(f.dlo1, f.dhi1, field_addr(md, n, 2 * lane + 1));
+                    uint32_t d0 = v0, d1 = v1;
+                    const uint32_t width = md & 127u;
+                    if (!((md >> 7) ? (width == 4) : (width == 32))) {  // d1 deltas from min_doc
+                        const uint32_t own = v0 + v1;
+                        const uint32_t incl = wave_incl_scan_u32(own);
+                        d0 = bm.x + (incl - own) + v0;
+                        d1 = d0 + v1;
+                    }
+                    const uint32_t f0 = field_val(f.tlo0, f.thi0, field_addr(mt, n, 2 * lane));
+                    const uint32_t f1 = field_val(f.tlo1, f.thi1, field_addr(mt, n, 2 * lane + 1));
+                    const double s0 = t_s0[uni(e_t[par][e])];
+                    const double tf0 = (double)f0, tf1 = (double)f1;
+                    double2 pp;
+                    pp.x = (tf0 * s0) / (tf0 + s_s1[f.fn & 0xff]);  // bm25.rs:355-358
+                    pp.y = (tf1 * s0) / (tf1 + s_s1[f.fn >> 8]);
+                    if (2 * lane >= n) d0 = NONE32;
+                    if (2 * lane + 1 >= n) d1 = NONE32;
+                    *reinterpret_cast<uint2 *>(&st_doc[i0]) = make_uint2(d0, d1);
+                    *reinterpret_cast<double2 *>(&st_p[i0]) = pp;
+                    dd[2 * r] = d0;
+                    dd[2 * r + 1] = d1;
                 }
                 PROF_T(wb);
-                // ---- pass A.2: link postings of [lo, hi) into the chain of their document
-                uint32_t my_slot[2][2];
+                // ---- pass A.2: link postings of [lo, hi) into the chain of their document.
+                // Four independent lock-free inserts per lane, issued together.
+                uint32_t slot[4], head[4];
 #pragma unroll
-                for (int r = 0; r < 2; ++r) {
-                    const uint32_t e = wave + r * CNW;
-                    const uint32_t i0 = e < nent ? (e_base[par][e] & 0x7fffu) + 2 * lane : 0u;
-#pragma unroll
-                    for (int h = 0; h < 2; ++h) {
-                        const uint32_t d = dd[r][h];
-                        const uint32_t i = i0 + h;
-                        my_slot[r][h] = NONE32;
-                        if (d >= lo && d < hi) {  // NONE32 never is
-                            uint32_t slot = (d * 0x9E3779B1u) >> (32 - C_SLOTS_LOG2);
-                            st_next[i] = NONE16;
-                            uint32_t head = atomicCAS(&s_slot[slot], NONE32, i);
-                            while (head != NONE32) {
-                                if (__hip_atomic_load(&st_doc[head], __ATOMIC_RELAXED,
-                                                      __HIP_MEMORY_SCOPE_WORKGROUP) == d) {
-                                    st_next[i] = (uint16_t)head;  // same document: push in front
-                                    const uint32_t seen = atomicCAS(&s_slot[slot], head, i);
-                                    if (seen == head) break;
-                                    head = seen;  // head moved meanwhile (never back to empty)
-                                } else {
-                                    slot = (slot + 1) & (C_SLOTS - 1);
-                                    head = atomicCAS(&s_slot[slot], NONE32, i);
-                                }
-                            }
-                            my_slot[r][h] = slot;
-                        }
+                for (int x = 0; x < 4; ++x) {
+                    const uint32_t d = dd[x];
+                    slot[x] = NONE32;
+                    head[x] = NONE32;
+                    if (d >= lo && d < hi) {  // NONE32 never is
+                        slot[x] = (d * 0x9E3779B1u) >> (32 - C_SLOTS_LOG2);
+                        st_next[ii[x]] = NONE16;
+                        head[x] = atomicCAS(&s_slot[slot[x]], NONE32, ii[x]);
                     }
+                }
+                for (;;) {
+                    bool pending = false;
+#pragma unroll
+                    for (int x = 0; x < 4; ++x) {
+                        if (head[x] == NONE32) continue;
+                        if (__hip_atomic_load(&st_doc[head[x]], __ATOMIC_RELAXED,
+                                              __HIP_MEMORY_SCOPE_WORKGROUP) == dd[x]) {
+                            st_next[ii[x]] = (uint16_t)head[x];  // same document: push in front
+                            const uint32_t seen = atomicCAS(&s_slot[slot[x]], head[x], ii[x]);
+                            head[x] = seen == head[x] ? NONE32 : seen;  // moved: retry (never empty)
+                        } else {
+                            slot[x] = (slot[x] + 1) & (C_SLOTS - 1);
+                            head[x] = atomicCAS(&s_slot[slot[x]], NONE32, ii[x]);
+                        }
+                        pending |= head[x] != NONE32;
+                    }
+                    if (!pending) break;
                 }
                 PROF_T(wc);
                 lds_barrier();  // X
                 PROF_T(wd);
+
+                // ---- the next tile's new blocks: start their loads now, decode after Y
+                fetched = false;
+                if (!uni(s_done[par ^ 1])) {
+                    const uint32_t nn = uni(s_nnew[par ^ 1]);
+#pragma unroll
+                    for (int r = 0; r < 2; ++r) {
+                        const uint32_t e = wave + r * CNW;
+                        if (e < nn) block_fetch(ix, uni4(e_meta[par ^ 1][e]), uni(e_j[par ^ 1][e]), lane, fetch[r]);
+                    }
+                    fetched = true;
+                }
 
                 // ---- pass B: chain heads add up their document and offer it
                 {
                     const unsigned long long theta = s_theta[par];
                     const uint32_t ntop = s_top.count;
                     const double ws = ntop >= k ? s_top.score[k - 1] : 0.0;
-                    const uint32_t wd = ntop >= k ? s_top.doc[k - 1] : 0u;
+                    const uint32_t wd2 = ntop >= k ? s_top.doc[k - 1] : 0u;
+                    uint32_t hd[4], nx[4];
+                    double pv[4];
 #pragma unroll
-                    for (int r = 0; r < 2; ++r) {
-                        const uint32_t e = wave + r * CNW;
-                        if (e >= nent) continue;
-                        const uint32_t i0 = (e_base[par][e] & 0x7fffu) + 2 * lane;
+                    for (int x = 0; x < 4; ++x) {
+                        hd[x] = slot[x] != NONE32 ? s_slot[slot[x]] : NONE32;
+                        pv[x] = st_p[ii[x]];
+                        nx[x] = st_next[ii[x]];
+                    }
 #pragma unroll
-                        for (int h = 0; h < 2; ++h) {
-                            const uint32_t slot = my_slot[r][h];
-                            const uint32_t i = i0 + h;
-                            if (slot == NONE32 || s_slot[slot] != i) continue;
-                            double score = st_p[i];
-                            const uint32_t j1 = st_next[i];
-                            if (j1 != NONE16) {
-                                const uint32_t j2 = st_next[j1];
-                                if (j2 == NONE16) {
-                                    score = score + st_p[j1];  // two addends commute
-                                } else {  // three or more: ascending staging index = key order
-                                    score = 0.0;
-                                    int last = -1;
-                                    for (;;) {
-                                        uint32_t best = NONE32;
-                                        for (uint32_t c = i; c != NONE16; c = st_next[c])
-                                            if ((int)c > last && c < best) best = c;
-                                        if (best == NONE32) break;
-                                        score += st_p[best];
-                                        last = (int)best;
-                                    }
+                    for (int x = 0; x < 4; ++x) {
+                        const uint32_t i = ii[x];
+                        if (slot[x] == NONE32 || hd[x] != i) continue;
+                        double score = pv[x];
+                        const uint32_t j1 = nx[x];
+                        if (j1 != NONE16) {
+                            const uint32_t j2 = st_next[j1];
+                            if (j2 == NONE16) {
+                                score = score + st_p[j1];  // two addends commute
+                            } else {  // three or more: ascending staging index = key order
+                                score = 0.0;
+                                int last = -1;
+                                for (;;) {
+                                    uint32_t best = NONE32;
+                                    for (uint32_t c = i; c != NONE16; c = st_next[c])
+                                        if ((int)c > last && c < best) best = c;
+                                    if (best == NONE32) break;
+                                    score += st_p[best];
+                                    last = (int)best;
                                 }
                             }
-                            s_slot[slot] = NONE32;
-                            if ((unsigned long long)__double_as_longlong(score) < theta) continue;
-                            const uint32_t d = st_doc[i];
-                            if (ntop >= k && !better(score, d, ws, wd)) continue;
-                            const uint32_t at = atomicAdd(&s_cand_cnt[par], 1u);
-                            st_p[i] = score;
-                            s_cand[at] = (uint16_t)i;
-                            if (at < (uint32_t)FAST_CAND) {
-                                c_score[par][at] = score;
-                                c_doc[par][at] = d;
-                            }
+                        }
+                        s_slot[slot[x]] = NONE32;
+                        if ((unsigned long long)__double_as_longlong(score) < theta) continue;
+                        const uint32_t d = dd[x];
+                        if (ntop >= k && !better(score, d, ws, wd2)) continue;
+                        const uint32_t at = atomicAdd(&s_cand_cnt[par], 1u);
+                        st_p[i] = score;
+                        s_cand[at] = (uint16_t)i;
+                        if (at < (uint32_t)FAST_CAND) {
+                            c_score[par][at] = score;
+                            c_doc[par][at] = d;
                         }
                     }
                 }
@@ -1468,6 +1567,11 @@ int vbm25_batch_kernel_ms(vbm25_batch *bt, double *avg_ms, uint32_t *n_launches)
 }
 
 #ifdef VBM25_PROFILE
+int vbm25_scan_occupancy(void) {
+    int blocks = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&blocks, scan_kernel<64>, CWG, 0) != hipSuccess) return -1;
+    return blocks;
+}
 // profiling builds only (not declared in include/vbm25.h): copy out the phase counters
 int vbm25_batch_profile(vbm25_batch *bt, unsigned long long *out, uint32_t n_workgroups) {
     HIP_TRY(hipDeviceSynchronize());
