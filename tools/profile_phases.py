@@ -43,10 +43,10 @@ w, p, tot = out[:, :8].astype(np.float64), out[:, 8:16].astype(np.float64), out[
 tiles = p[:, 7].sum()
 print(f"workgroups {NWG}, tiles {int(tiles)}, tiles/wg {tiles / NWG:.1f}, total cycles/wg {tot.mean():.0f}")
 print(f"entries per tile (worker wave 0's view of nent): {w[:, 7].sum() / tiles:.2f}")
-names_w = ["A1 decode", "A2 insert", "wait X", "B walk", "wait Y(+Z)"]
+names_w = ["A decode+mark", "wait X", "issue loads", "B fast/slow", "wait Y", "C heads+wipe", "wait Z(+W)"]
 for i, n in enumerate(names_w):
     print(f"worker  {n:12s} {w[:, i].sum() / tiles:9.0f} cycles/tile")
-names_p = ["setup+plan0 (per item)", "plan_start", "wait X", "plan_finish", "wait Y", "merge(+Z)"]
+names_p = ["setup+plan0 (per item)", "plan_start", "wait X", "plan_finish", "wait Y+Z", "merge(+W)", "  plan_start: drop+refill+theta"]
 for i, n in enumerate(names_p):
     d = NWG if i == 0 else tiles
     print(f"planner {n:22s} {p[:, i].sum() / d:9.0f} cycles/{'item' if i == 0 else 'tile'}")

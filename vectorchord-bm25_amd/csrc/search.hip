@@ -103,9 +103,11 @@ constexpr int CNW = 7;                   // worker waves per workgroup
 constexpr int CWG = (CNW + 1) * 64;      // + one planner / merger wave
 constexpr int C_BLOCKS = 2 * CNW;        // block slots of staging per workgroup (2 per worker)
 constexpr int C_POSTINGS = C_BLOCKS * 128;
-constexpr int C_SLOTS_LOG2 = 12;
+constexpr int C_SLOTS_LOG2 = 11;
 constexpr int C_SLOTS = 1 << C_SLOTS_LOG2;
 constexpr int CHAIN_MAX_TERMS = C_BLOCKS;  // queries with more indexed terms use scan_many_kernel
+constexpr int BM_BITS_LOG2 = 15;          // hashed document bitmaps: 32768 bits each
+constexpr int BM_WORDS = (1 << BM_BITS_LOG2) / 32;
 constexpr uint32_t NONE32 = 0xffffffffu;
 constexpr uint16_t NONE16 = 0xffffu;
 
@@ -608,6 +610,22 @@ __device__ __forceinline__ void block_fetch(const DevIndex &ix, const uint4 bm, 
     f.fn = reinterpret_cast<const uint16_t *>(ix.post_fn + 128ull * j)[lane];
 }
 
+// Reductions over lanes 0..15 (one DPP row); result valid in lane 15, broadcast with readlane.
+__device__ __forceinline__ uint32_t row16_min_bcast(uint32_t v) {
+    v = min(v, (uint32_t)__builtin_amdgcn_update_dpp(-1, (int)v, 0x111, 0xf, 0xf, false));
+    v = min(v, (uint32_t)__builtin_amdgcn_update_dpp(-1, (int)v, 0x112, 0xf, 0xf, false));
+    v = min(v, (uint32_t)__builtin_amdgcn_update_dpp(-1, (int)v, 0x114, 0xf, 0xf, false));
+    v = min(v, (uint32_t)__builtin_amdgcn_update_dpp(-1, (int)v, 0x118, 0xf, 0xf, false));
+    return (uint32_t)__builtin_amdgcn_readlane((int)v, 15);
+}
+__device__ __forceinline__ uint32_t row16_incl_sum(uint32_t v) {
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x111, 0xf, 0xf, false);
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x112, 0xf, 0xf, false);
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x114, 0xf, 0xf, false);
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x118, 0xf, 0xf, false);
+    return v;
+}
+
 // Workgroup barrier that orders LDS traffic only.  __syncthreads() also drains vmcnt, i.e. it
 // would wait for every global load in flight (the planner's metadata refills, the threshold
 // poll); all hand-offs inside the tile loop go through LDS.
@@ -685,7 +703,9 @@ __global__ void __launch_bounds__(CWG, 4) scan_kernel(DevIndex ix, DevBatch bt) 
     __shared__ uint32_t st_doc[C_POSTINGS];
     __shared__ double st_p[C_POSTINGS];
     __shared__ uint16_t st_next[C_POSTINGS];
-    __shared__ uint32_t s_slot[C_SLOTS];
+    __shared__ uint32_t s_slot[C_SLOTS];      // chain heads, slow path only
+    __shared__ uint32_t bm_seen[BM_WORDS];    // hashed doc bitmap: some posting of the tile
+    __shared__ uint32_t bm_multi[BM_WORDS];   // ... a second posting hit the same bit
     __shared__ uint16_t s_cand[C_POSTINGS];
     __shared__ double c_score[2][FAST_CAND];
     __shared__ uint32_t c_doc[2][FAST_CAND];
@@ -699,11 +719,17 @@ __global__ void __launch_bounds__(CWG, 4) scan_kernel(DevIndex ix, DevBatch bt) 
     __shared__ double t_s0[T];
     __shared__ uint32_t s_lo[2], s_hi[2], s_nent[2], s_nnew[2], s_cand_cnt[2], s_done[2];
     __shared__ unsigned long long s_theta[2];
+    __shared__ double s_kth_score;   // running top-k as seen by the workers' candidate filter
+    __shared__ uint32_t s_kth_doc, s_top_cnt;
 
     const uint32_t tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const uint32_t k = bt.k;
     for (int i = tid; i < 256; i += CWG) s_s1[i] = ix.s1[i];
     for (int i = tid; i < C_SLOTS; i += CWG) s_slot[i] = NONE32;
+    for (int i = tid; i < BM_WORDS; i += CWG) {
+        bm_seen[i] = 0;
+        bm_multi[i] = 0;
+    }
 
 #ifdef VBM25_PROFILE
     unsigned long long prof[8] = {0, 0, 0, 0, 0, 0, 0, 0};
@@ -736,7 +762,7 @@ __global__ void __launch_bounds__(CWG, 4) scan_kernel(DevIndex ix, DevBatch bt) 
                 }
                 const bool act = lane < m;
                 unsigned long long df = act ? ix.term_df[term] : 0ull;
-                unsigned long long sum = df;
+                unsigned long long sum = df, frac = 0;
 #pragma unroll
                 for (int o = 32; o > 0; o >>= 1) sum += __shfl_xor(sum, o);
                 if (act) {
@@ -749,10 +775,26 @@ __global__ void __launch_bounds__(CWG, 4) scan_kernel(DevIndex ix, DevBatch bt) 
                     p_rb = p_re = lo_b;
                     p_end = b1;
                     p_q = (uint32_t)(((unsigned long long)(C_BLOCKS - m) * df) / sum) + 1;
+                    frac = ((unsigned long long)(C_BLOCKS - m) * df) % sum;
                     uint32_t rs = 2;  // ring holds blocks [rb, rb + 2q]
                     while (rs < 2 * p_q + 1) rs <<= 1;
                     p_rmask = rs - 1;
                     t_s0[lane] = ix.term_s0[term];
+                }
+                {   // hand the block slots left over by the floor() to the largest remainders
+                    uint32_t used = row16_incl_sum(act ? p_q : 0u);
+                    const uint32_t left = (uint32_t)C_BLOCKS - (uint32_t)__builtin_amdgcn_readlane((int)used, 15);
+                    uint32_t rank = 0;
+                    for (uint32_t t = 0; t < m; ++t) {
+                        const unsigned long long ft = __shfl(frac, (int)t);
+                        rank += (ft > frac || (ft == frac && t < lane)) ? 1u : 0u;
+                    }
+                    if (act && rank < left) {
+                        p_q += 1;
+                        uint32_t rs = 2;
+                        while (rs < 2 * p_q + 1) rs <<= 1;
+                        p_rmask = rs - 1;
+                    }
                 }
                 const uint32_t xb = act ? 128 * p_q : 0, xr = act ? p_rmask + 1 : 0;
                 uint32_t ib = xb, ir = xr;
@@ -787,6 +829,7 @@ __global__ void __launch_bounds__(CWG, 4) scan_kernel(DevIndex ix, DevBatch bt) 
             // plan_finish(), which the caller runs after the next barrier
             auto plan_start = [&](uint32_t nb) {
                 const uint32_t hi_prev = p_hi;
+                PROF_T(hi_prev_t);
                 uint32_t nrb = p_rb;
                 if (act) {  // 1. drop blocks that end before the previous tile's end
                     while (nrb < p_re && s_ring[p_roff + (nrb & p_rmask)].y < hi_prev) ++nrb;
@@ -811,18 +854,15 @@ __global__ void __launch_bounds__(CWG, 4) scan_kernel(DevIndex ix, DevBatch bt) 
                     p_rb = nrb;
                 }
                 theta_next = __hip_atomic_load(&bt.theta[q], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                PROF_T(pm);
+                PROF_ADD(6, hi_prev_t, pm);
                 // 3. tile range
                 uint32_t lo_c = chi, hi_c = chi;
                 if (act && p_rb < p_end) {
                     lo_c = max(hi_prev, s_ring[p_roff + (p_rb & p_rmask)].x);
                     if (p_rb + p_q < p_end) hi_c = s_ring[p_roff + ((p_rb + p_q) & p_rmask)].x;
                 }
-#pragma unroll
-                for (int o = 8; o > 0; o >>= 1) {
-                    lo_c = min(lo_c, (uint32_t)__shfl_xor(lo_c, o));
-                    hi_c = min(hi_c, (uint32_t)__shfl_xor(hi_c, o));
-                }
-                const uint32_t lo_n = __shfl(lo_c, 0), hi_n = min(chi, (uint32_t)__shfl(hi_c, 0));
+                const uint32_t lo_n = row16_min_bcast(lo_c), hi_n = min(chi, row16_min_bcast(hi_c));
                 // 4. entries: newly admitted blocks first (they cost a decode: spread them
                 //    over the waves), then the blocks still resident from earlier tiles
                 uint32_t n_car = 0, n_new = 0, re_old = p_re;
@@ -835,16 +875,9 @@ __global__ void __launch_bounds__(CWG, 4) scan_kernel(DevIndex ix, DevBatch bt) 
                     n_new = j - re_old;
                     p_re = j;
                 }
-                uint32_t inc_n = n_new, inc_c = n_car;
-#pragma unroll
-                for (int o = 1; o < 16; o <<= 1) {
-                    const uint32_t yn = __shfl_up(inc_n, o), yc = __shfl_up(inc_c, o);
-                    if ((int)lane >= o) {
-                        inc_n += yn;
-                        inc_c += yc;
-                    }
-                }
-                const uint32_t tot_new = __shfl(inc_n, 15), tot_car = __shfl(inc_c, 15);
+                const uint32_t inc_n = row16_incl_sum(n_new), inc_c = row16_incl_sum(n_car);
+                const uint32_t tot_new = (uint32_t)__builtin_amdgcn_readlane((int)inc_n, 15);
+                const uint32_t tot_car = (uint32_t)__builtin_amdgcn_readlane((int)inc_c, 15);
                 if (act) {
                     uint32_t slot = p_slot;
                     uint32_t e_c = tot_new + inc_c - n_car, e_n = inc_n - n_new;
@@ -875,6 +908,43 @@ __global__ void __launch_bounds__(CWG, 4) scan_kernel(DevIndex ix, DevBatch bt) 
                 if (lane == 0) s_theta[nb] = theta_next;
             };
 
+            // running top-k: for k <= 64 one entry per lane in registers (sorted best first)
+            double r_score = 0.0;
+            uint32_t r_doc = NONE32, r_cnt = 0;
+            auto reg_offer = [&](bool has, double sc, uint32_t d) {
+                for (;;) {
+                    bool alive = has;
+                    if (alive && r_cnt >= k) {
+                        const double ks = __shfl(r_score, (int)k - 1);
+                        const uint32_t kd = __shfl(r_doc, (int)k - 1);
+                        alive = better(sc, d, ks, kd);
+                    }
+                    const unsigned long long mask = __ballot(alive);
+                    if (!mask) break;
+                    const int leader = __ffsll((long long)mask) - 1;
+                    const double cs = __shfl(sc, leader);
+                    const uint32_t cd = __shfl(d, leader);
+                    if ((int)lane == leader) has = false;
+                    const bool mine = lane < r_cnt && better(r_score, r_doc, cs, cd);
+                    const uint32_t pos = (uint32_t)__popcll(__ballot(mine));  // sorted: a prefix
+                    if (pos >= k) continue;
+                    const double us = __shfl_up(r_score, 1);
+                    const uint32_t ud = __shfl_up(r_doc, 1);
+                    if (lane > pos) {
+                        r_score = us;
+                        r_doc = ud;
+                    } else if (lane == pos) {
+                        r_score = cs;
+                        r_doc = cd;
+                    }
+                    r_cnt = r_cnt < k ? r_cnt + 1 : k;
+                }
+            };
+            if (lane == 0) {
+                s_top_cnt = 0;
+                s_kth_score = 0.0;
+                s_kth_doc = 0;
+            }
             bool done = plan_start(0);
             plan_finish(0);
             PROF_T(ps1);
@@ -890,6 +960,7 @@ __global__ void __launch_bounds__(CWG, 4) scan_kernel(DevIndex ix, DevBatch bt) 
                 plan_finish(par ^ 1);
                 PROF_T(pd);
                 lds_barrier();  // Y: pass B of this tile is finished
+                lds_barrier();  // Z: pass C (multi-term documents) is finished
                 PROF_T(pe);
                 PROF_ADD(1, pa, pb);
                 PROF_ADD(2, pb, pc);
@@ -913,20 +984,48 @@ __global__ void __launch_bounds__(CWG, 4) scan_kernel(DevIndex ix, DevBatch bt) 
                             d = st_doc[i];
                         }
                     }
-                    topk_offer<KMAX>(s_top, k, has, sc, d, lane);
+                    if constexpr (KMAX <= 64) reg_offer(has, sc, d);
+                    else topk_offer<KMAX>(s_top, k, has, sc, d, lane);
                 }
-                if (cnt && s_top.count >= k && lane == 0) {
-                    const unsigned long long bits =
-                        (unsigned long long)__double_as_longlong(s_top.score[k - 1]);
-                    if (bits > published) {
-                        atomicMax(&bt.theta[q], bits);
-                        published = bits;
+                if (cnt) {  // publish the new k-th entry to the workers and to the other chunks
+                    uint32_t n_now;
+                    double ks = 0.0;
+                    uint32_t kd = 0;
+                    if constexpr (KMAX <= 64) {
+                        n_now = r_cnt;
+                        ks = __shfl(r_score, (int)k - 1);
+                        kd = __shfl(r_doc, (int)k - 1);
+                    } else {
+                        n_now = s_top.count;
+                        if (n_now >= k) {
+                            ks = s_top.score[k - 1];
+                            kd = s_top.doc[k - 1];
+                        }
+                    }
+                    if (lane == 0) {
+                        s_top_cnt = n_now;
+                        if (n_now >= k) {
+                            s_kth_score = ks;
+                            s_kth_doc = kd;
+                            const unsigned long long bits = (unsigned long long)__double_as_longlong(ks);
+                            if (bits > published) {
+                                atomicMax(&bt.theta[q], bits);
+                                published = bits;
+                            }
+                        }
                     }
                 }
-                if (cnt > (uint32_t)FAST_CAND) lds_barrier();  // Z: staging had to survive
+                if (cnt > (uint32_t)FAST_CAND) lds_barrier();  // W: staging had to survive
                 PROF_T(pf);
                 PROF_ADD(5, pe, pf);
                 done = next_done;
+            }
+            if constexpr (KMAX <= 64) {  // chunk result straight from the registers
+                if (lane < r_cnt) {
+                    bt.res_score[(size_t)item * k + lane] = r_score;
+                    bt.res_doc[(size_t)item * k + lane] = r_doc;
+                }
+                if (lane == 0) bt.res_cnt[item] = r_cnt;
             }
         } else {
             // =====================================================================
@@ -986,43 +1085,24 @@ __global__ void __launch_bounds__(CWG, 4) scan_kernel(DevIndex ix, DevBatch bt) 
                     dd[2 * r + 1] = d1;
                 }
                 PROF_T(wb);
-                // ---- pass A.2: link postings of [lo, hi) into the chain of their document.
-                // Four independent lock-free inserts per lane, issued together.
-                uint32_t slot[4], head[4];
+                // ---- pass A.2: mark every posting of [lo, hi) in the hashed bitmaps.  A bit that
+                // was already set means "another posting may belong to the same document".
+                uint32_t bw[4], bb[4];
 #pragma unroll
                 for (int x = 0; x < 4; ++x) {
                     const uint32_t d = dd[x];
-                    slot[x] = NONE32;
-                    head[x] = NONE32;
-                    if (d >= lo && d < hi) {  // NONE32 never is
-                        slot[x] = (d * 0x9E3779B1u) >> (32 - C_SLOTS_LOG2);
-                        st_next[ii[x]] = NONE16;
-                        head[x] = atomicCAS(&s_slot[slot[x]], NONE32, ii[x]);
-                    }
+                    const uint32_t h = (d * 0x9E3779B1u) >> (32 - BM_BITS_LOG2);
+                    bw[x] = h >> 5;
+                    bb[x] = (d >= lo && d < hi) ? 1u << (h & 31) : 0u;  // NONE32 never is in range
                 }
-                for (;;) {
-                    bool pending = false;
 #pragma unroll
-                    for (int x = 0; x < 4; ++x) {
-                        if (head[x] == NONE32) continue;
-                        if (__hip_atomic_load(&st_doc[head[x]], __ATOMIC_RELAXED,
-                                              __HIP_MEMORY_SCOPE_WORKGROUP) == dd[x]) {
-                            st_next[ii[x]] = (uint16_t)head[x];  // same document: push in front
-                            const uint32_t seen = atomicCAS(&s_slot[slot[x]], head[x], ii[x]);
-                            head[x] = seen == head[x] ? NONE32 : seen;  // moved: retry (never empty)
-                        } else {
-                            slot[x] = (slot[x] + 1) & (C_SLOTS - 1);
-                            head[x] = atomicCAS(&s_slot[slot[x]], NONE32, ii[x]);
-                        }
-                        pending |= head[x] != NONE32;
-                    }
-                    if (!pending) break;
-                }
+                for (int x = 0; x < 4; ++x)
+                    if (bb[x] && (atomicOr(&bm_seen[bw[x]], bb[x]) & bb[x])) atomicOr(&bm_multi[bw[x]], bb[x]);
                 PROF_T(wc);
                 lds_barrier();  // X
                 PROF_T(wd);
 
-                // ---- the next tile's new blocks: start their loads now, decode after Y
+                // ---- the next tile's new blocks: start their loads now, decode after Z
                 fetched = false;
                 if (!uni(s_done[par ^ 1])) {
                     const uint32_t nn = uni(s_nnew[par ^ 1]);
@@ -1034,26 +1114,76 @@ __global__ void __launch_bounds__(CWG, 4) scan_kernel(DevIndex ix, DevBatch bt) 
                     fetched = true;
                 }
 
-                // ---- pass B: chain heads add up their document and offer it
-                {
-                    const unsigned long long theta = s_theta[par];
-                    const uint32_t ntop = s_top.count;
-                    const double ws = ntop >= k ? s_top.score[k - 1] : 0.0;
-                    const uint32_t wd2 = ntop >= k ? s_top.doc[k - 1] : 0u;
-                    uint32_t hd[4], nx[4];
-                    double pv[4];
-#pragma unroll
-                    for (int x = 0; x < 4; ++x) {
-                        hd[x] = slot[x] != NONE32 ? s_slot[slot[x]] : NONE32;
-                        pv[x] = st_p[ii[x]];
-                        nx[x] = st_next[ii[x]];
+                PROF_T(wd1);
+                // ---- pass B: a document whose bit nobody else hit has a single posting: its
+                // partial score IS its score.  The others are linked into chains (lock-free).
+                const unsigned long long theta = s_theta[par];
+                const uint32_t ntop = s_top_cnt;
+                const double ws = s_kth_score;
+                const uint32_t wd2 = s_kth_doc;
+                auto offer = [&](double score, uint32_t d, uint32_t i) {
+                    if ((unsigned long long)__double_as_longlong(score) < theta) return;
+                    if (ntop >= k && !better(score, d, ws, wd2)) return;
+                    const uint32_t at = atomicAdd(&s_cand_cnt[par], 1u);
+                    st_p[i] = score;
+                    s_cand[at] = (uint16_t)i;
+                    if (at < (uint32_t)FAST_CAND) {
+                        c_score[par][at] = score;
+                        c_doc[par][at] = d;
                     }
+                };
+                uint32_t slot[4], head[4];
+                bool any_slow = false;
+#pragma unroll
+                for (int x = 0; x < 4; ++x) {
+                    slot[x] = NONE32;
+                    head[x] = NONE32;
+                    if (!bb[x]) continue;
+                    if (!(bm_multi[bw[x]] & bb[x])) {
+                        offer(st_p[ii[x]], dd[x], ii[x]);
+                    } else {
+                        slot[x] = (dd[x] * 0x85EBCA6Bu) >> (32 - C_SLOTS_LOG2);
+                        st_next[ii[x]] = NONE16;
+                        head[x] = atomicCAS(&s_slot[slot[x]], NONE32, ii[x]);
+                        any_slow = true;
+                    }
+                }
+                if (__any(any_slow)) {
+                    for (;;) {
+                        bool pending = false;
+#pragma unroll
+                        for (int x = 0; x < 4; ++x) {
+                            if (head[x] == NONE32) continue;
+                            if (__hip_atomic_load(&st_doc[head[x]], __ATOMIC_RELAXED,
+                                                  __HIP_MEMORY_SCOPE_WORKGROUP) == dd[x]) {
+                                st_next[ii[x]] = (uint16_t)head[x];  // same document: push in front
+                                const uint32_t seen = atomicCAS(&s_slot[slot[x]], head[x], ii[x]);
+                                head[x] = seen == head[x] ? NONE32 : seen;  // moved: retry (never empty)
+                            } else {
+                                slot[x] = (slot[x] + 1) & (C_SLOTS - 1);
+                                head[x] = atomicCAS(&s_slot[slot[x]], NONE32, ii[x]);
+                            }
+                            pending |= head[x] != NONE32;
+                        }
+                        if (!pending) break;
+                    }
+                }
+                PROF_T(we);
+                lds_barrier();  // Y
+                PROF_T(we1);
+
+                // ---- pass C: chain heads add up their document and offer it; bitmaps are wiped
+                for (int i = tid; i < BM_WORDS / 4; i += CNW * 64) {
+                    reinterpret_cast<uint4 *>(bm_seen)[i] = make_uint4(0, 0, 0, 0);
+                    reinterpret_cast<uint4 *>(bm_multi)[i] = make_uint4(0, 0, 0, 0);
+                }
+                if (__any(any_slow)) {
 #pragma unroll
                     for (int x = 0; x < 4; ++x) {
                         const uint32_t i = ii[x];
-                        if (slot[x] == NONE32 || hd[x] != i) continue;
-                        double score = pv[x];
-                        const uint32_t j1 = nx[x];
+                        if (slot[x] == NONE32 || s_slot[slot[x]] != i) continue;
+                        double score = st_p[i];
+                        const uint32_t j1 = st_next[i];
                         if (j1 != NONE16) {
                             const uint32_t j2 = st_next[j1];
                             if (j2 == NONE16) {
@@ -1072,27 +1202,20 @@ __global__ void __launch_bounds__(CWG, 4) scan_kernel(DevIndex ix, DevBatch bt) 
                             }
                         }
                         s_slot[slot[x]] = NONE32;
-                        if ((unsigned long long)__double_as_longlong(score) < theta) continue;
-                        const uint32_t d = dd[x];
-                        if (ntop >= k && !better(score, d, ws, wd2)) continue;
-                        const uint32_t at = atomicAdd(&s_cand_cnt[par], 1u);
-                        st_p[i] = score;
-                        s_cand[at] = (uint16_t)i;
-                        if (at < (uint32_t)FAST_CAND) {
-                            c_score[par][at] = score;
-                            c_doc[par][at] = d;
-                        }
+                        offer(score, dd[x], i);
                     }
                 }
-                PROF_T(we);
-                lds_barrier();  // Y
-                if (s_cand_cnt[par] > (uint32_t)FAST_CAND) lds_barrier();  // Z
+                PROF_T(we2);
+                lds_barrier();  // Z
+                if (s_cand_cnt[par] > (uint32_t)FAST_CAND) lds_barrier();  // W
                 PROF_T(wf);
-                PROF_ADD(0, wa, wb);
-                PROF_ADD(1, wb, wc);
-                PROF_ADD(2, wc, wd);
-                PROF_ADD(3, wd, we);
-                PROF_ADD(4, we, wf);
+                PROF_ADD(0, wa, wc);    // A1 + A2
+                PROF_ADD(1, wc, wd);    // wait X
+                PROF_ADD(2, wd, wd1);   // issue next tile's loads
+                PROF_ADD(3, wd1, we);   // pass B
+                PROF_ADD(4, we, we1);   // wait Y
+                PROF_ADD(5, we1, we2);  // pass C
+                PROF_ADD(6, we2, wf);   // wait Z (+W)
 #ifdef VBM25_PROFILE
                 prof[7] += nent;
 #endif
@@ -1100,7 +1223,7 @@ __global__ void __launch_bounds__(CWG, 4) scan_kernel(DevIndex ix, DevBatch bt) 
         }
 
         __syncthreads();
-        {
+        if constexpr (KMAX > 64) {
             const uint32_t n = s_top.count;
             for (uint32_t i = tid; i < n; i += CWG) {
                 bt.res_score[(size_t)item * k + i] = s_top.score[i];
