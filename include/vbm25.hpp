@@ -1,0 +1,126 @@
+// vbm25.hpp -- C++ host mirror of the reference's interface for the query path, over the
+// C ABI of vbm25.h (header only).
+//
+// The reference is Rust; there is no rustc in the build image, so the host side that a
+// maintainer would write in Rust is mirrored here in C++ with the same
+// names, argument meaning and error behaviour:
+//   vbm25::intern        crates/bm25/src/vector.rs:19-35   (short path; see note)
+//   vbm25::Query         crates/bm25/src/vector.rs:96-134  (sorted unique 16-byte keys)
+//   vbm25::Index::search crates/bm25/src/search.rs:28-36   (bm25::search, filter == true)
+//   vbm25::merge_growing crates/bm25/src/search.rs:83-135  (hits of unsealed documents first)
+// Reference panics ("data corruption", "invalid data") and pgrx::error! become vbm25::Error.
+#ifndef VBM25_HPP
+#define VBM25_HPP
+
+#include <algorithm>
+#include <array>
+#include <cstring>
+#include <stdexcept>
+#include <string>
+#include <string_view>
+#include <vector>
+
+#include "vbm25.h"
+
+namespace vbm25 {
+
+constexpr size_t WIDTH = 16;  // crates/bm25/src/lib.rs:37
+using Key = std::array<uint8_t, WIDTH>;
+using Hit = vbm25_hit;
+
+struct Error : std::runtime_error {
+    int code;
+    Error(int c, const std::string &what) : std::runtime_error(what), code(c) {}
+};
+inline void check(int rc) {
+    if (rc != VBM25_OK) throw Error(rc, vbm25_last_error());
+}
+
+// vector.rs:19-35.  Lexemes of 16 bytes or more (or containing NUL) are hashed with
+// blake3::keyed_hash (blake3 1.8.4) in the reference; that dependency is outside the query
+// hot path and not reproduced: such lexemes raise VBM25_ERR_UNSUPPORTED here.
+inline Key intern(std::string_view s) {
+    if (s.size() < WIDTH && s.find('\0') == std::string_view::npos) {
+        Key k{};
+        std::memcpy(k.data(), s.data(), s.size());
+        return k;
+    }
+    throw Error(VBM25_ERR_UNSUPPORTED, "intern(): lexemes >= 16 bytes need blake3::keyed_hash");
+}
+
+// vector.rs:96-134
+class Query {
+  public:
+    explicit Query(std::vector<Key> keys) : keys_(std::move(keys)) {
+        for (size_t i = 1; i < keys_.size(); ++i)
+            if (!(keys_[i - 1] < keys_[i])) throw Error(VBM25_ERR_INVALID, "invalid data");  // Query::new
+    }
+    // cast_tsvector_to_query, src/datatype/tsvector.rs:96-105: intern, sort, dedup
+    template <class It>
+    static Query from_tokens(It first, It last) {
+        std::vector<Key> keys;
+        for (; first != last; ++first) keys.push_back(intern(*first));
+        std::sort(keys.begin(), keys.end());
+        keys.erase(std::unique(keys.begin(), keys.end()), keys.end());
+        return Query(std::move(keys));
+    }
+    const std::vector<Key> &keys() const { return keys_; }
+    size_t len() const { return keys_.size(); }
+    bool is_empty() const { return keys_.empty(); }
+
+  private:
+    std::vector<Key> keys_;
+};
+
+// HBM-resident sealed segment.
+class Index {
+  public:
+    Index(const vbm25_index_desc &desc, int device = 0) { check(vbm25_index_create(&desc, device, &h_)); }
+    ~Index() { vbm25_index_destroy(h_); }
+    Index(const Index &) = delete;
+    Index &operator=(const Index &) = delete;
+
+    // bm25::search(&index, k, &query, |_| true): best first, at most k hits.
+    std::vector<Hit> search(size_t k, const Query &query) const {
+        std::vector<uint32_t> ids(query.len());
+        if (!ids.empty())
+            check(vbm25_lookup_terms(h_, query.keys()[0].data(), uint32_t(ids.size()), ids.data()));
+        // unknown tokens are ignored (search.rs:59-61); key order == term id order
+        ids.erase(std::remove(ids.begin(), ids.end(), UINT32_MAX), ids.end());
+        const uint32_t off[2] = {0, uint32_t(ids.size())};
+        std::vector<Hit> hits(k);
+        uint32_t n = 0;
+        check(vbm25_search_batch(h_, ids.data(), off, 1, uint32_t(k), hits.data(), &n));
+        hits.resize(n);
+        return hits;
+    }
+    // The batched form the GPU is built for: queries as CSR of ascending term ids.
+    void search_batch(const std::vector<uint32_t> &term_ids, const std::vector<uint32_t> &q_off, size_t k,
+                      std::vector<Hit> &hits, std::vector<uint32_t> &n_hits) const {
+        const uint32_t nq = uint32_t(q_off.size() - 1);
+        hits.resize(size_t(nq) * k);
+        n_hits.resize(nq);
+        check(vbm25_search_batch(h_, term_ids.data(), q_off.data(), nq, uint32_t(k), hits.data(), n_hits.data()));
+    }
+    vbm25_index *handle() const { return h_; }
+
+  private:
+    vbm25_index *h_ = nullptr;
+};
+
+// search.rs:83-135 + 301-313: the growing (unsealed) segment is scored on the host by the
+// shim and merged in front of the sealed-segment hits; top-k of the union, best first.
+// `grow` must already be sorted best first.
+inline std::vector<Hit> merge_growing(const std::vector<Hit> &sealed, const std::vector<Hit> &grow, size_t k) {
+    std::vector<Hit> out;
+    out.reserve(std::min(k, sealed.size() + grow.size()));
+    size_t i = 0, j = 0;
+    while (out.size() < k && (i < sealed.size() || j < grow.size())) {
+        const bool take_grow = j < grow.size() && (i >= sealed.size() || grow[j].score > sealed[i].score);
+        out.push_back(take_grow ? grow[j++] : sealed[i++]);
+    }
+    return out;
+}
+
+}  // namespace vbm25
+#endif

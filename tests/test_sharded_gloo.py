@@ -1,0 +1,67 @@
+"""N > 1 path on CPU: two gloo processes shard a query batch, "search" their shard (the
+oracle stands in for the GPU here) and all-gather the hit records; the gathered records must
+equal the single-process result.  Covers shard_bounds / shard_queries / gather_hits."""
+import os
+import subprocess
+import sys
+import tempfile
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+WORKER = r'''
+import os, sys
+import numpy as np
+import torch
+import torch.distributed as dist
+sys.path.insert(0, sys.argv[1]); sys.path.insert(0, os.path.join(sys.argv[1], "tests"))
+import orc
+import vectorchord_bm25_amd as vb
+from corpus import make_corpus, make_queries
+
+rank, world, nq, k = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"]), int(sys.argv[3]), 10
+dist.init_process_group("gloo", rank=rank, world_size=world)
+c = make_corpus(3000, 300, seed=3, length="lognormal", mean_len=40)
+oix = orc.OracleIndex.build(1.2, 0.75, c["doc_len"], c["doc_payload"], c["term_key"], c["term_start"],
+                            c["post_doc"], c["post_tf"])
+terms, off = make_queries(c, nq, 4, seed=7)
+t, o = vb.sharded.shard_queries(terms, off, world, rank)
+hits, nh, _ = oix.search_batch(t, o, k, mode="brute", threads=1)
+local = torch.from_numpy(np.frombuffer(hits.tobytes(), dtype=np.int64).copy())
+allw = vb.sharded.gather_hits(local, nq, k)
+if rank == 0:
+    np.save(sys.argv[2], allw.numpy())
+dist.destroy_process_group()
+'''
+
+
+@pytest.mark.parametrize("nq", [16, 17])
+def test_two_rank_gather_equals_single_process(nq):
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import orc
+    from corpus import make_corpus, make_queries
+    import vectorchord_bm25_amd as vb
+
+    with tempfile.TemporaryDirectory() as d:
+        script = os.path.join(d, "worker.py")
+        open(script, "w").write(WORKER)
+        out = os.path.join(d, "out.npy")
+        port = 29500 + os.getpid() % 1000 + nq
+        subprocess.check_call(
+            [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+             "--master-addr", "127.0.0.1", "--master-port", str(port), script, ROOT, out, str(nq)],
+            timeout=300, stdout=subprocess.DEVNULL, stderr=subprocess.STDOUT)
+        got = np.load(out)
+    c = make_corpus(3000, 300, seed=3, length="lognormal", mean_len=40)
+    oix = orc.OracleIndex.build(1.2, 0.75, c["doc_len"], c["doc_payload"], c["term_key"], c["term_start"],
+                                c["post_doc"], c["post_tf"])
+    terms, off = make_queries(c, nq, 4, seed=7)
+    ref, _, _ = oix.search_batch(terms, off, 10, mode="brute", threads=1)
+    assert got.tobytes() == ref.tobytes()
+    # shard arithmetic
+    for world in (1, 2, 3, 8):
+        b = [vb.sharded.shard_bounds(nq, world, r) for r in range(world)]
+        assert b[0][0] == 0 and b[-1][1] == nq and all(b[i][1] == b[i + 1][0] for i in range(world - 1))
+        assert max(h - l for l, h in b) - min(h - l for l, h in b) <= 1

@@ -8,3 +8,4 @@ used by the tests and bench.py; it never touches oracle/.
 from ._lib import build, lib, library_path, Vbm25Error  # noqa: F401
 from .api import (  # noqa: F401
     HIT_DTYPE, Segment, GpuIndex, Batch, Query, intern, search, search_batch)
+from . import api, sharded  # noqa: F401,E402
