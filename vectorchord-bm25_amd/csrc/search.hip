@@ -639,6 +639,9 @@ __device__ __forceinline__ void lds_barrier() {
     asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
 }
 
+#ifndef VBM25_ABL
+#define VBM25_ABL 0
+#endif
 #ifdef VBM25_PROFILE
 #define PROF_T(var) const unsigned long long var = __builtin_readcyclecounter()
 #define PROF_ADD(slot, a, b) prof[slot] += (b) - (a)
@@ -1058,10 +1061,18 @@ __global__ void __launch_bounds__(CWG, 4) scan_kernel(DevIndex ix, DevBatch bt) 
                     }
                     const uint4 bm = uni4(e_meta[par][e]);
                     const uint32_t n = bm.w & 0xff, md = (bm.w >> 8) & 0xff, mt = (bm.w >> 16) & 0xff;
+#if VBM25_ABL == 5  // ablation: no payload loads, no field extraction
+                    BlockFetch f;
+                    f.fn = 0x3030;
+                    f.tlo0 = f.tlo1 = 1; f.thi0 = f.thi1 = 0;
+                    const uint32_t v0 = lane ? 3u : 0u, v1 = 2u;
+                    (void)fetched;
+#else
                     if (!fetched) block_fetch(ix, bm, uni(e_j[par][e]), lane, fetch[r]);
                     const BlockFetch &f = fetch[r];
                     const uint32_t v0 = field_val(f.dlo0, f.dhi0, field_addr(md, n, 2 * lane));
                     const uint32_t v1 = field_val(f.dlo1, f.dhi1, field_addr(md, n, 2 * lane + 1));
+#endif
                     uint32_t d0 = v0, d1 = v1;
                     const uint32_t width = md & 127u;
                     if (!((md >> 7) ? (width == 4) : (width == 32))) {  // d1 deltas from min_doc
@@ -1070,13 +1081,26 @@ __global__ void __launch_bounds__(CWG, 4) scan_kernel(DevIndex ix, DevBatch bt) 
                         d0 = bm.x + (incl - own) + v0;
                         d1 = d0 + v1;
                     }
+#if VBM25_ABL == 5
+                    const uint32_t f0 = 1, f1 = 1;
+                    (void)mt;
+#else
                     const uint32_t f0 = field_val(f.tlo0, f.thi0, field_addr(mt, n, 2 * lane));
                     const uint32_t f1 = field_val(f.tlo1, f.thi1, field_addr(mt, n, 2 * lane + 1));
+#endif
                     const double s0 = t_s0[uni(e_t[par][e])];
                     const double tf0 = (double)f0, tf1 = (double)f1;
                     double2 pp;
+#if VBM25_ABL == 2  // ablation: no divide
+                    pp.x = (tf0 * s0) * (tf0 + s_s1[f.fn & 0xff]);
+                    pp.y = (tf1 * s0) * (tf1 + s_s1[f.fn >> 8]);
+#elif VBM25_ABL == 3  // ablation: no scoring arithmetic
+                    pp.x = s0 + tf0;
+                    pp.y = s0 + tf1;
+#else
                     pp.x = (tf0 * s0) / (tf0 + s_s1[f.fn & 0xff]);  // bm25.rs:355-358
                     pp.y = (tf1 * s0) / (tf1 + s_s1[f.fn >> 8]);
+#endif
                     if (2 * lane >= n) d0 = NONE32;
                     if (2 * lane + 1 >= n) d1 = NONE32;
                     *reinterpret_cast<uint2 *>(&st_doc[i0]) = make_uint2(d0, d1);
@@ -1093,7 +1117,11 @@ __global__ void __launch_bounds__(CWG, 4) scan_kernel(DevIndex ix, DevBatch bt) 
                     const uint32_t d = dd[x];
                     const uint32_t h = (d * 0x9E3779B1u) >> (32 - BM_BITS_LOG2);
                     bw[x] = h >> 5;
+#if VBM25_ABL == 4  // ablation: no join at all (decode + staging only)
+                    bb[x] = 0u;
+#else
                     bb[x] = (d >= lo && d < hi) ? 1u << (h & 31) : 0u;  // NONE32 never is in range
+#endif
                 }
 #pragma unroll
                 for (int x = 0; x < 4; ++x)
@@ -1109,7 +1137,9 @@ __global__ void __launch_bounds__(CWG, 4) scan_kernel(DevIndex ix, DevBatch bt) 
 #pragma unroll
                     for (int r = 0; r < 2; ++r) {
                         const uint32_t e = wave + r * CNW;
+#if VBM25_ABL != 5
                         if (e < nn) block_fetch(ix, uni4(e_meta[par ^ 1][e]), uni(e_j[par ^ 1][e]), lane, fetch[r]);
+#endif
                     }
                     fetched = true;
                 }
