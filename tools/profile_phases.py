@@ -35,19 +35,21 @@ b.fetch()
 L = vb.lib()
 print("occupancy API: workgroups per CU =", L.vbm25_scan_occupancy())
 NWG = 2048
-out = np.zeros((NWG, 17), dtype=np.uint64)
+out = np.zeros((NWG, 33), dtype=np.uint64)
 L.vbm25_batch_profile.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32]
 b.run()
 assert L.vbm25_batch_profile(b.h, out.ctypes.data_as(C.c_void_p), NWG) == 0
-w, p, tot = out[:, :8].astype(np.float64), out[:, 8:16].astype(np.float64), out[:, 16].astype(np.float64)
+w, p, tot = out[:, :16].astype(np.float64), out[:, 16:32].astype(np.float64), out[:, 32].astype(np.float64)
 tiles = p[:, 7].sum()
 print(f"workgroups {NWG}, tiles {int(tiles)}, tiles/wg {tiles / NWG:.1f}, total cycles/wg {tot.mean():.0f}")
 print(f"entries per tile (worker wave 0's view of nent): {w[:, 7].sum() / tiles:.2f}")
 names_w = ["A decode+mark", "wait X", "issue loads", "B fast/slow", "wait Y", "C heads+wipe", "wait Z(+W)"]
 for i, n in enumerate(names_w):
     print(f"worker  {n:12s} {w[:, i].sum() / tiles:9.0f} cycles/tile")
-names_p = ["setup+plan0 (per item)", "plan_start", "wait X", "plan_finish", "wait Y+Z", "merge(+W)", "  plan_start: drop+refill+theta"]
+names_p = ["setup+plan0 (per item)", "plan_start", "wait X", "plan_finish", "wait Y+Z", "merge(+W)", "  slow postings (count, not cycles)"]
 for i, n in enumerate(names_p):
     d = NWG if i == 0 else tiles
     print(f"planner {n:22s} {p[:, i].sum() / d:9.0f} cycles/{'item' if i == 0 else 'tile'}")
+for i, n in [(8, "join: load list"), (9, "join: all-pairs"), (10, "join: >=3 addends"), (11, "join total (Y -> cand merge)"), (12, "cand merge"), (13, "publish"), (14, "candidates (count)")]:
+    print(f"planner   {n:30s} {p[:, i].sum() / tiles:9.1f} /tile")
 print(f"cycles per tile overall: {tot.sum() / tiles:.0f}")

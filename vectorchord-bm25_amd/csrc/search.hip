@@ -106,6 +106,7 @@ constexpr int C_POSTINGS = C_BLOCKS * 128;
 constexpr int C_SLOTS_LOG2 = 11;
 constexpr int C_SLOTS = 1 << C_SLOTS_LOG2;
 constexpr int CHAIN_MAX_TERMS = C_BLOCKS;  // queries with more indexed terms use scan_many_kernel
+constexpr int SLOW_CAP = 128;             // postings per tile joined exactly by the planner wave
 constexpr int BM_BITS_LOG2 = 15;          // hashed document bitmaps: 32768 bits each
 constexpr int BM_WORDS = (1 << BM_BITS_LOG2) / 32;
 constexpr uint32_t NONE32 = 0xffffffffu;
@@ -592,22 +593,61 @@ struct BlockFetch {  // raw dwords of one block for this lane: doc fields 0/1, t
     uint32_t dlo0, dhi0, dlo1, dhi1, tlo0, thi0, tlo1, thi1;
     uint32_t fn;  // two fieldnorm bytes
 };
+// Bit-packed blocks: a lane's two values (indices 2L, 2L+1) sit in adjacent lane streams at the
+// same step, so their words are one aligned 8-byte pair in group w and one in group w+1.
+__device__ __forceinline__ void pair_fetch(const uint8_t *__restrict__ p, uint32_t width, uint32_t lane,
+                                           uint32_t &lo0, uint32_t &hi0, uint32_t &lo1, uint32_t &hi1) {
+    const uint32_t bit = (lane >> 1) * width;          // step t = (2L) >> 2
+    const uint32_t off = 16 * (bit >> 5) + 8 * (lane & 1);  // streams l0 = 2*(L&1), l0 + 1
+    const uint2 a = *reinterpret_cast<const uint2 *>(p + off);
+    const uint2 b = *reinterpret_cast<const uint2 *>(p + off + 16);  // may be the next payload: unused then
+    lo0 = a.x;
+    lo1 = a.y;
+    hi0 = b.x;
+    hi1 = b.y;
+}
+__device__ __forceinline__ void pair_extract(uint32_t width, uint32_t lane, uint32_t lo0, uint32_t hi0,
+                                             uint32_t lo1, uint32_t hi1, uint32_t &v0, uint32_t &v1) {
+    const uint32_t sh = ((lane >> 1) * width) & 31;
+    const uint32_t mask = width >= 32 ? 0xffffffffu : (1u << width) - 1u;
+    v0 = (uint32_t)((((unsigned long long)hi0 << 32) | lo0) >> sh) & mask;
+    v1 = (uint32_t)((((unsigned long long)hi1 << 32) | lo1) >> sh) & mask;
+}
 __device__ __forceinline__ void block_fetch(const DevIndex &ix, const uint4 bm, uint32_t j,
                                             uint32_t lane, BlockFetch &f) {
     const uint32_t n = bm.w & 0xff, md = (bm.w >> 8) & 0xff, mt = (bm.w >> 16) & 0xff;
     const uint8_t *body = ix.blob + 8ull * bm.z;
     const uint8_t *tbody = body + ((payload_bytes(md, n) + 7u) & ~7u);
-    const FieldAddr a0 = field_addr(md, n, 2 * lane), a1 = field_addr(md, n, 2 * lane + 1);
-    const FieldAddr b0 = field_addr(mt, n, 2 * lane), b1 = field_addr(mt, n, 2 * lane + 1);
-    f.dlo0 = *reinterpret_cast<const uint32_t *>(body + a0.off0);
-    f.dhi0 = *reinterpret_cast<const uint32_t *>(body + a0.off1);
-    f.dlo1 = *reinterpret_cast<const uint32_t *>(body + a1.off0);
-    f.dhi1 = *reinterpret_cast<const uint32_t *>(body + a1.off1);
-    f.tlo0 = *reinterpret_cast<const uint32_t *>(tbody + b0.off0);
-    f.thi0 = *reinterpret_cast<const uint32_t *>(tbody + b0.off1);
-    f.tlo1 = *reinterpret_cast<const uint32_t *>(tbody + b1.off0);
-    f.thi1 = *reinterpret_cast<const uint32_t *>(tbody + b1.off1);
+    if ((md >> 7) == 0) {  // full block (both streams bit-packed, compression.rs:42-52,99-103)
+        pair_fetch(body, md & 127u, lane, f.dlo0, f.dhi0, f.dlo1, f.dhi1);
+        pair_fetch(tbody, mt & 127u, lane, f.tlo0, f.thi0, f.tlo1, f.thi1);
+    } else {               // tail block: byte-packed, generic addressing
+        const FieldAddr a0 = field_addr(md, n, 2 * lane), a1 = field_addr(md, n, 2 * lane + 1);
+        const FieldAddr b0 = field_addr(mt, n, 2 * lane), b1 = field_addr(mt, n, 2 * lane + 1);
+        f.dlo0 = *reinterpret_cast<const uint32_t *>(body + a0.off0);
+        f.dhi0 = *reinterpret_cast<const uint32_t *>(body + a0.off1);
+        f.dlo1 = *reinterpret_cast<const uint32_t *>(body + a1.off0);
+        f.dhi1 = *reinterpret_cast<const uint32_t *>(body + a1.off1);
+        f.tlo0 = *reinterpret_cast<const uint32_t *>(tbody + b0.off0);
+        f.thi0 = *reinterpret_cast<const uint32_t *>(tbody + b0.off1);
+        f.tlo1 = *reinterpret_cast<const uint32_t *>(tbody + b1.off0);
+        f.thi1 = *reinterpret_cast<const uint32_t *>(tbody + b1.off1);
+    }
     f.fn = reinterpret_cast<const uint16_t *>(ix.post_fn + 128ull * j)[lane];
+}
+// fields of a fetched block: document-id deltas (or raw ids) and term frequencies
+__device__ __forceinline__ void block_fields(const uint4 bm, uint32_t lane, const BlockFetch &f,
+                                             uint32_t &v0, uint32_t &v1, uint32_t &f0, uint32_t &f1) {
+    const uint32_t n = bm.w & 0xff, md = (bm.w >> 8) & 0xff, mt = (bm.w >> 16) & 0xff;
+    if ((md >> 7) == 0) {
+        pair_extract(md & 127u, lane, f.dlo0, f.dhi0, f.dlo1, f.dhi1, v0, v1);
+        pair_extract(mt & 127u, lane, f.tlo0, f.thi0, f.tlo1, f.thi1, f0, f1);
+    } else {
+        v0 = field_val(f.dlo0, f.dhi0, field_addr(md, n, 2 * lane));
+        v1 = field_val(f.dlo1, f.dhi1, field_addr(md, n, 2 * lane + 1));
+        f0 = field_val(f.tlo0, f.thi0, field_addr(mt, n, 2 * lane));
+        f1 = field_val(f.tlo1, f.thi1, field_addr(mt, n, 2 * lane + 1));
+    }
 }
 
 // Reductions over lanes 0..15 (one DPP row); result valid in lane 15, broadcast with readlane.
@@ -624,6 +664,20 @@ __device__ __forceinline__ uint32_t row16_incl_sum(uint32_t v) {
     v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x114, 0xf, 0xf, false);
     v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x118, 0xf, 0xf, false);
     return v;
+}
+
+__device__ __forceinline__ double readlane_f64(double v, uint32_t src_lane) {  // src_lane uniform
+    const int lo = __builtin_amdgcn_readlane(__double2loint(v), (int)src_lane);
+    const int hi = __builtin_amdgcn_readlane(__double2hiint(v), (int)src_lane);
+    return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ uint32_t wave_shr1_u32(uint32_t v) {  // lane l gets lane l-1 (lane 0: itself)
+    return (uint32_t)__builtin_amdgcn_update_dpp((int)v, (int)v, 0x138, 0xf, 0xf, false);  // wave_shr:1
+}
+__device__ __forceinline__ double wave_shr1_f64(double v) {
+    const uint32_t lo = wave_shr1_u32((uint32_t)__double2loint(v));
+    const uint32_t hi = wave_shr1_u32((uint32_t)__double2hiint(v));
+    return __hiloint2double((int)hi, (int)lo);
 }
 
 // Workgroup barrier that orders LDS traffic only.  __syncthreads() also drains vmcnt, i.e. it
@@ -707,8 +761,15 @@ __global__ void __launch_bounds__(CWG, 4) scan_kernel(DevIndex ix, DevBatch bt) 
     __shared__ double st_p[C_POSTINGS];
     __shared__ uint16_t st_next[C_POSTINGS];
     __shared__ uint32_t s_slot[C_SLOTS];      // chain heads, slow path only
-    __shared__ uint32_t bm_seen[BM_WORDS];    // hashed doc bitmap: some posting of the tile
-    __shared__ uint32_t bm_multi[BM_WORDS];   // ... a second posting hit the same bit
+    // two independently hashed bitmap pairs per tile parity: "some posting hit this bit" /
+    // "a second posting hit it".  A posting is slow only if it collides under BOTH hashes.
+    __shared__ uint32_t bm_seen[2][2][BM_WORDS];
+    __shared__ uint32_t bm_multi[2][2][BM_WORDS];
+    // postings whose bit was hit twice ("slow"): joined exactly by the planner wave
+    __shared__ uint32_t sl_doc[2][SLOW_CAP];
+    __shared__ double sl_p[2][SLOW_CAP];
+    __shared__ uint16_t sl_idx[2][SLOW_CAP];
+    __shared__ uint32_t sl_cnt[2];
     __shared__ uint16_t s_cand[C_POSTINGS];
     __shared__ double c_score[2][FAST_CAND];
     __shared__ uint32_t c_doc[2][FAST_CAND];
@@ -729,13 +790,13 @@ __global__ void __launch_bounds__(CWG, 4) scan_kernel(DevIndex ix, DevBatch bt) 
     const uint32_t k = bt.k;
     for (int i = tid; i < 256; i += CWG) s_s1[i] = ix.s1[i];
     for (int i = tid; i < C_SLOTS; i += CWG) s_slot[i] = NONE32;
-    for (int i = tid; i < BM_WORDS; i += CWG) {
-        bm_seen[i] = 0;
-        bm_multi[i] = 0;
+    for (int i = tid; i < 4 * BM_WORDS; i += CWG) {
+        (&bm_seen[0][0][0])[i] = 0;
+        (&bm_multi[0][0][0])[i] = 0;
     }
 
 #ifdef VBM25_PROFILE
-    unsigned long long prof[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    unsigned long long prof[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
     const unsigned long long prof_t0 = __builtin_readcyclecounter();
 #endif
     const uint32_t n_items = *bt.n_items;
@@ -820,6 +881,7 @@ __global__ void __launch_bounds__(CWG, 4) scan_kernel(DevIndex ix, DevBatch bt) 
                 if (lane == 0) {
                     s_top.count = 0;
                     s_cand_cnt[0] = 0;
+                    sl_cnt[0] = 0;
                 }
             }
             const bool act = lane < m;
@@ -832,7 +894,6 @@ __global__ void __launch_bounds__(CWG, 4) scan_kernel(DevIndex ix, DevBatch bt) 
             // plan_finish(), which the caller runs after the next barrier
             auto plan_start = [&](uint32_t nb) {
                 const uint32_t hi_prev = p_hi;
-                PROF_T(hi_prev_t);
                 uint32_t nrb = p_rb;
                 if (act) {  // 1. drop blocks that end before the previous tile's end
                     while (nrb < p_re && s_ring[p_roff + (nrb & p_rmask)].y < hi_prev) ++nrb;
@@ -857,8 +918,7 @@ __global__ void __launch_bounds__(CWG, 4) scan_kernel(DevIndex ix, DevBatch bt) 
                     p_rb = nrb;
                 }
                 theta_next = __hip_atomic_load(&bt.theta[q], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                PROF_T(pm);
-                PROF_ADD(6, hi_prev_t, pm);
+                (void)0;
                 // 3. tile range
                 uint32_t lo_c = chi, hi_c = chi;
                 if (act && p_rb < p_end) {
@@ -901,6 +961,7 @@ __global__ void __launch_bounds__(CWG, 4) scan_kernel(DevIndex ix, DevBatch bt) 
                     s_nnew[nb] = tot_new;
                     s_done[nb] = lo_n >= chi ? 1u : 0u;
                     s_cand_cnt[nb] = 0;
+                    sl_cnt[nb] = 0;
                 }
                 p_hi = hi_n;
                 return lo_n >= chi;
@@ -914,25 +975,21 @@ __global__ void __launch_bounds__(CWG, 4) scan_kernel(DevIndex ix, DevBatch bt) 
             // running top-k: for k <= 64 one entry per lane in registers (sorted best first)
             double r_score = 0.0;
             uint32_t r_doc = NONE32, r_cnt = 0;
+            double kth_s = 0.0;   // k-th entry, uniform copies (valid once r_cnt == k)
+            uint32_t kth_d = 0;
             auto reg_offer = [&](bool has, double sc, uint32_t d) {
                 for (;;) {
-                    bool alive = has;
-                    if (alive && r_cnt >= k) {
-                        const double ks = __shfl(r_score, (int)k - 1);
-                        const uint32_t kd = __shfl(r_doc, (int)k - 1);
-                        alive = better(sc, d, ks, kd);
-                    }
+                    const bool alive = has && (r_cnt < k || better(sc, d, kth_s, kth_d));
                     const unsigned long long mask = __ballot(alive);
                     if (!mask) break;
-                    const int leader = __ffsll((long long)mask) - 1;
-                    const double cs = __shfl(sc, leader);
-                    const uint32_t cd = __shfl(d, leader);
-                    if ((int)lane == leader) has = false;
+                    const uint32_t leader = (uint32_t)__ffsll((long long)mask) - 1;
+                    const double cs = readlane_f64(sc, leader);
+                    const uint32_t cd = (uint32_t)__builtin_amdgcn_readlane((int)d, (int)leader);
+                    if (lane == leader) has = false;
                     const bool mine = lane < r_cnt && better(r_score, r_doc, cs, cd);
                     const uint32_t pos = (uint32_t)__popcll(__ballot(mine));  // sorted: a prefix
-                    if (pos >= k) continue;
-                    const double us = __shfl_up(r_score, 1);
-                    const uint32_t ud = __shfl_up(r_doc, 1);
+                    const double us = wave_shr1_f64(r_score);
+                    const uint32_t ud = wave_shr1_u32(r_doc);
                     if (lane > pos) {
                         r_score = us;
                         r_doc = ud;
@@ -941,6 +998,10 @@ __global__ void __launch_bounds__(CWG, 4) scan_kernel(DevIndex ix, DevBatch bt) 
                         r_doc = cd;
                     }
                     r_cnt = r_cnt < k ? r_cnt + 1 : k;
+                    if (r_cnt >= k) {
+                        kth_s = readlane_f64(r_score, k - 1);
+                        kth_d = (uint32_t)__builtin_amdgcn_readlane((int)r_doc, (int)k - 1);
+                    }
                 }
             };
             if (lane == 0) {
@@ -954,6 +1015,102 @@ __global__ void __launch_bounds__(CWG, 4) scan_kernel(DevIndex ix, DevBatch bt) 
             PROF_ADD(0, ps0, ps1);
             lds_barrier();  // S
             unsigned long long published = 0;
+            // exact join of the postings that collided under both hashes: each lane holds one
+            // (two past 64) of them and meets all the others through readlane (no LDS traffic).
+            // Group leader = smallest staging index = first key.
+            auto join = [&](auto nc_tag, const uint32_t par, const uint32_t nslow) {
+                constexpr int NC = decltype(nc_tag)::value;
+                uint32_t jd[NC], ji[NC], same[NC], minidx[NC], mate[NC];
+                double jp[NC];
+#pragma unroll
+                for (int c = 0; c < NC; ++c) {
+                    const uint32_t e = c * 64 + lane;
+                    const bool v = e < nslow;
+                    jd[c] = v ? sl_doc[par][e] : NONE32;
+                    ji[c] = v ? (uint32_t)sl_idx[par][e] : NONE32;
+                    jp[c] = v ? sl_p[par][e] : 0.0;
+                    same[c] = 0;
+                    minidx[c] = ji[c];
+                    mate[c] = 0;
+                }
+                PROF_T(m1);
+#pragma unroll
+                for (int c2 = 0; c2 < NC; ++c2) {
+                    const uint32_t n2 = min(64u, nslow - c2 * 64);
+                    for (uint32_t j = 0; j < n2; ++j) {
+                        const uint32_t dj = (uint32_t)__builtin_amdgcn_readlane((int)jd[c2], (int)j);
+                        const uint32_t ij = (uint32_t)__builtin_amdgcn_readlane((int)ji[c2], (int)j);
+#pragma unroll
+                        for (int c = 0; c < NC; ++c) {
+                            const bool hit = dj == jd[c] && ij != ji[c];
+                            same[c] += hit ? 1u : 0u;
+                            mate[c] = hit ? c2 * 64 + j : mate[c];
+                            minidx[c] = hit ? min(minidx[c], ij) : minidx[c];
+                        }
+                    }
+                }
+                PROF_T(m2);
+                PROF_ADD(9, m1, m2);
+#pragma unroll
+                for (int c = 0; c < NC; ++c) {
+                    const bool lead = jd[c] != NONE32 && minidx[c] == ji[c];
+                    double score = jp[c];
+                    if (__ballot(lead && same[c] >= 1)) {
+                        // partner's partial score (two addends commute)
+                        double op = 0.0;
+#pragma unroll
+                        for (int c2 = 0; c2 < NC; ++c2) {
+                            const double v = __shfl(jp[c2], (int)(mate[c] & 63));
+                            if ((mate[c] >> 6) == (uint32_t)c2) op = v;
+                        }
+                        if (lead && same[c] == 1) score = jp[c] + op;
+                    }
+                    if (__ballot(lead && same[c] >= 2)) {
+                        // three or more addends: ascending staging index = key order,
+                        // one pass over the list per addend
+                        double acc = 0.0;
+                        int last = -1;
+                        const bool l3 = lead && same[c] >= 2;
+                        for (;;) {
+                            uint32_t best = NONE32;
+                            double bp = 0.0;
+#pragma unroll
+                            for (int c2 = 0; c2 < NC; ++c2) {
+                                const uint32_t n2 = min(64u, nslow - c2 * 64);
+                                for (uint32_t j = 0; j < n2; ++j) {
+                                    const uint32_t dj = (uint32_t)__builtin_amdgcn_readlane((int)jd[c2], (int)j);
+                                    const uint32_t ij = (uint32_t)__builtin_amdgcn_readlane((int)ji[c2], (int)j);
+                                    const double pj = readlane_f64(jp[c2], j);
+                                    if (l3 && dj == jd[c] && (int)ij > last && ij < best) {
+                                        best = ij;
+                                        bp = pj;
+                                    }
+                                }
+                            }
+                            if (!__ballot(best != NONE32)) break;
+                            if (best != NONE32) {
+                                acc += bp;
+                                last = (int)best;
+                            }
+                        }
+                        if (l3) score = acc;
+                    }
+                    if (__ballot(lead)) {
+                        if constexpr (KMAX <= 64) reg_offer(lead, score, jd[c]);
+                        else topk_offer<KMAX>(s_top, k, lead, score, jd[c], lane);
+                    }
+                }
+            };
+            uint32_t pend_n = 0, pend_par = 0;  // slow list of the previous tile, joined one tile late
+            auto run_pending_join = [&]() {
+                if (!pend_n) return;
+                PROF_T(j0);
+                if (pend_n <= 64) join(std::integral_constant<int, 1>(), pend_par, pend_n);
+                else join(std::integral_constant<int, SLOW_CAP / 64>(), pend_par, pend_n);
+                pend_n = 0;
+                PROF_T(j1);
+                PROF_ADD(11, j0, j1);
+            };
             for (uint32_t par = 0; !done; par ^= 1) {
                 PROF_T(pa);
                 const bool next_done = plan_start(par ^ 1);
@@ -961,9 +1118,9 @@ __global__ void __launch_bounds__(CWG, 4) scan_kernel(DevIndex ix, DevBatch bt) 
                 lds_barrier();  // X: pass A of this tile is finished
                 PROF_T(pc);
                 plan_finish(par ^ 1);
+                run_pending_join();  // while the workers run pass B
                 PROF_T(pd);
                 lds_barrier();  // Y: pass B of this tile is finished
-                lds_barrier();  // Z: pass C (multi-term documents) is finished
                 PROF_T(pe);
                 PROF_ADD(1, pa, pb);
                 PROF_ADD(2, pb, pc);
@@ -972,7 +1129,22 @@ __global__ void __launch_bounds__(CWG, 4) scan_kernel(DevIndex ix, DevBatch bt) 
 #ifdef VBM25_PROFILE
                 prof[7] += 1;
 #endif
-                const uint32_t cnt = s_cand_cnt[par];
+                const uint32_t nslow = uni(sl_cnt[par]);
+#ifdef VBM25_PROFILE
+                prof[6] += nslow;
+#endif
+                if (nslow > (uint32_t)SLOW_CAP) {
+                    lds_barrier();  // F1: the workers join the tile themselves
+                    lds_barrier();  // F2
+                } else if (nslow) {
+                    pend_n = nslow;
+                    pend_par = par;
+                }
+                PROF_T(m4);
+                const uint32_t cnt = uni(s_cand_cnt[par]);
+#ifdef VBM25_PROFILE
+                prof[14] += cnt;
+#endif
                 for (uint32_t base = 0; base < cnt; base += 64) {
                     const bool has = base + lane < cnt;
                     double sc = 0;
@@ -990,14 +1162,16 @@ __global__ void __launch_bounds__(CWG, 4) scan_kernel(DevIndex ix, DevBatch bt) 
                     if constexpr (KMAX <= 64) reg_offer(has, sc, d);
                     else topk_offer<KMAX>(s_top, k, has, sc, d, lane);
                 }
-                if (cnt) {  // publish the new k-th entry to the workers and to the other chunks
+                PROF_T(m5);
+                PROF_ADD(12, m4, m5);
+                if (cnt || nslow) {  // publish the new k-th entry (joins show up one tile late) to the workers and to the other chunks
                     uint32_t n_now;
                     double ks = 0.0;
                     uint32_t kd = 0;
                     if constexpr (KMAX <= 64) {
                         n_now = r_cnt;
-                        ks = __shfl(r_score, (int)k - 1);
-                        kd = __shfl(r_doc, (int)k - 1);
+                        ks = kth_s;
+                        kd = kth_d;
                     } else {
                         n_now = s_top.count;
                         if (n_now >= k) {
@@ -1018,11 +1192,14 @@ __global__ void __launch_bounds__(CWG, 4) scan_kernel(DevIndex ix, DevBatch bt) 
                         }
                     }
                 }
+                PROF_T(m6);
+                PROF_ADD(13, m5, m6);
                 if (cnt > (uint32_t)FAST_CAND) lds_barrier();  // W: staging had to survive
                 PROF_T(pf);
                 PROF_ADD(5, pe, pf);
                 done = next_done;
             }
+            run_pending_join();
             if constexpr (KMAX <= 64) {  // chunk result straight from the registers
                 if (lane < r_cnt) {
                     bt.res_score[(size_t)item * k + lane] = r_score;
@@ -1060,19 +1237,11 @@ __global__ void __launch_bounds__(CWG, 4) scan_kernel(DevIndex ix, DevBatch bt) 
                         continue;
                     }
                     const uint4 bm = uni4(e_meta[par][e]);
-                    const uint32_t n = bm.w & 0xff, md = (bm.w >> 8) & 0xff, mt = (bm.w >> 16) & 0xff;
-#if VBM25_ABL == 5  // ablation: no payload loads, no field extraction
-                    BlockFetch f;
-                    f.fn = 0x3030;
-                    f.tlo0 = f.tlo1 = 1; f.thi0 = f.thi1 = 0;
-                    const uint32_t v0 = lane ? 3u : 0u, v1 = 2u;
-                    (void)fetched;
-#else
+                    const uint32_t n = bm.w & 0xff, md = (bm.w >> 8) & 0xff;
                     if (!fetched) block_fetch(ix, bm, uni(e_j[par][e]), lane, fetch[r]);
                     const BlockFetch &f = fetch[r];
-                    const uint32_t v0 = field_val(f.dlo0, f.dhi0, field_addr(md, n, 2 * lane));
-                    const uint32_t v1 = field_val(f.dlo1, f.dhi1, field_addr(md, n, 2 * lane + 1));
-#endif
+                    uint32_t v0, v1, f0, f1;
+                    block_fields(bm, lane, f, v0, v1, f0, f1);
                     uint32_t d0 = v0, d1 = v1;
                     const uint32_t width = md & 127u;
                     if (!((md >> 7) ? (width == 4) : (width == 32))) {  // d1 deltas from min_doc
@@ -1081,13 +1250,6 @@ __global__ void __launch_bounds__(CWG, 4) scan_kernel(DevIndex ix, DevBatch bt) 
                         d0 = bm.x + (incl - own) + v0;
                         d1 = d0 + v1;
                     }
-#if VBM25_ABL == 5
-                    const uint32_t f0 = 1, f1 = 1;
-                    (void)mt;
-#else
-                    const uint32_t f0 = field_val(f.tlo0, f.thi0, field_addr(mt, n, 2 * lane));
-                    const uint32_t f1 = field_val(f.tlo1, f.thi1, field_addr(mt, n, 2 * lane + 1));
-#endif
                     const double s0 = t_s0[uni(e_t[par][e])];
                     const double tf0 = (double)f0, tf1 = (double)f1;
                     double2 pp;
@@ -1111,42 +1273,48 @@ __global__ void __launch_bounds__(CWG, 4) scan_kernel(DevIndex ix, DevBatch bt) 
                 PROF_T(wb);
                 // ---- pass A.2: mark every posting of [lo, hi) in the hashed bitmaps.  A bit that
                 // was already set means "another posting may belong to the same document".
-                uint32_t bw[4], bb[4];
+                uint32_t bw[4], bb[4], cw[4], cb[4];
 #pragma unroll
                 for (int x = 0; x < 4; ++x) {
                     const uint32_t d = dd[x];
                     const uint32_t h = (d * 0x9E3779B1u) >> (32 - BM_BITS_LOG2);
+                    const uint32_t g = (d * 0x85EBCA6Bu + 0x27D4EB2Fu) >> (32 - BM_BITS_LOG2);
                     bw[x] = h >> 5;
+                    cw[x] = g >> 5;
 #if VBM25_ABL == 4  // ablation: no join at all (decode + staging only)
                     bb[x] = 0u;
 #else
                     bb[x] = (d >= lo && d < hi) ? 1u << (h & 31) : 0u;  // NONE32 never is in range
 #endif
+                    cb[x] = bb[x] ? 1u << (g & 31) : 0u;
                 }
 #pragma unroll
-                for (int x = 0; x < 4; ++x)
-                    if (bb[x] && (atomicOr(&bm_seen[bw[x]], bb[x]) & bb[x])) atomicOr(&bm_multi[bw[x]], bb[x]);
+                for (int x = 0; x < 4; ++x) {
+                    if (!bb[x]) continue;
+                    const uint32_t o1 = atomicOr(&bm_seen[par][0][bw[x]], bb[x]);
+                    const uint32_t o2 = atomicOr(&bm_seen[par][1][cw[x]], cb[x]);
+                    if (o1 & bb[x]) atomicOr(&bm_multi[par][0][bw[x]], bb[x]);
+                    if (o2 & cb[x]) atomicOr(&bm_multi[par][1][cw[x]], cb[x]);
+                }
                 PROF_T(wc);
                 lds_barrier();  // X
                 PROF_T(wd);
 
-                // ---- the next tile's new blocks: start their loads now, decode after Z
+                // ---- the next tile's new blocks: start their loads now, decode after Y
                 fetched = false;
                 if (!uni(s_done[par ^ 1])) {
                     const uint32_t nn = uni(s_nnew[par ^ 1]);
 #pragma unroll
                     for (int r = 0; r < 2; ++r) {
                         const uint32_t e = wave + r * CNW;
-#if VBM25_ABL != 5
                         if (e < nn) block_fetch(ix, uni4(e_meta[par ^ 1][e]), uni(e_j[par ^ 1][e]), lane, fetch[r]);
-#endif
                     }
                     fetched = true;
                 }
-
                 PROF_T(wd1);
+
                 // ---- pass B: a document whose bit nobody else hit has a single posting: its
-                // partial score IS its score.  The others are linked into chains (lock-free).
+                // partial score IS its score.  The others go to the planner's exact join.
                 const unsigned long long theta = s_theta[par];
                 const uint32_t ntop = s_top_cnt;
                 const double ws = s_kth_score;
@@ -1162,23 +1330,40 @@ __global__ void __launch_bounds__(CWG, 4) scan_kernel(DevIndex ix, DevBatch bt) 
                         c_doc[par][at] = d;
                     }
                 };
-                uint32_t slot[4], head[4];
-                bool any_slow = false;
+                uint32_t slow_mask = 0;
 #pragma unroll
                 for (int x = 0; x < 4; ++x) {
-                    slot[x] = NONE32;
-                    head[x] = NONE32;
                     if (!bb[x]) continue;
-                    if (!(bm_multi[bw[x]] & bb[x])) {
-                        offer(st_p[ii[x]], dd[x], ii[x]);
+                    const double p = st_p[ii[x]];
+                    if (!((bm_multi[par][0][bw[x]] & bb[x]) && (bm_multi[par][1][cw[x]] & cb[x]))) {
+                        offer(p, dd[x], ii[x]);
                     } else {
-                        slot[x] = (dd[x] * 0x85EBCA6Bu) >> (32 - C_SLOTS_LOG2);
-                        st_next[ii[x]] = NONE16;
-                        head[x] = atomicCAS(&s_slot[slot[x]], NONE32, ii[x]);
-                        any_slow = true;
+                        slow_mask |= 1u << x;
+                        const uint32_t at = atomicAdd(&sl_cnt[par], 1u);
+                        if (at < (uint32_t)SLOW_CAP) {
+                            sl_doc[par][at] = dd[x];
+                            sl_p[par][at] = p;
+                            sl_idx[par][at] = (uint16_t)ii[x];
+                        }
                     }
                 }
-                if (__any(any_slow)) {
+                PROF_T(we);
+                lds_barrier();  // Y
+                PROF_T(we1);
+                const uint32_t nslow = uni(sl_cnt[par]);
+                if (nslow > (uint32_t)SLOW_CAP) {
+                    // ---- fallback (dense tiles): the workers join the slow postings themselves
+                    uint32_t slot[4], head[4];
+#pragma unroll
+                    for (int x = 0; x < 4; ++x) {
+                        slot[x] = NONE32;
+                        head[x] = NONE32;
+                        if (slow_mask & (1u << x)) {
+                            slot[x] = (dd[x] * 0x85EBCA6Bu) >> (32 - C_SLOTS_LOG2);
+                            st_next[ii[x]] = NONE16;
+                            head[x] = atomicCAS(&s_slot[slot[x]], NONE32, ii[x]);
+                        }
+                    }
                     for (;;) {
                         bool pending = false;
 #pragma unroll
@@ -1197,17 +1382,7 @@ __global__ void __launch_bounds__(CWG, 4) scan_kernel(DevIndex ix, DevBatch bt) 
                         }
                         if (!pending) break;
                     }
-                }
-                PROF_T(we);
-                lds_barrier();  // Y
-                PROF_T(we1);
-
-                // ---- pass C: chain heads add up their document and offer it; bitmaps are wiped
-                for (int i = tid; i < BM_WORDS / 4; i += CNW * 64) {
-                    reinterpret_cast<uint4 *>(bm_seen)[i] = make_uint4(0, 0, 0, 0);
-                    reinterpret_cast<uint4 *>(bm_multi)[i] = make_uint4(0, 0, 0, 0);
-                }
-                if (__any(any_slow)) {
+                    lds_barrier();  // F1
 #pragma unroll
                     for (int x = 0; x < 4; ++x) {
                         const uint32_t i = ii[x];
@@ -1234,9 +1409,14 @@ __global__ void __launch_bounds__(CWG, 4) scan_kernel(DevIndex ix, DevBatch bt) 
                         s_slot[slot[x]] = NONE32;
                         offer(score, dd[x], i);
                     }
+                    lds_barrier();  // F2
+                }
+                // this tile's bitmaps are used again two tiles from now: wipe them
+                for (int i = tid; i < 2 * BM_WORDS / 4; i += CNW * 64) {
+                    reinterpret_cast<uint4 *>(&bm_seen[par][0][0])[i] = make_uint4(0, 0, 0, 0);
+                    reinterpret_cast<uint4 *>(&bm_multi[par][0][0])[i] = make_uint4(0, 0, 0, 0);
                 }
                 PROF_T(we2);
-                lds_barrier();  // Z
                 if (s_cand_cnt[par] > (uint32_t)FAST_CAND) lds_barrier();  // W
                 PROF_T(wf);
                 PROF_ADD(0, wa, wc);    // A1 + A2
@@ -1265,9 +1445,9 @@ __global__ void __launch_bounds__(CWG, 4) scan_kernel(DevIndex ix, DevBatch bt) 
 #ifdef VBM25_PROFILE
     // per workgroup: 8 counters of worker wave 0, 8 of the planner wave, total cycles
     if (bt.prof && lane == 0 && (wave == 0 || wave == PLANNER)) {
-        unsigned long long *o = bt.prof + (size_t)blockIdx.x * 17 + (wave == 0 ? 0 : 8);
-        for (int i = 0; i < 8; ++i) o[i] = prof[i];
-        if (wave == 0) bt.prof[(size_t)blockIdx.x * 17 + 16] = __builtin_readcyclecounter() - prof_t0;
+        unsigned long long *o = bt.prof + (size_t)blockIdx.x * 33 + (wave == 0 ? 0 : 16);
+        for (int i = 0; i < 16; ++i) o[i] = prof[i];
+        if (wave == 0) bt.prof[(size_t)blockIdx.x * 33 + 32] = __builtin_readcyclecounter() - prof_t0;
     }
 #endif
 }
@@ -1583,8 +1763,8 @@ int vbm25_batch_create(vbm25_index *ix, uint32_t max_queries, uint32_t max_total
         return rc;
     HIP_TRY(hipMemset(bt->error_flag.p, 0, 4));
 #ifdef VBM25_PROFILE
-    if (int rc2 = bt->prof.alloc(8ull * 17 * TARGET_ITEMS)) return rc2;
-    HIP_TRY(hipMemset(bt->prof.p, 0, 8ull * 17 * TARGET_ITEMS));
+    if (int rc2 = bt->prof.alloc(8ull * 33 * TARGET_ITEMS)) return rc2;
+    HIP_TRY(hipMemset(bt->prof.p, 0, 8ull * 33 * TARGET_ITEMS));
 #endif
     *out = bt.release();
     return VBM25_OK;
@@ -1728,7 +1908,7 @@ int vbm25_scan_occupancy(void) {
 // profiling builds only (not declared in include/vbm25.h): copy out the phase counters
 int vbm25_batch_profile(vbm25_batch *bt, unsigned long long *out, uint32_t n_workgroups) {
     HIP_TRY(hipDeviceSynchronize());
-    HIP_TRY(hipMemcpy(out, bt->prof.p, 8ull * 17 * n_workgroups, hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(out, bt->prof.p, 8ull * 33 * n_workgroups, hipMemcpyDeviceToHost));
     return VBM25_OK;
 }
 #endif
