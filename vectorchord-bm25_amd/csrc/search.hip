@@ -24,6 +24,7 @@
 #include <algorithm>
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <memory>
 #include <vector>
@@ -68,8 +69,9 @@ struct DevIndex {
 };
 
 struct Item {
-    uint32_t q, doc_lo, doc_hi, m;  // m = number of indexed terms of query q
+    uint32_t q, doc_lo, doc_hi, m;  // m = number of indexed terms of query q | ITEM_DENSE
 };
+constexpr uint32_t ITEM_DENSE = 0x80000000u;  // postings per document high: dense-window path
 
 struct DevBatch {
     const uint32_t *term_ids;
@@ -85,7 +87,8 @@ struct DevBatch {
     vbm25_hit *hits;
     uint32_t *n_hits;
     uint32_t *error_flag;
-    unsigned long long *prof;  // VBM25_PROFILE builds: 17 counters per workgroup
+    const uint8_t *q_dense;    // per query: 1 = dense (many postings per document), host decided
+    unsigned long long *prof;  // VBM25_PROFILE builds: 33 counters per workgroup
 };
 
 constexpr int WG = 256;
@@ -109,6 +112,7 @@ constexpr int CHAIN_MAX_TERMS = C_BLOCKS;  // queries with more indexed terms us
 constexpr int SLOW_CAP = 128;             // postings per tile joined exactly by the planner wave
 constexpr int BM_BITS_LOG2 = 15;          // hashed document bitmaps: 32768 bits each
 constexpr int BM_WORDS = (1 << BM_BITS_LOG2) / 32;
+constexpr int REG_K = 256;                // largest k whose running top-k lives in registers
 constexpr uint32_t NONE32 = 0xffffffffu;
 constexpr uint16_t NONE16 = 0xffffu;
 
@@ -280,6 +284,7 @@ __global__ void __launch_bounds__(PLAN_WG) plan_kernel(DevIndex ix, DevBatch bt,
         const uint32_t c = chunks_of(q);
         uint32_t nterms = 0;
         for (uint32_t p = bt.q_off[q]; p < bt.q_off[q + 1]; ++p) nterms += bt.term_ids[p] < ix.n_terms;
+        if (bt.q_dense[q]) nterms |= ITEM_DENSE;
         bt.q_item_base[q] = min(base, max_items);
         for (uint32_t i = 0; i < c && base + i < max_items; ++i) {
             Item it;
@@ -386,6 +391,7 @@ __global__ void __launch_bounds__(WG) scan_many_kernel(DevIndex ix, DevBatch bt)
     for (uint32_t item = blockIdx.x; item < n_items; item += gridDim.x) {
         const Item it = bt.items[item];
         if (it.m <= (uint32_t)CHAIN_MAX_TERMS) continue;  // handled by scan_kernel
+        const bool force_dense = (it.m & ITEM_DENSE) != 0;
         const uint32_t q = it.q, clo = it.doc_lo, chi = it.doc_hi;
         __syncthreads();  // previous item fully done with LDS
         if (tid == 0) {
@@ -404,7 +410,7 @@ __global__ void __launch_bounds__(WG) scan_many_kernel(DevIndex ix, DevBatch bt)
             s_m = m;
             s_sumdf = sum;
             s_top.count = 0;
-            s_dense = (m >= (uint32_t)CAP_BLOCKS) ? 1u : 0u;
+            s_dense = (force_dense || m >= (uint32_t)CAP_BLOCKS) ? 1u : 0u;
         }
         __syncthreads();
         const uint32_t m = s_m;
@@ -680,6 +686,75 @@ __device__ __forceinline__ double wave_shr1_f64(double v) {
     return __hiloint2double((int)hi, (int)lo);
 }
 
+// ---------------------------------------------------------------------------
+// Running top-k of ONE wave held in registers: RK rows of 64 entries, sorted best first, entry e
+// in row e / 64 at lane e % 64.  Insert = ballot/popcount for the position, DPP wave shift,
+// rows chained through lane 63 -> lane 0.  No LDS traffic.
+// ---------------------------------------------------------------------------
+template <int RK>
+struct RegTopK {
+    double score[RK];
+    uint32_t doc[RK];
+    uint32_t cnt;
+    double kth_s;   // k-th entry, uniform copies (valid once cnt == k)
+    uint32_t kth_d;
+    __device__ __forceinline__ void init() {
+#pragma unroll
+        for (int r = 0; r < RK; ++r) {
+            score[r] = 0.0;
+            doc[r] = NONE32;
+        }
+        cnt = 0;
+        kth_s = 0.0;
+        kth_d = 0;
+    }
+    // offer one candidate per lane (`has` marks validity); all 64 lanes call
+    __device__ __forceinline__ void offer(bool has, double sc, uint32_t d, uint32_t k, uint32_t lane) {
+        for (;;) {
+            const bool alive = has && (cnt < k || better(sc, d, kth_s, kth_d));
+            const unsigned long long mask = __ballot(alive);
+            if (!mask) break;
+            const uint32_t leader = (uint32_t)__ffsll((long long)mask) - 1;
+            const double cs = readlane_f64(sc, leader);
+            const uint32_t cd = (uint32_t)__builtin_amdgcn_readlane((int)d, (int)leader);
+            if (lane == leader) has = false;
+            uint32_t pos = 0;  // entries better than the candidate: a prefix of the list
+#pragma unroll
+            for (int r = 0; r < RK; ++r)
+                pos += (uint32_t)__popcll(__ballot(r * 64 + lane < cnt && better(score[r], doc[r], cs, cd)));
+            double carry_s = 0.0;
+            uint32_t carry_d = NONE32;
+#pragma unroll
+            for (int r = 0; r < RK; ++r) {
+                const double us = wave_shr1_f64(score[r]);
+                const uint32_t ud = wave_shr1_u32(doc[r]);
+                const double out_s = readlane_f64(score[r], 63);
+                const uint32_t out_d = (uint32_t)__builtin_amdgcn_readlane((int)doc[r], 63);
+                const uint32_t e = r * 64 + lane;
+                if (e > pos) {
+                    score[r] = lane == 0 ? carry_s : us;
+                    doc[r] = lane == 0 ? carry_d : ud;
+                } else if (e == pos) {
+                    score[r] = cs;
+                    doc[r] = cd;
+                }
+                carry_s = out_s;
+                carry_d = out_d;
+            }
+            cnt = cnt < k ? cnt + 1 : k;
+            if (cnt >= k) {
+#pragma unroll
+                for (int r = 0; r < RK; ++r)
+                    if ((k - 1) / 64 == (uint32_t)r) {
+                        kth_s = readlane_f64(score[r], (k - 1) & 63);
+                        kth_d = (uint32_t)__builtin_amdgcn_readlane((int)doc[r], (int)((k - 1) & 63));
+                    }
+            }
+        }
+    }
+};
+
+
 // Workgroup barrier that orders LDS traffic only.  __syncthreads() also drains vmcnt, i.e. it
 // would wait for every global load in flight (the planner's metadata refills, the threshold
 // poll); all hand-offs inside the tile loop go through LDS.
@@ -774,7 +849,7 @@ __global__ void __launch_bounds__(CWG, 4) scan_kernel(DevIndex ix, DevBatch bt) 
     __shared__ double c_score[2][FAST_CAND];
     __shared__ uint32_t c_doc[2][FAST_CAND];
     __shared__ double s_s1[256];
-    __shared__ TopK<KMAX> s_top;
+    __shared__ TopK<(KMAX > REG_K ? KMAX : 1)> s_top;  // LDS list only for k > REG_K
     __shared__ uint4 s_ring[RING];
     __shared__ uint4 e_meta[2][C_BLOCKS];     // entries of a tile: new blocks first, then carried
     __shared__ uint32_t e_j[2][C_BLOCKS];
@@ -802,7 +877,7 @@ __global__ void __launch_bounds__(CWG, 4) scan_kernel(DevIndex ix, DevBatch bt) 
     const uint32_t n_items = *bt.n_items;
     for (uint32_t item = blockIdx.x; item < n_items; item += gridDim.x) {
         const Item it = bt.items[item];
-        if (it.m > (uint32_t)T) continue;  // scan_many_kernel's
+        if (it.m > (uint32_t)T) continue;  // many terms or dense: scan_many_kernel's
         const uint32_t q = it.q, clo = it.doc_lo, chi = it.doc_hi;
         __syncthreads();
 
@@ -972,38 +1047,11 @@ __global__ void __launch_bounds__(CWG, 4) scan_kernel(DevIndex ix, DevBatch bt) 
                 if (lane == 0) s_theta[nb] = theta_next;
             };
 
-            // running top-k: for k <= 64 one entry per lane in registers (sorted best first)
-            double r_score = 0.0;
-            uint32_t r_doc = NONE32, r_cnt = 0;
-            double kth_s = 0.0;   // k-th entry, uniform copies (valid once r_cnt == k)
-            uint32_t kth_d = 0;
-            auto reg_offer = [&](bool has, double sc, uint32_t d) {
-                for (;;) {
-                    const bool alive = has && (r_cnt < k || better(sc, d, kth_s, kth_d));
-                    const unsigned long long mask = __ballot(alive);
-                    if (!mask) break;
-                    const uint32_t leader = (uint32_t)__ffsll((long long)mask) - 1;
-                    const double cs = readlane_f64(sc, leader);
-                    const uint32_t cd = (uint32_t)__builtin_amdgcn_readlane((int)d, (int)leader);
-                    if (lane == leader) has = false;
-                    const bool mine = lane < r_cnt && better(r_score, r_doc, cs, cd);
-                    const uint32_t pos = (uint32_t)__popcll(__ballot(mine));  // sorted: a prefix
-                    const double us = wave_shr1_f64(r_score);
-                    const uint32_t ud = wave_shr1_u32(r_doc);
-                    if (lane > pos) {
-                        r_score = us;
-                        r_doc = ud;
-                    } else if (lane == pos) {
-                        r_score = cs;
-                        r_doc = cd;
-                    }
-                    r_cnt = r_cnt < k ? r_cnt + 1 : k;
-                    if (r_cnt >= k) {
-                        kth_s = readlane_f64(r_score, k - 1);
-                        kth_d = (uint32_t)__builtin_amdgcn_readlane((int)r_doc, (int)k - 1);
-                    }
-                }
-            };
+            // running top-k: for k <= REG_K in registers (RegTopK), else a sorted list in LDS
+            constexpr int RK = KMAX <= REG_K ? KMAX / 64 : 1;
+            RegTopK<RK> rtop;
+            rtop.init();
+            auto reg_offer = [&](bool has, double sc, uint32_t d) { rtop.offer(has, sc, d, k, lane); };
             if (lane == 0) {
                 s_top_cnt = 0;
                 s_kth_score = 0.0;
@@ -1096,8 +1144,8 @@ __global__ void __launch_bounds__(CWG, 4) scan_kernel(DevIndex ix, DevBatch bt) 
                         if (l3) score = acc;
                     }
                     if (__ballot(lead)) {
-                        if constexpr (KMAX <= 64) reg_offer(lead, score, jd[c]);
-                        else topk_offer<KMAX>(s_top, k, lead, score, jd[c], lane);
+                        if constexpr (KMAX <= REG_K) reg_offer(lead, score, jd[c]);
+                        else topk_offer<(KMAX > REG_K ? KMAX : 1)>(s_top, k, lead, score, jd[c], lane);
                     }
                 }
             };
@@ -1159,8 +1207,8 @@ __global__ void __launch_bounds__(CWG, 4) scan_kernel(DevIndex ix, DevBatch bt) 
                             d = st_doc[i];
                         }
                     }
-                    if constexpr (KMAX <= 64) reg_offer(has, sc, d);
-                    else topk_offer<KMAX>(s_top, k, has, sc, d, lane);
+                    if constexpr (KMAX <= REG_K) reg_offer(has, sc, d);
+                    else topk_offer<(KMAX > REG_K ? KMAX : 1)>(s_top, k, has, sc, d, lane);
                 }
                 PROF_T(m5);
                 PROF_ADD(12, m4, m5);
@@ -1168,10 +1216,10 @@ __global__ void __launch_bounds__(CWG, 4) scan_kernel(DevIndex ix, DevBatch bt) 
                     uint32_t n_now;
                     double ks = 0.0;
                     uint32_t kd = 0;
-                    if constexpr (KMAX <= 64) {
-                        n_now = r_cnt;
-                        ks = kth_s;
-                        kd = kth_d;
+                    if constexpr (KMAX <= REG_K) {
+                        n_now = rtop.cnt;
+                        ks = rtop.kth_s;
+                        kd = rtop.kth_d;
                     } else {
                         n_now = s_top.count;
                         if (n_now >= k) {
@@ -1200,12 +1248,16 @@ __global__ void __launch_bounds__(CWG, 4) scan_kernel(DevIndex ix, DevBatch bt) 
                 done = next_done;
             }
             run_pending_join();
-            if constexpr (KMAX <= 64) {  // chunk result straight from the registers
-                if (lane < r_cnt) {
-                    bt.res_score[(size_t)item * k + lane] = r_score;
-                    bt.res_doc[(size_t)item * k + lane] = r_doc;
+            if constexpr (KMAX <= REG_K) {  // chunk result straight from the registers
+#pragma unroll
+                for (int r = 0; r < RK; ++r) {
+                    const uint32_t e = r * 64 + lane;
+                    if (e < rtop.cnt) {
+                        bt.res_score[(size_t)item * k + e] = rtop.score[r];
+                        bt.res_doc[(size_t)item * k + e] = rtop.doc[r];
+                    }
                 }
-                if (lane == 0) bt.res_cnt[item] = r_cnt;
+                if (lane == 0) bt.res_cnt[item] = rtop.cnt;
             }
         } else {
             // =====================================================================
@@ -1433,7 +1485,7 @@ __global__ void __launch_bounds__(CWG, 4) scan_kernel(DevIndex ix, DevBatch bt) 
         }
 
         __syncthreads();
-        if constexpr (KMAX > 64) {
+        if constexpr (KMAX > REG_K) {
             const uint32_t n = s_top.count;
             for (uint32_t i = tid; i < n; i += CWG) {
                 bt.res_score[(size_t)item * k + i] = s_top.score[i];
@@ -1457,13 +1509,16 @@ __global__ void __launch_bounds__(CWG, 4) scan_kernel(DevIndex ix, DevBatch bt) 
 // ---------------------------------------------------------------------------
 template <int KMAX>
 __global__ void __launch_bounds__(64) merge_kernel(DevIndex ix, DevBatch bt) {
-    __shared__ TopK<KMAX> s_top;
+    __shared__ TopK<(KMAX > REG_K ? KMAX : 1)> s_top;
+    constexpr int RK = KMAX <= REG_K ? KMAX / 64 : 1;
+    RegTopK<RK> rtop;
+    rtop.init();
     const uint32_t q = blockIdx.x, lane = threadIdx.x, k = bt.k;
     if (lane == 0) s_top.count = 0;
     __builtin_amdgcn_wave_barrier();
     const uint32_t i0 = bt.q_item_base[q], i1 = bt.q_item_base[q + 1];
     for (uint32_t item = i0; item < i1; ++item) {
-        const uint32_t cnt = bt.res_cnt[item];
+        const uint32_t cnt = uni(bt.res_cnt[item]);
         for (uint32_t base = 0; base < cnt; base += 64) {
             const bool has = base + lane < cnt;
             double sc = 0;
@@ -1472,19 +1527,28 @@ __global__ void __launch_bounds__(64) merge_kernel(DevIndex ix, DevBatch bt) {
                 sc = bt.res_score[(size_t)item * k + base + lane];
                 d = bt.res_doc[(size_t)item * k + base + lane];
             }
-            topk_offer<KMAX>(s_top, k, has, sc, d, lane);
+            if constexpr (KMAX <= REG_K) rtop.offer(has, sc, d, k, lane);
+            else topk_offer<(KMAX > REG_K ? KMAX : 1)>(s_top, k, has, sc, d, lane);
         }
     }
     __builtin_amdgcn_wave_barrier();
-    const uint32_t n = s_top.count;
-    for (uint32_t i = lane; i < n; i += 64) {
+    auto emit = [&](uint32_t i, double sc, uint32_t d) {
         // 24-byte record written as three 64-bit words so that padding bytes are zero
-        const uint32_t d = s_top.doc[i];
         const uint16_t *pl = ix.doc_payload + 3ull * d;
         unsigned long long *out = reinterpret_cast<unsigned long long *>(bt.hits + (size_t)q * k + i);
-        out[0] = (unsigned long long)__double_as_longlong(s_top.score[i]);
+        out[0] = (unsigned long long)__double_as_longlong(sc);
         out[1] = (unsigned long long)d | (unsigned long long)pl[0] << 32 | (unsigned long long)pl[1] << 48;
         out[2] = (unsigned long long)pl[2];
+    };
+    uint32_t n;
+    if constexpr (KMAX <= REG_K) {
+        n = rtop.cnt;
+#pragma unroll
+        for (int r = 0; r < RK; ++r)
+            if (r * 64 + lane < n) emit(r * 64 + lane, rtop.score[r], rtop.doc[r]);
+    } else {
+        n = s_top.count;
+        for (uint32_t i = lane; i < n; i += 64) emit(i, s_top.score[i], s_top.doc[i]);
     }
     if (lane == 0) bt.n_hits[q] = n;
 }
@@ -1523,6 +1587,7 @@ struct vbm25_index {
     DevIndex dev{};
     uint32_t n_docs = 0, n_terms = 0, n_blocks = 0;
     std::vector<uint8_t> term_key;  // host copy for vbm25_lookup_terms
+    std::vector<uint32_t> term_df_host;  // host copy for query routing
     DeviceBuffer term_df, term_first_block, term_s0, blk_min_doc, blk_max_doc, blk_meta, blob,
         post_fn, doc_payload, s1;
     uint64_t device_bytes = 0;
@@ -1532,7 +1597,7 @@ struct vbm25_batch {
     vbm25_index *index = nullptr;
     uint32_t max_queries = 0, max_terms = 0, k = 0, nq = 0, max_items = 0;
     DeviceBuffer term_ids, q_off, items, n_items, q_item_base, theta, res_score, res_doc, res_cnt,
-        hits, n_hits, error_flag, prof;
+        hits, n_hits, error_flag, prof, q_dense;
     bool timing = false;
     bool has_many_terms = false;  // some query has more than CHAIN_MAX_TERMS indexed terms
     std::vector<std::pair<hipEvent_t, hipEvent_t>> events;
@@ -1612,6 +1677,8 @@ int use_device(int device) {
 template <class F>
 int dispatch_k(uint32_t k, F &&f) {
     if (k <= 64) return f(std::integral_constant<int, 64>());
+    if (k <= 128) return f(std::integral_constant<int, 128>());
+    if (k <= 256) return f(std::integral_constant<int, 256>());
     return f(std::integral_constant<int, 1024>());
 }
 
@@ -1644,6 +1711,7 @@ int vbm25_index_create(const vbm25_index_desc *d, int device, vbm25_index **out)
     ix->n_terms = d->n_terms;
     ix->n_blocks = d->n_blocks;
     ix->term_key.assign(d->term_key, d->term_key + 16ull * d->n_terms);
+    ix->term_df_host.assign(d->term_df, d->term_df + d->n_terms);
 
     std::vector<double> s0(d->n_terms);
     for (uint32_t t = 0; t < d->n_terms; ++t) s0[t] = bm25_s0(d->n_docs, d->term_df[t], d->k1);
@@ -1759,7 +1827,8 @@ int vbm25_batch_create(vbm25_index *ix, uint32_t max_queries, uint32_t max_total
         (rc = bt->res_doc.alloc(4ull * bt->max_items * k)) ||
         (rc = bt->res_cnt.alloc(4ull * bt->max_items)) ||
         (rc = bt->hits.alloc(sizeof(vbm25_hit) * size_t(max_queries) * k)) ||
-        (rc = bt->n_hits.alloc(4ull * max_queries)) || (rc = bt->error_flag.alloc(4)))
+        (rc = bt->n_hits.alloc(4ull * max_queries)) || (rc = bt->error_flag.alloc(4)) ||
+        (rc = bt->q_dense.alloc(max_queries)))
         return rc;
     HIP_TRY(hipMemset(bt->error_flag.p, 0, 4));
 #ifdef VBM25_PROFILE
@@ -1782,13 +1851,25 @@ int vbm25_batch_set_queries(vbm25_batch *bt, const uint32_t *term_ids, const uin
     if (nq > bt->max_queries) return set_error(VBM25_ERR_INVALID, "%u queries exceed the batch capacity %u", nq, bt->max_queries);
     if (q_off[0] != 0) return set_error(VBM25_ERR_INVALID, "q_off[0] must be 0");
     bool many = false;
+    // Routing: the chain kernel is built for sparse queries; a query with many postings per
+    // document (Zipf head terms) or more than CHAIN_MAX_TERMS indexed terms takes the
+    // dense-window kernel.  Tuning knob: VBM25_DENSE_X1000 (postings per 1000 documents).
+    const char *env = std::getenv("VBM25_DENSE_X1000");
+    const unsigned long long dense_x1000 = env ? (unsigned long long)std::atoll(env) : 100ull;
+    std::vector<uint8_t> dense(nq, 0);
     for (uint32_t q = 0; q < nq; ++q) {
         if (q_off[q + 1] < q_off[q]) return set_error(VBM25_ERR_INVALID, "q_off not monotone at query %u", q);
         uint32_t valid = 0;
+        unsigned long long postings = 0;
         for (uint32_t p = q_off[q]; p < q_off[q + 1]; ++p) {
             if (p > q_off[q] && term_ids[p] <= term_ids[p - 1])  // Query::checked_new, vector.rs:106-110
                 return set_error(VBM25_ERR_INVALID, "query %u: term ids must be strictly ascending", q);
             valid += term_ids[p] < bt->index->n_terms;
+            if (term_ids[p] < bt->index->n_terms) postings += bt->index->term_df_host[term_ids[p]];
+        }
+        if (postings * 1000ull >= dense_x1000 * bt->index->n_docs) {
+            dense[q] = 1;
+            many = true;
         }
         many |= valid > (uint32_t)CHAIN_MAX_TERMS;
         if (valid > MAX_TERMS)
@@ -1798,6 +1879,7 @@ int vbm25_batch_set_queries(vbm25_batch *bt, const uint32_t *term_ids, const uin
     if (int rc = use_device(bt->index->device)) return rc;
     if (q_off[nq]) HIP_TRY(hipMemcpy(bt->term_ids.p, term_ids, 4ull * q_off[nq], hipMemcpyHostToDevice));
     HIP_TRY(hipMemcpy(bt->q_off.p, q_off, 4ull * (nq + 1), hipMemcpyHostToDevice));
+    if (nq) HIP_TRY(hipMemcpy(bt->q_dense.p, dense.data(), nq, hipMemcpyHostToDevice));
     bt->nq = nq;
     bt->has_many_terms = many;
     return VBM25_OK;
@@ -1823,6 +1905,7 @@ int vbm25_batch_run(vbm25_batch *bt, void *hip_stream) {
     db.hits = bt->hits.as<vbm25_hit>();
     db.n_hits = bt->n_hits.as<uint32_t>();
     db.error_flag = bt->error_flag.as<uint32_t>();
+    db.q_dense = bt->q_dense.as<uint8_t>();
     db.prof = bt->prof.as<unsigned long long>();
     const DevIndex &ix = bt->index->dev;
     HIP_TRY(hipMemsetAsync(bt->theta.p, 0, 8ull * bt->nq, st));
@@ -1843,7 +1926,8 @@ int vbm25_batch_run(vbm25_batch *bt, void *hip_stream) {
     const int rc = dispatch_k(bt->k, [&](auto kmax) {
         scan_kernel<decltype(kmax)::value><<<grid, CWG, 0, st>>>(ix, db);
         if (bt->timing) HIP_TRY(hipEventRecord(e1, st));
-        if (bt->has_many_terms) scan_many_kernel<decltype(kmax)::value><<<grid, WG, 0, st>>>(ix, db);
+        if (bt->has_many_terms)  // queries with many terms or many postings per document
+            scan_many_kernel<decltype(kmax)::value><<<grid, WG, 0, st>>>(ix, db);
         merge_kernel<decltype(kmax)::value><<<bt->nq, 64, 0, st>>>(ix, db);
         return int(VBM25_OK);
     });
