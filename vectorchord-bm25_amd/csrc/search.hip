@@ -1926,7 +1926,7 @@ int vbm25_batch_run(vbm25_batch *bt, void *hip_stream) {
     const int rc = dispatch_k(bt->k, [&](auto kmax) {
         scan_kernel<decltype(kmax)::value><<<grid, CWG, 0, st>>>(ix, db);
         if (bt->timing) HIP_TRY(hipEventRecord(e1, st));
-        if (bt->has_many_terms)  // queries with many terms or many postings per document
+        if (bt->has_many_terms || std::getenv("VBM25_FORCE_MANY_LAUNCH"))  // many terms / dense queries
             scan_many_kernel<decltype(kmax)::value><<<grid, WG, 0, st>>>(ix, db);
         merge_kernel<decltype(kmax)::value><<<bt->nq, 64, 0, st>>>(ix, db);
         return int(VBM25_OK);
