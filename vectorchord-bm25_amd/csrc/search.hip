@@ -88,6 +88,8 @@ struct DevBatch {
     uint32_t *n_hits;
     uint32_t *error_flag;
     const uint8_t *q_dense;    // per query: 1 = dense (many postings per document), host decided
+    unsigned long long *spill; // per scan workgroup: candidates that did not fit the LDS buffer
+    uint32_t *item_failed;     // per item: 1 = the chain kernel gave up (dense tile), redo it
     unsigned long long *prof;  // VBM25_PROFILE builds: 33 counters per workgroup
 };
 
@@ -102,15 +104,18 @@ constexpr uint32_t TARGET_ITEMS = 2048;
 constexpr uint32_t MIN_CHUNK_POSTINGS = 8192;
 constexpr int PLAN_WG = 1024;
 // chain kernel (scan_kernel) geometry
-constexpr int CNW = 7;                   // worker waves per workgroup
-constexpr int CWG = (CNW + 1) * 64;      // + one planner / merger wave
+constexpr int CNW = 6;                   // worker waves per workgroup
+constexpr int CWG = (CNW + 2) * 64;      // + one planner / merger wave + one joiner wave
 constexpr int C_BLOCKS = 2 * CNW;        // block slots of staging per workgroup (2 per worker)
 constexpr int C_POSTINGS = C_BLOCKS * 128;
 constexpr int C_SLOTS_LOG2 = 11;
 constexpr int C_SLOTS = 1 << C_SLOTS_LOG2;
 constexpr int CHAIN_MAX_TERMS = C_BLOCKS;  // queries with more indexed terms use scan_many_kernel
-constexpr int SLOW_CAP = 128;             // postings per tile joined exactly by the planner wave
-constexpr int BM_BITS_LOG2 = 15;          // hashed document bitmaps: 32768 bits each
+constexpr int SLOW_CAP = 64;              // colliding postings per tile kept in LDS (rest: global spill)
+constexpr int SLOW_ABORT = 512;           // beyond this the tile is dense: give the item to scan_many_kernel
+constexpr int JC_CAP = 64;                // joined documents per tile kept in LDS (rest: global spill)
+constexpr int CAND_CAP = 96;              // fast-path documents per tile kept in LDS (rest: global spill)
+constexpr int BM_BITS_LOG2 = 14;          // hashed document bitmaps: 16384 bits each
 constexpr int BM_WORDS = (1 << BM_BITS_LOG2) / 32;
 constexpr int REG_K = 256;                // largest k whose running top-k lives in registers
 constexpr uint32_t NONE32 = 0xffffffffu;
@@ -390,8 +395,9 @@ __global__ void __launch_bounds__(WG) scan_many_kernel(DevIndex ix, DevBatch bt)
     const uint32_t n_items = *bt.n_items;
     for (uint32_t item = blockIdx.x; item < n_items; item += gridDim.x) {
         const Item it = bt.items[item];
-        if (it.m <= (uint32_t)CHAIN_MAX_TERMS) continue;  // handled by scan_kernel
-        const bool force_dense = (it.m & ITEM_DENSE) != 0;
+        const bool failed = it.m <= (uint32_t)CHAIN_MAX_TERMS && bt.item_failed[item] != 0;
+        if (it.m <= (uint32_t)CHAIN_MAX_TERMS && !failed) continue;  // done by scan_kernel
+        const bool force_dense = failed || (it.m & ITEM_DENSE) != 0;
         const uint32_t q = it.q, clo = it.doc_lo, chi = it.doc_hi;
         __syncthreads();  // previous item fully done with LDS
         if (tid == 0) {
@@ -827,48 +833,49 @@ __device__ __forceinline__ void decode_doc_ids_dpp(const uint8_t *__restrict__ p
 }
 
 template <int KMAX>
-__global__ void __launch_bounds__(CWG, 4) scan_kernel(DevIndex ix, DevBatch bt) {
+__global__ void __launch_bounds__(CWG, 6) scan_kernel(DevIndex ix, DevBatch bt) {
     constexpr int T = CHAIN_MAX_TERMS;
-    constexpr int RING = 128;            // metadata ring entries (power-of-two ring per term)
-    constexpr int FAST_CAND = 64;        // candidates merged without stopping the workers
-    constexpr uint32_t PLANNER = CNW;    // the last wave plans and merges, waves 0..CNW-1 work
+    constexpr int RING = 64;              // metadata ring entries (power-of-two ring per term)
+    constexpr uint32_t PLANNER = CNW;     // waves 0..CNW-1 work: entries w and w + CNW of a tile
+    constexpr uint32_t JOINER = CNW + 1;  // exact join of colliding postings, one tile late
+    // staging: decoded postings of the resident blocks (needed again when a block is carried)
     __shared__ uint32_t st_doc[C_POSTINGS];
     __shared__ double st_p[C_POSTINGS];
-    __shared__ uint16_t st_next[C_POSTINGS];
-    __shared__ uint32_t s_slot[C_SLOTS];      // chain heads, slow path only
-    // two independently hashed bitmap pairs per tile parity: "some posting hit this bit" /
-    // "a second posting hit it".  A posting is slow only if it collides under BOTH hashes.
-    __shared__ uint32_t bm_seen[2][2][BM_WORDS];
-    __shared__ uint32_t bm_multi[2][2][BM_WORDS];
-    // postings whose bit was hit twice ("slow"): joined exactly by the planner wave
-    __shared__ uint32_t sl_doc[2][SLOW_CAP];
+    // two independently hashed bitmap pairs per tile, three tiles in rotation: "some posting hit
+    // this bit" / "a second posting hit it".  A posting is slow only if it collides under BOTH.
+    __shared__ uint32_t bm_seen[3][2][BM_WORDS];
+    __shared__ uint32_t bm_multi[3][2][BM_WORDS];
+    __shared__ uint32_t sl_doc[2][SLOW_CAP];  // slow postings of a tile (copies)
     __shared__ double sl_p[2][SLOW_CAP];
     __shared__ uint16_t sl_idx[2][SLOW_CAP];
-    __shared__ uint32_t sl_cnt[2];
-    __shared__ uint16_t s_cand[C_POSTINGS];
-    __shared__ double c_score[2][FAST_CAND];
-    __shared__ uint32_t c_doc[2][FAST_CAND];
+    __shared__ double jc_score[2][JC_CAP];    // documents produced by the join, for the merger
+    __shared__ uint32_t jc_doc[2][JC_CAP];
+    __shared__ double c_score[2][CAND_CAP];   // documents of the fast path (overflow: global spill)
+    __shared__ uint32_t c_doc[2][CAND_CAP];
     __shared__ double s_s1[256];
     __shared__ TopK<(KMAX > REG_K ? KMAX : 1)> s_top;  // LDS list only for k > REG_K
     __shared__ uint4 s_ring[RING];
     __shared__ uint4 e_meta[2][C_BLOCKS];     // entries of a tile: new blocks first, then carried
-    __shared__ uint32_t e_j[2][C_BLOCKS];
-    __shared__ uint16_t e_base[2][C_BLOCKS];  // staging base of the block's region slot
-    __shared__ uint8_t e_t[2][C_BLOCKS];
+    __shared__ uint2 e_aux[2][C_BLOCKS];      // {block index, staging base | term << 16}
     __shared__ double t_s0[T];
-    __shared__ uint32_t s_lo[2], s_hi[2], s_nent[2], s_nnew[2], s_cand_cnt[2], s_done[2];
-    __shared__ unsigned long long s_theta[2];
-    __shared__ double s_kth_score;   // running top-k as seen by the workers' candidate filter
+    // tile header {lo, hi, nent, nnew | done << 16}, per-tile counters, shared filter state
+    __shared__ uint4 s_hdr[2];
+    __shared__ uint32_t s_cand_cnt[2], sl_cnt[2], jc_cnt[2], s_abort;
+    __shared__ unsigned long long s_theta;
+    __shared__ double s_kth_score;
     __shared__ uint32_t s_kth_doc, s_top_cnt;
 
     const uint32_t tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const uint32_t k = bt.k;
     for (int i = tid; i < 256; i += CWG) s_s1[i] = ix.s1[i];
-    for (int i = tid; i < C_SLOTS; i += CWG) s_slot[i] = NONE32;
-    for (int i = tid; i < 4 * BM_WORDS; i += CWG) {
+    for (int i = tid; i < 6 * BM_WORDS; i += CWG) {
         (&bm_seen[0][0][0])[i] = 0;
         (&bm_multi[0][0][0])[i] = 0;
     }
+    // rarely used overflow areas in HBM, per workgroup: [cand | slow | join][2 bufs][C_POSTINGS][2 words]
+    unsigned long long *spill_s = bt.spill + (size_t)blockIdx.x * 3 * 2 * C_POSTINGS * 2;
+    unsigned long long *spill_l = spill_s + 2 * C_POSTINGS * 2;
+    unsigned long long *spill_j = spill_l + 2 * C_POSTINGS * 2;
 
 #ifdef VBM25_PROFILE
     unsigned long long prof[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
@@ -880,13 +887,13 @@ __global__ void __launch_bounds__(CWG, 4) scan_kernel(DevIndex ix, DevBatch bt) 
         if (it.m > (uint32_t)T) continue;  // many terms or dense: scan_many_kernel's
         const uint32_t q = it.q, clo = it.doc_lo, chi = it.doc_hi;
         __syncthreads();
+        if (tid == 0) s_abort = 0;
 
         if (wave == PLANNER) {
             // =====================================================================
-            // Planner wave: lane t owns term t.  Runs one tile ahead of the workers;
-            // everything it decides depends on block metadata only.
+            // Planner / merger wave: lane t owns term t.  Plans one tile ahead (block
+            // metadata only) and owns the running top-k.
             // =====================================================================
-            PROF_T(ps0);
             uint32_t p_rb = 0, p_re = 0, p_end = 0, p_q = 1, p_rmask = 0, p_roff = 0, p_base = 0,
                      p_slot = 0;  // p_slot = region slot of block p_rb (p_rb mod p_q, incremental)
             uint32_t m = 0;
@@ -915,38 +922,24 @@ __global__ void __launch_bounds__(CWG, 4) scan_kernel(DevIndex ix, DevBatch bt) 
                     p_end = b1;
                     p_q = (uint32_t)(((unsigned long long)(C_BLOCKS - m) * df) / sum) + 1;
                     frac = ((unsigned long long)(C_BLOCKS - m) * df) % sum;
-                    uint32_t rs = 2;  // ring holds blocks [rb, rb + 2q]
-                    while (rs < 2 * p_q + 1) rs <<= 1;
-                    p_rmask = rs - 1;
                     t_s0[lane] = ix.term_s0[term];
                 }
                 {   // hand the block slots left over by the floor() to the largest remainders
-                    uint32_t used = row16_incl_sum(act ? p_q : 0u);
+                    const uint32_t used = row16_incl_sum(act ? p_q : 0u);
                     const uint32_t left = (uint32_t)C_BLOCKS - (uint32_t)__builtin_amdgcn_readlane((int)used, 15);
                     uint32_t rank = 0;
                     for (uint32_t t = 0; t < m; ++t) {
                         const unsigned long long ft = __shfl(frac, (int)t);
                         rank += (ft > frac || (ft == frac && t < lane)) ? 1u : 0u;
                     }
-                    if (act && rank < left) {
-                        p_q += 1;
-                        uint32_t rs = 2;
-                        while (rs < 2 * p_q + 1) rs <<= 1;
-                        p_rmask = rs - 1;
-                    }
+                    if (act && rank < left) p_q += 1;
+                    uint32_t rs = 2;  // ring holds blocks [rb, rb + 2q]
+                    while (rs < 2 * p_q + 1) rs <<= 1;
+                    p_rmask = rs - 1;
                 }
                 const uint32_t xb = act ? 128 * p_q : 0, xr = act ? p_rmask + 1 : 0;
-                uint32_t ib = xb, ir = xr;
-#pragma unroll
-                for (int o = 1; o < 16; o <<= 1) {
-                    const uint32_t yb = __shfl_up(ib, o), yr = __shfl_up(ir, o);
-                    if ((int)lane >= o) {
-                        ib += yb;
-                        ir += yr;
-                    }
-                }
-                p_base = ib - xb;
-                p_roff = ir - xr;
+                p_base = row16_incl_sum(xb) - xb;
+                p_roff = row16_incl_sum(xr) - xr;
                 if (act) {  // initial fill of the metadata ring: blocks [rb, rb + 2q]
                     for (uint32_t i = 0; i <= 2 * p_q; ++i) {
                         const uint32_t j = p_rb + i;
@@ -955,8 +948,13 @@ __global__ void __launch_bounds__(CWG, 4) scan_kernel(DevIndex ix, DevBatch bt) 
                 }
                 if (lane == 0) {
                     s_top.count = 0;
-                    s_cand_cnt[0] = 0;
-                    sl_cnt[0] = 0;
+                    s_cand_cnt[0] = s_cand_cnt[1] = 0;
+                    sl_cnt[0] = sl_cnt[1] = 0;
+                    jc_cnt[0] = jc_cnt[1] = 0;
+                    s_top_cnt = 0;
+                    s_kth_score = 0.0;
+                    s_kth_doc = 0;
+                    s_theta = 0;
                 }
             }
             const bool act = lane < m;
@@ -965,8 +963,8 @@ __global__ void __launch_bounds__(CWG, 4) scan_kernel(DevIndex ix, DevBatch bt) 
             uint32_t at0 = NONE32, at1 = NONE32;
             unsigned long long theta_next = 0;
 
-            // plan the tile after [.., p_hi) into buffer nb; the loads it starts are consumed by
-            // plan_finish(), which the caller runs after the next barrier
+            // plan the tile after [.., p_hi) into buffer nb (header + entries).  The loads it
+            // starts are consumed by plan_finish(), after the next barrier.
             auto plan_start = [&](uint32_t nb) {
                 const uint32_t hi_prev = p_hi;
                 uint32_t nrb = p_rb;
@@ -993,7 +991,6 @@ __global__ void __launch_bounds__(CWG, 4) scan_kernel(DevIndex ix, DevBatch bt) 
                     p_rb = nrb;
                 }
                 theta_next = __hip_atomic_load(&bt.theta[q], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                (void)0;
                 // 3. tile range
                 uint32_t lo_c = chi, hi_c = chi;
                 if (act && p_rb < p_end) {
@@ -1001,8 +998,8 @@ __global__ void __launch_bounds__(CWG, 4) scan_kernel(DevIndex ix, DevBatch bt) 
                     if (p_rb + p_q < p_end) hi_c = s_ring[p_roff + ((p_rb + p_q) & p_rmask)].x;
                 }
                 const uint32_t lo_n = row16_min_bcast(lo_c), hi_n = min(chi, row16_min_bcast(hi_c));
-                // 4. entries: newly admitted blocks first (they cost a decode: spread them
-                //    over the waves), then the blocks still resident from earlier tiles
+                // 4. entries: newly admitted blocks first (they cost a decode), then the blocks
+                //    still resident from earlier tiles
                 uint32_t n_car = 0, n_new = 0, re_old = p_re;
                 if (act && lo_n < chi) {
                     const uint32_t lim = min(p_rb + p_q, p_end);
@@ -1023,231 +1020,145 @@ __global__ void __launch_bounds__(CWG, 4) scan_kernel(DevIndex ix, DevBatch bt) 
                         const uint32_t j = p_rb + i;
                         const uint32_t e = i < n_car ? e_c++ : e_n++;
                         e_meta[nb][e] = s_ring[p_roff + (j & p_rmask)];
-                        e_j[nb][e] = j;
-                        e_base[nb][e] = (uint16_t)(p_base + slot * 128);
-                        e_t[nb][e] = (uint8_t)lane;
+                        e_aux[nb][e] = make_uint2(j, (p_base + slot * 128) | (lane << 16));
                         if (++slot == p_q) slot = 0;
                     }
                 }
-                if (lane == 0) {
-                    s_lo[nb] = lo_n;
-                    s_hi[nb] = hi_n;
-                    s_nent[nb] = tot_new + tot_car;
-                    s_nnew[nb] = tot_new;
-                    s_done[nb] = lo_n >= chi ? 1u : 0u;
-                    s_cand_cnt[nb] = 0;
-                    sl_cnt[nb] = 0;
-                }
+                const bool fin = lo_n >= chi;
+                if (lane == 0) s_hdr[nb] = make_uint4(lo_n, hi_n, tot_new + tot_car, tot_new | (fin ? 0x10000u : 0u));
                 p_hi = hi_n;
-                return lo_n >= chi;
+                return fin;
             };
-            auto plan_finish = [&](uint32_t nb) {
+            auto plan_finish = [&]() {
                 if (at0 != NONE32) s_ring[at0] = pf0;
                 if (at1 != NONE32) s_ring[at1] = pf1;
-                if (lane == 0) s_theta[nb] = theta_next;
+                if (lane == 0) s_theta = theta_next;
             };
 
             // running top-k: for k <= REG_K in registers (RegTopK), else a sorted list in LDS
             constexpr int RK = KMAX <= REG_K ? KMAX / 64 : 1;
             RegTopK<RK> rtop;
             rtop.init();
-            auto reg_offer = [&](bool has, double sc, uint32_t d) { rtop.offer(has, sc, d, k, lane); };
-            if (lane == 0) {
-                s_top_cnt = 0;
-                s_kth_score = 0.0;
-                s_kth_doc = 0;
-            }
-            bool done = plan_start(0);
-            plan_finish(0);
-            PROF_T(ps1);
-            PROF_ADD(0, ps0, ps1);
-            lds_barrier();  // S
+            auto offer1 = [&](bool has, double sc, uint32_t d) {
+                if constexpr (KMAX <= REG_K) rtop.offer(has, sc, d, k, lane);
+                else topk_offer<(KMAX > REG_K ? KMAX : 1)>(s_top, k, has, sc, d, lane);
+            };
+            auto offer_list = [&](const double *sc_arr, const uint32_t *d_arr, uint32_t cnt) {
+                for (uint32_t base = 0; base < cnt; base += 64) {
+                    const bool has = base + lane < cnt;
+                    offer1(has, has ? sc_arr[base + lane] : 0.0, has ? d_arr[base + lane] : 0u);
+                }
+            };
             unsigned long long published = 0;
-            // exact join of the postings that collided under both hashes: each lane holds one
-            // (two past 64) of them and meets all the others through readlane (no LDS traffic).
-            // Group leader = smallest staging index = first key.
-            auto join = [&](auto nc_tag, const uint32_t par, const uint32_t nslow) {
-                constexpr int NC = decltype(nc_tag)::value;
-                uint32_t jd[NC], ji[NC], same[NC], minidx[NC], mate[NC];
-                double jp[NC];
-#pragma unroll
-                for (int c = 0; c < NC; ++c) {
-                    const uint32_t e = c * 64 + lane;
-                    const bool v = e < nslow;
-                    jd[c] = v ? sl_doc[par][e] : NONE32;
-                    ji[c] = v ? (uint32_t)sl_idx[par][e] : NONE32;
-                    jp[c] = v ? sl_p[par][e] : 0.0;
-                    same[c] = 0;
-                    minidx[c] = ji[c];
-                    mate[c] = 0;
-                }
-                PROF_T(m1);
-#pragma unroll
-                for (int c2 = 0; c2 < NC; ++c2) {
-                    const uint32_t n2 = min(64u, nslow - c2 * 64);
-                    for (uint32_t j = 0; j < n2; ++j) {
-                        const uint32_t dj = (uint32_t)__builtin_amdgcn_readlane((int)jd[c2], (int)j);
-                        const uint32_t ij = (uint32_t)__builtin_amdgcn_readlane((int)ji[c2], (int)j);
-#pragma unroll
-                        for (int c = 0; c < NC; ++c) {
-                            const bool hit = dj == jd[c] && ij != ji[c];
-                            same[c] += hit ? 1u : 0u;
-                            mate[c] = hit ? c2 * 64 + j : mate[c];
-                            minidx[c] = hit ? min(minidx[c], ij) : minidx[c];
-                        }
+            auto publish = [&]() {  // new k-th entry -> candidate filters of this and other chunks
+                uint32_t n_now;
+                double ks = 0.0;
+                uint32_t kd = 0;
+                if constexpr (KMAX <= REG_K) {
+                    n_now = rtop.cnt;
+                    ks = rtop.kth_s;
+                    kd = rtop.kth_d;
+                } else {
+                    n_now = s_top.count;
+                    if (n_now >= k) {
+                        ks = s_top.score[k - 1];
+                        kd = s_top.doc[k - 1];
                     }
                 }
-                PROF_T(m2);
-                PROF_ADD(9, m1, m2);
-#pragma unroll
-                for (int c = 0; c < NC; ++c) {
-                    const bool lead = jd[c] != NONE32 && minidx[c] == ji[c];
-                    double score = jp[c];
-                    if (__ballot(lead && same[c] >= 1)) {
-                        // partner's partial score (two addends commute)
-                        double op = 0.0;
-#pragma unroll
-                        for (int c2 = 0; c2 < NC; ++c2) {
-                            const double v = __shfl(jp[c2], (int)(mate[c] & 63));
-                            if ((mate[c] >> 6) == (uint32_t)c2) op = v;
+                if (lane == 0) {
+                    s_top_cnt = n_now;
+                    if (n_now >= k) {
+                        s_kth_score = ks;
+                        s_kth_doc = kd;
+                        const unsigned long long bits = (unsigned long long)__double_as_longlong(ks);
+                        if (bits > published) {
+                            atomicMax(&bt.theta[q], bits);
+                            published = bits;
                         }
-                        if (lead && same[c] == 1) score = jp[c] + op;
-                    }
-                    if (__ballot(lead && same[c] >= 2)) {
-                        // three or more addends: ascending staging index = key order,
-                        // one pass over the list per addend
-                        double acc = 0.0;
-                        int last = -1;
-                        const bool l3 = lead && same[c] >= 2;
-                        for (;;) {
-                            uint32_t best = NONE32;
-                            double bp = 0.0;
-#pragma unroll
-                            for (int c2 = 0; c2 < NC; ++c2) {
-                                const uint32_t n2 = min(64u, nslow - c2 * 64);
-                                for (uint32_t j = 0; j < n2; ++j) {
-                                    const uint32_t dj = (uint32_t)__builtin_amdgcn_readlane((int)jd[c2], (int)j);
-                                    const uint32_t ij = (uint32_t)__builtin_amdgcn_readlane((int)ji[c2], (int)j);
-                                    const double pj = readlane_f64(jp[c2], j);
-                                    if (l3 && dj == jd[c] && (int)ij > last && ij < best) {
-                                        best = ij;
-                                        bp = pj;
-                                    }
-                                }
-                            }
-                            if (!__ballot(best != NONE32)) break;
-                            if (best != NONE32) {
-                                acc += bp;
-                                last = (int)best;
-                            }
-                        }
-                        if (l3) score = acc;
-                    }
-                    if (__ballot(lead)) {
-                        if constexpr (KMAX <= REG_K) reg_offer(lead, score, jd[c]);
-                        else topk_offer<(KMAX > REG_K ? KMAX : 1)>(s_top, k, lead, score, jd[c], lane);
                     }
                 }
             };
-            uint32_t pend_n = 0, pend_par = 0;  // slow list of the previous tile, joined one tile late
-            auto run_pending_join = [&]() {
-                if (!pend_n) return;
-                PROF_T(j0);
-                if (pend_n <= 64) join(std::integral_constant<int, 1>(), pend_par, pend_n);
-                else join(std::integral_constant<int, SLOW_CAP / 64>(), pend_par, pend_n);
-                pend_n = 0;
-                PROF_T(j1);
-                PROF_ADD(11, j0, j1);
+            // fast-path documents of tile buffer b (LDS part + global spill); also detects a slow
+            // list that did not fit (-> abort the item, it is redone by scan_many_kernel)
+            auto merge_cand = [&](uint32_t b) {
+                const uint32_t cnt = uni(s_cand_cnt[b]);
+                if (uni(sl_cnt[b]) > (uint32_t)SLOW_ABORT && lane == 0) s_abort = 1;
+#ifdef VBM25_PROFILE
+                {
+                    const uint32_t ns = uni(sl_cnt[b]);
+                    if (ns > prof[8]) prof[8] = ns;
+                    prof[9] += ns;
+                    prof[10] += ns > 64 ? 1 : 0;
+                    prof[11] += cnt;
+                    if (cnt > prof[12]) prof[12] = cnt;
+                }
+#endif
+                if (!cnt) return;
+                offer_list(c_score[b], c_doc[b], min(cnt, (uint32_t)CAND_CAP));
+                for (uint32_t base = CAND_CAP; base < cnt; base += 64) {
+                    const bool has = base + lane < cnt;
+                    double sc = 0.0;
+                    uint32_t d = 0;
+                    if (has) {
+                        const unsigned long long *sp = spill_s + ((size_t)b * C_POSTINGS + (base + lane - CAND_CAP)) * 2;
+                        sc = __longlong_as_double((long long)__hip_atomic_load(sp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+                        d = (uint32_t)__hip_atomic_load(sp + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    }
+                    offer1(has, sc, d);
+                }
+                if (lane == 0) s_cand_cnt[b] = 0;
+                publish();
             };
-            for (uint32_t par = 0; !done; par ^= 1) {
-                PROF_T(pa);
+            // documents produced by the joiner for tile buffer b
+            auto merge_jc = [&](uint32_t b) {
+                const uint32_t jcnt = uni(jc_cnt[b]);
+                if (!jcnt) return;
+                offer_list(jc_score[b], jc_doc[b], min(jcnt, (uint32_t)JC_CAP));
+                for (uint32_t base = JC_CAP; base < jcnt; base += 64) {
+                    const bool has = base + lane < jcnt;
+                    double sc = 0.0;
+                    uint32_t d = 0;
+                    if (has) {
+                        const unsigned long long *sp = spill_j + ((size_t)b * C_POSTINGS + (base + lane - JC_CAP)) * 2;
+                        sc = __longlong_as_double((long long)__hip_atomic_load(sp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+                        d = (uint32_t)__hip_atomic_load(sp + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    }
+                    offer1(has, sc, d);
+                }
+                if (lane == 0) jc_cnt[b] = 0;
+                publish();
+            };
+
+            bool done = plan_start(0);
+            plan_finish();
+            lds_barrier();  // S
+            // tile i: plan i+1, barrier X_i, then merge what is complete: fast path of tile i-1
+            // (its pass B ended before X_i) and the join of tile i-2 (the joiner ran it between
+            // X_{i-1} and X_i); both live in buffer (i-1) & 1 ... (i-2) & 1 respectively
+            for (uint32_t par = 0;; par ^= 1) {
+                if (done) break;
                 const bool next_done = plan_start(par ^ 1);
-                PROF_T(pb);
-                lds_barrier();  // X: pass A of this tile is finished
-                PROF_T(pc);
-                plan_finish(par ^ 1);
-                run_pending_join();  // while the workers run pass B
-                PROF_T(pd);
-                lds_barrier();  // Y: pass B of this tile is finished
-                PROF_T(pe);
-                PROF_ADD(1, pa, pb);
-                PROF_ADD(2, pb, pc);
-                PROF_ADD(3, pc, pd);
-                PROF_ADD(4, pd, pe);
+                lds_barrier();  // X
+                if (uni(s_abort)) break;
+                plan_finish();
+                merge_cand(par ^ 1);  // fast path of tile i-1: its pass B ended before X_i
+                merge_jc(par);        // join of tile i-2: ran between X_{i-1} and X_i
 #ifdef VBM25_PROFILE
                 prof[7] += 1;
 #endif
-                const uint32_t nslow = uni(sl_cnt[par]);
-#ifdef VBM25_PROFILE
-                prof[6] += nslow;
-#endif
-                if (nslow > (uint32_t)SLOW_CAP) {
-                    lds_barrier();  // F1: the workers join the tile themselves
-                    lds_barrier();  // F2
-                } else if (nslow) {
-                    pend_n = nslow;
-                    pend_par = par;
-                }
-                PROF_T(m4);
-                const uint32_t cnt = uni(s_cand_cnt[par]);
-#ifdef VBM25_PROFILE
-                prof[14] += cnt;
-#endif
-                for (uint32_t base = 0; base < cnt; base += 64) {
-                    const bool has = base + lane < cnt;
-                    double sc = 0;
-                    uint32_t d = 0;
-                    if (has) {
-                        if (cnt <= (uint32_t)FAST_CAND) {
-                            sc = c_score[par][base + lane];
-                            d = c_doc[par][base + lane];
-                        } else {
-                            const uint32_t i = s_cand[base + lane];
-                            sc = st_p[i];
-                            d = st_doc[i];
-                        }
-                    }
-                    if constexpr (KMAX <= REG_K) reg_offer(has, sc, d);
-                    else topk_offer<(KMAX > REG_K ? KMAX : 1)>(s_top, k, has, sc, d, lane);
-                }
-                PROF_T(m5);
-                PROF_ADD(12, m4, m5);
-                if (cnt || nslow) {  // publish the new k-th entry (joins show up one tile late) to the workers and to the other chunks
-                    uint32_t n_now;
-                    double ks = 0.0;
-                    uint32_t kd = 0;
-                    if constexpr (KMAX <= REG_K) {
-                        n_now = rtop.cnt;
-                        ks = rtop.kth_s;
-                        kd = rtop.kth_d;
-                    } else {
-                        n_now = s_top.count;
-                        if (n_now >= k) {
-                            ks = s_top.score[k - 1];
-                            kd = s_top.doc[k - 1];
-                        }
-                    }
-                    if (lane == 0) {
-                        s_top_cnt = n_now;
-                        if (n_now >= k) {
-                            s_kth_score = ks;
-                            s_kth_doc = kd;
-                            const unsigned long long bits = (unsigned long long)__double_as_longlong(ks);
-                            if (bits > published) {
-                                atomicMax(&bt.theta[q], bits);
-                                published = bits;
-                            }
-                        }
-                    }
-                }
-                PROF_T(m6);
-                PROF_ADD(13, m5, m6);
-                if (cnt > (uint32_t)FAST_CAND) lds_barrier();  // W: staging had to survive
-                PROF_T(pf);
-                PROF_ADD(5, pe, pf);
                 done = next_done;
             }
-            run_pending_join();
+            __syncthreads();  // E1: every wave left the tile loop; the joiner flushes its list
+            __syncthreads();  // E2
+            const bool failed = uni(s_abort) != 0 || uni(sl_cnt[0]) > (uint32_t)SLOW_ABORT || uni(sl_cnt[1]) > (uint32_t)SLOW_ABORT;
+            merge_cand(0);
+            merge_cand(1);
+            merge_jc(0);
+            merge_jc(1);
+            if (lane == 0) bt.item_failed[item] = failed ? 1u : 0u;
+#ifdef VBM25_PROFILE
+            prof[6] += failed ? 1 : 0;
+#endif
             if constexpr (KMAX <= REG_K) {  // chunk result straight from the registers
 #pragma unroll
                 for (int r = 0; r < RK; ++r) {
@@ -1259,38 +1170,198 @@ __global__ void __launch_bounds__(CWG, 4) scan_kernel(DevIndex ix, DevBatch bt) 
                 }
                 if (lane == 0) bt.res_cnt[item] = rtop.cnt;
             }
-        } else {
+        } else if (wave == JOINER) {
             // =====================================================================
-            // Worker waves: entries wave, wave + CNW of every tile
+            // Joiner wave: exact join of the postings that collided under both hashes.  Each
+            // lane holds one of them and meets all the others through readlane (no LDS traffic);
+            // group leader = smallest staging index = first key.  The list of tile i is complete
+            // at barrier X_{i+1} and is joined before X_{i+2}.
             // =====================================================================
-            BlockFetch fetch[2];
-            bool fetched = false;  // fetch[] holds the raw words of this tile's new blocks
+            // item e of tile buffer b: the first SLOW_CAP live in LDS, the rest in the global spill
+            auto item_at = [&](uint32_t b, uint32_t e, uint32_t &d, uint32_t &idx, double &p) {
+                if (e < (uint32_t)SLOW_CAP) {
+                    d = sl_doc[b][e];
+                    idx = sl_idx[b][e];
+                    p = sl_p[b][e];
+                } else {
+                    const unsigned long long *sp = spill_l + ((size_t)b * C_POSTINGS + (e - SLOW_CAP)) * 2;
+                    p = __longlong_as_double((long long)__hip_atomic_load(sp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+                    const unsigned long long w = __hip_atomic_load(sp + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    d = (uint32_t)w;
+                    idx = (uint32_t)(w >> 32);
+                }
+            };
+            auto emit = [&](uint32_t b, bool lead, double score, uint32_t d) {
+                if (lead && !(s_top_cnt >= k && !better(score, d, s_kth_score, s_kth_doc))) {
+                    const uint32_t at = atomicAdd(&jc_cnt[b], 1u);
+                    if (at < (uint32_t)JC_CAP) {
+                        jc_score[b][at] = score;
+                        jc_doc[b][at] = d;
+                    } else {
+                        unsigned long long *sp = spill_j + ((size_t)b * C_POSTINGS + (at - JC_CAP)) * 2;
+                        __hip_atomic_store(sp, (unsigned long long)__double_as_longlong(score), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        __hip_atomic_store(sp + 1, (unsigned long long)d, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                    }
+                }
+            };
+            auto join = [&](uint32_t b) {
+                const uint32_t n = uni(sl_cnt[b]);
+                if (n == 0 || n > (uint32_t)SLOW_ABORT) return;  // overflow: the planner aborts the item
+                if (n <= 64) {
+                    const bool v = lane < n;
+                    const uint32_t jd = v ? sl_doc[b][lane] : NONE32;
+                    const uint32_t ji = v ? (uint32_t)sl_idx[b][lane] : NONE32;
+                    const double jp = v ? sl_p[b][lane] : 0.0;
+                    uint32_t same = 0, minidx = ji, mate = 0;
+                    for (uint32_t j = 0; j < n; ++j) {
+                        const uint32_t dj = (uint32_t)__builtin_amdgcn_readlane((int)jd, (int)j);
+                        const uint32_t ij = (uint32_t)__builtin_amdgcn_readlane((int)ji, (int)j);
+                        const bool hit = dj == jd && ij != ji;
+                        same += hit ? 1u : 0u;
+                        mate = hit ? j : mate;
+                        minidx = hit ? min(minidx, ij) : minidx;
+                    }
+                    const bool lead = v && minidx == ji;
+                    double score = jp;
+                    if (__ballot(lead && same >= 1)) {
+                        const double op = __shfl(jp, (int)mate);
+                        if (lead && same == 1) score = jp + op;  // two addends commute
+                    }
+                    if (__ballot(lead && same >= 2)) {
+                        // three or more addends: ascending staging index = key order, one pass
+                        // over the list per addend
+                        double acc = 0.0;
+                        int last = -1;
+                        const bool l3 = lead && same >= 2;
+                        for (;;) {
+                            uint32_t best = NONE32;
+                            double bp = 0.0;
+                            for (uint32_t j = 0; j < n; ++j) {
+                                const uint32_t dj = (uint32_t)__builtin_amdgcn_readlane((int)jd, (int)j);
+                                const uint32_t ij = (uint32_t)__builtin_amdgcn_readlane((int)ji, (int)j);
+                                const double pj = readlane_f64(jp, j);
+                                if (l3 && dj == jd && (int)ij > last && ij < best) {
+                                    best = ij;
+                                    bp = pj;
+                                }
+                            }
+                            if (!__ballot(best != NONE32)) break;
+                            if (best != NONE32) {
+                                acc += bp;
+                                last = (int)best;
+                            }
+                        }
+                        if (l3) score = acc;
+                    }
+                    emit(b, lead, score, jd);
+                } else {
+                    // rare: a long list.  Same join, every lane owns one item per round and reads
+                    // all the others (LDS / spill broadcast reads).
+                    for (uint32_t base = 0; base < n; base += 64) {
+                        const bool v = base + lane < n;
+                        uint32_t jd = NONE32, ji = NONE32;
+                        double jp = 0.0;
+                        if (v) item_at(b, base + lane, jd, ji, jp);
+                        uint32_t same = 0, minidx = ji;
+                        for (uint32_t j = 0; j < n; ++j) {
+                            uint32_t dj, ij;
+                            double pj;
+                            item_at(b, j, dj, ij, pj);
+                            const bool hit = dj == jd && ij != ji;
+                            same += hit ? 1u : 0u;
+                            minidx = hit ? min(minidx, ij) : minidx;
+                        }
+                        const bool lead = v && minidx == ji;
+                        double score = jp;
+                        if (__ballot(lead && same >= 1)) {  // ordered sum over the group
+                            double acc = 0.0;
+                            int last = -1;
+                            const bool l2 = lead && same >= 1;
+                            for (;;) {
+                                uint32_t best = NONE32;
+                                double bp = 0.0;
+                                for (uint32_t j = 0; j < n; ++j) {
+                                    uint32_t dj, ij;
+                                    double pj;
+                                    item_at(b, j, dj, ij, pj);
+                                    if (l2 && dj == jd && (int)ij > last && ij < best) {
+                                        best = ij;
+                                        bp = pj;
+                                    }
+                                }
+                                if (!__ballot(best != NONE32)) break;
+                                if (best != NONE32) {
+                                    acc += bp;
+                                    last = (int)best;
+                                }
+                            }
+                            if (l2) score = acc;
+                        }
+                        emit(b, lead, score, jd);
+                    }
+                }
+                if (lane == 0) sl_cnt[b] = 0;
+            };
             lds_barrier();  // S
             for (uint32_t par = 0;; par ^= 1) {
-                if (uni(s_done[par])) break;
-                const uint32_t lo = uni(s_lo[par]), hi = uni(s_hi[par]), nent = uni(s_nent[par]), nnew = uni(s_nnew[par]);
-                PROF_T(wa);
+                if (uni(s_hdr[par].w) & 0x10000u) break;
+                lds_barrier();  // X
+                if (uni(s_abort)) break;
+                join(par ^ 1);  // the previous tile's list
+            }
+            __syncthreads();  // E1
+            join(0);
+            join(1);
+            __syncthreads();  // E2
+        } else {
+            // =====================================================================
+            // Worker waves: entries w and w + CNW of every tile; ONE barrier per tile
+            // =====================================================================
+            BlockFetch fetch[2];
+            uint4 ent_m[2];   // this tile's entries (wave-uniform)
+            uint2 ent_a[2];
+            bool fetched = false;
+            lds_barrier();  // S
+            uint4 hdr = uni4(s_hdr[0]);
+#pragma unroll
+            for (int r = 0; r < 2; ++r) {
+                const uint32_t e = wave + r * CNW;
+                ent_m[r] = uni4(e_meta[0][e < (uint32_t)C_BLOCKS ? e : 0]);
+                const uint2 a = e_aux[0][e < (uint32_t)C_BLOCKS ? e : 0];
+                ent_a[r] = make_uint2(uni(a.x), uni(a.y));
+            }
+            unsigned long long theta = 0;
+            uint32_t ntop = 0, kdoc = 0;
+            double kscore = 0.0;
+            uint32_t tile = 0;
+            for (uint32_t par = 0;; par ^= 1, ++tile) {
+                if (hdr.w & 0x10000u) break;
+                const uint32_t lo = hdr.x, hi = hdr.y, nent = hdr.z, nnew = hdr.w & 0xffffu;
+                const uint32_t bbuf = tile % 3;
 
-                // ---- pass A.1: decode this wave's new blocks into staging
-                uint32_t dd[4], ii[4];
+                // ---- pass A.1: decode this wave's new blocks into staging; fetch carried ones
+                uint32_t dd[4];
+                double pp[4];
 #pragma unroll
                 for (int r = 0; r < 2; ++r) {
                     const uint32_t e = wave + r * CNW;
                     dd[2 * r] = dd[2 * r + 1] = NONE32;
-                    ii[2 * r] = ii[2 * r + 1] = 0;
+                    pp[2 * r] = pp[2 * r + 1] = 0.0;
+                    const uint32_t i0 = (ent_a[r].y & 0xffffu) + 2 * lane;
                     if (e >= nent) continue;
-                    const uint32_t i0 = uni(e_base[par][e]) + 2 * lane;
-                    ii[2 * r] = i0;
-                    ii[2 * r + 1] = i0 + 1;
                     if (e >= nnew) {  // carried over from an earlier tile: already staged
                         const uint2 v = *reinterpret_cast<const uint2 *>(&st_doc[i0]);
+                        const double2 w = *reinterpret_cast<const double2 *>(&st_p[i0]);
                         dd[2 * r] = v.x;
                         dd[2 * r + 1] = v.y;
+                        pp[2 * r] = w.x;
+                        pp[2 * r + 1] = w.y;
                         continue;
                     }
-                    const uint4 bm = uni4(e_meta[par][e]);
+                    const uint4 bm = ent_m[r];
                     const uint32_t n = bm.w & 0xff, md = (bm.w >> 8) & 0xff;
-                    if (!fetched) block_fetch(ix, bm, uni(e_j[par][e]), lane, fetch[r]);
+                    if (!fetched) block_fetch(ix, bm, ent_a[r].x, lane, fetch[r]);
                     const BlockFetch &f = fetch[r];
                     uint32_t v0, v1, f0, f1;
                     block_fields(bm, lane, f, v0, v1, f0, f1);
@@ -1302,186 +1373,125 @@ __global__ void __launch_bounds__(CWG, 4) scan_kernel(DevIndex ix, DevBatch bt) 
                         d0 = bm.x + (incl - own) + v0;
                         d1 = d0 + v1;
                     }
-                    const double s0 = t_s0[uni(e_t[par][e])];
+                    const double s0 = t_s0[ent_a[r].y >> 16];
                     const double tf0 = (double)f0, tf1 = (double)f1;
-                    double2 pp;
-#if VBM25_ABL == 2  // ablation: no divide
-                    pp.x = (tf0 * s0) * (tf0 + s_s1[f.fn & 0xff]);
-                    pp.y = (tf1 * s0) * (tf1 + s_s1[f.fn >> 8]);
-#elif VBM25_ABL == 3  // ablation: no scoring arithmetic
-                    pp.x = s0 + tf0;
-                    pp.y = s0 + tf1;
-#else
-                    pp.x = (tf0 * s0) / (tf0 + s_s1[f.fn & 0xff]);  // bm25.rs:355-358
-                    pp.y = (tf1 * s0) / (tf1 + s_s1[f.fn >> 8]);
-#endif
+                    double2 w;
+                    w.x = (tf0 * s0) / (tf0 + s_s1[f.fn & 0xff]);  // bm25.rs:355-358
+                    w.y = (tf1 * s0) / (tf1 + s_s1[f.fn >> 8]);
                     if (2 * lane >= n) d0 = NONE32;
                     if (2 * lane + 1 >= n) d1 = NONE32;
                     *reinterpret_cast<uint2 *>(&st_doc[i0]) = make_uint2(d0, d1);
-                    *reinterpret_cast<double2 *>(&st_p[i0]) = pp;
+                    *reinterpret_cast<double2 *>(&st_p[i0]) = w;
                     dd[2 * r] = d0;
                     dd[2 * r + 1] = d1;
+                    pp[2 * r] = w.x;
+                    pp[2 * r + 1] = w.y;
                 }
-                PROF_T(wb);
                 // ---- pass A.2: mark every posting of [lo, hi) in the hashed bitmaps.  A bit that
                 // was already set means "another posting may belong to the same document".
-                uint32_t bw[4], bb[4], cw[4], cb[4];
+                uint32_t inr = 0;  // bit x: posting x is inside [lo, hi)
 #pragma unroll
                 for (int x = 0; x < 4; ++x) {
                     const uint32_t d = dd[x];
-                    const uint32_t h = (d * 0x9E3779B1u) >> (32 - BM_BITS_LOG2);
-                    const uint32_t g = (d * 0x85EBCA6Bu + 0x27D4EB2Fu) >> (32 - BM_BITS_LOG2);
-                    bw[x] = h >> 5;
-                    cw[x] = g >> 5;
-#if VBM25_ABL == 4  // ablation: no join at all (decode + staging only)
-                    bb[x] = 0u;
-#else
-                    bb[x] = (d >= lo && d < hi) ? 1u << (h & 31) : 0u;  // NONE32 never is in range
-#endif
-                    cb[x] = bb[x] ? 1u << (g & 31) : 0u;
+                    if (d >= lo && d < hi) {  // NONE32 never is
+                        inr |= 1u << x;
+                        const uint32_t h = (d * 0x9E3779B1u) >> (32 - BM_BITS_LOG2);
+                        const uint32_t g = (d * 0x85EBCA6Bu + 0x27D4EB2Fu) >> (32 - BM_BITS_LOG2);
+                        const uint32_t hb = 1u << (h & 31), gb = 1u << (g & 31);
+                        const uint32_t o1 = atomicOr(&bm_seen[bbuf][0][h >> 5], hb);
+                        const uint32_t o2 = atomicOr(&bm_seen[bbuf][1][g >> 5], gb);
+                        if (o1 & hb) atomicOr(&bm_multi[bbuf][0][h >> 5], hb);
+                        if (o2 & gb) atomicOr(&bm_multi[bbuf][1][g >> 5], gb);
+                    }
                 }
+                lds_barrier();  // X: all marks of this tile are in; everybody finished tile - 1
+                if (uni(s_abort)) break;
+
+                // ---- next tile: header, this wave's entries, filter state -- one LDS round trip;
+                // then the loads of its new blocks
+                const uint4 nh = uni4(s_hdr[par ^ 1]);
+                uint4 nm[2];
+                uint2 na[2];
+#pragma unroll
+                for (int r = 0; r < 2; ++r) {
+                    const uint32_t e = wave + r * CNW;
+                    nm[r] = uni4(e_meta[par ^ 1][e < (uint32_t)C_BLOCKS ? e : 0]);
+                    const uint2 a2 = e_aux[par ^ 1][e < (uint32_t)C_BLOCKS ? e : 0];
+                    na[r] = make_uint2(uni(a2.x), uni(a2.y));
+                }
+                theta = s_theta;
+                ntop = s_top_cnt;
+                kscore = s_kth_score;
+                kdoc = s_kth_doc;
+                // the bitmaps of the previous tile are free now (next used two tiles from here)
+                {
+                    const uint32_t wb = (tile + 2) % 3;
+                    for (int i = tid; i < 2 * BM_WORDS / 4; i += CNW * 64) {
+                        reinterpret_cast<uint4 *>(&bm_seen[wb][0][0])[i] = make_uint4(0, 0, 0, 0);
+                        reinterpret_cast<uint4 *>(&bm_multi[wb][0][0])[i] = make_uint4(0, 0, 0, 0);
+                    }
+                }
+                // ---- pass B: a document whose bit nobody else hit has a single posting: its
+                // partial score IS its score.  The others go to the joiner.
 #pragma unroll
                 for (int x = 0; x < 4; ++x) {
-                    if (!bb[x]) continue;
-                    const uint32_t o1 = atomicOr(&bm_seen[par][0][bw[x]], bb[x]);
-                    const uint32_t o2 = atomicOr(&bm_seen[par][1][cw[x]], cb[x]);
-                    if (o1 & bb[x]) atomicOr(&bm_multi[par][0][bw[x]], bb[x]);
-                    if (o2 & cb[x]) atomicOr(&bm_multi[par][1][cw[x]], cb[x]);
+                    if (!(inr & (1u << x))) continue;
+                    const double p = pp[x];
+                    const uint32_t d = dd[x];
+                    const uint32_t h = (d * 0x9E3779B1u) >> (32 - BM_BITS_LOG2);
+                    const uint32_t g = (d * 0x85EBCA6Bu + 0x27D4EB2Fu) >> (32 - BM_BITS_LOG2);
+                    if (!((bm_multi[bbuf][0][h >> 5] >> (h & 31)) & (bm_multi[bbuf][1][g >> 5] >> (g & 31)) & 1u)) {
+                        if ((unsigned long long)__double_as_longlong(p) < theta) continue;
+                        if (ntop >= k && !better(p, d, kscore, kdoc)) continue;
+                        const uint32_t at = atomicAdd(&s_cand_cnt[par], 1u);
+                        if (at < (uint32_t)CAND_CAP) {
+                            c_score[par][at] = p;
+                            c_doc[par][at] = d;
+                        } else {  // cold tiles: more candidates than the LDS buffer holds
+                            unsigned long long *sp = spill_s + ((size_t)par * C_POSTINGS + (at - CAND_CAP)) * 2;
+                            __hip_atomic_store(sp, (unsigned long long)__double_as_longlong(p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                            __hip_atomic_store(sp + 1, (unsigned long long)d, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // landed before the next barrier
+                        }
+                    } else {
+                        const uint32_t idx = (ent_a[x >> 1].y & 0xffffu) + 2 * lane + (x & 1);  // staging index
+                        const uint32_t at = atomicAdd(&sl_cnt[par], 1u);
+                        if (at < (uint32_t)SLOW_CAP) {
+                            sl_doc[par][at] = d;
+                            sl_p[par][at] = p;
+                            sl_idx[par][at] = (uint16_t)idx;
+                        } else if (at < (uint32_t)SLOW_ABORT) {
+                            unsigned long long *sp = spill_l + ((size_t)par * C_POSTINGS + (at - SLOW_CAP)) * 2;
+                            __hip_atomic_store(sp, (unsigned long long)__double_as_longlong(p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                            __hip_atomic_store(sp + 1, (unsigned long long)d | (unsigned long long)idx << 32, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                        }
+                    }
                 }
-                PROF_T(wc);
-                lds_barrier();  // X
-                PROF_T(wd);
-
-                // ---- the next tile's new blocks: start their loads now, decode after Y
+                // ---- loads of the next tile's new blocks (consumed after the next barrier)
                 fetched = false;
-                if (!uni(s_done[par ^ 1])) {
-                    const uint32_t nn = uni(s_nnew[par ^ 1]);
+                if (!(nh.w & 0x10000u)) {
+                    const uint32_t nn = nh.w & 0xffffu;
 #pragma unroll
                     for (int r = 0; r < 2; ++r) {
                         const uint32_t e = wave + r * CNW;
-                        if (e < nn) block_fetch(ix, uni4(e_meta[par ^ 1][e]), uni(e_j[par ^ 1][e]), lane, fetch[r]);
+                        if (e < nn) block_fetch(ix, nm[r], na[r].x, lane, fetch[r]);
                     }
                     fetched = true;
                 }
-                PROF_T(wd1);
-
-                // ---- pass B: a document whose bit nobody else hit has a single posting: its
-                // partial score IS its score.  The others go to the planner's exact join.
-                const unsigned long long theta = s_theta[par];
-                const uint32_t ntop = s_top_cnt;
-                const double ws = s_kth_score;
-                const uint32_t wd2 = s_kth_doc;
-                auto offer = [&](double score, uint32_t d, uint32_t i) {
-                    if ((unsigned long long)__double_as_longlong(score) < theta) return;
-                    if (ntop >= k && !better(score, d, ws, wd2)) return;
-                    const uint32_t at = atomicAdd(&s_cand_cnt[par], 1u);
-                    st_p[i] = score;
-                    s_cand[at] = (uint16_t)i;
-                    if (at < (uint32_t)FAST_CAND) {
-                        c_score[par][at] = score;
-                        c_doc[par][at] = d;
-                    }
-                };
-                uint32_t slow_mask = 0;
+                // roll over to the next tile
+                hdr = nh;
 #pragma unroll
-                for (int x = 0; x < 4; ++x) {
-                    if (!bb[x]) continue;
-                    const double p = st_p[ii[x]];
-                    if (!((bm_multi[par][0][bw[x]] & bb[x]) && (bm_multi[par][1][cw[x]] & cb[x]))) {
-                        offer(p, dd[x], ii[x]);
-                    } else {
-                        slow_mask |= 1u << x;
-                        const uint32_t at = atomicAdd(&sl_cnt[par], 1u);
-                        if (at < (uint32_t)SLOW_CAP) {
-                            sl_doc[par][at] = dd[x];
-                            sl_p[par][at] = p;
-                            sl_idx[par][at] = (uint16_t)ii[x];
-                        }
-                    }
+                for (int r = 0; r < 2; ++r) {
+                    ent_m[r] = nm[r];
+                    ent_a[r] = na[r];
                 }
-                PROF_T(we);
-                lds_barrier();  // Y
-                PROF_T(we1);
-                const uint32_t nslow = uni(sl_cnt[par]);
-                if (nslow > (uint32_t)SLOW_CAP) {
-                    // ---- fallback (dense tiles): the workers join the slow postings themselves
-                    uint32_t slot[4], head[4];
-#pragma unroll
-                    for (int x = 0; x < 4; ++x) {
-                        slot[x] = NONE32;
-                        head[x] = NONE32;
-                        if (slow_mask & (1u << x)) {
-                            slot[x] = (dd[x] * 0x85EBCA6Bu) >> (32 - C_SLOTS_LOG2);
-                            st_next[ii[x]] = NONE16;
-                            head[x] = atomicCAS(&s_slot[slot[x]], NONE32, ii[x]);
-                        }
-                    }
-                    for (;;) {
-                        bool pending = false;
-#pragma unroll
-                        for (int x = 0; x < 4; ++x) {
-                            if (head[x] == NONE32) continue;
-                            if (__hip_atomic_load(&st_doc[head[x]], __ATOMIC_RELAXED,
-                                                  __HIP_MEMORY_SCOPE_WORKGROUP) == dd[x]) {
-                                st_next[ii[x]] = (uint16_t)head[x];  // same document: push in front
-                                const uint32_t seen = atomicCAS(&s_slot[slot[x]], head[x], ii[x]);
-                                head[x] = seen == head[x] ? NONE32 : seen;  // moved: retry (never empty)
-                            } else {
-                                slot[x] = (slot[x] + 1) & (C_SLOTS - 1);
-                                head[x] = atomicCAS(&s_slot[slot[x]], NONE32, ii[x]);
-                            }
-                            pending |= head[x] != NONE32;
-                        }
-                        if (!pending) break;
-                    }
-                    lds_barrier();  // F1
-#pragma unroll
-                    for (int x = 0; x < 4; ++x) {
-                        const uint32_t i = ii[x];
-                        if (slot[x] == NONE32 || s_slot[slot[x]] != i) continue;
-                        double score = st_p[i];
-                        const uint32_t j1 = st_next[i];
-                        if (j1 != NONE16) {
-                            const uint32_t j2 = st_next[j1];
-                            if (j2 == NONE16) {
-                                score = score + st_p[j1];  // two addends commute
-                            } else {  // three or more: ascending staging index = key order
-                                score = 0.0;
-                                int last = -1;
-                                for (;;) {
-                                    uint32_t best = NONE32;
-                                    for (uint32_t c = i; c != NONE16; c = st_next[c])
-                                        if ((int)c > last && c < best) best = c;
-                                    if (best == NONE32) break;
-                                    score += st_p[best];
-                                    last = (int)best;
-                                }
-                            }
-                        }
-                        s_slot[slot[x]] = NONE32;
-                        offer(score, dd[x], i);
-                    }
-                    lds_barrier();  // F2
-                }
-                // this tile's bitmaps are used again two tiles from now: wipe them
-                for (int i = tid; i < 2 * BM_WORDS / 4; i += CNW * 64) {
-                    reinterpret_cast<uint4 *>(&bm_seen[par][0][0])[i] = make_uint4(0, 0, 0, 0);
-                    reinterpret_cast<uint4 *>(&bm_multi[par][0][0])[i] = make_uint4(0, 0, 0, 0);
-                }
-                PROF_T(we2);
-                if (s_cand_cnt[par] > (uint32_t)FAST_CAND) lds_barrier();  // W
-                PROF_T(wf);
-                PROF_ADD(0, wa, wc);    // A1 + A2
-                PROF_ADD(1, wc, wd);    // wait X
-                PROF_ADD(2, wd, wd1);   // issue next tile's loads
-                PROF_ADD(3, wd1, we);   // pass B
-                PROF_ADD(4, we, we1);   // wait Y
-                PROF_ADD(5, we1, we2);  // pass C
-                PROF_ADD(6, we2, wf);   // wait Z (+W)
 #ifdef VBM25_PROFILE
                 prof[7] += nent;
 #endif
             }
+            __syncthreads();  // E1
+            __syncthreads();  // E2
         }
 
         __syncthreads();
@@ -1495,7 +1505,6 @@ __global__ void __launch_bounds__(CWG, 4) scan_kernel(DevIndex ix, DevBatch bt) 
         }
     }
 #ifdef VBM25_PROFILE
-    // per workgroup: 8 counters of worker wave 0, 8 of the planner wave, total cycles
     if (bt.prof && lane == 0 && (wave == 0 || wave == PLANNER)) {
         unsigned long long *o = bt.prof + (size_t)blockIdx.x * 33 + (wave == 0 ? 0 : 16);
         for (int i = 0; i < 16; ++i) o[i] = prof[i];
@@ -1597,7 +1606,7 @@ struct vbm25_batch {
     vbm25_index *index = nullptr;
     uint32_t max_queries = 0, max_terms = 0, k = 0, nq = 0, max_items = 0;
     DeviceBuffer term_ids, q_off, items, n_items, q_item_base, theta, res_score, res_doc, res_cnt,
-        hits, n_hits, error_flag, prof, q_dense;
+        hits, n_hits, error_flag, prof, q_dense, spill, item_failed;
     bool timing = false;
     bool has_many_terms = false;  // some query has more than CHAIN_MAX_TERMS indexed terms
     std::vector<std::pair<hipEvent_t, hipEvent_t>> events;
@@ -1828,7 +1837,9 @@ int vbm25_batch_create(vbm25_index *ix, uint32_t max_queries, uint32_t max_total
         (rc = bt->res_cnt.alloc(4ull * bt->max_items)) ||
         (rc = bt->hits.alloc(sizeof(vbm25_hit) * size_t(max_queries) * k)) ||
         (rc = bt->n_hits.alloc(4ull * max_queries)) || (rc = bt->error_flag.alloc(4)) ||
-        (rc = bt->q_dense.alloc(max_queries)))
+        (rc = bt->q_dense.alloc(max_queries)) ||
+        (rc = bt->spill.alloc(size_t(TARGET_ITEMS) * 3 * 2 * C_POSTINGS * 16)) ||
+        (rc = bt->item_failed.alloc(4ull * bt->max_items)))
         return rc;
     HIP_TRY(hipMemset(bt->error_flag.p, 0, 4));
 #ifdef VBM25_PROFILE
@@ -1906,9 +1917,12 @@ int vbm25_batch_run(vbm25_batch *bt, void *hip_stream) {
     db.n_hits = bt->n_hits.as<uint32_t>();
     db.error_flag = bt->error_flag.as<uint32_t>();
     db.q_dense = bt->q_dense.as<uint8_t>();
+    db.spill = bt->spill.as<unsigned long long>();
+    db.item_failed = bt->item_failed.as<uint32_t>();
     db.prof = bt->prof.as<unsigned long long>();
     const DevIndex &ix = bt->index->dev;
     HIP_TRY(hipMemsetAsync(bt->theta.p, 0, 8ull * bt->nq, st));
+    HIP_TRY(hipMemsetAsync(bt->item_failed.p, 0, 4ull * bt->max_items, st));
     plan_kernel<<<1, PLAN_WG, 0, st>>>(ix, db, bt->max_items);
     hipEvent_t e0 = nullptr, e1 = nullptr;
     if (bt->timing) {
@@ -1926,8 +1940,8 @@ int vbm25_batch_run(vbm25_batch *bt, void *hip_stream) {
     const int rc = dispatch_k(bt->k, [&](auto kmax) {
         scan_kernel<decltype(kmax)::value><<<grid, CWG, 0, st>>>(ix, db);
         if (bt->timing) HIP_TRY(hipEventRecord(e1, st));
-        if (bt->has_many_terms || std::getenv("VBM25_FORCE_MANY_LAUNCH"))  // many terms / dense queries
-            scan_many_kernel<decltype(kmax)::value><<<grid, WG, 0, st>>>(ix, db);
+        // many-term / dense queries, and items the chain kernel gave up on (empty launch: 5 us)
+        scan_many_kernel<decltype(kmax)::value><<<grid, WG, 0, st>>>(ix, db);
         merge_kernel<decltype(kmax)::value><<<bt->nq, 64, 0, st>>>(ix, db);
         return int(VBM25_OK);
     });
