@@ -184,3 +184,34 @@ def test_corrupt_index_is_rejected():
     with pytest.raises(vb.Vbm25Error) as e:
         vb.GpuIndex(desc)
     assert e.value.code == -2
+
+
+def test_correlated_terms_spill_and_abort_paths():
+    """Terms that co-occur in the same documents: almost every posting of a tile collides with
+    a partner, which exercises (a) the joiner's long-list path (more than 64 colliding postings
+    per tile, overflow kept in the HBM spill), (b) the give-up path (more than 512: the item is
+    redone by the dense-window kernel) and (c) documents with three and more addends."""
+    n_docs = 600_000
+    rng = np.random.default_rng(42)
+    base = np.sort(rng.choice(n_docs, 9000, replace=False)).astype(np.uint32)
+    lists = [
+        base,                                                     # t0
+        base,                                                     # t1: same documents as t0
+        np.sort(np.r_[base[::7], rng.choice(n_docs, 6000, replace=False)]).astype(np.uint32),  # t2: 1/7 of t0 + noise
+        np.sort(np.r_[base[::3], rng.choice(n_docs, 2000, replace=False)]).astype(np.uint32),  # t3: 1/3 of t0 + noise
+        np.sort(rng.choice(n_docs, 7000, replace=False)).astype(np.uint32),                     # t4: independent
+    ]
+    lists = [np.unique(l) for l in lists]
+    keys = np.zeros((len(lists), 16), dtype=np.uint8)
+    keys[:, 0] = np.arange(len(lists)) + ord("a")
+    term_start = np.r_[0, np.cumsum([len(l) for l in lists])].astype(np.uint64)
+    post_doc = np.concatenate(lists)
+    post_tf = rng.integers(1, 4, len(post_doc)).astype(np.uint32)
+    seg = vb.Segment.build(1.2, 0.75, rng.integers(5, 400, n_docs).astype(np.uint32),
+                           np.zeros((n_docs, 3), dtype=np.uint16), keys, term_start, post_doc, post_tf)
+    seg, gix, oix = both(seg=seg)
+    queries = [[0, 1], [0, 2], [0, 3], [0, 1, 2, 3], [0, 1, 2, 3, 4], [2, 3, 4], [1, 4], [0, 2, 4]]
+    terms = np.array([t for q in queries for t in q], dtype=np.uint32)
+    off = np.r_[0, np.cumsum([len(q) for q in queries])].astype(np.uint32)
+    for k in (10, 100):
+        check_batch(gix, oix, terms, off, k)
