@@ -52,6 +52,6 @@ for i, n in enumerate(names_p):
     print(f"planner {n:22s} {p[:, i].sum() / d:9.0f} cycles/{'item' if i == 0 else 'tile'}")
 for i, n in [(8, "join: load list"), (9, "join: all-pairs"), (10, "join: >=3 addends"), (11, "join total (Y -> cand merge)"), (12, "cand merge"), (13, "publish"), (14, "candidates (count)")]:
     print(f"planner   {n:30s} {p[:, i].sum() / tiles:9.1f} /tile")
-print("failed items:", int(p[:, 6].sum()))
+print("failed items:", int(p[:, 6].sum()), "| hot tiles:", int(p[:, 13].sum()), "of", int(tiles))
 print("slow list: max", int(p[:, 8].max()), "mean/tile", p[:, 9].sum() / tiles, "tiles > 64:", int(p[:, 10].sum()), "| cand mean/tile", p[:, 11].sum() / tiles, "max", int(p[:, 12].max()))
 print(f"cycles per tile overall: {tot.sum() / tiles:.0f}")

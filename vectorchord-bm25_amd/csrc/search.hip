@@ -59,6 +59,8 @@ struct DevIndex {
     const uint32_t *term_df;
     const uint32_t *term_first_block;
     const double *term_s0;       // idf * (k1 + 1), host-computed (libm log)
+    const uint32_t *term_wand_tf;  // TokenTuple WAND pair: the posting that maximises tf()
+    const uint8_t *term_wand_fn;
     const uint32_t *blk_min_doc;
     const uint32_t *blk_max_doc;
     const uint4 *blk_meta;       // {min_doc, max_doc, off8, n | meta_doc<<8 | meta_tf<<16 | wand_fn<<24}
@@ -598,8 +600,7 @@ __device__ __forceinline__ FieldAddr field_addr(uint32_t meta, uint32_t n, uint3
     return a;
 }
 __device__ __forceinline__ uint32_t field_val(uint32_t lo, uint32_t hi, const FieldAddr &a) {
-    const unsigned long long both = ((unsigned long long)hi << 32) | lo;
-    return (uint32_t)(both >> a.sh) & a.mask;
+    return __builtin_amdgcn_alignbit(hi, lo, a.sh) & a.mask;  // ((hi:lo) >> sh), sh < 32
 }
 struct BlockFetch {  // raw dwords of one block for this lane: doc fields 0/1, tf fields 0/1
     uint32_t dlo0, dhi0, dlo1, dhi1, tlo0, thi0, tlo1, thi1;
@@ -622,8 +623,8 @@ __device__ __forceinline__ void pair_extract(uint32_t width, uint32_t lane, uint
                                              uint32_t lo1, uint32_t hi1, uint32_t &v0, uint32_t &v1) {
     const uint32_t sh = ((lane >> 1) * width) & 31;
     const uint32_t mask = width >= 32 ? 0xffffffffu : (1u << width) - 1u;
-    v0 = (uint32_t)((((unsigned long long)hi0 << 32) | lo0) >> sh) & mask;
-    v1 = (uint32_t)((((unsigned long long)hi1 << 32) | lo1) >> sh) & mask;
+    v0 = __builtin_amdgcn_alignbit(hi0, lo0, sh) & mask;  // ((hi:lo) >> sh), sh < 32
+    v1 = __builtin_amdgcn_alignbit(hi1, lo1, sh) & mask;
 }
 __device__ __forceinline__ void block_fetch(const DevIndex &ix, const uint4 bm, uint32_t j,
                                             uint32_t lane, BlockFetch &f) {
@@ -840,7 +841,8 @@ __global__ void __launch_bounds__(CWG, 6) scan_kernel(DevIndex ix, DevBatch bt) 
     constexpr uint32_t JOINER = CNW + 1;  // exact join of colliding postings, one tile late
     // staging: decoded postings of the resident blocks (needed again when a block is carried)
     __shared__ uint32_t st_doc[C_POSTINGS];
-    __shared__ double st_p[C_POSTINGS];
+    __shared__ uint32_t st_tf[C_POSTINGS];
+    __shared__ uint8_t st_fn[C_POSTINGS];
     // two independently hashed bitmap pairs per tile, three tiles in rotation: "some posting hit
     // this bit" / "a second posting hit it".  A posting is slow only if it collides under BOTH.
     __shared__ uint32_t bm_seen[3][2][BM_WORDS];
@@ -897,6 +899,7 @@ __global__ void __launch_bounds__(CWG, 6) scan_kernel(DevIndex ix, DevBatch bt) 
             uint32_t p_rb = 0, p_re = 0, p_end = 0, p_q = 1, p_rmask = 0, p_roff = 0, p_base = 0,
                      p_slot = 0;  // p_slot = region slot of block p_rb (p_rb mod p_q, incremental)
             uint32_t m = 0;
+            unsigned long long ub_bits = 0;  // bits of the largest single-posting score (+ margin)
             {
                 const uint32_t qb = bt.q_off[q], qe = bt.q_off[q + 1];
                 uint32_t term = NONE32;
@@ -923,6 +926,18 @@ __global__ void __launch_bounds__(CWG, 6) scan_kernel(DevIndex ix, DevBatch bt) 
                     p_q = (uint32_t)(((unsigned long long)(C_BLOCKS - m) * df) / sum) + 1;
                     frac = ((unsigned long long)(C_BLOCKS - m) * df) % sum;
                     t_s0[lane] = ix.term_s0[term];
+                }
+                {   // Cursor::new, search.rs:363: token_upper_bound = Cache::evaluate(token WAND pair)
+                    double ub = 0.0;
+                    if (act) {
+                        const double wtf = (double)ix.term_wand_tf[term];
+                        ub = (wtf * ix.term_s0[term]) / (wtf + ix.s1[ix.term_wand_fn[term]]);
+                    }
+#pragma unroll
+                    for (int o = 8; o > 0; o >>= 1) ub = fmax(ub, __shfl_xor(ub, o));
+                    // margin: the pair maximises tf() at flush time; Cache::evaluate of another
+                    // posting may round one ulp higher
+                    ub_bits = (unsigned long long)__double_as_longlong(readlane_f64(ub, 0) * (1.0 + 1e-12));
                 }
                 {   // hand the block slots left over by the floor() to the largest remainders
                     const uint32_t used = row16_incl_sum(act ? p_q : 0u);
@@ -1025,7 +1040,15 @@ __global__ void __launch_bounds__(CWG, 6) scan_kernel(DevIndex ix, DevBatch bt) 
                     }
                 }
                 const bool fin = lo_n >= chi;
-                if (lane == 0) s_hdr[nb] = make_uint4(lo_n, hi_n, tot_new + tot_car, tot_new | (fin ? 0x10000u : 0u));
+                // hot tile: the shared threshold already exceeds every single-posting score, so only
+                // documents with two or more postings can still enter the top-k
+                const bool hot = theta_next > ub_bits;
+#ifdef VBM25_PROFILE
+                prof[13] += hot ? 1 : 0;
+#endif
+                if (lane == 0)
+                    s_hdr[nb] = make_uint4(lo_n, hi_n, tot_new + tot_car,
+                                           tot_new | (fin ? 0x10000u : 0u) | (hot ? 0x20000u : 0u));
                 p_hi = hi_n;
                 return fin;
             };
@@ -1341,22 +1364,23 @@ __global__ void __launch_bounds__(CWG, 6) scan_kernel(DevIndex ix, DevBatch bt) 
                 const uint32_t bbuf = tile % 3;
 
                 // ---- pass A.1: decode this wave's new blocks into staging; fetch carried ones
-                uint32_t dd[4];
-                double pp[4];
+                uint32_t dd[4], tt[4], fnp[2];  // doc ids, term frequencies, packed fieldnorm pairs
 #pragma unroll
                 for (int r = 0; r < 2; ++r) {
                     const uint32_t e = wave + r * CNW;
                     dd[2 * r] = dd[2 * r + 1] = NONE32;
-                    pp[2 * r] = pp[2 * r + 1] = 0.0;
+                    tt[2 * r] = tt[2 * r + 1] = 0;
+                    fnp[r] = 0;
                     const uint32_t i0 = (ent_a[r].y & 0xffffu) + 2 * lane;
                     if (e >= nent) continue;
                     if (e >= nnew) {  // carried over from an earlier tile: already staged
                         const uint2 v = *reinterpret_cast<const uint2 *>(&st_doc[i0]);
-                        const double2 w = *reinterpret_cast<const double2 *>(&st_p[i0]);
+                        const uint2 w = *reinterpret_cast<const uint2 *>(&st_tf[i0]);
                         dd[2 * r] = v.x;
                         dd[2 * r + 1] = v.y;
-                        pp[2 * r] = w.x;
-                        pp[2 * r + 1] = w.y;
+                        tt[2 * r] = w.x;
+                        tt[2 * r + 1] = w.y;
+                        fnp[r] = *reinterpret_cast<const uint16_t *>(&st_fn[i0]);
                         continue;
                     }
                     const uint4 bm = ent_m[r];
@@ -1373,19 +1397,16 @@ __global__ void __launch_bounds__(CWG, 6) scan_kernel(DevIndex ix, DevBatch bt) 
                         d0 = bm.x + (incl - own) + v0;
                         d1 = d0 + v1;
                     }
-                    const double s0 = t_s0[ent_a[r].y >> 16];
-                    const double tf0 = (double)f0, tf1 = (double)f1;
-                    double2 w;
-                    w.x = (tf0 * s0) / (tf0 + s_s1[f.fn & 0xff]);  // bm25.rs:355-358
-                    w.y = (tf1 * s0) / (tf1 + s_s1[f.fn >> 8]);
                     if (2 * lane >= n) d0 = NONE32;
                     if (2 * lane + 1 >= n) d1 = NONE32;
                     *reinterpret_cast<uint2 *>(&st_doc[i0]) = make_uint2(d0, d1);
-                    *reinterpret_cast<double2 *>(&st_p[i0]) = w;
+                    *reinterpret_cast<uint2 *>(&st_tf[i0]) = make_uint2(f0, f1);
+                    *reinterpret_cast<uint16_t *>(&st_fn[i0]) = (uint16_t)f.fn;
                     dd[2 * r] = d0;
                     dd[2 * r + 1] = d1;
-                    pp[2 * r] = w.x;
-                    pp[2 * r + 1] = w.y;
+                    tt[2 * r] = f0;
+                    tt[2 * r + 1] = f1;
+                    fnp[r] = f.fn;
                 }
                 // ---- pass A.2: mark every posting of [lo, hi) in the hashed bitmaps.  A bit that
                 // was already set means "another posting may belong to the same document".
@@ -1395,7 +1416,7 @@ __global__ void __launch_bounds__(CWG, 6) scan_kernel(DevIndex ix, DevBatch bt) 
                     const uint32_t d = dd[x];
                     if (d >= lo && d < hi) {  // NONE32 never is
                         inr |= 1u << x;
-                        const uint32_t h = (d * 0x9E3779B1u) >> (32 - BM_BITS_LOG2);
+                        const uint32_t h = d & ((1u << BM_BITS_LOG2) - 1u);  // ids of a tile lie in a narrow range
                         const uint32_t g = (d * 0x85EBCA6Bu + 0x27D4EB2Fu) >> (32 - BM_BITS_LOG2);
                         const uint32_t hb = 1u << (h & 31), gb = 1u << (g & 31);
                         const uint32_t o1 = atomicOr(&bm_seen[bbuf][0][h >> 5], hb);
@@ -1432,15 +1453,21 @@ __global__ void __launch_bounds__(CWG, 6) scan_kernel(DevIndex ix, DevBatch bt) 
                     }
                 }
                 // ---- pass B: a document whose bit nobody else hit has a single posting: its
-                // partial score IS its score.  The others go to the joiner.
+                // partial score IS its score.  In a hot tile such a document cannot reach the top-k
+                // and no score is computed at all.  The others go to the joiner (with their score).
+                const bool hot = (hdr.w & 0x20000u) != 0;
 #pragma unroll
                 for (int x = 0; x < 4; ++x) {
                     if (!(inr & (1u << x))) continue;
-                    const double p = pp[x];
                     const uint32_t d = dd[x];
-                    const uint32_t h = (d * 0x9E3779B1u) >> (32 - BM_BITS_LOG2);
+                    const uint32_t h = d & ((1u << BM_BITS_LOG2) - 1u);  // ids of a tile lie in a narrow range
                     const uint32_t g = (d * 0x85EBCA6Bu + 0x27D4EB2Fu) >> (32 - BM_BITS_LOG2);
-                    if (!((bm_multi[bbuf][0][h >> 5] >> (h & 31)) & (bm_multi[bbuf][1][g >> 5] >> (g & 31)) & 1u)) {
+                    const bool single = !((bm_multi[bbuf][0][h >> 5] >> (h & 31)) & (bm_multi[bbuf][1][g >> 5] >> (g & 31)) & 1u);
+                    if (single && hot) continue;
+                    // Cache::evaluate, bm25.rs:355-358
+                    const double tf = (double)tt[x];
+                    const double p = (tf * t_s0[ent_a[x >> 1].y >> 16]) / (tf + s_s1[(fnp[x >> 1] >> (8 * (x & 1))) & 0xff]);
+                    if (single) {
                         if ((unsigned long long)__double_as_longlong(p) < theta) continue;
                         if (ntop >= k && !better(p, d, kscore, kdoc)) continue;
                         const uint32_t at = atomicAdd(&s_cand_cnt[par], 1u);
@@ -1597,7 +1624,7 @@ struct vbm25_index {
     uint32_t n_docs = 0, n_terms = 0, n_blocks = 0;
     std::vector<uint8_t> term_key;  // host copy for vbm25_lookup_terms
     std::vector<uint32_t> term_df_host;  // host copy for query routing
-    DeviceBuffer term_df, term_first_block, term_s0, blk_min_doc, blk_max_doc, blk_meta, blob,
+    DeviceBuffer term_wand_tf, term_wand_fn, term_df, term_first_block, term_s0, blk_min_doc, blk_max_doc, blk_meta, blob,
         post_fn, doc_payload, s1;
     uint64_t device_bytes = 0;
 };
@@ -1626,7 +1653,7 @@ int check_desc(const vbm25_index_desc *d) {
     if (!d->n_docs) return set_error(VBM25_ERR_INVALID, "index without documents");
     if (!(d->k1 >= 1.2 && d->k1 <= 2.0) || !(d->b >= 0.0 && d->b <= 1.0))
         return set_error(VBM25_ERR_INVALID, "k1 must be in [1.2, 2] and b in [0, 1]");
-    if (d->n_terms && (!d->term_key || !d->term_df || !d->term_first_block))
+    if (d->n_terms && (!d->term_key || !d->term_df || !d->term_first_block || !d->term_wand_tf || !d->term_wand_fn))
         return set_error(VBM25_ERR_INVALID, "term arrays missing");
     if (d->n_blocks && (!d->blk_min_doc || !d->blk_max_doc || !d->blk_n || !d->blk_meta_doc ||
                         !d->blk_meta_tf || !d->blk_off8 || !d->blob))
@@ -1740,6 +1767,8 @@ int vbm25_index_create(const vbm25_index_desc *d, int device, vbm25_index **out)
     if ((rc = ix->term_df.upload(d->term_df, 4ull * d->n_terms)) ||
         (rc = ix->term_first_block.upload(d->term_first_block, 4ull * (d->n_terms + 1))) ||
         (rc = ix->term_s0.upload(s0.data(), 8ull * d->n_terms)) ||
+        (rc = ix->term_wand_tf.upload(d->term_wand_tf, 4ull * d->n_terms)) ||
+        (rc = ix->term_wand_fn.upload(d->term_wand_fn, d->n_terms)) ||
         (rc = ix->blk_min_doc.upload(d->blk_min_doc, 4ull * d->n_blocks)) ||
         (rc = ix->blk_max_doc.upload(d->blk_max_doc, 4ull * d->n_blocks)) ||
         (rc = ix->blk_meta.upload(meta.data(), 16ull * d->n_blocks)) ||
@@ -1771,6 +1800,8 @@ int vbm25_index_create(const vbm25_index_desc *d, int device, vbm25_index **out)
     ix->dev.term_df = ix->term_df.as<uint32_t>();
     ix->dev.term_first_block = ix->term_first_block.as<uint32_t>();
     ix->dev.term_s0 = ix->term_s0.as<double>();
+    ix->dev.term_wand_tf = ix->term_wand_tf.as<uint32_t>();
+    ix->dev.term_wand_fn = ix->term_wand_fn.as<uint8_t>();
     ix->dev.blk_min_doc = ix->blk_min_doc.as<uint32_t>();
     ix->dev.blk_max_doc = ix->blk_max_doc.as<uint32_t>();
     ix->dev.blk_meta = ix->blk_meta.as<uint4>();
