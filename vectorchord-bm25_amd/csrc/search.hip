@@ -610,7 +610,7 @@ struct BlockFetch {  // raw dwords of one block for this lane: doc fields 0/1, t
 // same step, so their words are one aligned 8-byte pair in group w and one in group w+1.
 __device__ __forceinline__ void pair_fetch(const uint8_t *__restrict__ p, uint32_t width, uint32_t lane,
                                            uint32_t &lo0, uint32_t &hi0, uint32_t &lo1, uint32_t &hi1) {
-    const uint32_t bit = (lane >> 1) * width;          // step t = (2L) >> 2
+    const uint32_t bit = __umul24(lane >> 1, width);   // step t = (2L) >> 2
     const uint32_t off = 16 * (bit >> 5) + 8 * (lane & 1);  // streams l0 = 2*(L&1), l0 + 1
     const uint2 a = *reinterpret_cast<const uint2 *>(p + off);
     const uint2 b = *reinterpret_cast<const uint2 *>(p + off + 16);  // may be the next payload: unused then
@@ -621,7 +621,7 @@ __device__ __forceinline__ void pair_fetch(const uint8_t *__restrict__ p, uint32
 }
 __device__ __forceinline__ void pair_extract(uint32_t width, uint32_t lane, uint32_t lo0, uint32_t hi0,
                                              uint32_t lo1, uint32_t hi1, uint32_t &v0, uint32_t &v1) {
-    const uint32_t sh = ((lane >> 1) * width) & 31;
+    const uint32_t sh = __umul24(lane >> 1, width) & 31;
     const uint32_t mask = width >= 32 ? 0xffffffffu : (1u << width) - 1u;
     v0 = __builtin_amdgcn_alignbit(hi0, lo0, sh) & mask;  // ((hi:lo) >> sh), sh < 32
     v1 = __builtin_amdgcn_alignbit(hi1, lo1, sh) & mask;
@@ -1417,7 +1417,7 @@ __global__ void __launch_bounds__(CWG, 6) scan_kernel(DevIndex ix, DevBatch bt) 
                     if (d >= lo && d < hi) {  // NONE32 never is
                         inr |= 1u << x;
                         const uint32_t h = d & ((1u << BM_BITS_LOG2) - 1u);  // ids of a tile lie in a narrow range
-                        const uint32_t g = (d * 0x85EBCA6Bu + 0x27D4EB2Fu) >> (32 - BM_BITS_LOG2);
+                        const uint32_t g = (__umul24(d >> BM_BITS_LOG2, 97u) + d) & ((1u << BM_BITS_LOG2) - 1u);  // never equal for two ids that share h
                         const uint32_t hb = 1u << (h & 31), gb = 1u << (g & 31);
                         const uint32_t o1 = atomicOr(&bm_seen[bbuf][0][h >> 5], hb);
                         const uint32_t o2 = atomicOr(&bm_seen[bbuf][1][g >> 5], gb);
@@ -1461,7 +1461,7 @@ __global__ void __launch_bounds__(CWG, 6) scan_kernel(DevIndex ix, DevBatch bt) 
                     if (!(inr & (1u << x))) continue;
                     const uint32_t d = dd[x];
                     const uint32_t h = d & ((1u << BM_BITS_LOG2) - 1u);  // ids of a tile lie in a narrow range
-                    const uint32_t g = (d * 0x85EBCA6Bu + 0x27D4EB2Fu) >> (32 - BM_BITS_LOG2);
+                    const uint32_t g = (__umul24(d >> BM_BITS_LOG2, 97u) + d) & ((1u << BM_BITS_LOG2) - 1u);  // never equal for two ids that share h
                     const bool single = !((bm_multi[bbuf][0][h >> 5] >> (h & 31)) & (bm_multi[bbuf][1][g >> 5] >> (g & 31)) & 1u);
                     if (single && hot) continue;
                     // Cache::evaluate, bm25.rs:355-358
