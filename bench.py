@@ -122,23 +122,41 @@ def main():
         raise SystemExit("bench.py needs an MI355X: the HIP path has no CPU fallback")
     torch.cuda.set_device(local_rank)
     dist = None
-    if world > 1:
+    # VBM25_BENCH_FORCE_DIST=1 runs the RCCL code path even with one rank (GPU test of the N>1 path)
+    use_dist = world > 1 or os.environ.get("VBM25_BENCH_FORCE_DIST") == "1"
+    if use_dist:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        os.environ.setdefault("MASTER_PORT", "29511")
+        dist.init_process_group("nccl", rank=rank, world_size=world,
+                                device_id=torch.device("cuda", local_rank))
 
     n_docs, vocab, mean_len, len_mode, zipf_s, nq, nterms, k = WORKLOADS[args.workload]
     if args.queries:
         nq = args.queries
-    threads = args.build_threads or max(1, usable_cpus() // world)
+    threads = args.build_threads or usable_cpus()
     t0 = time.perf_counter()
-    if args.cache and os.path.exists(args.cache):
-        seg = vb.Segment.load(args.cache)
+    cache = args.cache
+    if use_dist and not cache:
+        # one node: rank 0 builds the (deterministic) segment once, the other ranks load it
+        shm = "/dev/shm" if os.path.isdir("/dev/shm") else "/tmp"
+        cache = os.path.join(shm, f"vbm25_{args.workload}_{os.environ.get('MASTER_PORT', '0')}.seg")
+        if rank == 0 and os.path.exists(cache):
+            os.remove(cache)
+        dist.barrier()
+    if use_dist and rank != 0:
+        dist.barrier()  # rank 0 has written the file
+        seg = vb.Segment.load(cache)
     else:
-        seg = vb.Segment.synth(n_docs, vocab, mean_len=mean_len, len_mode=len_mode, zipf_s=zipf_s,
-                               seed=20260925, threads=threads)
-        if args.cache and rank == 0:
-            seg.save(args.cache)
+        if cache and os.path.exists(cache):
+            seg = vb.Segment.load(cache)
+        else:
+            seg = vb.Segment.synth(n_docs, vocab, mean_len=mean_len, len_mode=len_mode, zipf_s=zipf_s,
+                                   seed=20260925, threads=threads)
+            if cache:
+                seg.save(cache)
+        if use_dist:
+            dist.barrier()
     t_build = time.perf_counter() - t0
     t0 = time.perf_counter()
     gix = vb.GpuIndex(seg, device=local_rank)
@@ -150,7 +168,7 @@ def main():
     batch.set_queries(terms, off)
     stream = torch.cuda.current_stream()
     local = None
-    if world > 1:
+    if use_dist:
         import ctypes as C
         hp, nh = C.c_void_p(), C.c_void_p()
         vb._lib.check(vb.lib().vbm25_batch_device_results(batch.h, C.byref(hp), C.byref(nh)))
@@ -158,13 +176,13 @@ def main():
 
     def step():
         batch.run(stream.cuda_stream)
-        if world > 1:  # the path's only exchange: every rank gets all top-k lists
+        if use_dist:  # the path's only exchange: every rank gets all top-k lists
             return vb.sharded.gather_hits(local, world * nq, k)
 
     for _ in range(args.warmup):
         step()
     torch.cuda.synchronize()
-    if world > 1:
+    if use_dist:
         dist.barrier()
     batch.set_timing(True)
     torch.cuda.synchronize()
@@ -172,12 +190,12 @@ def main():
     for _ in range(args.steps):
         step()
     torch.cuda.synchronize()
-    if world > 1:
+    if use_dist:
         dist.barrier()
     elapsed = time.perf_counter() - t0
     kernel_ms, n_launch = batch.kernel_ms()
     batch.set_timing(False)
-    if world > 1:
+    if use_dist:
         t = torch.tensor([elapsed], dtype=torch.float64, device=f"cuda:{local_rank}")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
@@ -196,6 +214,7 @@ def main():
     s = hits["score"]
     assert (s[:, :-1] >= s[:, 1:]).all()
 
+    result_line = None
     if rank == 0:
         ms_per_step = 1e3 * elapsed / args.steps
         out = {
@@ -230,9 +249,21 @@ def main():
                            "kernel_ms": round(kernel_ms, 4), "launches_timed": n_launch}
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(seg, terms, off, k)
-        print(json.dumps(out), flush=True)
-    if world > 1:
-        dist.destroy_process_group()
+        result_line = json.dumps(out)
+    if use_dist:
+        if rank == 0 and not args.cache and cache and os.path.exists(cache):
+            os.remove(cache)
+        dist.destroy_process_group()  # RCCL prints its banner here: keep the JSON line last
+    if rank == 0:
+        sys.stdout.flush()
+        print(result_line, flush=True)
+    if use_dist:
+        # librccl prints a version banner to stdout from its exit handlers; the contract is ONE
+        # JSON line from rank 0, so leave without running them (everything is flushed and the
+        # process group is already destroyed)
+        sys.stdout.flush()
+        sys.stderr.flush()
+        os._exit(0)
 
 
 if __name__ == "__main__":

@@ -215,3 +215,18 @@ def test_correlated_terms_spill_and_abort_paths():
     off = np.r_[0, np.cumsum([len(q) for q in queries])].astype(np.uint32)
     for k in (10, 100):
         check_batch(gix, oix, terms, off, k)
+
+
+def test_bench_distributed_code_path_single_rank():
+    """bench.py's N>1 code path (RCCL init, segment hand-over through /dev/shm, device-buffer
+    view for torch, all-gather of the hit records) with one rank on the one GPU of this box."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, VBM25_BENCH_FORCE_DIST="1", RANK="0", WORLD_SIZE="1", LOCAL_RANK="0",
+               MASTER_ADDR="127.0.0.1", MASTER_PORT="29533")
+    out = subprocess.check_output([sys.executable, os.path.join(root, "bench.py"), "--gpus", "1", "--workload", "C2",
+                                   "--queries", "64", "--steps", "3", "--warmup", "1", "--no-cpu-baseline"],
+                                  env=env, text=True, timeout=600)
+    line = json.loads([l for l in out.splitlines() if l.startswith("{")][-1])
+    assert line["n_gpus"] == 1 and line["value"] > 0 and line["roofline"]["frac"] > 0
