@@ -139,7 +139,14 @@ def main():
     cache = args.cache
     if use_dist and not cache:
         # one node: rank 0 builds the (deterministic) segment once, the other ranks load it
-        shm = "/dev/shm" if os.path.isdir("/dev/shm") else "/tmp"
+        import shutil
+        need = 6 * n_docs * mean_len  # generous bound of the segment file size
+        shm = "/tmp"
+        try:
+            if os.path.isdir("/dev/shm") and shutil.disk_usage("/dev/shm").free > need:
+                shm = "/dev/shm"
+        except OSError:
+            pass
         cache = os.path.join(shm, f"vbm25_{args.workload}_{os.environ.get('MASTER_PORT', '0')}.seg")
         if rank == 0 and os.path.exists(cache):
             os.remove(cache)
