@@ -3,17 +3,22 @@
 // /root/reference/crates/bm25/src/search.rs:28-282 (bm25::search) for the sealed segment.
 //
 // Shape of the computation (DESIGN.md has the full story):
-//   plan_kernel   one workgroup: splits every query into doc-range chunks of roughly equal
-//                 posting counts -> work items (query, doc_lo, doc_hi)
-//   scan_kernel   one workgroup per item (grid-stride): walks the chunk in doc-range tiles;
-//                 per tile, term by term (ascending key order = the summation order of
-//                 evaluate.rs:43-72), each wave decodes one 128-posting block (bit-unpack +
-//                 wave prefix sum, search.rs:498-518 / compression.rs:65-136), evaluates
-//                 Cache::evaluate (bm25.rs:355-358) in f64 and accumulates per document in an
-//                 LDS hash table; the tile's documents are then filtered against the running
-//                 top-k (Results, search.rs:284-314) kept sorted in LDS.  A per-query threshold
-//                 is shared between workgroups through a 64-bit atomic max on the score bits.
-//   merge_kernel  one wave per query: merges the per-chunk top-k lists, adds payloads.
+//   plan_kernel       one workgroup: splits every query into doc-range chunks of roughly equal
+//                     posting counts -> work items (query, doc_lo, doc_hi, #terms | dense flag)
+//   scan_kernel       sparse queries (<= 12 indexed terms): one workgroup per item walks the
+//                     chunk in doc-range tiles with one barrier per tile.  Worker waves decode
+//                     128-posting blocks (bit-unpack + DPP prefix sum, search.rs:498-518 /
+//                     compression.rs:65-136), mark every posting in hashed LDS bitmaps and drop
+//                     or score (Cache::evaluate, bm25.rs:355-358) documents with a single
+//                     posting; a joiner wave adds up, in ascending key order (evaluate.rs:43-72),
+//                     the documents whose postings collide; a planner wave plans the tiles from
+//                     block metadata staged in LDS and owns the running top-k (Results,
+//                     search.rs:284-314).  A per-query threshold is shared between workgroups
+//                     through a 64-bit atomic max on the score bits.
+//   scan_many_kernel  queries with many terms or many postings per document, and items the
+//                     sparse kernel gave up on: term-phased accumulation in dense doc windows
+//                     or an LDS hash table.
+//   merge_kernel      one wave per query: merges the per-chunk top-k lists, adds payloads.
 //
 // Result order is canonical: score descending, ties by ascending doc id.  All f64 arithmetic
 // is IEEE (compiled with -ffp-contract=off, no fast-math): results are bit-identical to the
@@ -110,8 +115,6 @@ constexpr int CNW = 6;                   // worker waves per workgroup
 constexpr int CWG = (CNW + 2) * 64;      // + one planner / merger wave + one joiner wave
 constexpr int C_BLOCKS = 2 * CNW;        // block slots of staging per workgroup (2 per worker)
 constexpr int C_POSTINGS = C_BLOCKS * 128;
-constexpr int C_SLOTS_LOG2 = 11;
-constexpr int C_SLOTS = 1 << C_SLOTS_LOG2;
 constexpr int CHAIN_MAX_TERMS = C_BLOCKS;  // queries with more indexed terms use scan_many_kernel
 constexpr int SLOW_CAP = 64;              // colliding postings per tile kept in LDS (rest: global spill)
 constexpr int SLOW_ABORT = 512;           // beyond this the tile is dense: give the item to scan_many_kernel
@@ -121,7 +124,6 @@ constexpr int BM_BITS_LOG2 = 14;          // hashed document bitmaps: 16384 bits
 constexpr int BM_WORDS = (1 << BM_BITS_LOG2) / 32;
 constexpr int REG_K = 256;                // largest k whose running top-k lives in registers
 constexpr uint32_t NONE32 = 0xffffffffu;
-constexpr uint16_t NONE16 = 0xffffu;
 
 // ---------------------------------------------------------------------------
 // Block decode: one wave, two postings per lane (value indices 2*lane, 2*lane+1)
@@ -775,9 +777,6 @@ __device__ __forceinline__ void lds_barrier() {
     asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
 }
 
-#ifndef VBM25_ABL
-#define VBM25_ABL 0
-#endif
 #ifdef VBM25_PROFILE
 #define PROF_T(var) const unsigned long long var = __builtin_readcyclecounter()
 #define PROF_ADD(slot, a, b) prof[slot] += (b) - (a)
@@ -815,23 +814,6 @@ __device__ __forceinline__ uint32_t wave_incl_scan_u32(uint32_t x) {
     return x;
 }
 
-__device__ __forceinline__ void decode_doc_ids_dpp(const uint8_t *__restrict__ p, uint32_t meta,
-                                                   uint32_t n, uint32_t min_doc, uint32_t lane,
-                                                   uint32_t &d0, uint32_t &d1) {
-    uint32_t v0, v1;
-    decode_fields(p, meta, n, lane, v0, v1);
-    const uint32_t width = meta & 127u;
-    const bool raw = (meta >> 7) ? (width == 4) : (width == 32);
-    if (raw) {
-        d0 = v0;
-        d1 = v1;
-        return;
-    }
-    const uint32_t own = v0 + v1;
-    const uint32_t incl = wave_incl_scan_u32(own);
-    d0 = min_doc + (incl - own) + v0;
-    d1 = d0 + v1;
-}
 
 template <int KMAX>
 __global__ void __launch_bounds__(CWG, 6) scan_kernel(DevIndex ix, DevBatch bt) {
