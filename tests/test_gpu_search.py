@@ -230,3 +230,30 @@ def test_bench_distributed_code_path_single_rank():
                                   env=env, text=True, timeout=600)
     line = json.loads([l for l in out.splitlines() if l.startswith("{")][-1])
     assert line["n_gpus"] == 1 and line["value"] > 0 and line["roofline"]["frac"] > 0
+
+
+def test_c3_full_size_sample_parity():
+    """BASELINE config C3 at full size (10M docs / 30k vocab, 5-term queries, top-10): a sample of
+    the bench's own queries against both oracles, plus batch invariance at 1024 queries."""
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    from bench import make_queries as bench_queries, usable_cpus
+    seg = vb.Segment.synth(10_000_000, 30000, mean_len=100, len_mode=1, seed=20260925, threads=usable_cpus())
+    gix = vb.GpuIndex(seg)
+    terms, off = bench_queries(seg, 30000, 1024, 5, seed=1, zipf_s=0.0)
+    hits, nh = vb.search_batch(gix, terms, off, 10)
+    assert (nh == 10).all()
+    oix = orc.OracleIndex.from_arrays(seg.meta(), seg.arrays())
+    sample = list(range(0, 1024, 37))
+    st = np.concatenate([terms[off[q]:off[q + 1]] for q in sample])
+    so = (np.arange(len(sample) + 1) * 5).astype(np.uint32)
+    ob, onb, _ = oix.search_batch(st, so, 10, mode="brute", threads=usable_cpus())
+    ow, onw, _ = oix.search_batch(st, so, 10, mode="wand", threads=usable_cpus())
+    for i, q in enumerate(sample):
+        assert_bit_exact(ob[i, :onb[i]], hits[q, :nh[q]], what=f"q{q} vs brute")
+        assert_same_ranking(ow[i, :onw[i]], hits[q, :nh[q]], ref_ext=oix.search_brute(st[so[i]:so[i + 1]], 300),
+                            what=f"q{q} vs wand")
+    # the sampled queries alone give the same records as inside the 1024-query batch
+    h2, n2 = vb.search_batch(gix, st, so, 10)
+    for f in ("score", "doc_id", "payload"):
+        assert np.array_equal(h2[f], hits[sample][f]), f
