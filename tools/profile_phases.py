@@ -34,7 +34,7 @@ b.run()
 b.fetch()
 L = vb.lib()
 print("occupancy API: workgroups per CU =", L.vbm25_scan_occupancy())
-NWG = 2048
+NWG = 1536
 out = np.zeros((NWG, 33), dtype=np.uint64)
 L.vbm25_batch_profile.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32]
 b.run()

@@ -107,7 +107,7 @@ constexpr int SLOTS = 1 << SLOTS_LOG2;  // hash table slots per workgroup
 constexpr int CAP_BLOCKS = SLOTS / 2 / 128;  // blocks admitted per tile in hash mode
 constexpr int MAX_TERMS = 128;         // terms per query handled on the GPU
 constexpr uint32_t EMPTY = 0xffffffffu;
-constexpr uint32_t TARGET_ITEMS = 2048;
+constexpr uint32_t TARGET_ITEMS = 1536;  // 2 x (256 CUs x 3 resident workgroups): measured best of 768..3072
 constexpr uint32_t MIN_CHUNK_POSTINGS = 8192;
 constexpr int PLAN_WG = 1024;
 // chain kernel (scan_kernel) geometry
