@@ -236,12 +236,36 @@ post_fn_kernel(uint32_t n_blocks, uint32_t n_docs, const uint4 *__restrict__ blk
 // ---------------------------------------------------------------------------
 // Planner
 // ---------------------------------------------------------------------------
+// Block-wide inclusive scan of one u64 per thread (PLAN_WG threads): wave scans + one LDS hop.
+__device__ __forceinline__ unsigned long long plan_incl_scan(unsigned long long v, unsigned long long *s_wave,
+                                                             unsigned long long &total) {
+    const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const unsigned long long y = __shfl_up(v, o);
+        if ((int)lane >= o) v += y;
+    }
+    if (lane == 63) s_wave[wave] = v;
+    __syncthreads();
+    unsigned long long before = 0, all = 0;
+    for (uint32_t w = 0; w < PLAN_WG / 64; ++w) {
+        const unsigned long long x = s_wave[w];
+        if (w < wave) before += x;
+        all += x;
+    }
+    __syncthreads();
+    total = all;
+    return v + before;
+}
+
 __global__ void __launch_bounds__(PLAN_WG) plan_kernel(DevIndex ix, DevBatch bt, uint32_t max_items) {
-    __shared__ unsigned long long s_part[PLAN_WG];
-    __shared__ unsigned long long s_total;
+    __shared__ unsigned long long s_wave[PLAN_WG / 64];
     const uint32_t tid = threadIdx.x;
     const uint32_t per = (bt.nq + PLAN_WG - 1) / PLAN_WG;
     const uint32_t q0 = min(bt.nq, tid * per), q1 = min(bt.nq, q0 + per);
+    // per-launch state of the scan kernels (saves two memset launches per step)
+    for (uint32_t i = tid; i < bt.nq; i += PLAN_WG) bt.theta[i] = 0;
+    for (uint32_t i = tid; i < max_items; i += PLAN_WG) bt.item_failed[i] = 0;
 
     auto postings_of = [&](uint32_t q) {
         unsigned long long t = 0;
@@ -253,18 +277,10 @@ __global__ void __launch_bounds__(PLAN_WG) plan_kernel(DevIndex ix, DevBatch bt,
     };
     unsigned long long local = 0;
     for (uint32_t q = q0; q < q1; ++q) local += postings_of(q);
-    s_part[tid] = local;
-    __syncthreads();
-    if (tid == 0) {
-        unsigned long long t = 0;
-        for (int i = 0; i < PLAN_WG; ++i) t += s_part[i];
-        s_total = t;
-    }
-    __syncthreads();
-    const unsigned long long total = s_total;
+    unsigned long long total = 0;
+    plan_incl_scan(local, s_wave, total);
     unsigned long long chunk = (total + TARGET_ITEMS - 1) / TARGET_ITEMS;
     if (chunk < MIN_CHUNK_POSTINGS) chunk = MIN_CHUNK_POSTINGS;
-    __syncthreads();
     auto chunks_of = [&](uint32_t q) -> uint32_t {
         unsigned long long t = postings_of(q);
         if (t == 0) return 0u;
@@ -274,21 +290,14 @@ __global__ void __launch_bounds__(PLAN_WG) plan_kernel(DevIndex ix, DevBatch bt,
     };
     unsigned long long cnt = 0;
     for (uint32_t q = q0; q < q1; ++q) cnt += chunks_of(q);
-    s_part[tid] = cnt;
-    __syncthreads();
-    if (tid == 0) {  // exclusive scan over 1024 partial sums (tiny)
-        unsigned long long run = 0;
-        for (int i = 0; i < PLAN_WG; ++i) {
-            unsigned long long c = s_part[i];
-            s_part[i] = run;
-            run += c;
-        }
+    unsigned long long run = 0;
+    const unsigned long long incl = plan_incl_scan(cnt, s_wave, run);
+    if (tid == 0) {
         *bt.n_items = (uint32_t)min(run, (unsigned long long)max_items);
         if (run > max_items) atomicOr(bt.error_flag, 2u);
         bt.q_item_base[bt.nq] = (uint32_t)min(run, (unsigned long long)max_items);
     }
-    __syncthreads();
-    uint32_t base = (uint32_t)s_part[tid];
+    uint32_t base = (uint32_t)(incl - cnt);
     for (uint32_t q = q0; q < q1; ++q) {
         const uint32_t c = chunks_of(q);
         uint32_t nterms = 0;
@@ -1934,8 +1943,6 @@ int vbm25_batch_run(vbm25_batch *bt, void *hip_stream) {
     db.item_failed = bt->item_failed.as<uint32_t>();
     db.prof = bt->prof.as<unsigned long long>();
     const DevIndex &ix = bt->index->dev;
-    HIP_TRY(hipMemsetAsync(bt->theta.p, 0, 8ull * bt->nq, st));
-    HIP_TRY(hipMemsetAsync(bt->item_failed.p, 0, 4ull * bt->max_items, st));
     plan_kernel<<<1, PLAN_WG, 0, st>>>(ix, db, bt->max_items);
     hipEvent_t e0 = nullptr, e1 = nullptr;
     if (bt->timing) {
