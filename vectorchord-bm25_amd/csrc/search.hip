@@ -1615,6 +1615,7 @@ struct vbm25_index {
     uint32_t n_docs = 0, n_terms = 0, n_blocks = 0;
     std::vector<uint8_t> term_key;  // host copy for vbm25_lookup_terms
     std::vector<uint32_t> term_df_host;  // host copy for query routing
+    vbm25_batch *scratch = nullptr;      // batch object re-used by vbm25_search_batch
     DeviceBuffer term_wand_tf, term_wand_fn, term_df, term_first_block, term_s0, blk_min_doc, blk_max_doc, blk_meta, blob,
         post_fn, doc_payload, s1;
     uint64_t device_bytes = 0;
@@ -1811,6 +1812,7 @@ int vbm25_index_create(const vbm25_index_desc *d, int device, vbm25_index **out)
 void vbm25_index_destroy(vbm25_index *ix) {
     if (!ix) return;
     (void)hipSetDevice(ix->device);
+    if (ix->scratch) vbm25_batch_destroy(ix->scratch);
     delete ix;
 }
 
@@ -2035,12 +2037,19 @@ int vbm25_search_batch(vbm25_index *ix, const uint32_t *term_ids, const uint32_t
                        uint32_t k, vbm25_hit *hits, uint32_t *n_hits) {
     if (!ix || !q_off) return set_error(VBM25_ERR_INVALID, "NULL argument");
     if (nq == 0) return k ? VBM25_OK : set_error(VBM25_ERR_INVALID, "number of needed rows is set to 0");
-    vbm25_batch *bt = nullptr;
-    if (int rc = vbm25_batch_create(ix, nq, q_off[nq] ? q_off[nq] : 1, k, &bt)) return rc;
+    // the index keeps one batch object for this convenience entry point and re-uses it while
+    // the shape fits (device buffers of a batch are far more expensive to create than a search)
+    vbm25_batch *bt = ix->scratch;
+    const uint32_t n_terms = q_off[nq] ? q_off[nq] : 1;
+    if (!bt || bt->k != k || bt->max_queries < nq || bt->max_terms < n_terms) {
+        if (bt) vbm25_batch_destroy(bt);
+        ix->scratch = nullptr;
+        if (int rc = vbm25_batch_create(ix, std::max(nq, 16u), std::max(n_terms, 256u), k, &bt)) return rc;
+        ix->scratch = bt;
+    }
     int rc = vbm25_batch_set_queries(bt, term_ids, q_off, nq);
     if (!rc) rc = vbm25_batch_run(bt, nullptr);
     if (!rc) rc = vbm25_batch_fetch(bt, hits, n_hits);
-    vbm25_batch_destroy(bt);
     return rc;
 }
 
