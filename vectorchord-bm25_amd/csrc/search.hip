@@ -856,7 +856,7 @@ __global__ void __launch_bounds__(CWG, 6) scan_kernel(DevIndex ix, DevBatch bt) 
     __shared__ uint32_t s_cand_cnt[2], sl_cnt[2], jc_cnt[2], s_abort;
     __shared__ unsigned long long s_theta;
     __shared__ double s_kth_score;
-    __shared__ uint32_t s_kth_doc, s_top_cnt;
+    __shared__ uint32_t s_top_cnt;
 
     const uint32_t tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const uint32_t k = bt.k;
@@ -959,7 +959,6 @@ __global__ void __launch_bounds__(CWG, 6) scan_kernel(DevIndex ix, DevBatch bt) 
                     jc_cnt[0] = jc_cnt[1] = 0;
                     s_top_cnt = 0;
                     s_kth_score = 0.0;
-                    s_kth_doc = 0;
                     s_theta = 0;
                 }
             }
@@ -1067,23 +1066,19 @@ __global__ void __launch_bounds__(CWG, 6) scan_kernel(DevIndex ix, DevBatch bt) 
             auto publish = [&]() {  // new k-th entry -> candidate filters of this and other chunks
                 uint32_t n_now;
                 double ks = 0.0;
-                uint32_t kd = 0;
                 if constexpr (KMAX <= REG_K) {
                     n_now = rtop.cnt;
                     ks = rtop.kth_s;
-                    kd = rtop.kth_d;
                 } else {
                     n_now = s_top.count;
                     if (n_now >= k) {
                         ks = s_top.score[k - 1];
-                        kd = s_top.doc[k - 1];
                     }
                 }
                 if (lane == 0) {
                     s_top_cnt = n_now;
                     if (n_now >= k) {
                         s_kth_score = ks;
-                        s_kth_doc = kd;
                         const unsigned long long bits = (unsigned long long)__double_as_longlong(ks);
                         if (bits > published) {
                             atomicMax(&bt.theta[q], bits);
@@ -1206,7 +1201,10 @@ __global__ void __launch_bounds__(CWG, 6) scan_kernel(DevIndex ix, DevBatch bt) 
                 }
             };
             auto emit = [&](uint32_t b, bool lead, double score, uint32_t d) {
-                if (lead && !(s_top_cnt >= k && !better(score, d, s_kth_score, s_kth_doc))) {
+                // pre-filter on the score alone, strictly: the merger publishes {count, score, doc} with
+                // separate stores while this wave runs, and a torn (new score, old doc) pair must not
+                // drop a document that ties the k-th score; the merger applies the exact rule
+                if (lead && !(s_top_cnt >= k && score < s_kth_score)) {
                     const uint32_t at = atomicAdd(&jc_cnt[b], 1u);
                     if (at < (uint32_t)JC_CAP) {
                         jc_score[b][at] = score;
@@ -1346,7 +1344,7 @@ __global__ void __launch_bounds__(CWG, 6) scan_kernel(DevIndex ix, DevBatch bt) 
                 ent_a[r] = make_uint2(uni(a.x), uni(a.y));
             }
             unsigned long long theta = 0;
-            uint32_t ntop = 0, kdoc = 0;
+            uint32_t ntop = 0;
             double kscore = 0.0;
             uint32_t tile = 0;
             for (uint32_t par = 0;; par ^= 1, ++tile) {
@@ -1434,7 +1432,6 @@ __global__ void __launch_bounds__(CWG, 6) scan_kernel(DevIndex ix, DevBatch bt) 
                 theta = s_theta;
                 ntop = s_top_cnt;
                 kscore = s_kth_score;
-                kdoc = s_kth_doc;
                 // the bitmaps of the previous tile are free now (next used two tiles from here)
                 {
                     const uint32_t wb = (tile + 2) % 3;
@@ -1460,7 +1457,8 @@ __global__ void __launch_bounds__(CWG, 6) scan_kernel(DevIndex ix, DevBatch bt) 
                     const double p = (tf * t_s0[ent_a[x >> 1].y >> 16]) / (tf + s_s1[(fnp[x >> 1] >> (8 * (x & 1))) & 0xff]);
                     if (single) {
                         if ((unsigned long long)__double_as_longlong(p) < theta) continue;
-                        if (ntop >= k && !better(p, d, kscore, kdoc)) continue;
+                        // score alone, strictly (see the joiner's emit): ties go to the merger
+                        if (ntop >= k && p < kscore) continue;
                         const uint32_t at = atomicAdd(&s_cand_cnt[par], 1u);
                         if (at < (uint32_t)CAND_CAP) {
                             c_score[par][at] = p;
