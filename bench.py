@@ -249,7 +249,7 @@ def main():
             traffic = pmc.get(args.workload, {}).get("hbm_bytes_per_launch")
         except Exception:
             pass
-        out["roofline"] = {"bound": "hbm", "kernel": "scan_kernel", "achieved": round(achieved, 1),
+        out["roofline"] = {"bound": "hbm", "kernel": "scan_cursor_kernel", "achieved": round(achieved, 1),
                            "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                            "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": traffic,
                            "algorithmic_bytes_per_launch": int(algo_bytes),

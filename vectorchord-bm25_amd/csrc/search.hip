@@ -69,6 +69,7 @@ struct DevIndex {
     const uint32_t *blk_min_doc;
     const uint32_t *blk_max_doc;
     const uint4 *blk_meta;       // {min_doc, max_doc, off8, n | meta_doc<<8 | meta_tf<<16 | wand_fn<<24}
+    const double *blk_ub;        // Cache::evaluate(block WAND pair) x (1 + 1e-12): no posting of the block scores higher
     const uint8_t *blob;
     const uint8_t *post_fn;      // derived: fieldnorm of every posting, 128 bytes per block
     const uint16_t *doc_payload;
@@ -98,6 +99,9 @@ struct DevBatch {
     unsigned long long *spill; // per scan workgroup: candidates that did not fit the LDS buffer
     uint32_t *item_failed;     // per item: 1 = the chain kernel gave up (dense tile), redo it
     unsigned long long *prof;  // VBM25_PROFILE builds: 33 counters per workgroup
+    uint32_t *work_ctr;        // next item of the cursor kernel (reset by plan_kernel)
+    uint32_t *hist;            // per query: CUR_HB score buckets, documents accepted by any item
+    uint32_t chain_min_terms;  // scan_kernel leaves queries with fewer terms to scan_cursor_kernel
 };
 
 constexpr int WG = 256;
@@ -258,7 +262,8 @@ __device__ __forceinline__ unsigned long long plan_incl_scan(unsigned long long 
     return v + before;
 }
 
-__global__ void __launch_bounds__(PLAN_WG) plan_kernel(DevIndex ix, DevBatch bt, uint32_t max_items) {
+__global__ void __launch_bounds__(PLAN_WG) plan_kernel(DevIndex ix, DevBatch bt, uint32_t max_items,
+                                                       uint32_t target_items, uint32_t min_chunk) {
     __shared__ unsigned long long s_wave[PLAN_WG / 64];
     const uint32_t tid = threadIdx.x;
     const uint32_t per = (bt.nq + PLAN_WG - 1) / PLAN_WG;
@@ -266,6 +271,7 @@ __global__ void __launch_bounds__(PLAN_WG) plan_kernel(DevIndex ix, DevBatch bt,
     // per-launch state of the scan kernels (saves two memset launches per step)
     for (uint32_t i = tid; i < bt.nq; i += PLAN_WG) bt.theta[i] = 0;
     for (uint32_t i = tid; i < max_items; i += PLAN_WG) bt.item_failed[i] = 0;
+    if (tid == 0) *bt.work_ctr = 0;
 
     auto postings_of = [&](uint32_t q) {
         unsigned long long t = 0;
@@ -279,8 +285,8 @@ __global__ void __launch_bounds__(PLAN_WG) plan_kernel(DevIndex ix, DevBatch bt,
     for (uint32_t q = q0; q < q1; ++q) local += postings_of(q);
     unsigned long long total = 0;
     plan_incl_scan(local, s_wave, total);
-    unsigned long long chunk = (total + TARGET_ITEMS - 1) / TARGET_ITEMS;
-    if (chunk < MIN_CHUNK_POSTINGS) chunk = MIN_CHUNK_POSTINGS;
+    unsigned long long chunk = (total + target_items - 1) / target_items;
+    if (chunk < min_chunk) chunk = min_chunk;
     auto chunks_of = [&](uint32_t q) -> uint32_t {
         unsigned long long t = postings_of(q);
         if (t == 0) return 0u;
@@ -877,7 +883,7 @@ __global__ void __launch_bounds__(CWG, 6) scan_kernel(DevIndex ix, DevBatch bt) 
     const uint32_t n_items = *bt.n_items;
     for (uint32_t item = blockIdx.x; item < n_items; item += gridDim.x) {
         const Item it = bt.items[item];
-        if (it.m > (uint32_t)T) continue;  // many terms or dense: scan_many_kernel's
+        if (it.m > (uint32_t)T || it.m < bt.chain_min_terms) continue;  // the other kernels'
         const uint32_t q = it.q, clo = it.doc_lo, chi = it.doc_hi;
         __syncthreads();
         if (tid == 0) s_abort = 0;
@@ -1529,6 +1535,8 @@ __global__ void __launch_bounds__(CWG, 6) scan_kernel(DevIndex ix, DevBatch bt) 
 #endif
 }
 
+#include "scan_cursor.h"
+
 // ---------------------------------------------------------------------------
 // Merge of per-chunk lists -> hits
 // ---------------------------------------------------------------------------
@@ -1614,7 +1622,7 @@ struct vbm25_index {
     std::vector<uint8_t> term_key;  // host copy for vbm25_lookup_terms
     std::vector<uint32_t> term_df_host;  // host copy for query routing
     vbm25_batch *scratch = nullptr;      // batch object re-used by vbm25_search_batch
-    DeviceBuffer term_wand_tf, term_wand_fn, term_df, term_first_block, term_s0, blk_min_doc, blk_max_doc, blk_meta, blob,
+    DeviceBuffer term_wand_tf, term_wand_fn, term_df, term_first_block, term_s0, blk_min_doc, blk_max_doc, blk_meta, blk_ub, blob,
         post_fn, doc_payload, s1;
     uint64_t device_bytes = 0;
 };
@@ -1623,9 +1631,13 @@ struct vbm25_batch {
     vbm25_index *index = nullptr;
     uint32_t max_queries = 0, max_terms = 0, k = 0, nq = 0, max_items = 0;
     DeviceBuffer term_ids, q_off, items, n_items, q_item_base, theta, res_score, res_doc, res_cnt,
-        hits, n_hits, error_flag, prof, q_dense, spill, item_failed;
+        hits, n_hits, error_flag, prof, q_dense, spill, item_failed, work_ctr, hist;
     bool timing = false;
     bool has_many_terms = false;  // some query has more than CHAIN_MAX_TERMS indexed terms
+    bool use_cursor = false;      // k <= REG_K: queries with at most CUR_T terms take scan_cursor_kernel
+    bool has_mid_terms = false;   // some sparse query has CUR_T < terms <= CHAIN_MAX_TERMS
+    uint32_t cur_mt = 1;          // most indexed terms among the cursor kernel's queries
+    uint32_t target_items = TARGET_ITEMS;
     std::vector<std::pair<hipEvent_t, hipEvent_t>> events;
     size_t events_used = 0;
     ~vbm25_batch() {
@@ -1751,6 +1763,20 @@ int vbm25_index_create(const vbm25_index_desc *d, int device, vbm25_index **out)
         meta[j].w = uint32_t(d->blk_n[j]) | uint32_t(d->blk_meta_doc[j]) << 8 |
                     uint32_t(d->blk_meta_tf[j]) << 16 | uint32_t(d->blk_wand_fn ? d->blk_wand_fn[j] : 0) << 24;
     }
+    // block upper bounds (search.rs:377-380 evaluates the block WAND pair per visited block; here once)
+    std::vector<double> blk_ub(d->n_blocks);
+    for (uint32_t t = 0; t < d->n_terms; ++t) {
+        const double wtf = double(d->term_wand_tf[t]);
+        const double tub = (wtf * s0[t]) / (wtf + s1[d->term_wand_fn[t]]);
+        for (uint32_t j = d->term_first_block[t]; j < d->term_first_block[t + 1]; ++j) {
+            double ub = tub;
+            if (d->blk_wand_fn && d->blk_wand_tf) {
+                const double tf = double(d->blk_wand_tf[j]);
+                ub = (tf * s0[t]) / (tf + s1[d->blk_wand_fn[j]]);
+            }
+            blk_ub[j] = ub * (1.0 + 1e-12);  // margin: another posting's evaluate may round one ulp higher
+        }
+    }
     DeviceBuffer fieldnorm, err;
     int rc = 0;
     const size_t blob_alloc = ((size_t(d->blob_bytes) + 15) & ~size_t(15)) + 64;  // slack for word reads
@@ -1762,6 +1788,7 @@ int vbm25_index_create(const vbm25_index_desc *d, int device, vbm25_index **out)
         (rc = ix->blk_min_doc.upload(d->blk_min_doc, 4ull * d->n_blocks)) ||
         (rc = ix->blk_max_doc.upload(d->blk_max_doc, 4ull * d->n_blocks)) ||
         (rc = ix->blk_meta.upload(meta.data(), 16ull * d->n_blocks)) ||
+        (rc = ix->blk_ub.upload(blk_ub.data(), 8ull * d->n_blocks)) ||
         (rc = ix->blob.alloc(blob_alloc)) ||
         (rc = ix->post_fn.alloc(128ull * d->n_blocks)) ||
         (rc = ix->doc_payload.upload(d->doc_payload, 6ull * d->n_docs)) ||
@@ -1795,12 +1822,13 @@ int vbm25_index_create(const vbm25_index_desc *d, int device, vbm25_index **out)
     ix->dev.blk_min_doc = ix->blk_min_doc.as<uint32_t>();
     ix->dev.blk_max_doc = ix->blk_max_doc.as<uint32_t>();
     ix->dev.blk_meta = ix->blk_meta.as<uint4>();
+    ix->dev.blk_ub = ix->blk_ub.as<double>();
     ix->dev.blob = ix->blob.as<uint8_t>();
     ix->dev.post_fn = ix->post_fn.as<uint8_t>();
     ix->dev.doc_payload = ix->doc_payload.as<uint16_t>();
     ix->dev.s1 = ix->s1.as<double>();
     for (const DeviceBuffer *b : {&ix->term_df, &ix->term_first_block, &ix->term_s0, &ix->blk_min_doc,
-                                  &ix->blk_max_doc, &ix->blk_meta, &ix->blob, &ix->post_fn,
+                                  &ix->blk_max_doc, &ix->blk_meta, &ix->blk_ub, &ix->blob, &ix->post_fn,
                                   &ix->doc_payload, &ix->s1})
         ix->device_bytes += b->bytes;
     *out = ix.release();
@@ -1847,7 +1875,14 @@ int vbm25_batch_create(vbm25_index *ix, uint32_t max_queries, uint32_t max_total
     bt->max_queries = max_queries;
     bt->max_terms = max_total_terms;
     bt->k = k;
-    bt->max_items = max_queries + TARGET_ITEMS;
+    {
+        const char *env = std::getenv("VBM25_NO_CURSOR");
+        bt->use_cursor = k <= (uint32_t)REG_K && !(env && env[0] == '1');
+        const char *ti = std::getenv("VBM25_CUR_ITEMS");
+        bt->target_items = bt->use_cursor ? (ti ? (uint32_t)std::atoi(ti) : CUR_TARGET_ITEMS) : TARGET_ITEMS;
+        if (bt->target_items < TARGET_ITEMS) bt->target_items = TARGET_ITEMS;
+    }
+    bt->max_items = max_queries + bt->target_items;
     int rc = 0;
     if ((rc = bt->term_ids.alloc(4ull * max_total_terms)) ||
         (rc = bt->q_off.alloc(4ull * (max_queries + 1))) ||
@@ -1861,12 +1896,13 @@ int vbm25_batch_create(vbm25_index *ix, uint32_t max_queries, uint32_t max_total
         (rc = bt->n_hits.alloc(4ull * max_queries)) || (rc = bt->error_flag.alloc(4)) ||
         (rc = bt->q_dense.alloc(max_queries)) ||
         (rc = bt->spill.alloc(size_t(TARGET_ITEMS) * 3 * 2 * C_POSTINGS * 16)) ||
-        (rc = bt->item_failed.alloc(4ull * bt->max_items)))
+        (rc = bt->item_failed.alloc(4ull * bt->max_items)) || (rc = bt->work_ctr.alloc(4)) ||
+        (rc = bt->hist.alloc(4ull * CUR_HB * max_queries)))
         return rc;
     HIP_TRY(hipMemset(bt->error_flag.p, 0, 4));
 #ifdef VBM25_PROFILE
-    if (int rc2 = bt->prof.alloc(8ull * 33 * TARGET_ITEMS)) return rc2;
-    HIP_TRY(hipMemset(bt->prof.p, 0, 8ull * 33 * TARGET_ITEMS));
+    if (int rc2 = bt->prof.alloc(8ull * 33 * CUR_GRID)) return rc2;
+    HIP_TRY(hipMemset(bt->prof.p, 0, 8ull * 33 * CUR_GRID));
 #endif
     *out = bt.release();
     return VBM25_OK;
@@ -1883,7 +1919,8 @@ int vbm25_batch_set_queries(vbm25_batch *bt, const uint32_t *term_ids, const uin
     if (!bt || !q_off) return set_error(VBM25_ERR_INVALID, "NULL argument");
     if (nq > bt->max_queries) return set_error(VBM25_ERR_INVALID, "%u queries exceed the batch capacity %u", nq, bt->max_queries);
     if (q_off[0] != 0) return set_error(VBM25_ERR_INVALID, "q_off[0] must be 0");
-    bool many = false;
+    bool many = false, mid = false;
+    uint32_t cur_mt = 1;
     // Routing: the chain kernel is built for sparse queries; a query with many postings per
     // document (Zipf head terms) or more than CHAIN_MAX_TERMS indexed terms takes the
     // dense-window kernel.  Tuning knob: VBM25_DENSE_X1000 (postings per 1000 documents).
@@ -1905,6 +1942,10 @@ int vbm25_batch_set_queries(vbm25_batch *bt, const uint32_t *term_ids, const uin
             many = true;
         }
         many |= valid > (uint32_t)CHAIN_MAX_TERMS;
+        if (!dense[q]) {
+            if (valid <= (uint32_t)CUR_T) cur_mt = std::max(cur_mt, valid);
+            else if (valid <= (uint32_t)CHAIN_MAX_TERMS) mid = true;
+        }
         if (valid > MAX_TERMS)
             return set_error(VBM25_ERR_UNSUPPORTED, "query %u has %u indexed terms; the GPU path handles up to %d", q, valid, MAX_TERMS);
     }
@@ -1915,6 +1956,8 @@ int vbm25_batch_set_queries(vbm25_batch *bt, const uint32_t *term_ids, const uin
     if (nq) HIP_TRY(hipMemcpy(bt->q_dense.p, dense.data(), nq, hipMemcpyHostToDevice));
     bt->nq = nq;
     bt->has_many_terms = many;
+    bt->has_mid_terms = mid;
+    bt->cur_mt = cur_mt;
     return VBM25_OK;
 }
 
@@ -1942,8 +1985,13 @@ int vbm25_batch_run(vbm25_batch *bt, void *hip_stream) {
     db.spill = bt->spill.as<unsigned long long>();
     db.item_failed = bt->item_failed.as<uint32_t>();
     db.prof = bt->prof.as<unsigned long long>();
+    db.hist = bt->hist.as<uint32_t>();
+    db.work_ctr = bt->work_ctr.as<uint32_t>();
+    db.chain_min_terms = bt->use_cursor ? (uint32_t)CUR_T + 1u : 0u;
     const DevIndex &ix = bt->index->dev;
-    plan_kernel<<<1, PLAN_WG, 0, st>>>(ix, db, bt->max_items);
+    if (bt->use_cursor) HIP_TRY(hipMemsetAsync(bt->hist.p, 0, 4ull * CUR_HB * bt->nq, st));
+    plan_kernel<<<1, PLAN_WG, 0, st>>>(ix, db, bt->max_items, bt->target_items,
+                                       bt->use_cursor ? CUR_MIN_CHUNK_POSTINGS : MIN_CHUNK_POSTINGS);
     hipEvent_t e0 = nullptr, e1 = nullptr;
     if (bt->timing) {
         if (bt->events_used == bt->events.size()) {
@@ -1958,7 +2006,14 @@ int vbm25_batch_run(vbm25_batch *bt, void *hip_stream) {
     }
     const uint32_t grid = std::min<uint32_t>(bt->max_items, TARGET_ITEMS);
     const int rc = dispatch_k(bt->k, [&](auto kmax) {
-        scan_kernel<decltype(kmax)::value><<<grid, CWG, 0, st>>>(ix, db);
+        constexpr int KM = decltype(kmax)::value;
+        if constexpr (KM <= REG_K) {
+            if (bt->use_cursor) {
+                // persistent single-wave workgroups; items are handed out through bt.work_ctr
+                scan_cursor_kernel<KM><<<CUR_GRID, 64, 4 * cur_lds_words(bt->cur_mt), st>>>(ix, db, bt->cur_mt);
+            }
+        }
+        if (!bt->use_cursor || bt->has_mid_terms) scan_kernel<KM><<<grid, CWG, 0, st>>>(ix, db);
         if (bt->timing) HIP_TRY(hipEventRecord(e1, st));
         // many-term / dense queries, and items the chain kernel gave up on (empty launch: 5 us)
         scan_many_kernel<decltype(kmax)::value><<<grid, WG, 0, st>>>(ix, db);
