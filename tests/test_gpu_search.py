@@ -58,6 +58,41 @@ def test_random_corpora(length, zipf, nterms, k):
     check_batch(gix, oix, terms, off, k)
 
 
+@pytest.mark.parametrize("nterms,k", [(1, 10), (8, 256), (9, 10), (12, 64)])
+def test_kernel_routing_by_term_count(nterms, k):
+    """Queries of 1..8 indexed terms (k <= 256) take the cursor kernel, 9..12 the tile kernel; a
+    single-term query is all single-posting documents (the cold pass)."""
+    c = make_corpus(150_000, 3000, seed=11, length="lognormal", mean_len=60)
+    seg, gix, oix = both(c)
+    terms, off = make_queries(c, 24, nterms, seed=5)
+    check_batch(gix, oix, terms, off, k)
+
+
+def test_mixed_batch_all_kernels():
+    """One batch whose queries are spread over the cursor, tile and many-term kernels, with unknown
+    tokens and an empty query in between."""
+    c = make_corpus(150_000, 3000, seed=12, length="lognormal", mean_len=60)
+    seg, gix, oix = both(c)
+    rng = np.random.default_rng(3)
+    n_terms = seg.meta()["n_terms"]
+    sizes = [1, 2, 5, 8, 9, 10, 12, 13, 20, 40, 0, 3, 7, 11, 6, 4]
+    qs = []
+    for i, n in enumerate(sizes):
+        t = np.sort(rng.choice(n_terms, n, replace=False)).astype(np.uint32)
+        if i % 5 == 1 and n:
+            t = np.r_[t, np.uint32(0xFFFFFFFF)]  # unknown token: ignored (search.rs:59-61)
+        qs.append(t.astype(np.uint32))
+    terms = np.concatenate(qs).astype(np.uint32)
+    off = np.r_[0, np.cumsum([len(q) for q in qs])].astype(np.uint32)
+    hits, nh = vb.search_batch(gix, terms, off, 10)
+    assert nh[sizes.index(0)] == 0
+    for q in range(len(sizes)):
+        t = terms[off[q]:off[q + 1]]
+        t = t[t != 0xFFFFFFFF]
+        want = oix.search_brute(t, 10)
+        assert_bit_exact(want, hits[q, :nh[q]], what=f"q{q} ({sizes[q]} terms) vs brute")
+
+
 def test_fuzz_shape_100_term_queries_top100():
     # tests/fuzz:43-59 shape: 10 000 docs x 100 draws of 10 000 tokens, ~100-term queries
     c = make_corpus(10000, 10000, seed=11, length="fixed", mean_len=100)

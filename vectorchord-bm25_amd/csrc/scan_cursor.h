@@ -30,7 +30,7 @@ constexpr int CUR_BM_WORDS = (1 << CUR_BM_LOG2) / 32;
 constexpr int CUR_TCLR = 8;              // blocks between two wipes of the bitmaps
 constexpr int CUR_PCAP = 96;             // pending documents per wave (5 terms: 10216 B of LDS per wave, 16 waves per CU)
 constexpr int CUR_HB = 256;              // score buckets of the per-query histogram
-constexpr uint32_t CUR_TARGET_ITEMS = 7168;   // ~1.75 x the 4096 resident waves: measured best of 2048..65536 (long runs per wave matter)
+constexpr uint32_t CUR_TARGET_ITEMS = 4096;   // = the resident waves (256 CUs x 16): one long run per wave (plan_kernel)
 constexpr uint32_t CUR_MIN_CHUNK_POSTINGS = 2048;
 constexpr uint32_t CUR_GRID = 256 * 24;  // persistent single-wave workgroups
 

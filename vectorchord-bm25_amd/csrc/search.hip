@@ -290,7 +290,10 @@ __global__ void __launch_bounds__(PLAN_WG) plan_kernel(DevIndex ix, DevBatch bt,
     auto chunks_of = [&](uint32_t q) -> uint32_t {
         unsigned long long t = postings_of(q);
         if (t == 0) return 0u;
-        unsigned long long c = (t + chunk - 1) / chunk;
+        // nearest, not ceil: a batch of similar queries gets the same count for all of them, i.e. the
+        // item count lands on the target (a multiple of the resident waves) instead of ~8 % above it
+        unsigned long long c = (t + chunk / 2) / chunk;
+        if (c == 0) c = 1;
         if (c > ix.n_docs) c = ix.n_docs;
         return (uint32_t)c;
     };
