@@ -25,10 +25,18 @@
 // lists) is handed to scan_many_kernel through item_failed.
 
 constexpr int CUR_T = 8;                 // terms per query (lanes of one resolve group <= 8)
-constexpr int CUR_BM_LOG2 = 14;          // bits per hashed bitmap (two bitmaps per wave)
+// Tuning knobs (-D...): measured on C3 -- wipe every 16 blocks: same time, every 4: +10 %; 8 Kbit bitmaps +
+// 64 pending + 5 waves per SIMD (96 VGPRs, spills): +35 %.
+#ifndef CUR_BM_LOG2_V
+#define CUR_BM_LOG2_V 14
+#define CUR_TCLR_V 8
+#define CUR_PCAP_V 96
+#define CUR_MINW_V 4
+#endif
+constexpr int CUR_BM_LOG2 = CUR_BM_LOG2_V;  // bits per hashed bitmap (two bitmaps per wave)
 constexpr int CUR_BM_WORDS = (1 << CUR_BM_LOG2) / 32;
-constexpr int CUR_TCLR = 8;              // blocks between two wipes of the bitmaps
-constexpr int CUR_PCAP = 96;             // pending documents per wave (5 terms: 10216 B of LDS per wave, 16 waves per CU)
+constexpr int CUR_TCLR = CUR_TCLR_V;      // blocks between two wipes of the bitmaps
+constexpr int CUR_PCAP = CUR_PCAP_V;             // pending documents per wave (5 terms: 10216 B of LDS per wave, 16 waves per CU)
 constexpr int CUR_HB = 256;              // score buckets of the per-query histogram
 constexpr uint32_t CUR_TARGET_ITEMS = 4096;   // = the resident waves (256 CUs x 16): one long run per wave (plan_kernel)
 constexpr uint32_t CUR_MIN_CHUNK_POSTINGS = 2048;
@@ -54,7 +62,7 @@ __device__ __forceinline__ double shfl_f64(double v, uint32_t src) {  // all lan
 }
 
 template <int KMAX>
-__global__ void __launch_bounds__(64, 4) scan_cursor_kernel(DevIndex ix, DevBatch bt, uint32_t mt) {
+__global__ void __launch_bounds__(64, CUR_MINW_V) scan_cursor_kernel(DevIndex ix, DevBatch bt, uint32_t mt) {
     static_assert(KMAX <= REG_K, "register top-k only");
     constexpr int RK = KMAX / 64;
     constexpr uint32_t BMM = (1u << CUR_BM_LOG2) - 1u;
