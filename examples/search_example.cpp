@@ -31,6 +31,21 @@ int main(int argc, char **argv) {
     vbm25_index_desc desc;
     vbm25::check(vbm25_segment_desc(seg, &desc));
     std::printf("segment: %u docs, %u terms, %u blocks\n", desc.n_docs, desc.n_terms, desc.n_blocks);
+    {   // one unsealed document holding two of the query's tokens (search.rs:83-135, host side)
+        vbm25::GrowingDocs g;
+        for (const vbm25::Key &key : {vbm25::intern("10"), vbm25::intern("9")}) {
+            g.key.push_back(key);
+            g.tf.push_back(2);
+        }
+        g.start.push_back(g.key.size());
+        g.fieldnorm.push_back(20);
+        g.payload = {1, 2, 3};
+        const std::vector<vbm25::Hit> grow = vbm25::search_growing(desc, q, 5, g);
+        const std::vector<vbm25::Hit> merged = vbm25::merge_growing({}, grow, 5);
+        std::printf("growing: %zu hit(s), merged %zu, payload (%u,%u,%u), score > 0: %d\n", grow.size(), merged.size(),
+                    merged.empty() ? 0 : merged[0].payload[0], merged.empty() ? 0 : merged[0].payload[1],
+                    merged.empty() ? 0 : merged[0].payload[2], !merged.empty() && merged[0].score > 0);
+    }
     if (host_only) {
         try {
             vbm25::Index ix(desc, 0);

@@ -122,6 +122,34 @@ uint64_t vbm25_query_bytes(const vbm25_index_desc *, const uint32_t *term_ids, u
                            uint32_t k);
 
 /* ------------------------------------------------------------------------
+ * Host side of the shim: the growing (unsealed) segment, search.rs:83-135.
+ * Documents inserted since the last VACUUM live in VectorTuples, not in
+ * posting lists; the reference scores every one of them on the CPU before the
+ * WAND loop, and so does the shim -- these two functions are that code.
+ *
+ * vbm25_growing_search: `query_keys` = the Query's sorted 16-byte keys; keys
+ * without a TokenTuple are dropped (search.rs:59-61) and the others get the
+ * sealed segment's statistics (Cache::new, search.rs:69-75).  Documents are
+ * given as CSR over their elements (VectorTuple `Element{key, value}`, in
+ * tuple order): score = sum of Cache::evaluate(fieldnorm, tf) over the elements
+ * whose key is in the query, in element order; deleted documents are skipped; a
+ * document enters only if threshold < score (so zero-score documents never
+ * do, and a document tying the k-th score does not replace it).  Output: at
+ * most k hits, best first, ties by document order; doc_id = 0xFFFFFFFF - index
+ * of the document in the growing list (not a sealed document id).
+ *
+ * vbm25_merge_hits: top-k of the union of two best-first lists (sealed hits from
+ * the device, growing hits from above); on equal scores sealed hits come first
+ * (the reference leaves ties to BinaryHeap; unpinned).
+ * ---------------------------------------------------------------------- */
+int vbm25_growing_search(const vbm25_index_desc *desc, const uint8_t *query_keys, uint32_t n_keys,
+                         uint32_t k, uint32_t n_grow, const uint64_t *g_start, const uint8_t *g_key,
+                         const uint32_t *g_tf, const uint8_t *g_fieldnorm, const uint16_t *g_payload,
+                         const uint8_t *g_deleted, vbm25_hit *hits, uint32_t *n_hits);
+int vbm25_merge_hits(const vbm25_hit *sealed, uint32_t n_sealed, const vbm25_hit *grow, uint32_t n_grow,
+                     uint32_t k, vbm25_hit *out, uint32_t *n_out);
+
+/* ------------------------------------------------------------------------
  * Device side
  * ---------------------------------------------------------------------- */
 typedef struct vbm25_index vbm25_index; /* owns the HBM copy of one sealed segment */

@@ -7,7 +7,7 @@
 //   vbm25::intern        crates/bm25/src/vector.rs:19-35   (short path; see note)
 //   vbm25::Query         crates/bm25/src/vector.rs:96-134  (sorted unique 16-byte keys)
 //   vbm25::Index::search crates/bm25/src/search.rs:28-36   (bm25::search, filter == true)
-//   vbm25::merge_growing crates/bm25/src/search.rs:83-135  (hits of unsealed documents first)
+//   vbm25::search_growing, vbm25::merge_growing   crates/bm25/src/search.rs:83-135  (unsealed documents, host side)
 // Reference panics ("data corruption", "invalid data") and pgrx::error! become vbm25::Error.
 #ifndef VBM25_HPP
 #define VBM25_HPP
@@ -108,17 +108,36 @@ class Index {
     vbm25_index *h_ = nullptr;
 };
 
-// search.rs:83-135 + 301-313: the growing (unsealed) segment is scored on the host by the
-// shim and merged in front of the sealed-segment hits; top-k of the union, best first.
-// `grow` must already be sorted best first.
+// The growing (unsealed) segment, search.rs:83-135: documents as CSR over their VectorTuple elements.
+struct GrowingDocs {
+    std::vector<uint64_t> start{0};      // n + 1 offsets into key / tf
+    std::vector<Key> key;                // Element.key
+    std::vector<uint32_t> tf;            // Element.value
+    std::vector<uint8_t> fieldnorm;      // VectorTuple::_2.fieldnorm
+    std::vector<uint16_t> payload;       // VectorTuple::_0.payload, n x 3
+    std::vector<uint8_t> deleted;        // VectorTuple::_0.deleted
+    size_t size() const { return start.size() - 1; }
+};
+// Scores the unsealed documents with the sealed segment's statistics (host code, as in the reference).
+inline std::vector<Hit> search_growing(const vbm25_index_desc &desc, const Query &query, size_t k,
+                                       const GrowingDocs &g) {
+    std::vector<Hit> hits(k);
+    uint32_t n = 0;
+    check(vbm25_growing_search(&desc, query.is_empty() ? nullptr : query.keys()[0].data(), uint32_t(query.len()),
+                               uint32_t(k), uint32_t(g.size()), g.start.data(),
+                               g.key.empty() ? nullptr : g.key[0].data(), g.tf.data(), g.fieldnorm.data(),
+                               g.payload.data(), g.deleted.empty() ? nullptr : g.deleted.data(), hits.data(), &n));
+    hits.resize(n);
+    return hits;
+}
+// search.rs:83-135 + 301-313: top-k of the union of the sealed hits (device) and the growing hits
+// (host), best first; on equal scores sealed hits come first.
 inline std::vector<Hit> merge_growing(const std::vector<Hit> &sealed, const std::vector<Hit> &grow, size_t k) {
-    std::vector<Hit> out;
-    out.reserve(std::min(k, sealed.size() + grow.size()));
-    size_t i = 0, j = 0;
-    while (out.size() < k && (i < sealed.size() || j < grow.size())) {
-        const bool take_grow = j < grow.size() && (i >= sealed.size() || grow[j].score > sealed[i].score);
-        out.push_back(take_grow ? grow[j++] : sealed[i++]);
-    }
+    std::vector<Hit> out(k);
+    uint32_t n = 0;
+    check(vbm25_merge_hits(sealed.data(), uint32_t(sealed.size()), grow.data(), uint32_t(grow.size()), uint32_t(k),
+                           out.data(), &n));
+    out.resize(n);
     return out;
 }
 

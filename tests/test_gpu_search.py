@@ -252,6 +252,43 @@ def test_correlated_terms_spill_and_abort_paths():
         check_batch(gix, oix, terms, off, k)
 
 
+def test_growing_segment_merged_with_device_hits():
+    """The shim's full result: sealed hits from the device + unsealed documents scored on the host
+    (vbm25_growing_search) + vbm25_merge_hits, against the oracle's search with a growing segment."""
+    c = make_corpus(30_000, 800, seed=31, length="lognormal", mean_len=50)
+    seg, gix, oix = both(c)
+    a = seg.arrays()
+    n_terms = seg.meta()["n_terms"]
+    terms, off = make_queries(c, 10, 4, seed=2)
+    rng = np.random.default_rng(8)
+    for q in range(len(off) - 1):
+        t = terms[off[q]:off[q + 1]]
+        t = t[t < n_terms]
+        starts, ranks, keys, tfs = [0], [], [], []
+        for _ in range(40):
+            own = sorted(set(rng.choice(n_terms, 6, replace=False).tolist()) |
+                         set(rng.choice(t, rng.integers(0, len(t) + 1), replace=False).tolist()))
+            for r in own:
+                ranks.append(r)
+                keys.append(a["term_key"][r].tobytes())
+                tfs.append(int(rng.integers(1, 5)))
+            starts.append(len(ranks))
+        fn = rng.integers(0, 100, 40).astype(np.uint8)
+        pl = rng.integers(0, 60000, (40, 3)).astype(np.uint16)
+        dl = (rng.random(40) < 0.2).astype(np.uint8)
+        query = vb.Query([a["term_key"][r].tobytes() for r in t])
+        gkeys = np.frombuffer(b"".join(keys), np.uint8)
+        for k in (3, 25):
+            sealed, n = vb.search_batch(gix, t, np.array([0, len(t)], np.uint32), k)
+            grow = vb.growing_search(seg, query, k, starts, gkeys, tfs, fn, pl, dl)
+            merged = vb.merge_hits(sealed[0, :n[0]], grow, k)
+            ref = oix.search_wand_growing(t, k, np.array(starts, np.uint64), np.array(ranks, np.uint32),
+                                          np.array(tfs, np.uint32), fn, pl, dl)
+            ext = vb.merge_hits(oix.search_brute(t, k + 300),
+                                vb.growing_search(seg, query, k + 300, starts, gkeys, tfs, fn, pl, dl), k + 300)
+            assert_same_ranking(ref, merged, ref_ext=ext, what=f"q{q} k={k} growing + device")
+
+
 def test_bench_distributed_code_path_single_rank():
     """bench.py's N>1 code path (RCCL init, segment hand-over through /dev/shm, device-buffer
     view for torch, all-gather of the hit records) with one rank on the one GPU of this box."""

@@ -49,6 +49,8 @@ ABI = {
     "vbm25_segment_save": (i32, [vp, C.c_char_p]),
     "vbm25_segment_load": (i32, [C.c_char_p, vp]),
     "vbm25_query_bytes": (u64, [vp, vp, u32, u32]),
+    "vbm25_growing_search": (i32, [vp, vp, u32, u32, u32, vp, vp, vp, vp, vp, vp, vp, vp]),
+    "vbm25_merge_hits": (i32, [vp, u32, vp, u32, u32, vp, vp]),
     "vbm25_index_create": (i32, [vp, i32, vp]),
     "vbm25_index_destroy": (None, [vp]),
     "vbm25_index_device_bytes": (u64, [vp]),

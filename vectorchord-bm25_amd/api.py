@@ -254,3 +254,32 @@ def search(index, k, query):
     ids = np.sort(ids[ids != 0xffffffff])  # unknown tokens are ignored (search.rs:59-61)
     hits, n = search_batch(index, ids, np.array([0, len(ids)], dtype=np.uint32), k)
     return hits[0, :n[0]]
+
+
+def growing_search(segment_or_desc, query, k, g_start, g_key, g_tf, g_fieldnorm, g_payload, g_deleted=None):
+    """Host side of the shim for unsealed documents (search.rs:83-135): `query` is a Query, the
+    documents are a CSR over their elements (16-byte keys + term frequencies)."""
+    desc = segment_or_desc.desc if isinstance(segment_or_desc, Segment) else segment_or_desc
+    keys = np.frombuffer(b"".join(query.keys), dtype=np.uint8) if query.keys else np.zeros(0, np.uint8)
+    g_start = np.ascontiguousarray(g_start, dtype=np.uint64)
+    g_key = np.ascontiguousarray(g_key, dtype=np.uint8)
+    g_tf = np.ascontiguousarray(g_tf, dtype=np.uint32)
+    g_fieldnorm = np.ascontiguousarray(g_fieldnorm, dtype=np.uint8)
+    g_payload = np.ascontiguousarray(g_payload, dtype=np.uint16)
+    g_deleted = None if g_deleted is None else np.ascontiguousarray(g_deleted, dtype=np.uint8)
+    hits = np.zeros(max(k, 1), dtype=HIT_DTYPE)
+    n = C.c_uint32()
+    check(lib().vbm25_growing_search(C.byref(desc), _p(keys), len(query.keys), k, len(g_start) - 1,
+                                     _p(g_start), _p(g_key), _p(g_tf), _p(g_fieldnorm), _p(g_payload),
+                                     _p(g_deleted), _p(hits), C.byref(n)))
+    return hits[:n.value]
+
+
+def merge_hits(sealed, grow, k):
+    """Top-k of the union of two best-first hit lists (the last step of the shim)."""
+    sealed = np.ascontiguousarray(sealed, dtype=HIT_DTYPE)
+    grow = np.ascontiguousarray(grow, dtype=HIT_DTYPE)
+    out = np.zeros(max(k, 1), dtype=HIT_DTYPE)
+    n = C.c_uint32()
+    check(lib().vbm25_merge_hits(_p(sealed), len(sealed), _p(grow), len(grow), k, _p(out), C.byref(n)))
+    return out[:n.value]

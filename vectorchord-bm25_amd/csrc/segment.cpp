@@ -656,4 +656,86 @@ uint64_t vbm25_query_bytes(const vbm25_index_desc *d, const uint32_t *term_ids, 
     return bytes + 14ull * k;
 }
 
+// search.rs:83-135: the growing segment is scanned document by document before the WAND loop.
+int vbm25_growing_search(const vbm25_index_desc *d, const uint8_t *query_keys, uint32_t n_keys, uint32_t k,
+                         uint32_t n_grow, const uint64_t *g_start, const uint8_t *g_key, const uint32_t *g_tf,
+                         const uint8_t *g_fieldnorm, const uint16_t *g_payload, const uint8_t *g_deleted,
+                         vbm25_hit *hits, uint32_t *n_hits) {
+    if (!d || !n_hits || (!hits && k) || (n_keys && !query_keys))
+        return set_error(VBM25_ERR_INVALID, "NULL argument");
+    if (k == 0) return set_error(VBM25_ERR_INVALID, "number of needed rows is set to 0");  // default.rs:114-116
+    if (n_grow && (!g_start || !g_fieldnorm || !g_payload)) return set_error(VBM25_ERR_INVALID, "growing arrays missing");
+    *n_hits = 0;
+    for (uint32_t i = 1; i < n_keys; ++i)  // Query::checked_new, vector.rs:106-110
+        if (std::memcmp(query_keys + 16ull * (i - 1), query_keys + 16ull * i, 16) >= 0)
+            return set_error(VBM25_ERR_INVALID, "query keys must be strictly ascending");
+    // tokens of the query that the sealed segment knows, with their Cache (search.rs:53-77)
+    struct Tok {
+        const uint8_t *key;
+        double s0;
+    };
+    std::vector<Tok> toks;
+    for (uint32_t i = 0; i < n_keys; ++i) {
+        const uint8_t *key = query_keys + 16ull * i;
+        uint32_t lo = 0, hi = d->n_terms;
+        while (lo < hi) {
+            const uint32_t mid = (lo + hi) >> 1;
+            if (std::memcmp(d->term_key + 16ull * mid, key, 16) < 0) lo = mid + 1; else hi = mid;
+        }
+        if (lo < d->n_terms && !std::memcmp(d->term_key + 16ull * lo, key, 16))
+            toks.push_back({key, bm25_s0(d->n_docs, d->term_df[lo], d->k1)});
+    }
+    double s1[256];
+    bm25_tables(d->n_docs, d->sum_len, d->k1, d->b, s1);
+    // Results (search.rs:284-314) restated as a sorted list: threshold = k-th score once k are held
+    std::vector<vbm25_hit> top;
+    top.reserve(k + 1);
+    double threshold = 0.0;
+    for (uint32_t g = 0; g < n_grow; ++g) {
+        if (g_deleted && g_deleted[g]) continue;  // search.rs:113
+        if (g_start[g + 1] < g_start[g]) return set_error(VBM25_ERR_INVALID, "g_start not monotone at %u", g);
+        double result = 0.0;
+        for (uint64_t p = g_start[g]; p < g_start[g + 1]; ++p) {
+            const uint8_t *key = g_key + 16ull * p;
+            size_t lo = 0, hi = toks.size();  // tokens.binary_search_by_key, search.rs:102,115
+            while (lo < hi) {
+                const size_t mid = (lo + hi) >> 1;
+                if (std::memcmp(toks[mid].key, key, 16) < 0) lo = mid + 1; else hi = mid;
+            }
+            if (lo < toks.size() && !std::memcmp(toks[lo].key, key, 16)) {
+                const double tf = double(g_tf[p]);
+                result += (tf * toks[lo].s0) / (tf + s1[g_fieldnorm[g]]);  // Cache::evaluate, bm25.rs:355-358
+            }
+        }
+        if (!(threshold < result)) continue;  // search.rs:121
+        vbm25_hit h{};
+        h.score = result;
+        h.doc_id = UINT32_MAX - g;
+        std::memcpy(h.payload, g_payload + 3ull * g, 6);
+        // best first; among equal scores the earlier document stays ahead
+        size_t pos = top.size();
+        while (pos > 0 && top[pos - 1].score < result) --pos;
+        top.insert(top.begin() + pos, h);
+        if (top.size() > k) top.pop_back();
+        if (top.size() == k) threshold = std::max(threshold, top.back().score);
+    }
+    std::copy(top.begin(), top.end(), hits);
+    *n_hits = uint32_t(top.size());
+    return VBM25_OK;
+}
+
+int vbm25_merge_hits(const vbm25_hit *sealed, uint32_t n_sealed, const vbm25_hit *grow, uint32_t n_grow,
+                     uint32_t k, vbm25_hit *out, uint32_t *n_out) {
+    if (!n_out || (!out && k) || (n_sealed && !sealed) || (n_grow && !grow))
+        return set_error(VBM25_ERR_INVALID, "NULL argument");
+    uint32_t i = 0, j = 0, n = 0;
+    while (n < k && (i < n_sealed || j < n_grow)) {
+        const bool take_grow = j < n_grow && (i >= n_sealed || grow[j].score > sealed[i].score);
+        out[n++] = take_grow ? grow[j++] : sealed[i++];
+    }
+    *n_out = n;
+    return VBM25_OK;
+}
+
+
 }  // extern "C"
