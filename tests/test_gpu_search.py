@@ -219,6 +219,21 @@ def test_corrupt_index_is_rejected():
     with pytest.raises(vb.Vbm25Error) as e:
         vb.GpuIndex(desc)
     assert e.value.code == -2
+    # a WAND pair that does not bound its block: the scan kernels prune with it, so it is checked
+    arrs = {k: v.copy() for k, v in seg.arrays().items()}
+    arrs["blk_wand_tf"][:] = 1
+    arrs["blk_wand_fn"][:] = 255  # the longest documents: the smallest score a posting can have
+    desc, keep = vb.api.desc_from_arrays(seg.meta(), arrs)
+    with pytest.raises(vb.Vbm25Error) as e:
+        vb.GpuIndex(desc)
+    assert e.value.code == -2 and "WAND" in str(e.value)
+    arrs = {k: v.copy() for k, v in seg.arrays().items()}
+    arrs["term_wand_tf"][:] = 1
+    arrs["term_wand_fn"][:] = 255
+    desc, keep = vb.api.desc_from_arrays(seg.meta(), arrs)
+    with pytest.raises(vb.Vbm25Error) as e:
+        vb.GpuIndex(desc)
+    assert e.value.code == -2
 
 
 def test_correlated_terms_spill_and_abort_paths():

@@ -205,27 +205,36 @@ __device__ __forceinline__ void decode_doc_ids(const uint8_t *__restrict__ p, ui
 // ---------------------------------------------------------------------------
 // Index preparation: fieldnorm of every posting + structural validation
 // ---------------------------------------------------------------------------
-__global__ void __launch_bounds__(256)
-post_fn_kernel(uint32_t n_blocks, uint32_t n_docs, const uint4 *__restrict__ blk_meta,
-               const uint8_t *__restrict__ blob, const uint8_t *__restrict__ doc_fieldnorm,
-               uint8_t *__restrict__ post_fn, uint32_t *__restrict__ error_flag) {
+struct PostFnArgs {
+    uint32_t n_blocks, n_docs, n_terms;
+    const uint4 *blk_meta;
+    const uint8_t *blob, *doc_fieldnorm;
+    uint8_t *post_fn;
+    uint32_t *error_flag;
+    // upper bounds to verify: the scan kernels prune with them
+    const uint32_t *term_first_block, *term_wand_tf;
+    const uint8_t *term_wand_fn;
+    const double *term_s0, *s1, *blk_ub;
+};
+__global__ void __launch_bounds__(256) post_fn_kernel(PostFnArgs a) {
     const uint32_t lane = threadIdx.x & 63;
     const uint32_t j = blockIdx.x * (blockDim.x / 64) + (threadIdx.x >> 6);
-    if (j >= n_blocks) return;
-    const uint4 m = blk_meta[j];
-    const uint32_t n = m.w & 0xff, md = (m.w >> 8) & 0xff;
+    if (j >= a.n_blocks) return;
+    const uint4 m = a.blk_meta[j];
+    const uint32_t n = m.w & 0xff, md = (m.w >> 8) & 0xff, mt = (m.w >> 16) & 0xff;
+    const uint8_t *body = a.blob + 8ull * m.z;
     uint32_t d0, d1;
-    decode_doc_ids(blob + 8ull * m.z, md, n, m.x, lane, d0, d1);
+    decode_doc_ids(body, md, n, m.x, lane, d0, d1);
     const uint32_t i0 = 2 * lane, i1 = i0 + 1;
     uint8_t f0 = 0, f1 = 0;
     bool bad = false;
     if (i0 < n) {
-        bad |= d0 >= n_docs;
-        if (d0 < n_docs) f0 = doc_fieldnorm[d0];
+        bad |= d0 >= a.n_docs;
+        if (d0 < a.n_docs) f0 = a.doc_fieldnorm[d0];
     }
     if (i1 < n) {
-        bad |= d1 >= n_docs || d1 <= d0;
-        if (d1 < n_docs) f1 = doc_fieldnorm[d1];
+        bad |= d1 >= a.n_docs || d1 <= d0;
+        if (d1 < a.n_docs) f1 = a.doc_fieldnorm[d1];
     }
     // strictly increasing across lanes, first = min_doc, last = max_doc
     const uint32_t prev = __shfl_up(d1, 1);
@@ -233,8 +242,32 @@ post_fn_kernel(uint32_t n_blocks, uint32_t n_docs, const uint4 *__restrict__ blk
     if (i0 == 0) bad |= d0 != m.x;
     if (i0 == n - 1) bad |= d0 != m.y;
     if (i1 == n - 1) bad |= d1 != m.y;
-    if (bad) atomicOr(error_flag, 1u);
-    reinterpret_cast<uchar2 *>(post_fn + 128ull * j)[lane] = make_uchar2(f0, f1);
+    if (bad) atomicOr(a.error_flag, 1u);
+    reinterpret_cast<uchar2 *>(a.post_fn + 128ull * j)[lane] = make_uchar2(f0, f1);
+
+    // The WAND pairs must bound every posting: Cache::evaluate of each posting against the block's
+    // bound (blk_ub, margin included) and the token's (search.rs:363,377-380).
+    uint32_t lo = 0, hi = a.n_terms;  // the term of block j: term_first_block[t] <= j < [t + 1]
+    while (hi - lo > 1) {
+        const uint32_t mid = (lo + hi) >> 1;
+        if (a.term_first_block[mid] <= j) lo = mid; else hi = mid;
+    }
+    const double s0 = a.term_s0[lo];
+    const double wtf = (double)a.term_wand_tf[lo];
+    const double tub = ((wtf * s0) / (wtf + a.s1[a.term_wand_fn[lo]])) * (1.0 + 1e-12);
+    const double bub = a.blk_ub[j];
+    uint32_t t0, t1;
+    decode_fields(body + ((payload_bytes(md, n) + 7u) & ~7u), mt, n, lane, t0, t1);
+    bool loose = false;
+    if (i0 < n) {
+        const double tf = (double)t0, p = (tf * s0) / (tf + a.s1[f0]);
+        loose |= p > bub || p > tub;
+    }
+    if (i1 < n) {
+        const double tf = (double)t1, p = (tf * s0) / (tf + a.s1[f1]);
+        loose |= p > bub || p > tub;
+    }
+    if (loose) atomicOr(a.error_flag, 2u);
 }
 
 // ---------------------------------------------------------------------------
@@ -1803,17 +1836,34 @@ int vbm25_index_create(const vbm25_index_desc *d, int device, vbm25_index **out)
     if (d->blob_bytes) HIP_TRY(hipMemcpy(ix->blob.p, d->blob, d->blob_bytes, hipMemcpyHostToDevice));
     if (d->n_blocks) {
         const uint32_t grid = (d->n_blocks + 3) / 4;
-        post_fn_kernel<<<grid, 256>>>(d->n_blocks, d->n_docs, ix->blk_meta.as<uint4>(),
-                                      ix->blob.as<uint8_t>(), fieldnorm.as<uint8_t>(),
-                                      ix->post_fn.as<uint8_t>(), err.as<uint32_t>());
+        PostFnArgs pa{};
+        pa.n_blocks = d->n_blocks;
+        pa.n_docs = d->n_docs;
+        pa.n_terms = d->n_terms;
+        pa.blk_meta = ix->blk_meta.as<uint4>();
+        pa.blob = ix->blob.as<uint8_t>();
+        pa.doc_fieldnorm = fieldnorm.as<uint8_t>();
+        pa.post_fn = ix->post_fn.as<uint8_t>();
+        pa.error_flag = err.as<uint32_t>();
+        pa.term_first_block = ix->term_first_block.as<uint32_t>();
+        pa.term_wand_tf = ix->term_wand_tf.as<uint32_t>();
+        pa.term_wand_fn = ix->term_wand_fn.as<uint8_t>();
+        pa.term_s0 = ix->term_s0.as<double>();
+        pa.s1 = ix->s1.as<double>();
+        pa.blk_ub = ix->blk_ub.as<double>();
+        post_fn_kernel<<<grid, 256>>>(pa);
         HIP_TRY(hipGetLastError());
     }
     uint32_t flag = 0;
     HIP_TRY(hipMemcpy(&flag, err.p, 4, hipMemcpyDeviceToHost));
-    if (flag)
+    if (flag & 1u)
         return set_error(VBM25_ERR_CORRUPT,
                          "posting blocks do not decode to strictly increasing ids within "
                          "[min_doc, max_doc] below n_docs");
+    if (flag & 2u)
+        return set_error(VBM25_ERR_CORRUPT,
+                         "a posting scores above its block's / token's WAND pair "
+                         "(search.rs:363,377-380 prune with those bounds)");
     ix->dev.n_docs = d->n_docs;
     ix->dev.n_terms = d->n_terms;
     ix->dev.n_blocks = d->n_blocks;
