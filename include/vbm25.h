@@ -150,6 +150,51 @@ int vbm25_merge_hits(const vbm25_hit *sealed, uint32_t n_sealed, const vbm25_hit
                      uint32_t k, vbm25_hit *out, uint32_t *n_out);
 
 /* ------------------------------------------------------------------------
+ * Host side: reading a bm25 index relation in the reference's own on-disk
+ * format (PostgreSQL 8 KiB pages), the step between PostgreSQL and the GPU.
+ *
+ * `read_page(ctx, page_id)` returns the 8192-byte image of one page of the index
+ * relation (the shim wraps ReadBuffer / a snapshot of the relation file), or
+ * NULL.  Page layout: src/index/storage.rs:49-170 over PostgreSQL's page header
+ * (24 B) + 4-byte line pointers (slots are 1-based) + 8-byte special area
+ * Opaque{next, flags} (crates/bm25/src/lib.rs:41-46).
+ *
+ * vbm25_segment_from_pages walks what search() reads, in the order maintain.rs
+ * :104-161 walks it: Meta (page 0, slot 1: magic "vchordbm", version 1, k1, b,
+ * ptr_jump) -> Jump -> documents tape -> tokens tape -> summaries tape ->
+ * blocks tape (tuples.rs:48-94,141-203,756-781,833-862,900-934,973-1025), and
+ * checks while flattening that every token's summaries and every summary's
+ * block sit where the WAND pointers say.  The result is an ordinary
+ * vbm25_segment: vbm25_segment_desc + vbm25_index_create put it on the GPU
+ * with no re-encoding (block bodies are copied byte for byte).  Anything the
+ * reference would panic on ("data corruption", bad magic / version) returns
+ * VBM25_ERR_CORRUPT.
+ *
+ * vbm25_growing_from_pages collects the unsealed documents of the same relation
+ * (vectors tape from Jump.ptr_vectors; VectorTuple _2 / _1 / _0, tuples.rs
+ * :326-426, state machine of search.rs:83-135) in the CSR form
+ * vbm25_growing_search takes.
+ * ---------------------------------------------------------------------- */
+typedef const uint8_t *(*vbm25_read_page_fn)(void *ctx, uint32_t page_id);
+int vbm25_segment_from_pages(vbm25_read_page_fn read_page, void *ctx, vbm25_segment **out);
+
+typedef struct vbm25_growing vbm25_growing;
+typedef struct vbm25_growing_desc {
+    uint32_t n_docs;
+    uint32_t _pad;
+    uint64_t n_elements;
+    const uint64_t *start;     /* n_docs + 1 */
+    const uint8_t *key;        /* n_elements x 16 */
+    const uint32_t *tf;        /* n_elements */
+    const uint8_t *fieldnorm;  /* n_docs */
+    const uint16_t *payload;   /* n_docs x 3 */
+    const uint8_t *deleted;    /* n_docs */
+} vbm25_growing_desc;
+int vbm25_growing_from_pages(vbm25_read_page_fn read_page, void *ctx, vbm25_growing **out);
+int vbm25_growing_get_desc(const vbm25_growing *, vbm25_growing_desc *out);
+void vbm25_growing_free(vbm25_growing *);
+
+/* ------------------------------------------------------------------------
  * Device side
  * ---------------------------------------------------------------------- */
 typedef struct vbm25_index vbm25_index; /* owns the HBM copy of one sealed segment */

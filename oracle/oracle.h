@@ -136,6 +136,20 @@ uint32_t orc_search_wand_growing(const orc_index *, const uint32_t *terms, uint3
 int64_t orc_evaluate(const orc_index *, const uint32_t *doc_terms, const uint32_t *doc_tfs,
                      uint32_t n_doc_terms, const uint32_t *terms, uint32_t n_terms);
 
+/* ---- the reference's on-disk layout (oracle/pages.cpp; parity unpinned, see its header) ----
+ * A relation of PostgreSQL 8 KiB pages written the way build.rs:22-71 / flush.rs:40-158 /
+ * insert.rs:23-79 write it: Meta, documents / tokens / summaries / blocks tapes, address trees,
+ * vectors tape (growing segment), Jump.  Used to test the product's page reader. */
+typedef struct orc_pages orc_pages;
+orc_pages *orc_pages_build(const orc_index *, const uint8_t *seed32 /* may be NULL */);
+void orc_pages_insert(orc_pages *, const uint16_t *payload3, uint32_t n_elem, const uint8_t *keys,
+                      const uint32_t *tfs);
+void orc_pages_mark_deleted_growing(orc_pages *, uint32_t nth);
+uint32_t orc_pages_count(const orc_pages *);
+const uint8_t *orc_pages_get(const orc_pages *, uint32_t page_id);
+uint8_t *orc_pages_get_mut(orc_pages *, uint32_t page_id);
+void orc_pages_free(orc_pages *);
+
 /* Algorithmic bytes of one query per SURVEY section 8(d). */
 uint64_t orc_query_bytes(const orc_index *, const uint32_t *terms, uint32_t n_terms, uint32_t k);
 

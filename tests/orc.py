@@ -104,6 +104,20 @@ def lib():
     L.orc_evaluate.argtypes = [vp, vp, vp, C.c_uint32, vp, C.c_uint32]
     L.orc_query_bytes.restype = C.c_uint64
     L.orc_query_bytes.argtypes = [vp, vp, C.c_uint32, C.c_uint32]
+    L.orc_pages_build.restype = vp
+    L.orc_pages_build.argtypes = [vp, vp]
+    L.orc_pages_insert.restype = None
+    L.orc_pages_insert.argtypes = [vp, vp, C.c_uint32, vp, vp]
+    L.orc_pages_mark_deleted_growing.restype = None
+    L.orc_pages_mark_deleted_growing.argtypes = [vp, C.c_uint32]
+    L.orc_pages_count.restype = C.c_uint32
+    L.orc_pages_count.argtypes = [vp]
+    L.orc_pages_get.restype = vp
+    L.orc_pages_get.argtypes = [vp, C.c_uint32]
+    L.orc_pages_get_mut.restype = vp
+    L.orc_pages_get_mut.argtypes = [vp, C.c_uint32]
+    L.orc_pages_free.restype = None
+    L.orc_pages_free.argtypes = [vp]
     _lib = L
     return L
 
@@ -267,3 +281,42 @@ def heap_script(keys, ops):
     npop = lib().orc_heap_script(_p(keys), _p(ops), len(ops), _p(popped), _p(sorted_),
                                  C.byref(ns))
     return popped[:npop], sorted_[:ns.value]
+
+
+class Pages:
+    """A relation in the reference's on-disk layout (oracle/pages.cpp): build.rs + flush.rs pages
+    of an OracleIndex, plus insert.rs for unsealed documents."""
+
+    def __init__(self, index, seed=None):
+        seed = np.frombuffer(bytes(seed), np.uint8) if seed is not None else None
+        self.h = C.c_void_p(lib().orc_pages_build(index.h, _p(seed) if seed is not None else None))
+
+    def __del__(self):
+        try:
+            if self.h:
+                lib().orc_pages_free(self.h)
+        except Exception:
+            pass
+
+    def insert(self, payload, keys, tfs):
+        payload = np.ascontiguousarray(payload, dtype=np.uint16)
+        keys = np.frombuffer(b"".join(keys), np.uint8) if len(keys) else np.zeros(0, np.uint8)
+        tfs = np.ascontiguousarray(tfs, dtype=np.uint32)
+        lib().orc_pages_insert(self.h, _p(payload), len(tfs), _p(keys) if len(tfs) else None,
+                               _p(tfs) if len(tfs) else None)
+
+    def mark_deleted_growing(self, nth):
+        lib().orc_pages_mark_deleted_growing(self.h, nth)
+
+    def __len__(self):
+        return int(lib().orc_pages_count(self.h))
+
+    def address(self, i):
+        """Address of page i's 8192 bytes (stable until the next insert)."""
+        return lib().orc_pages_get(self.h, i) if i < len(self) else None
+
+    def page(self, i, writable=False):
+        ptr = lib().orc_pages_get_mut(self.h, i)
+        buf = (C.c_uint8 * 8192).from_address(ptr)
+        a = np.frombuffer(buf, dtype=np.uint8)
+        return a if writable else a.copy()

@@ -304,6 +304,40 @@ def test_growing_segment_merged_with_device_hits():
             assert_same_ranking(ref, merged, ref_ext=ext, what=f"q{q} k={k} growing + device")
 
 
+def test_index_read_from_reference_format_pages():
+    """PostgreSQL-page relation (oracle/pages.cpp, the reference's on-disk layout) -> page reader ->
+    HBM -> search, with unsealed documents from the same relation merged on the host."""
+    c = make_corpus(12_000, 600, seed=17, length="lognormal", mean_len=40)
+    seg0, _, oix = both(c)
+    pages = orc.Pages(oix)
+    a = seg0.arrays()
+    rng = np.random.default_rng(6)
+    n_terms = seg0.meta()["n_terms"]
+    grow_docs = []
+    for _ in range(25):
+        ranks = np.sort(rng.choice(n_terms, int(rng.integers(1, 30)), replace=False))
+        tfs = rng.integers(1, 5, len(ranks)).astype(np.uint32)
+        pages.insert(rng.integers(0, 60000, 3).astype(np.uint16), [a["term_key"][r].tobytes() for r in ranks], tfs)
+        grow_docs.append((ranks, tfs))
+    pl = [pages.page(i) for i in range(len(pages))]
+    seg = vb.segment_from_pages(pl)
+    g = vb.growing_from_pages(pl)
+    gix = vb.GpuIndex(seg)
+    terms, off = make_queries(c, 16, 4, seed=4)
+    check_batch(gix, oix, terms, off, 10)
+    # with the growing segment: oracle takes term ranks for the unsealed documents
+    g_rank = np.concatenate([r for r, _ in grow_docs]).astype(np.uint32)
+    for q in range(len(off) - 1):
+        t = terms[off[q]:off[q + 1]]
+        t = t[t < n_terms]
+        query = vb.Query([a["term_key"][r].tobytes() for r in t])
+        sealed, n = vb.search_batch(gix, t, np.array([0, len(t)], np.uint32), 10)
+        merged = vb.merge_hits(sealed[0, :n[0]], vb.growing_search(seg, query, 10, **g), 10)
+        ref = oix.search_wand_growing(t, 10, g["g_start"], g_rank, g["g_tf"], g["g_fieldnorm"], g["g_payload"], g["g_deleted"])
+        ext = vb.merge_hits(oix.search_brute(t, 310), vb.growing_search(seg, query, 310, **g), 310)
+        assert_same_ranking(ref, merged, ref_ext=ext, what=f"q{q} pages + growing")
+
+
 def test_bench_distributed_code_path_single_rank():
     """bench.py's N>1 code path (RCCL init, segment hand-over through /dev/shm, device-buffer
     view for torch, all-gather of the hit records) with one rank on the one GPU of this box."""

@@ -283,3 +283,57 @@ def merge_hits(sealed, grow, k):
     n = C.c_uint32()
     check(lib().vbm25_merge_hits(_p(sealed), len(sealed), _p(grow), len(grow), k, _p(out), C.byref(n)))
     return out[:n.value]
+
+
+READ_PAGE_FN = C.CFUNCTYPE(C.c_void_p, C.c_void_p, C.c_uint32)
+
+
+class GrowingDesc(C.Structure):
+    _fields_ = [("n_docs", C.c_uint32), ("_pad", C.c_uint32), ("n_elements", C.c_uint64),
+                ("start", C.c_void_p), ("key", C.c_void_p), ("tf", C.c_void_p),
+                ("fieldnorm", C.c_void_p), ("payload", C.c_void_p), ("deleted", C.c_void_p)]
+
+
+def _page_reader(pages):
+    """`pages`: a sequence of 8192-byte page images (bytes / numpy uint8), or a callable
+    page_id -> address.  Returns (callback object, keepalive)."""
+    if callable(pages):
+        cb = READ_PAGE_FN(lambda ctx, i: pages(i))
+        return cb, pages
+    bufs = [np.frombuffer(bytes(p), dtype=np.uint8) if not isinstance(p, np.ndarray) else p for p in pages]
+    for b in bufs:
+        if b.size != 8192:
+            raise ValueError("a page image is 8192 bytes")
+    cb = READ_PAGE_FN(lambda ctx, i: bufs[i].ctypes.data if i < len(bufs) else None)
+    return cb, bufs
+
+
+def segment_from_pages(pages):
+    """Flatten a bm25 index relation in the reference's on-disk format (vbm25_segment_from_pages)."""
+    cb, keep = _page_reader(pages)
+    out = C.c_void_p()
+    check(lib().vbm25_segment_from_pages(C.cast(cb, C.c_void_p), None, C.byref(out)))
+    return Segment(out)
+
+
+def growing_from_pages(pages):
+    """The unsealed documents of the relation as the arrays growing_search takes
+    (dict: g_start, g_key, g_tf, g_fieldnorm, g_payload, g_deleted; copies)."""
+    cb, keep = _page_reader(pages)
+    h = C.c_void_p()
+    check(lib().vbm25_growing_from_pages(C.cast(cb, C.c_void_p), None, C.byref(h)))
+    try:
+        d = GrowingDesc()
+        check(lib().vbm25_growing_get_desc(h, C.byref(d)))
+
+        def arr(ptr, n, dt):
+            if not n or not ptr:
+                return np.zeros(0, dtype=dt)
+            buf = (C.c_uint8 * (n * np.dtype(dt).itemsize)).from_address(ptr)
+            return np.frombuffer(buf, dtype=dt).copy()
+        return dict(g_start=arr(d.start, d.n_docs + 1, np.uint64), g_key=arr(d.key, 16 * d.n_elements, np.uint8),
+                    g_tf=arr(d.tf, d.n_elements, np.uint32), g_fieldnorm=arr(d.fieldnorm, d.n_docs, np.uint8),
+                    g_payload=arr(d.payload, 3 * d.n_docs, np.uint16).reshape(-1, 3),
+                    g_deleted=arr(d.deleted, d.n_docs, np.uint8))
+    finally:
+        lib().vbm25_growing_free(h)

@@ -393,7 +393,6 @@ void Segment::desc(vbm25_index_desc *d) const {
 
 using namespace vbm25;
 
-struct vbm25_segment : vbm25::Segment {};
 
 // ---- save / load: little-endian dump of the arrays -------------------------
 namespace {

@@ -43,4 +43,7 @@ struct Segment {
 };
 
 }  // namespace vbm25
+
+struct vbm25_segment : vbm25::Segment {};
+
 #endif
