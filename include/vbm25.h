@@ -149,6 +149,15 @@ int vbm25_growing_search(const vbm25_index_desc *desc, const uint8_t *query_keys
 int vbm25_merge_hits(const vbm25_hit *sealed, uint32_t n_sealed, const vbm25_hit *grow, uint32_t n_grow,
                      uint32_t k, vbm25_hit *out, uint32_t *n_out);
 
+/* bm25::evaluate (evaluate.rs:22-74): one document against one query with the sealed segment's
+ * statistics -- what `tsvector <&> bm25query` computes when it runs as a plain function
+ * (operators.rs:48-54, which returns the negated value).  Host code, as in the reference.  The
+ * document's elements (key, tf) must be in ascending key order (vector.rs:50-75); its length is the
+ * saturating sum of the tfs; result = sum over the query's keys found in both the document and the
+ * index of idf(N, df) * tf(fieldnorm, tf, k1, b, avgdl), in key order (bm25.rs:285-295). */
+int vbm25_evaluate(const vbm25_index_desc *desc, const uint8_t *doc_key, const uint32_t *doc_tf,
+                   uint32_t n_doc_elements, const uint8_t *query_keys, uint32_t n_keys, double *score);
+
 /* ------------------------------------------------------------------------
  * Host side: reading a bm25 index relation in the reference's own on-disk
  * format (PostgreSQL 8 KiB pages), the step between PostgreSQL and the GPU.

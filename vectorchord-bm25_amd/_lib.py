@@ -51,6 +51,7 @@ ABI = {
     "vbm25_query_bytes": (u64, [vp, vp, u32, u32]),
     "vbm25_growing_search": (i32, [vp, vp, u32, u32, u32, vp, vp, vp, vp, vp, vp, vp, vp]),
     "vbm25_merge_hits": (i32, [vp, u32, vp, u32, u32, vp, vp]),
+    "vbm25_evaluate": (i32, [vp, vp, vp, u32, vp, u32, vp]),
     "vbm25_segment_from_pages": (i32, [vp, vp, vp]),
     "vbm25_growing_from_pages": (i32, [vp, vp, vp]),
     "vbm25_growing_get_desc": (i32, [vp, vp]),

@@ -337,3 +337,15 @@ def growing_from_pages(pages):
                     g_deleted=arr(d.deleted, d.n_docs, np.uint8))
     finally:
         lib().vbm25_growing_free(h)
+
+
+def evaluate(segment_or_desc, doc_keys, doc_tfs, query):
+    """bm25::evaluate (evaluate.rs:22-74): the `<&>` operator as a plain function; the SQL operator
+    returns the negation of this value (operators.rs:54)."""
+    desc = segment_or_desc.desc if isinstance(segment_or_desc, Segment) else segment_or_desc
+    dk = np.frombuffer(b"".join(doc_keys), dtype=np.uint8) if len(doc_keys) else np.zeros(0, np.uint8)
+    dt = np.ascontiguousarray(doc_tfs, dtype=np.uint32)
+    qk = np.frombuffer(b"".join(query.keys), dtype=np.uint8) if query.keys else np.zeros(0, np.uint8)
+    out = C.c_double()
+    check(lib().vbm25_evaluate(C.byref(desc), _p(dk), _p(dt), len(dt), _p(qk), len(query.keys), C.byref(out)))
+    return out.value

@@ -737,4 +737,43 @@ int vbm25_merge_hits(const vbm25_hit *sealed, uint32_t n_sealed, const vbm25_hit
 }
 
 
+// evaluate.rs:22-74
+int vbm25_evaluate(const vbm25_index_desc *d, const uint8_t *doc_key, const uint32_t *doc_tf, uint32_t n_doc,
+                   const uint8_t *query_keys, uint32_t n_keys, double *score) {
+    if (!d || !score || (n_doc && (!doc_key || !doc_tf)) || (n_keys && !query_keys))
+        return set_error(VBM25_ERR_INVALID, "NULL argument");
+    for (uint32_t i = 1; i < n_doc; ++i)  // Document::checked_new, vector.rs:56-61
+        if (std::memcmp(doc_key + 16ull * (i - 1), doc_key + 16ull * i, 16) >= 0)
+            return set_error(VBM25_ERR_INVALID, "document keys must be strictly ascending");
+    for (uint32_t i = 1; i < n_keys; ++i)
+        if (std::memcmp(query_keys + 16ull * (i - 1), query_keys + 16ull * i, 16) >= 0)
+            return set_error(VBM25_ERR_INVALID, "query keys must be strictly ascending");
+    uint64_t length = 0;  // Document::length, vector.rs:77-83: saturating
+    for (uint32_t i = 0; i < n_doc; ++i) length = std::min<uint64_t>(length + doc_tf[i], UINT32_MAX);
+    const uint8_t fieldnorm = length_to_fieldnorm(uint32_t(length));
+    const double avgdl = double(d->sum_len) / double(d->n_docs);
+    const double k1 = d->k1, b = d->b;
+    const double document_length = double(fieldnorm_lengths()[fieldnorm]);
+    size_t cursor = 0;
+    double result = 0.0;
+    for (uint32_t i = 0; i < n_keys; ++i) {
+        const uint8_t *key = query_keys + 16ull * i;
+        while (cursor < n_doc && std::memcmp(doc_key + 16ull * cursor, key, 16) < 0) ++cursor;
+        if (!(cursor < n_doc && !std::memcmp(doc_key + 16ull * cursor, key, 16))) continue;
+        uint32_t lo = 0, hi = d->n_terms;  // address_tokens::read
+        while (lo < hi) {
+            const uint32_t mid = (lo + hi) >> 1;
+            if (std::memcmp(d->term_key + 16ull * mid, key, 16) < 0) lo = mid + 1; else hi = mid;
+        }
+        if (!(lo < d->n_terms && !std::memcmp(d->term_key + 16ull * lo, key, 16))) continue;
+        const double term_frequency = double(doc_tf[cursor]);
+        const double idf = std::log((double(d->n_docs) + 1.0) / (double(d->term_df[lo]) + 0.5));  // bm25.rs:285-289
+        const double tf = (term_frequency * (k1 + 1.0)) /
+                          (term_frequency + k1 * (1.0 - b + b * document_length / avgdl));        // bm25.rs:291-295
+        result += idf * tf;
+    }
+    *score = result;
+    return VBM25_OK;
+}
+
 }  // extern "C"
