@@ -1674,6 +1674,7 @@ struct vbm25_batch {
     bool has_mid_terms = false;   // some sparse query has CUR_T < terms <= CHAIN_MAX_TERMS
     uint32_t cur_mt = 1;          // most indexed terms among the cursor kernel's queries
     uint32_t target_items = TARGET_ITEMS;
+    uint32_t min_chunk = MIN_CHUNK_POSTINGS;
     std::vector<std::pair<hipEvent_t, hipEvent_t>> events;
     size_t events_used = 0;
     ~vbm25_batch() {
@@ -1934,6 +1935,9 @@ int vbm25_batch_create(vbm25_index *ix, uint32_t max_queries, uint32_t max_total
         const char *ti = std::getenv("VBM25_CUR_ITEMS");
         bt->target_items = bt->use_cursor ? (ti ? (uint32_t)std::atoi(ti) : CUR_TARGET_ITEMS) : TARGET_ITEMS;
         if (bt->target_items < TARGET_ITEMS) bt->target_items = TARGET_ITEMS;
+        const char *mc = std::getenv("VBM25_CUR_MIN_CHUNK");
+        bt->min_chunk = bt->use_cursor ? (mc ? (uint32_t)std::atoi(mc) : CUR_MIN_CHUNK_POSTINGS) : MIN_CHUNK_POSTINGS;
+        if (bt->min_chunk < 128) bt->min_chunk = 128;
     }
     bt->max_items = max_queries + bt->target_items;
     int rc = 0;
@@ -2043,8 +2047,7 @@ int vbm25_batch_run(vbm25_batch *bt, void *hip_stream) {
     db.chain_min_terms = bt->use_cursor ? (uint32_t)CUR_T + 1u : 0u;
     const DevIndex &ix = bt->index->dev;
     if (bt->use_cursor) HIP_TRY(hipMemsetAsync(bt->hist.p, 0, 4ull * CUR_HB * bt->nq, st));
-    plan_kernel<<<1, PLAN_WG, 0, st>>>(ix, db, bt->max_items, bt->target_items,
-                                       bt->use_cursor ? CUR_MIN_CHUNK_POSTINGS : MIN_CHUNK_POSTINGS);
+    plan_kernel<<<1, PLAN_WG, 0, st>>>(ix, db, bt->max_items, bt->target_items, bt->min_chunk);
     hipEvent_t e0 = nullptr, e1 = nullptr;
     if (bt->timing) {
         if (bt->events_used == bt->events.size()) {
