@@ -165,3 +165,52 @@ def test_corruption_is_reported_not_crashed():
     broken(lambda cp: cp[ptr_summaries].__setitem__(soff + 12, cp[ptr_summaries][soff + 12] + 1))
     with pytest.raises(vb.Vbm25Error):
         vb.segment_from_pages([])
+
+
+def test_random_damage_never_crashes_the_reader():
+    """Byte flips anywhere in the relation: the reader returns a segment or VBM25_ERR_CORRUPT, and a
+    segment it returns passes the library's own structural checks or is rejected by them -- it never
+    reads outside the 8 KiB images (the process would die)."""
+    c, seg, oix, pages = _relation(n_docs=1500, vocab=120, seed=5)
+    a = seg.arrays()
+    for i in range(6):
+        pages.insert(np.array([i, 1, 2], np.uint16), [a["term_key"][r].tobytes() for r in (1, 5, 9)], [1, 2, 3])
+    pl = _page_list(pages)
+    rng = np.random.default_rng(0)
+    outcomes = {"ok": 0, "corrupt": 0}
+    for it in range(300):
+        cp = [p.copy() for p in pl]
+        for _ in range(int(rng.integers(1, 4))):
+            pg = int(rng.integers(0, len(cp)))
+            if rng.random() < 0.5:   # header / line pointers / special area
+                pos = int(rng.choice(np.r_[np.arange(12, 60), np.arange(8184, 8192)]))
+            else:
+                pos = int(rng.integers(0, 8192))
+            cp[pg][pos] = int(rng.integers(0, 256))
+        for fn in (vb.segment_from_pages, vb.growing_from_pages):
+            try:
+                fn(cp)
+                outcomes["ok"] += 1
+            except vb.Vbm25Error as e:
+                assert e.code in (-2, -1)
+                outcomes["corrupt"] += 1
+    assert outcomes["ok"] > 0 and outcomes["corrupt"] > 0
+
+
+def test_page_reader_under_asan(tmp_path):
+    """tests/native/fuzz_pages.cpp: 4000 randomly damaged relations through the reader built with
+    AddressSanitizer + UBSan (out-of-bounds reads would abort the run)."""
+    import os
+    import shutil
+    import subprocess
+    if not shutil.which("g++"):
+        pytest.skip("no g++")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = str(tmp_path / "fuzz_pages")
+    src = [os.path.join(root, p) for p in ("tests/native/fuzz_pages.cpp", "vectorchord-bm25_amd/csrc/pages.cpp",
+                                           "vectorchord-bm25_amd/csrc/segment.cpp", "oracle/oracle.cpp", "oracle/pages.cpp")]
+    subprocess.check_call(["g++", "-std=c++17", "-O1", "-g", "-fsanitize=address,undefined", "-fno-omit-frame-pointer",
+                           "-pthread", *src, "-o", exe])
+    out = subprocess.run([exe], capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-4000:]
+    assert "fuzz done" in out.stdout

@@ -5,6 +5,7 @@
 
 #include <cstring>
 #include <memory>
+#include <unordered_set>
 
 using namespace vbm25;
 
@@ -53,6 +54,7 @@ struct PageView {
 struct Relation {
     vbm25_read_page_fn fn;
     void *ctx;
+    mutable std::unordered_set<uint32_t> walked;  // a page belongs to one tape, once: damaged links must not loop
     PageView read(uint32_t id) const {
         const uint8_t *p = fn(ctx, id);
         if (!p) throw Corrupt{"page cannot be read", id};
@@ -63,8 +65,8 @@ struct Relation {
 // tape.rs:169-199: every tuple of every page from `first` following Opaque.next
 template <class F>
 void walk_tape(const Relation &rel, uint32_t first, F &&visit) {
-    uint64_t guard = 0;
     for (uint32_t cur = first; cur != NONE;) {
+        if (!rel.walked.insert(cur).second) throw Corrupt{"page linked twice", cur};
         const PageView pg = rel.read(cur);
         const uint16_t n = pg.len();
         for (uint16_t i = 1; i <= n; ++i) {
@@ -73,7 +75,6 @@ void walk_tape(const Relation &rel, uint32_t first, F &&visit) {
             visit(cur, i, t, size);
         }
         cur = pg.next();
-        if (++guard > (1ull << 32)) throw Corrupt{"tape does not end", cur};
     }
 }
 
@@ -124,7 +125,7 @@ int vbm25_segment_from_pages(vbm25_read_page_fn read_page, void *ctx, vbm25_segm
     if (!read_page || !out) return set_error(VBM25_ERR_INVALID, "NULL argument");
     *out = nullptr;
     try {
-        const Relation rel{read_page, ctx};
+        const Relation rel{read_page, ctx, {}};
         auto seg = std::make_unique<vbm25_segment>();
         const Jump jump = read_meta_jump(rel, seg->k1, seg->b);
         seg->n_docs = jump.n_docs;
@@ -219,7 +220,7 @@ int vbm25_growing_from_pages(vbm25_read_page_fn read_page, void *ctx, vbm25_grow
     if (!read_page || !out) return set_error(VBM25_ERR_INVALID, "NULL argument");
     *out = nullptr;
     try {
-        const Relation rel{read_page, ctx};
+        const Relation rel{read_page, ctx, {}};
         double k1, b;
         const Jump jump = read_meta_jump(rel, k1, b);
         if (jump.ptr_vectors == NONE) throw Corrupt{"no vectors tape", 0};  // search.rs:85
