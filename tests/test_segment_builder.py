@@ -129,3 +129,15 @@ def test_segment_save_load_and_query_bytes():
     oix = orc.OracleIndex.from_arrays(seg.meta(), a)
     for terms in ([0], [1, 5, 99], [3, 500]):
         assert seg.query_bytes(terms, 10) == oix.query_bytes(terms, 10)
+
+
+def test_segment_file_with_bogus_length_is_rejected(tmp_path):
+    seg = vb.Segment.synth(2000, 100, mean_len=20, threads=2)
+    path = str(tmp_path / "s.seg")
+    seg.save(path)
+    raw = bytearray(open(path, "rb").read())
+    raw[64:72] = (2 ** 60).to_bytes(8, "little")  # bogus length of the first array
+    open(path, "wb").write(raw)
+    with pytest.raises(vb.Vbm25Error) as e:
+        vb.Segment.load(path)
+    assert e.value.code == -2

@@ -403,9 +403,10 @@ bool put(FILE *f, const std::vector<T> &v) {
     return fwrite(&n, 8, 1, f) == 1 && (n == 0 || fwrite(v.data(), sizeof(T), n, f) == n);
 }
 template <class T>
-bool get(FILE *f, std::vector<T> &v) {
+bool get(FILE *f, std::vector<T> &v, uint64_t file_bytes) {
     uint64_t n = 0;
     if (fread(&n, 8, 1, f) != 1) return false;
+    if (n > file_bytes / sizeof(T)) return false;  // a length the file cannot hold: not a segment file
     v.resize(n);
     return n == 0 || fread(v.data(), sizeof(T), n, f) == n;
 }
@@ -622,6 +623,9 @@ int vbm25_segment_load(const char *path, vbm25_segment **out) {
     FILE *f = std::fopen(path, "rb");
     if (!f) return set_error(VBM25_ERR_INVALID, "cannot open %s", path);
     auto s = std::make_unique<vbm25_segment>();
+    std::fseek(f, 0, SEEK_END);
+    const uint64_t fb = uint64_t(std::ftell(f));
+    std::fseek(f, 0, SEEK_SET);
     uint64_t hdr[6];
     bool ok = fread(hdr, 8, 6, f) == 6 && hdr[0] == SEG_MAGIC && fread(&s->k1, 8, 1, f) == 1 &&
               fread(&s->b, 8, 1, f) == 1;
@@ -630,12 +634,12 @@ int vbm25_segment_load(const char *path, vbm25_segment **out) {
         s->n_terms = uint32_t(hdr[2]);
         s->n_blocks = uint32_t(hdr[3]);
         s->sum_len = hdr[4];
-        ok = get(f, s->term_key) && get(f, s->term_df) && get(f, s->term_wand_fn) &&
-             get(f, s->term_wand_tf) && get(f, s->term_first_block) && get(f, s->blk_min_doc) &&
-             get(f, s->blk_max_doc) && get(f, s->blk_n) && get(f, s->blk_wand_fn) &&
-             get(f, s->blk_wand_tf) && get(f, s->blk_meta_doc) && get(f, s->blk_meta_tf) &&
-             get(f, s->blk_off8) && get(f, s->blob) && get(f, s->doc_fieldnorm) &&
-             get(f, s->doc_payload) && get(f, s->token_term);
+        ok = get(f, s->term_key, fb) && get(f, s->term_df, fb) && get(f, s->term_wand_fn, fb) &&
+             get(f, s->term_wand_tf, fb) && get(f, s->term_first_block, fb) && get(f, s->blk_min_doc, fb) &&
+             get(f, s->blk_max_doc, fb) && get(f, s->blk_n, fb) && get(f, s->blk_wand_fn, fb) &&
+             get(f, s->blk_wand_tf, fb) && get(f, s->blk_meta_doc, fb) && get(f, s->blk_meta_tf, fb) &&
+             get(f, s->blk_off8, fb) && get(f, s->blob, fb) && get(f, s->doc_fieldnorm, fb) &&
+             get(f, s->doc_payload, fb) && get(f, s->token_term, fb);
     }
     std::fclose(f);
     if (!ok) return set_error(VBM25_ERR_CORRUPT, "%s is not a vbm25 segment file", path);
