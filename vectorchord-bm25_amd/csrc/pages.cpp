@@ -212,7 +212,9 @@ int vbm25_segment_from_pages(vbm25_read_page_fn read_page, void *ctx, vbm25_segm
     } catch (const Corrupt &c) {
         return set_error(VBM25_ERR_CORRUPT, "data corruption: %s (page %u)", c.what, c.page);
     } catch (const std::bad_alloc &) {
-        return set_error(VBM25_ERR_INVALID, "out of host memory while flattening the index");
+        return set_error(VBM25_ERR_NOMEM, "out of host memory while flattening the index");
+    } catch (const std::exception &e) {
+        return set_error(VBM25_ERR_INVALID, "internal error: %s", e.what());
     }
 }
 
@@ -267,7 +269,9 @@ int vbm25_growing_from_pages(vbm25_read_page_fn read_page, void *ctx, vbm25_grow
     } catch (const Corrupt &c) {
         return set_error(VBM25_ERR_CORRUPT, "data corruption: %s (page %u)", c.what, c.page);
     } catch (const std::bad_alloc &) {
-        return set_error(VBM25_ERR_INVALID, "out of host memory while reading the growing segment");
+        return set_error(VBM25_ERR_NOMEM, "out of host memory while reading the growing segment");
+    } catch (const std::exception &e) {
+        return set_error(VBM25_ERR_INVALID, "internal error: %s", e.what());
     }
 }
 

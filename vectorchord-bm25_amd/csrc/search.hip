@@ -1764,7 +1764,7 @@ extern "C" {
 const char *vbm25_last_error(void) { return g_error; }
 const char *vbm25_version(void) { return "vbm25-mi355x 0.1 (gfx950)"; }
 
-int vbm25_index_create(const vbm25_index_desc *d, int device, vbm25_index **out) {
+static int vbm25_index_create_impl(const vbm25_index_desc *d, int device, vbm25_index **out) {
     if (!out) return set_error(VBM25_ERR_INVALID, "out is NULL");
     *out = nullptr;
     if (int rc = check_desc(d)) return rc;
@@ -1913,7 +1913,7 @@ int vbm25_lookup_terms(const vbm25_index *ix, const uint8_t *keys, uint32_t n, u
     return VBM25_OK;
 }
 
-int vbm25_batch_create(vbm25_index *ix, uint32_t max_queries, uint32_t max_total_terms, uint32_t k,
+static int vbm25_batch_create_impl(vbm25_index *ix, uint32_t max_queries, uint32_t max_total_terms, uint32_t k,
                        vbm25_batch **out) {
     if (!out) return set_error(VBM25_ERR_INVALID, "out is NULL");
     *out = nullptr;
@@ -1971,7 +1971,7 @@ void vbm25_batch_destroy(vbm25_batch *bt) {
     delete bt;
 }
 
-int vbm25_batch_set_queries(vbm25_batch *bt, const uint32_t *term_ids, const uint32_t *q_off,
+static int vbm25_batch_set_queries_impl(vbm25_batch *bt, const uint32_t *term_ids, const uint32_t *q_off,
                             uint32_t nq) {
     if (!bt || !q_off) return set_error(VBM25_ERR_INVALID, "NULL argument");
     if (nq > bt->max_queries) return set_error(VBM25_ERR_INVALID, "%u queries exceed the batch capacity %u", nq, bt->max_queries);
@@ -2018,7 +2018,7 @@ int vbm25_batch_set_queries(vbm25_batch *bt, const uint32_t *term_ids, const uin
     return VBM25_OK;
 }
 
-int vbm25_batch_run(vbm25_batch *bt, void *hip_stream) {
+static int vbm25_batch_run_impl(vbm25_batch *bt, void *hip_stream) {
     if (!bt) return set_error(VBM25_ERR_INVALID, "batch is NULL");
     if (!bt->nq) return VBM25_OK;
     if (int rc = use_device(bt->index->device)) return rc;
@@ -2081,7 +2081,7 @@ int vbm25_batch_run(vbm25_batch *bt, void *hip_stream) {
     return VBM25_OK;
 }
 
-int vbm25_batch_fetch(vbm25_batch *bt, vbm25_hit *hits, uint32_t *n_hits) {
+static int vbm25_batch_fetch_impl(vbm25_batch *bt, vbm25_hit *hits, uint32_t *n_hits) {
     if (!bt || (!hits && bt->nq) || (!n_hits && bt->nq)) return set_error(VBM25_ERR_INVALID, "NULL argument");
     if (int rc = use_device(bt->index->device)) return rc;
     HIP_TRY(hipDeviceSynchronize());
@@ -2142,7 +2142,7 @@ int vbm25_batch_profile(vbm25_batch *bt, unsigned long long *out, uint32_t n_wor
 }
 #endif
 
-int vbm25_search_batch(vbm25_index *ix, const uint32_t *term_ids, const uint32_t *q_off, uint32_t nq,
+static int vbm25_search_batch_impl(vbm25_index *ix, const uint32_t *term_ids, const uint32_t *q_off, uint32_t nq,
                        uint32_t k, vbm25_hit *hits, uint32_t *n_hits) {
     if (!ix || !q_off) return set_error(VBM25_ERR_INVALID, "NULL argument");
     if (nq == 0) return k ? VBM25_OK : set_error(VBM25_ERR_INVALID, "number of needed rows is set to 0");
@@ -2160,6 +2160,33 @@ int vbm25_search_batch(vbm25_index *ix, const uint32_t *term_ids, const uint32_t
     if (!rc) rc = vbm25_batch_run(bt, nullptr);
     if (!rc) rc = vbm25_batch_fetch(bt, hits, n_hits);
     return rc;
+}
+
+int vbm25_index_create(const vbm25_index_desc *d, int device, vbm25_index **out) {
+    return guarded([&] { return vbm25_index_create_impl(d, device, out); });
+}
+
+int vbm25_batch_create(vbm25_index *ix, uint32_t max_queries, uint32_t max_total_terms, uint32_t k,
+                       vbm25_batch **out) {
+    return guarded([&] { return vbm25_batch_create_impl(ix, max_queries, max_total_terms, k, out); });
+}
+
+int vbm25_batch_set_queries(vbm25_batch *bt, const uint32_t *term_ids, const uint32_t *q_off,
+                            uint32_t nq) {
+    return guarded([&] { return vbm25_batch_set_queries_impl(bt, term_ids, q_off, nq); });
+}
+
+int vbm25_batch_run(vbm25_batch *bt, void *hip_stream) {
+    return guarded([&] { return vbm25_batch_run_impl(bt, hip_stream); });
+}
+
+int vbm25_batch_fetch(vbm25_batch *bt, vbm25_hit *hits, uint32_t *n_hits) {
+    return guarded([&] { return vbm25_batch_fetch_impl(bt, hits, n_hits); });
+}
+
+int vbm25_search_batch(vbm25_index *ix, const uint32_t *term_ids, const uint32_t *q_off, uint32_t nq,
+                       uint32_t k, vbm25_hit *hits, uint32_t *n_hits) {
+    return guarded([&] { return vbm25_search_batch_impl(ix, term_ids, q_off, nq, k, hits, n_hits); });
 }
 
 }  // extern "C"

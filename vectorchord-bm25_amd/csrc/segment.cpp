@@ -601,7 +601,7 @@ int vbm25_segment_desc(const vbm25_segment *seg, vbm25_index_desc *out) {
 
 void vbm25_segment_free(vbm25_segment *seg) { delete seg; }
 
-int vbm25_segment_save(const vbm25_segment *s, const char *path) {
+static int vbm25_segment_save_impl(const vbm25_segment *s, const char *path) {
     if (!s || !path) return set_error(VBM25_ERR_INVALID, "NULL argument");
     FILE *f = std::fopen(path, "wb");
     if (!f) return set_error(VBM25_ERR_INVALID, "cannot open %s for writing", path);
@@ -617,7 +617,7 @@ int vbm25_segment_save(const vbm25_segment *s, const char *path) {
     return ok ? VBM25_OK : set_error(VBM25_ERR_INVALID, "short write to %s", path);
 }
 
-int vbm25_segment_load(const char *path, vbm25_segment **out) {
+static int vbm25_segment_load_impl(const char *path, vbm25_segment **out) {
     if (!path || !out) return set_error(VBM25_ERR_INVALID, "NULL argument");
     *out = nullptr;
     FILE *f = std::fopen(path, "rb");
@@ -660,7 +660,7 @@ uint64_t vbm25_query_bytes(const vbm25_index_desc *d, const uint32_t *term_ids, 
 }
 
 // search.rs:83-135: the growing segment is scanned document by document before the WAND loop.
-int vbm25_growing_search(const vbm25_index_desc *d, const uint8_t *query_keys, uint32_t n_keys, uint32_t k,
+static int vbm25_growing_search_impl(const vbm25_index_desc *d, const uint8_t *query_keys, uint32_t n_keys, uint32_t k,
                          uint32_t n_grow, const uint64_t *g_start, const uint8_t *g_key, const uint32_t *g_tf,
                          const uint8_t *g_fieldnorm, const uint16_t *g_payload, const uint8_t *g_deleted,
                          vbm25_hit *hits, uint32_t *n_hits) {
@@ -778,6 +778,21 @@ int vbm25_evaluate(const vbm25_index_desc *d, const uint8_t *doc_key, const uint
     }
     *score = result;
     return VBM25_OK;
+}
+
+int vbm25_segment_load(const char *path, vbm25_segment **out) {
+    return guarded([&] { return vbm25_segment_load_impl(path, out); });
+}
+
+int vbm25_growing_search(const vbm25_index_desc *d, const uint8_t *query_keys, uint32_t n_keys, uint32_t k,
+                         uint32_t n_grow, const uint64_t *g_start, const uint8_t *g_key, const uint32_t *g_tf,
+                         const uint8_t *g_fieldnorm, const uint16_t *g_payload, const uint8_t *g_deleted,
+                         vbm25_hit *hits, uint32_t *n_hits) {
+    return guarded([&] { return vbm25_growing_search_impl(d, query_keys, n_keys, k, n_grow, g_start, g_key, g_tf, g_fieldnorm, g_payload, g_deleted, hits, n_hits); });
+}
+
+int vbm25_segment_save(const vbm25_segment *s, const char *path) {
+    return guarded([&] { return vbm25_segment_save_impl(s, path); });
 }
 
 }  // extern "C"

@@ -4,6 +4,8 @@
 #define VBM25_INTERNAL_H
 
 #include <cstdint>
+#include <exception>
+#include <new>
 #include <vector>
 
 #include "../../include/vbm25.h"
@@ -12,6 +14,21 @@ namespace vbm25 {
 
 // Thread-local error text; returns `code` so callers can `return set_error(...)`.
 int set_error(int code, const char *fmt, ...) __attribute__((format(printf, 2, 3)));
+
+// No C++ exception may cross the C ABI (the reference's crate is #![deny(ffi_unwind_calls)], src/lib.rs:16):
+// every entry point that allocates runs its body through this.
+template <class F>
+int guarded(F &&body) noexcept {
+    try {
+        return body();
+    } catch (const std::bad_alloc &) {
+        return set_error(VBM25_ERR_NOMEM, "out of host memory");
+    } catch (const std::exception &e) {
+        return set_error(VBM25_ERR_INVALID, "internal error: %s", e.what());
+    } catch (...) {
+        return set_error(VBM25_ERR_INVALID, "internal error");
+    }
+}
 
 // bm25.rs:15-283
 const uint32_t *fieldnorm_lengths();
