@@ -1,5 +1,6 @@
 #!/usr/bin/env python3
-"""Phase timers of scan_kernel (libvbm25_prof.so, built with -DVBM25_PROFILE).
+"""Phase timers of scan_kernel, the tile kernel (libvbm25_prof.so, built with -DVBM25_PROFILE); run with
+VBM25_NO_CURSOR=1, otherwise the cursor kernel serves these queries (tools/profile_cursor.py).
 Prints average cycles per tile of one worker wave and of the planner wave."""
 import ctypes as C
 import os

@@ -837,22 +837,23 @@ __device__ __forceinline__ void lds_barrier() {
 #endif
 
 // ---------------------------------------------------------------------------
-// Posting scan, chain formulation: queries with at most CHAIN_MAX_TERMS indexed terms.
+// Posting scan, tile formulation (scan_kernel): queries with CUR_T < terms <= CHAIN_MAX_TERMS, and every
+// query of at most CHAIN_MAX_TERMS terms when k > REG_K or the cursor kernel is switched off.
 //
-// Per workgroup: C_BLOCKS block slots of staging in LDS (doc id, partial score, chain link
-// per posting), split into per-term regions in key order, so that a posting's staging index
-// orders postings by term.  Per doc-range tile [lo, hi):
-//   plan    hi = smallest min_doc of the first block that does not fit a term's region;
-//           entries = blocks still resident from the previous tile ("carried", not decoded
-//           again) + newly admitted blocks; block metadata comes from an LDS ring that is
-//           refilled one tile ahead
-//   pass A  one wave per entry: decode (unless carried), Cache::evaluate, then link every
-//           posting with lo <= doc < hi into the chain of its document (open-addressed LDS
-//           table of chain heads, lock-free CAS) -- no ordering between terms is needed here
-//   pass B  the head posting of each document walks its chain and adds the partial scores in
-//           ascending staging index = ascending key order (two addends commute; three or
-//           more are selected in order), resets the table slot, and offers the document to
-//           the top-k list if it can still make it
+// Per workgroup: CNW worker waves + one planner / merger wave + one joiner wave; C_BLOCKS block slots of
+// staging in LDS (doc id, tf, fieldnorm per posting), split into per-term regions in key order, so that
+// a posting's staging index orders postings by term.  Per doc-range tile [lo, hi), ONE LDS-only barrier:
+//   plan    (planner, one tile ahead) hi = smallest min_doc of the first block that does not fit a term's
+//           region; entries = newly admitted blocks + blocks still resident from earlier tiles
+//           ("carried", decoded once per chunk); block metadata comes from an LDS ring
+//   pass A  (workers, two entries each) decode (unless carried) from words fetched one tile earlier, stage,
+//           mark every posting of [lo, hi) in two independently hashed seen / multi bitmap pairs
+//   pass B  (workers) postings whose multi bit is clear under either hash are whole documents: dropped in
+//           hot tiles (threshold above every token upper bound), else scored and filtered; the others go
+//           to the tile's slow list
+//   join    (joiner, one tile late) exact join of the slow list in registers, sums in key order
+//   merge   (planner) running top-k in registers (k <= REG_K) or LDS; the k-th score is shared through LDS
+//           and, across the chunks of a query, through a 64-bit atomicMax on the score bits
 // ---------------------------------------------------------------------------
 __device__ __forceinline__ uint32_t wave_incl_scan_u32(uint32_t x) {
     // DPP row shifts inside 16-lane rows, then row broadcasts across rows (gfx9 wave64)
