@@ -1,0 +1,77 @@
+// device_types.h -- device-side views of the index and of one batch; constants of the kernels.
+// Part of libvbm25's single device translation unit: included by search.hip inside namespace vbm25, in
+// this order: device_types, decode, plan, topk_lds, scan_many, block_fetch, topk_reg, scan_tile,
+// scan_cursor, merge.
+
+// ---------------------------------------------------------------------------
+// Device-side view of the index and of one batch
+// ---------------------------------------------------------------------------
+struct DevIndex {
+    uint32_t n_docs, n_terms, n_blocks;
+    const uint32_t *term_df;
+    const uint32_t *term_first_block;
+    const double *term_s0;       // idf * (k1 + 1), host-computed (libm log)
+    const uint32_t *term_wand_tf;  // TokenTuple WAND pair: the posting that maximises tf()
+    const uint8_t *term_wand_fn;
+    const uint32_t *blk_min_doc;
+    const uint32_t *blk_max_doc;
+    const uint4 *blk_meta;       // {min_doc, max_doc, off8, n | meta_doc<<8 | meta_tf<<16 | wand_fn<<24}
+    const double *blk_ub;        // Cache::evaluate(block WAND pair) x (1 + 1e-12): no posting of the block scores higher
+    const uint8_t *blob;
+    const uint8_t *post_fn;      // derived: fieldnorm of every posting, 128 bytes per block
+    const uint16_t *doc_payload;
+    const double *s1;            // 256 entries
+};
+
+struct Item {
+    uint32_t q, doc_lo, doc_hi, m;  // m = number of indexed terms of query q | ITEM_DENSE
+};
+constexpr uint32_t ITEM_DENSE = 0x80000000u;  // postings per document high: dense-window path
+
+struct DevBatch {
+    const uint32_t *term_ids;
+    const uint32_t *q_off;
+    uint32_t nq, k;
+    Item *items;
+    uint32_t *n_items;
+    uint32_t *q_item_base;  // nq + 1
+    unsigned long long *theta;  // per query: bits of a lower bound of the k-th best score
+    double *res_score;      // per item: k entries
+    uint32_t *res_doc;
+    uint32_t *res_cnt;
+    vbm25_hit *hits;
+    uint32_t *n_hits;
+    uint32_t *error_flag;
+    const uint8_t *q_dense;    // per query: 1 = dense (many postings per document), host decided
+    unsigned long long *spill; // per scan workgroup: candidates that did not fit the LDS buffer
+    uint32_t *item_failed;     // per item: 1 = the chain kernel gave up (dense tile), redo it
+    unsigned long long *prof;  // VBM25_PROFILE builds: 33 counters per workgroup
+    uint32_t *work_ctr;        // next item of the cursor kernel (reset by plan_kernel)
+    uint32_t *hist;            // per query: CUR_HB score buckets, documents accepted by any item
+    uint32_t chain_min_terms;  // scan_kernel leaves queries with fewer terms to scan_cursor_kernel
+};
+
+constexpr int WG = 256;
+constexpr int NW = WG / 64;
+constexpr int SLOTS_LOG2 = 12;
+constexpr int SLOTS = 1 << SLOTS_LOG2;  // hash table slots per workgroup
+constexpr int CAP_BLOCKS = SLOTS / 2 / 128;  // blocks admitted per tile in hash mode
+constexpr int MAX_TERMS = 128;         // terms per query handled on the GPU
+constexpr uint32_t EMPTY = 0xffffffffu;
+constexpr uint32_t TARGET_ITEMS = 1536;  // 2 x (256 CUs x 3 resident workgroups): measured best of 768..3072
+constexpr uint32_t MIN_CHUNK_POSTINGS = 8192;
+constexpr int PLAN_WG = 1024;
+// chain kernel (scan_kernel) geometry
+constexpr int CNW = 6;                   // worker waves per workgroup
+constexpr int CWG = (CNW + 2) * 64;      // + one planner / merger wave + one joiner wave
+constexpr int C_BLOCKS = 2 * CNW;        // block slots of staging per workgroup (2 per worker)
+constexpr int C_POSTINGS = C_BLOCKS * 128;
+constexpr int CHAIN_MAX_TERMS = C_BLOCKS;  // queries with more indexed terms use scan_many_kernel
+constexpr int SLOW_CAP = 64;              // colliding postings per tile kept in LDS (rest: global spill)
+constexpr int SLOW_ABORT = 512;           // beyond this the tile is dense: give the item to scan_many_kernel
+constexpr int JC_CAP = 64;                // joined documents per tile kept in LDS (rest: global spill)
+constexpr int CAND_CAP = 96;              // fast-path documents per tile kept in LDS (rest: global spill)
+constexpr int BM_BITS_LOG2 = 14;          // hashed document bitmaps: 16384 bits each
+constexpr int BM_WORDS = (1 << BM_BITS_LOG2) / 32;
+constexpr int REG_K = 256;                // largest k whose running top-k lives in registers
+constexpr uint32_t NONE32 = 0xffffffffu;

@@ -1,0 +1,160 @@
+// plan.h -- post_fn_kernel (index preparation + validation) and plan_kernel (work items).
+// Part of libvbm25's single device translation unit: included by search.hip inside namespace vbm25, in
+// this order: device_types, decode, plan, topk_lds, scan_many, block_fetch, topk_reg, scan_tile,
+// scan_cursor, merge.
+
+// ---------------------------------------------------------------------------
+// Index preparation: fieldnorm of every posting + structural validation
+// ---------------------------------------------------------------------------
+struct PostFnArgs {
+    uint32_t n_blocks, n_docs, n_terms;
+    const uint4 *blk_meta;
+    const uint8_t *blob, *doc_fieldnorm;
+    uint8_t *post_fn;
+    uint32_t *error_flag;
+    // upper bounds to verify: the scan kernels prune with them
+    const uint32_t *term_first_block, *term_wand_tf;
+    const uint8_t *term_wand_fn;
+    const double *term_s0, *s1, *blk_ub;
+};
+__global__ void __launch_bounds__(256) post_fn_kernel(PostFnArgs a) {
+    const uint32_t lane = threadIdx.x & 63;
+    const uint32_t j = blockIdx.x * (blockDim.x / 64) + (threadIdx.x >> 6);
+    if (j >= a.n_blocks) return;
+    const uint4 m = a.blk_meta[j];
+    const uint32_t n = m.w & 0xff, md = (m.w >> 8) & 0xff, mt = (m.w >> 16) & 0xff;
+    const uint8_t *body = a.blob + 8ull * m.z;
+    uint32_t d0, d1;
+    decode_doc_ids(body, md, n, m.x, lane, d0, d1);
+    const uint32_t i0 = 2 * lane, i1 = i0 + 1;
+    uint8_t f0 = 0, f1 = 0;
+    bool bad = false;
+    if (i0 < n) {
+        bad |= d0 >= a.n_docs;
+        if (d0 < a.n_docs) f0 = a.doc_fieldnorm[d0];
+    }
+    if (i1 < n) {
+        bad |= d1 >= a.n_docs || d1 <= d0;
+        if (d1 < a.n_docs) f1 = a.doc_fieldnorm[d1];
+    }
+    // strictly increasing across lanes, first = min_doc, last = max_doc
+    const uint32_t prev = __shfl_up(d1, 1);
+    if (lane > 0 && i0 < n) bad |= d0 <= prev;
+    if (i0 == 0) bad |= d0 != m.x;
+    if (i0 == n - 1) bad |= d0 != m.y;
+    if (i1 == n - 1) bad |= d1 != m.y;
+    if (bad) atomicOr(a.error_flag, 1u);
+    reinterpret_cast<uchar2 *>(a.post_fn + 128ull * j)[lane] = make_uchar2(f0, f1);
+
+    // The WAND pairs must bound every posting: Cache::evaluate of each posting against the block's
+    // bound (blk_ub, margin included) and the token's (search.rs:363,377-380).
+    uint32_t lo = 0, hi = a.n_terms;  // the term of block j: term_first_block[t] <= j < [t + 1]
+    while (hi - lo > 1) {
+        const uint32_t mid = (lo + hi) >> 1;
+        if (a.term_first_block[mid] <= j) lo = mid; else hi = mid;
+    }
+    const double s0 = a.term_s0[lo];
+    const double wtf = (double)a.term_wand_tf[lo];
+    const double tub = ((wtf * s0) / (wtf + a.s1[a.term_wand_fn[lo]])) * (1.0 + 1e-12);
+    const double bub = a.blk_ub[j];
+    uint32_t t0, t1;
+    decode_fields(body + ((payload_bytes(md, n) + 7u) & ~7u), mt, n, lane, t0, t1);
+    bool loose = false;
+    if (i0 < n) {
+        const double tf = (double)t0, p = (tf * s0) / (tf + a.s1[f0]);
+        loose |= p > bub || p > tub;
+    }
+    if (i1 < n) {
+        const double tf = (double)t1, p = (tf * s0) / (tf + a.s1[f1]);
+        loose |= p > bub || p > tub;
+    }
+    if (loose) atomicOr(a.error_flag, 2u);
+}
+
+// ---------------------------------------------------------------------------
+// Planner
+// ---------------------------------------------------------------------------
+// Block-wide inclusive scan of one u64 per thread (PLAN_WG threads): wave scans + one LDS hop.
+__device__ __forceinline__ unsigned long long plan_incl_scan(unsigned long long v, unsigned long long *s_wave,
+                                                             unsigned long long &total) {
+    const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const unsigned long long y = __shfl_up(v, o);
+        if ((int)lane >= o) v += y;
+    }
+    if (lane == 63) s_wave[wave] = v;
+    __syncthreads();
+    unsigned long long before = 0, all = 0;
+    for (uint32_t w = 0; w < PLAN_WG / 64; ++w) {
+        const unsigned long long x = s_wave[w];
+        if (w < wave) before += x;
+        all += x;
+    }
+    __syncthreads();
+    total = all;
+    return v + before;
+}
+
+__global__ void __launch_bounds__(PLAN_WG) plan_kernel(DevIndex ix, DevBatch bt, uint32_t max_items,
+                                                       uint32_t target_items, uint32_t min_chunk) {
+    __shared__ unsigned long long s_wave[PLAN_WG / 64];
+    const uint32_t tid = threadIdx.x;
+    const uint32_t per = (bt.nq + PLAN_WG - 1) / PLAN_WG;
+    const uint32_t q0 = min(bt.nq, tid * per), q1 = min(bt.nq, q0 + per);
+    // per-launch state of the scan kernels (saves two memset launches per step)
+    for (uint32_t i = tid; i < bt.nq; i += PLAN_WG) bt.theta[i] = 0;
+    for (uint32_t i = tid; i < max_items; i += PLAN_WG) bt.item_failed[i] = 0;
+    if (tid == 0) *bt.work_ctr = 0;
+
+    auto postings_of = [&](uint32_t q) {
+        unsigned long long t = 0;
+        for (uint32_t p = bt.q_off[q]; p < bt.q_off[q + 1]; ++p) {
+            uint32_t term = bt.term_ids[p];
+            if (term < ix.n_terms) t += ix.term_df[term];
+        }
+        return t;
+    };
+    unsigned long long local = 0;
+    for (uint32_t q = q0; q < q1; ++q) local += postings_of(q);
+    unsigned long long total = 0;
+    plan_incl_scan(local, s_wave, total);
+    unsigned long long chunk = (total + target_items - 1) / target_items;
+    if (chunk < min_chunk) chunk = min_chunk;
+    auto chunks_of = [&](uint32_t q) -> uint32_t {
+        unsigned long long t = postings_of(q);
+        if (t == 0) return 0u;
+        // nearest, not ceil: a batch of similar queries gets the same count for all of them, i.e. the
+        // item count lands on the target (a multiple of the resident waves) instead of ~8 % above it
+        unsigned long long c = (t + chunk / 2) / chunk;
+        if (c == 0) c = 1;
+        if (c > ix.n_docs) c = ix.n_docs;
+        return (uint32_t)c;
+    };
+    unsigned long long cnt = 0;
+    for (uint32_t q = q0; q < q1; ++q) cnt += chunks_of(q);
+    unsigned long long run = 0;
+    const unsigned long long incl = plan_incl_scan(cnt, s_wave, run);
+    if (tid == 0) {
+        *bt.n_items = (uint32_t)min(run, (unsigned long long)max_items);
+        if (run > max_items) atomicOr(bt.error_flag, 2u);
+        bt.q_item_base[bt.nq] = (uint32_t)min(run, (unsigned long long)max_items);
+    }
+    uint32_t base = (uint32_t)(incl - cnt);
+    for (uint32_t q = q0; q < q1; ++q) {
+        const uint32_t c = chunks_of(q);
+        uint32_t nterms = 0;
+        for (uint32_t p = bt.q_off[q]; p < bt.q_off[q + 1]; ++p) nterms += bt.term_ids[p] < ix.n_terms;
+        if (bt.q_dense[q]) nterms |= ITEM_DENSE;
+        bt.q_item_base[q] = min(base, max_items);
+        for (uint32_t i = 0; i < c && base + i < max_items; ++i) {
+            Item it;
+            it.q = q;
+            it.doc_lo = (uint32_t)((unsigned long long)ix.n_docs * i / c);
+            it.doc_hi = (uint32_t)((unsigned long long)ix.n_docs * (i + 1) / c);
+            it.m = nterms;
+            bt.items[base + i] = it;
+        }
+        base += c;
+    }
+}

@@ -1,0 +1,194 @@
+// scan_many.h -- scan_many_kernel: many terms / dense queries / failed items.
+// Part of libvbm25's single device translation unit: included by search.hip inside namespace vbm25, in
+// this order: device_types, decode, plan, topk_lds, scan_many, block_fetch, topk_reg, scan_tile,
+// scan_cursor, merge.
+
+// ---------------------------------------------------------------------------
+// Posting scan
+// ---------------------------------------------------------------------------
+template <int KMAX>
+__global__ void __launch_bounds__(WG) scan_many_kernel(DevIndex ix, DevBatch bt) {
+    __shared__ uint32_t s_key[SLOTS];
+    __shared__ double s_val[SLOTS];
+    __shared__ uint16_t s_cand[SLOTS];
+    __shared__ double s_s1[256];
+    __shared__ TopK<KMAX> s_top;
+    __shared__ uint32_t t_cur[MAX_TERMS], t_end[MAX_TERMS], t_quota[MAX_TERMS];
+    __shared__ double t_s0[MAX_TERMS];
+    __shared__ uint32_t s_m, s_hi, s_next_lo, s_cand_cnt, s_dense;
+    __shared__ unsigned long long s_theta, s_sumdf;
+
+    const uint32_t tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const uint32_t k = bt.k;
+    for (int i = tid; i < 256; i += WG) s_s1[i] = ix.s1[i];
+
+    const uint32_t n_items = *bt.n_items;
+    for (uint32_t item = blockIdx.x; item < n_items; item += gridDim.x) {
+        const Item it = bt.items[item];
+        const bool failed = it.m <= (uint32_t)CHAIN_MAX_TERMS && bt.item_failed[item] != 0;
+        if (it.m <= (uint32_t)CHAIN_MAX_TERMS && !failed) continue;  // done by scan_kernel
+        const bool force_dense = failed || (it.m & ITEM_DENSE) != 0;
+        const uint32_t q = it.q, clo = it.doc_lo, chi = it.doc_hi;
+        __syncthreads();  // previous item fully done with LDS
+        if (tid == 0) {
+            // valid terms of the query, ascending (Query::new guarantees sorted keys)
+            uint32_t m = 0;
+            unsigned long long sum = 0;
+            for (uint32_t p = bt.q_off[q]; p < bt.q_off[q + 1]; ++p) {
+                const uint32_t term = bt.term_ids[p];
+                if (term >= ix.n_terms) continue;  // search.rs:59-61
+                if (m < MAX_TERMS) {
+                    t_cur[m] = term;  // resolved below
+                    sum += ix.term_df[term];
+                    ++m;
+                }
+            }
+            s_m = m;
+            s_sumdf = sum;
+            s_top.count = 0;
+            s_dense = (force_dense || m >= (uint32_t)CAP_BLOCKS) ? 1u : 0u;
+        }
+        __syncthreads();
+        const uint32_t m = s_m;
+        const bool dense = s_dense != 0;
+        if (tid < m) {
+            const uint32_t term = t_cur[tid];
+            const uint32_t b0 = ix.term_first_block[term], b1 = ix.term_first_block[term + 1];
+            // first block whose max_doc >= clo
+            uint32_t lo = b0, hi = b1;
+            while (lo < hi) {
+                const uint32_t mid = (lo + hi) >> 1;
+                if (ix.blk_max_doc[mid] < clo) lo = mid + 1; else hi = mid;
+            }
+            t_end[tid] = b1;
+            t_s0[tid] = ix.term_s0[term];
+            const unsigned long long df = ix.term_df[term];
+            const uint32_t share = (uint32_t)(((unsigned long long)(CAP_BLOCKS - (dense ? 0 : (int)m)) * df) / s_sumdf);
+            t_quota[tid] = share > 1 ? share : 1;
+            t_cur[tid] = lo;
+        }
+        __syncthreads();
+
+        uint32_t lo = clo;
+        unsigned long long published = 0;
+        while (lo < chi) {
+            // ---- tile bounds + table reset
+            if (tid == 0) {
+                s_hi = dense ? (chi - lo > (uint32_t)SLOTS ? lo + SLOTS : chi) : chi;
+                s_cand_cnt = 0;
+                s_next_lo = chi;
+                s_theta = __hip_atomic_load(&bt.theta[q], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+            for (int i = tid; i < SLOTS; i += WG) s_key[i] = EMPTY;
+            __syncthreads();
+            if (!dense && tid < m) {
+                const uint32_t j = t_cur[tid] + t_quota[tid];
+                if (j < t_end[tid]) atomicMin(&s_hi, ix.blk_min_doc[j]);
+            }
+            __syncthreads();
+            const uint32_t hi = s_hi;
+
+            // ---- accumulate, one term per phase (ascending key order)
+            for (uint32_t t = 0; t < m; ++t) {
+                const uint32_t jend = t_end[t];
+                const double s0 = t_s0[t];
+                for (uint32_t j = t_cur[t] + wave; j < jend; j += NW) {
+                    const uint4 bm = ix.blk_meta[j];
+                    if (bm.x >= hi) break;
+                    const uint32_t n = bm.w & 0xff, md = (bm.w >> 8) & 0xff, mt = (bm.w >> 16) & 0xff;
+                    const uint8_t *body = ix.blob + 8ull * bm.z;
+                    uint32_t d0, d1, f0, f1;
+                    decode_doc_ids(body, md, n, bm.x, lane, d0, d1);
+                    decode_fields(body + ((payload_bytes(md, n) + 7u) & ~7u), mt, n, lane, f0, f1);
+                    const uchar2 fn = reinterpret_cast<const uchar2 *>(ix.post_fn + 128ull * j)[lane];
+#pragma unroll
+                    for (int e = 0; e < 2; ++e) {
+                        const uint32_t i = 2 * lane + e;
+                        const uint32_t d = e ? d1 : d0;
+                        const uint32_t tfv = e ? f1 : f0;
+                        const uint32_t f = e ? fn.y : fn.x;
+                        if (i < n && d >= lo && d < hi) {
+                            const double tf = (double)tfv;
+                            const double p = (tf * s0) / (tf + s_s1[f]);  // bm25.rs:355-358
+                            const uint32_t key = d - lo;
+                            uint32_t slot = dense ? key : ((key * 0x9E3779B1u) >> (32 - SLOTS_LOG2));
+                            for (;;) {
+                                const uint32_t prev = atomicCAS(&s_key[slot], EMPTY, key);
+                                if (prev == EMPTY) {
+                                    s_val[slot] = p;
+                                    break;
+                                }
+                                if (prev == key) {
+                                    s_val[slot] += p;
+                                    break;
+                                }
+                                slot = (slot + 1) & (SLOTS - 1);
+                            }
+                        }
+                    }
+                }
+                __syncthreads();
+            }
+
+            // ---- candidates of this tile
+            {
+                const unsigned long long theta = s_theta;
+                const uint32_t n = s_top.count;
+                const double ws = n >= k ? s_top.score[k - 1] : 0.0;
+                const uint32_t wd = n >= k ? s_top.doc[k - 1] : 0u;
+                for (int i = tid; i < SLOTS; i += WG) {
+                    const uint32_t key = s_key[i];
+                    if (key == EMPTY) continue;
+                    const double sc = s_val[i];
+                    if ((unsigned long long)__double_as_longlong(sc) < theta) continue;
+                    if (n >= k && !better(sc, lo + key, ws, wd)) continue;
+                    const uint32_t at = atomicAdd(&s_cand_cnt, 1u);
+                    s_cand[at] = (uint16_t)i;
+                }
+            }
+            __syncthreads();
+            if (wave == 0) {
+                const uint32_t cnt = s_cand_cnt;
+                for (uint32_t base = 0; base < cnt; base += 64) {
+                    const bool has = base + lane < cnt;
+                    double sc = 0;
+                    uint32_t d = 0;
+                    if (has) {
+                        const uint32_t slot = s_cand[base + lane];
+                        sc = s_val[slot];
+                        d = lo + s_key[slot];
+                    }
+                    topk_offer<KMAX>(s_top, k, has, sc, d, lane);
+                }
+                if (s_top.count >= k && lane == 0) {
+                    const unsigned long long bits = (unsigned long long)__double_as_longlong(s_top.score[k - 1]);
+                    if (bits > published) {
+                        atomicMax(&bt.theta[q], bits);
+                        published = bits;
+                    }
+                }
+            }
+            // ---- advance cursors; next tile starts at the first remaining posting
+            if (tid < m) {
+                uint32_t j = t_cur[tid];
+                const uint32_t e = t_end[tid];
+                while (j < e && ix.blk_max_doc[j] < hi) ++j;
+                t_cur[tid] = j;
+                if (j < e) atomicMin(&s_next_lo, max(hi, ix.blk_min_doc[j]));
+            }
+            __syncthreads();
+            lo = max(hi, s_next_lo);
+        }
+
+        // ---- chunk result
+        __syncthreads();
+        {
+            const uint32_t n = s_top.count;
+            for (uint32_t i = tid; i < n; i += WG) {
+                bt.res_score[(size_t)item * k + i] = s_top.score[i];
+                bt.res_doc[(size_t)item * k + i] = s_top.doc[i];
+            }
+            if (tid == 0) bt.res_cnt[item] = n;
+        }
+    }
+}

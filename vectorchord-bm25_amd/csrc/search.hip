@@ -1,28 +1,20 @@
-// search.hip -- device half of libvbm25: batched BM25 top-k over compressed posting blocks
-// for MI355X (gfx950, wave64).  Replaces the traversal of
-// /root/reference/crates/bm25/src/search.rs:28-282 (bm25::search) for the sealed segment.
+// search.hip -- device half of libvbm25: batched BM25 top-k over compressed posting blocks for MI355X
+// (gfx950, wave64).  Replaces the traversal of /root/reference/crates/bm25/src/search.rs:28-282
+// (bm25::search) for the sealed segment.  One translation unit; the kernels live in headers:
+//   plan.h         post_fn_kernel (index preparation: per-posting fieldnorm stream + validation of block
+//                  structure and WAND bounds) and plan_kernel (queries -> doc-range work items)
+//   scan_cursor.h  scan_cursor_kernel: queries of <= 8 terms, k <= 256 -- one wave per item, cursors
+//                  processed in min_doc order (the dominant kernel)
+//   scan_tile.h    scan_kernel: 9..12 terms or k > 256 -- workgroup per item, doc-range tiles
+//   scan_many.h    scan_many_kernel: many terms, many postings per document, items the others gave up
+//   merge.h        merge_kernel: per-item top-k lists -> hits with payloads
+//   decode.h / block_fetch.h / topk_lds.h / topk_reg.h / device_types.h   shared pieces
+// This file: error text, host objects (index, batch) and the C ABI of include/vbm25.h.  DESIGN.md has
+// the full story.
 //
-// Shape of the computation (DESIGN.md has the full story):
-//   plan_kernel       one workgroup: splits every query into doc-range chunks of roughly equal
-//                     posting counts -> work items (query, doc_lo, doc_hi, #terms | dense flag)
-//   scan_kernel       sparse queries (<= 12 indexed terms): one workgroup per item walks the
-//                     chunk in doc-range tiles with one barrier per tile.  Worker waves decode
-//                     128-posting blocks (bit-unpack + DPP prefix sum, search.rs:498-518 /
-//                     compression.rs:65-136), mark every posting in hashed LDS bitmaps and drop
-//                     or score (Cache::evaluate, bm25.rs:355-358) documents with a single
-//                     posting; a joiner wave adds up, in ascending key order (evaluate.rs:43-72),
-//                     the documents whose postings collide; a planner wave plans the tiles from
-//                     block metadata staged in LDS and owns the running top-k (Results,
-//                     search.rs:284-314).  A per-query threshold is shared between workgroups
-//                     through a 64-bit atomic max on the score bits.
-//   scan_many_kernel  queries with many terms or many postings per document, and items the
-//                     sparse kernel gave up on: term-phased accumulation in dense doc windows
-//                     or an LDS hash table.
-//   merge_kernel      one wave per query: merges the per-chunk top-k lists, adds payloads.
-//
-// Result order is canonical: score descending, ties by ascending doc id.  All f64 arithmetic
-// is IEEE (compiled with -ffp-contract=off, no fast-math): results are bit-identical to the
-// CPU oracle's brute-force evaluation.
+// Result order is canonical: score descending, ties by ascending doc id.  All f64 arithmetic is IEEE
+// (compiled with -ffp-contract=off, no fast-math): results are bit-identical to the CPU oracle's
+// brute-force evaluation.
 
 #include <hip/hip_runtime.h>
 
@@ -56,1572 +48,16 @@ int set_error(int code, const char *fmt, ...) {
                              hipGetErrorString(e_), __FILE__, __LINE__);                     \
     } while (0)
 
-// ---------------------------------------------------------------------------
-// Device-side view of the index and of one batch
-// ---------------------------------------------------------------------------
-struct DevIndex {
-    uint32_t n_docs, n_terms, n_blocks;
-    const uint32_t *term_df;
-    const uint32_t *term_first_block;
-    const double *term_s0;       // idf * (k1 + 1), host-computed (libm log)
-    const uint32_t *term_wand_tf;  // TokenTuple WAND pair: the posting that maximises tf()
-    const uint8_t *term_wand_fn;
-    const uint32_t *blk_min_doc;
-    const uint32_t *blk_max_doc;
-    const uint4 *blk_meta;       // {min_doc, max_doc, off8, n | meta_doc<<8 | meta_tf<<16 | wand_fn<<24}
-    const double *blk_ub;        // Cache::evaluate(block WAND pair) x (1 + 1e-12): no posting of the block scores higher
-    const uint8_t *blob;
-    const uint8_t *post_fn;      // derived: fieldnorm of every posting, 128 bytes per block
-    const uint16_t *doc_payload;
-    const double *s1;            // 256 entries
-};
-
-struct Item {
-    uint32_t q, doc_lo, doc_hi, m;  // m = number of indexed terms of query q | ITEM_DENSE
-};
-constexpr uint32_t ITEM_DENSE = 0x80000000u;  // postings per document high: dense-window path
-
-struct DevBatch {
-    const uint32_t *term_ids;
-    const uint32_t *q_off;
-    uint32_t nq, k;
-    Item *items;
-    uint32_t *n_items;
-    uint32_t *q_item_base;  // nq + 1
-    unsigned long long *theta;  // per query: bits of a lower bound of the k-th best score
-    double *res_score;      // per item: k entries
-    uint32_t *res_doc;
-    uint32_t *res_cnt;
-    vbm25_hit *hits;
-    uint32_t *n_hits;
-    uint32_t *error_flag;
-    const uint8_t *q_dense;    // per query: 1 = dense (many postings per document), host decided
-    unsigned long long *spill; // per scan workgroup: candidates that did not fit the LDS buffer
-    uint32_t *item_failed;     // per item: 1 = the chain kernel gave up (dense tile), redo it
-    unsigned long long *prof;  // VBM25_PROFILE builds: 33 counters per workgroup
-    uint32_t *work_ctr;        // next item of the cursor kernel (reset by plan_kernel)
-    uint32_t *hist;            // per query: CUR_HB score buckets, documents accepted by any item
-    uint32_t chain_min_terms;  // scan_kernel leaves queries with fewer terms to scan_cursor_kernel
-};
-
-constexpr int WG = 256;
-constexpr int NW = WG / 64;
-constexpr int SLOTS_LOG2 = 12;
-constexpr int SLOTS = 1 << SLOTS_LOG2;  // hash table slots per workgroup
-constexpr int CAP_BLOCKS = SLOTS / 2 / 128;  // blocks admitted per tile in hash mode
-constexpr int MAX_TERMS = 128;         // terms per query handled on the GPU
-constexpr uint32_t EMPTY = 0xffffffffu;
-constexpr uint32_t TARGET_ITEMS = 1536;  // 2 x (256 CUs x 3 resident workgroups): measured best of 768..3072
-constexpr uint32_t MIN_CHUNK_POSTINGS = 8192;
-constexpr int PLAN_WG = 1024;
-// chain kernel (scan_kernel) geometry
-constexpr int CNW = 6;                   // worker waves per workgroup
-constexpr int CWG = (CNW + 2) * 64;      // + one planner / merger wave + one joiner wave
-constexpr int C_BLOCKS = 2 * CNW;        // block slots of staging per workgroup (2 per worker)
-constexpr int C_POSTINGS = C_BLOCKS * 128;
-constexpr int CHAIN_MAX_TERMS = C_BLOCKS;  // queries with more indexed terms use scan_many_kernel
-constexpr int SLOW_CAP = 64;              // colliding postings per tile kept in LDS (rest: global spill)
-constexpr int SLOW_ABORT = 512;           // beyond this the tile is dense: give the item to scan_many_kernel
-constexpr int JC_CAP = 64;                // joined documents per tile kept in LDS (rest: global spill)
-constexpr int CAND_CAP = 96;              // fast-path documents per tile kept in LDS (rest: global spill)
-constexpr int BM_BITS_LOG2 = 14;          // hashed document bitmaps: 16384 bits each
-constexpr int BM_WORDS = (1 << BM_BITS_LOG2) / 32;
-constexpr int REG_K = 256;                // largest k whose running top-k lives in registers
-constexpr uint32_t NONE32 = 0xffffffffu;
-
-// ---------------------------------------------------------------------------
-// Block decode: one wave, two postings per lane (value indices 2*lane, 2*lane+1)
-// ---------------------------------------------------------------------------
-__device__ __forceinline__ uint32_t bp_field(const uint32_t *__restrict__ w32, uint32_t b,
-                                             uint32_t i) {
-    // crates/simd/src/bitpacking.rs:58-98: lane l = i % 4 is an LSB-first stream of b-bit
-    // fields, its word w lives at 32-bit index 4*w + l.
-    const uint32_t l = i & 3, bit = (i >> 2) * b, w = bit >> 5, sh = bit & 31;
-    const uint32_t lo = w32[4 * w + l];
-    const uint32_t hi = (sh + b > 32) ? w32[4 * (w + 1) + l] : 0u;
-    const unsigned long long both = ((unsigned long long)hi << 32) | lo;
-    return (uint32_t)(both >> sh) & ((1u << b) - 1u);
-}
-
-__device__ __forceinline__ uint32_t byte_field(const uint8_t *__restrict__ p, uint32_t w,
-                                               uint32_t i) {
-    uint32_t v = 0;
-    for (uint32_t j = 0; j < w; ++j) v |= (uint32_t)p[i * w + j] << (8 * j);
-    return v;
-}
-
-// Raw fields of a block payload (no delta).  meta: bit 7 = byte packed, low bits = width.
-__device__ __forceinline__ void decode_fields(const uint8_t *__restrict__ p, uint32_t meta,
-                                              uint32_t n, uint32_t lane, uint32_t &v0,
-                                              uint32_t &v1) {
-    const uint32_t i0 = 2 * lane, i1 = i0 + 1;
-    const uint32_t width = meta & 127u;
-    v0 = 0;
-    v1 = 0;
-    if ((meta >> 7) == 0) {
-        const uint32_t *w32 = reinterpret_cast<const uint32_t *>(p);
-        if (width == 32) {
-            v0 = w32[i0];
-            v1 = w32[i1];
-        } else if (width != 0) {
-            v0 = bp_field(w32, width, i0);
-            v1 = bp_field(w32, width, i1);
-        }
-    } else {
-        if (i0 < n) v0 = byte_field(p, width, i0);
-        if (i1 < n) v1 = byte_field(p, width, i1);
-    }
-}
-
-__device__ __forceinline__ uint32_t payload_bytes(uint32_t meta, uint32_t n) {
-    return (meta >> 7) ? (meta & 127u) * n : 16u * (meta & 127u);
-}
-
-// Document ids of a block: d1 deltas in index order from min_doc
-// (bitpacking_u32_ordered.rs:191-218), except width 32 / bytewidth 4 = raw absolute.
-__device__ __forceinline__ void decode_doc_ids(const uint8_t *__restrict__ p, uint32_t meta,
-                                               uint32_t n, uint32_t min_doc, uint32_t lane,
-                                               uint32_t &d0, uint32_t &d1) {
-    uint32_t v0, v1;
-    decode_fields(p, meta, n, lane, v0, v1);
-    const uint32_t width = meta & 127u;
-    const bool raw = (meta >> 7) ? (width == 4) : (width == 32);
-    if (raw) {
-        d0 = v0;
-        d1 = v1;
-        return;
-    }
-    uint32_t x = v0 + v1;  // inclusive scan of the per-lane sums
-    const uint32_t own = x;
-#pragma unroll
-    for (int o = 1; o < 64; o <<= 1) {
-        uint32_t y = __shfl_up(x, o);
-        if ((int)lane >= o) x += y;
-    }
-    d0 = min_doc + (x - own) + v0;
-    d1 = d0 + v1;
-}
-
-// ---------------------------------------------------------------------------
-// Index preparation: fieldnorm of every posting + structural validation
-// ---------------------------------------------------------------------------
-struct PostFnArgs {
-    uint32_t n_blocks, n_docs, n_terms;
-    const uint4 *blk_meta;
-    const uint8_t *blob, *doc_fieldnorm;
-    uint8_t *post_fn;
-    uint32_t *error_flag;
-    // upper bounds to verify: the scan kernels prune with them
-    const uint32_t *term_first_block, *term_wand_tf;
-    const uint8_t *term_wand_fn;
-    const double *term_s0, *s1, *blk_ub;
-};
-__global__ void __launch_bounds__(256) post_fn_kernel(PostFnArgs a) {
-    const uint32_t lane = threadIdx.x & 63;
-    const uint32_t j = blockIdx.x * (blockDim.x / 64) + (threadIdx.x >> 6);
-    if (j >= a.n_blocks) return;
-    const uint4 m = a.blk_meta[j];
-    const uint32_t n = m.w & 0xff, md = (m.w >> 8) & 0xff, mt = (m.w >> 16) & 0xff;
-    const uint8_t *body = a.blob + 8ull * m.z;
-    uint32_t d0, d1;
-    decode_doc_ids(body, md, n, m.x, lane, d0, d1);
-    const uint32_t i0 = 2 * lane, i1 = i0 + 1;
-    uint8_t f0 = 0, f1 = 0;
-    bool bad = false;
-    if (i0 < n) {
-        bad |= d0 >= a.n_docs;
-        if (d0 < a.n_docs) f0 = a.doc_fieldnorm[d0];
-    }
-    if (i1 < n) {
-        bad |= d1 >= a.n_docs || d1 <= d0;
-        if (d1 < a.n_docs) f1 = a.doc_fieldnorm[d1];
-    }
-    // strictly increasing across lanes, first = min_doc, last = max_doc
-    const uint32_t prev = __shfl_up(d1, 1);
-    if (lane > 0 && i0 < n) bad |= d0 <= prev;
-    if (i0 == 0) bad |= d0 != m.x;
-    if (i0 == n - 1) bad |= d0 != m.y;
-    if (i1 == n - 1) bad |= d1 != m.y;
-    if (bad) atomicOr(a.error_flag, 1u);
-    reinterpret_cast<uchar2 *>(a.post_fn + 128ull * j)[lane] = make_uchar2(f0, f1);
-
-    // The WAND pairs must bound every posting: Cache::evaluate of each posting against the block's
-    // bound (blk_ub, margin included) and the token's (search.rs:363,377-380).
-    uint32_t lo = 0, hi = a.n_terms;  // the term of block j: term_first_block[t] <= j < [t + 1]
-    while (hi - lo > 1) {
-        const uint32_t mid = (lo + hi) >> 1;
-        if (a.term_first_block[mid] <= j) lo = mid; else hi = mid;
-    }
-    const double s0 = a.term_s0[lo];
-    const double wtf = (double)a.term_wand_tf[lo];
-    const double tub = ((wtf * s0) / (wtf + a.s1[a.term_wand_fn[lo]])) * (1.0 + 1e-12);
-    const double bub = a.blk_ub[j];
-    uint32_t t0, t1;
-    decode_fields(body + ((payload_bytes(md, n) + 7u) & ~7u), mt, n, lane, t0, t1);
-    bool loose = false;
-    if (i0 < n) {
-        const double tf = (double)t0, p = (tf * s0) / (tf + a.s1[f0]);
-        loose |= p > bub || p > tub;
-    }
-    if (i1 < n) {
-        const double tf = (double)t1, p = (tf * s0) / (tf + a.s1[f1]);
-        loose |= p > bub || p > tub;
-    }
-    if (loose) atomicOr(a.error_flag, 2u);
-}
-
-// ---------------------------------------------------------------------------
-// Planner
-// ---------------------------------------------------------------------------
-// Block-wide inclusive scan of one u64 per thread (PLAN_WG threads): wave scans + one LDS hop.
-__device__ __forceinline__ unsigned long long plan_incl_scan(unsigned long long v, unsigned long long *s_wave,
-                                                             unsigned long long &total) {
-    const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-#pragma unroll
-    for (int o = 1; o < 64; o <<= 1) {
-        const unsigned long long y = __shfl_up(v, o);
-        if ((int)lane >= o) v += y;
-    }
-    if (lane == 63) s_wave[wave] = v;
-    __syncthreads();
-    unsigned long long before = 0, all = 0;
-    for (uint32_t w = 0; w < PLAN_WG / 64; ++w) {
-        const unsigned long long x = s_wave[w];
-        if (w < wave) before += x;
-        all += x;
-    }
-    __syncthreads();
-    total = all;
-    return v + before;
-}
-
-__global__ void __launch_bounds__(PLAN_WG) plan_kernel(DevIndex ix, DevBatch bt, uint32_t max_items,
-                                                       uint32_t target_items, uint32_t min_chunk) {
-    __shared__ unsigned long long s_wave[PLAN_WG / 64];
-    const uint32_t tid = threadIdx.x;
-    const uint32_t per = (bt.nq + PLAN_WG - 1) / PLAN_WG;
-    const uint32_t q0 = min(bt.nq, tid * per), q1 = min(bt.nq, q0 + per);
-    // per-launch state of the scan kernels (saves two memset launches per step)
-    for (uint32_t i = tid; i < bt.nq; i += PLAN_WG) bt.theta[i] = 0;
-    for (uint32_t i = tid; i < max_items; i += PLAN_WG) bt.item_failed[i] = 0;
-    if (tid == 0) *bt.work_ctr = 0;
-
-    auto postings_of = [&](uint32_t q) {
-        unsigned long long t = 0;
-        for (uint32_t p = bt.q_off[q]; p < bt.q_off[q + 1]; ++p) {
-            uint32_t term = bt.term_ids[p];
-            if (term < ix.n_terms) t += ix.term_df[term];
-        }
-        return t;
-    };
-    unsigned long long local = 0;
-    for (uint32_t q = q0; q < q1; ++q) local += postings_of(q);
-    unsigned long long total = 0;
-    plan_incl_scan(local, s_wave, total);
-    unsigned long long chunk = (total + target_items - 1) / target_items;
-    if (chunk < min_chunk) chunk = min_chunk;
-    auto chunks_of = [&](uint32_t q) -> uint32_t {
-        unsigned long long t = postings_of(q);
-        if (t == 0) return 0u;
-        // nearest, not ceil: a batch of similar queries gets the same count for all of them, i.e. the
-        // item count lands on the target (a multiple of the resident waves) instead of ~8 % above it
-        unsigned long long c = (t + chunk / 2) / chunk;
-        if (c == 0) c = 1;
-        if (c > ix.n_docs) c = ix.n_docs;
-        return (uint32_t)c;
-    };
-    unsigned long long cnt = 0;
-    for (uint32_t q = q0; q < q1; ++q) cnt += chunks_of(q);
-    unsigned long long run = 0;
-    const unsigned long long incl = plan_incl_scan(cnt, s_wave, run);
-    if (tid == 0) {
-        *bt.n_items = (uint32_t)min(run, (unsigned long long)max_items);
-        if (run > max_items) atomicOr(bt.error_flag, 2u);
-        bt.q_item_base[bt.nq] = (uint32_t)min(run, (unsigned long long)max_items);
-    }
-    uint32_t base = (uint32_t)(incl - cnt);
-    for (uint32_t q = q0; q < q1; ++q) {
-        const uint32_t c = chunks_of(q);
-        uint32_t nterms = 0;
-        for (uint32_t p = bt.q_off[q]; p < bt.q_off[q + 1]; ++p) nterms += bt.term_ids[p] < ix.n_terms;
-        if (bt.q_dense[q]) nterms |= ITEM_DENSE;
-        bt.q_item_base[q] = min(base, max_items);
-        for (uint32_t i = 0; i < c && base + i < max_items; ++i) {
-            Item it;
-            it.q = q;
-            it.doc_lo = (uint32_t)((unsigned long long)ix.n_docs * i / c);
-            it.doc_hi = (uint32_t)((unsigned long long)ix.n_docs * (i + 1) / c);
-            it.m = nterms;
-            bt.items[base + i] = it;
-        }
-        base += c;
-    }
-}
-
-// ---------------------------------------------------------------------------
-// Sorted top-k list in LDS, maintained by ONE wave.
-// Order: score descending, then doc id ascending ("better").
-// ---------------------------------------------------------------------------
-__device__ __forceinline__ bool better(double sa, uint32_t da, double sb, uint32_t db) {
-    return sa > sb || (sa == sb && da < db);
-}
-
-template <int KMAX>
-struct TopK {
-    double score[KMAX];
-    uint32_t doc[KMAX];
-    uint32_t count;
-};
-
-// Wave-cooperative insert of (s, d); caller guarantees it qualifies.  All 64 lanes call.
-template <int KMAX>
-__device__ __forceinline__ void topk_insert(TopK<KMAX> &L, uint32_t k, double s, uint32_t d,
-                                            uint32_t lane) {
-    const uint32_t n = L.count;
-    uint32_t c = 0;
-    for (uint32_t i = lane; i < n; i += 64) c += better(L.score[i], L.doc[i], s, d) ? 1u : 0u;
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) c += __shfl_xor(c, o);
-    const uint32_t pos = c;
-    const uint32_t newn = n < k ? n + 1 : k;
-    if (pos >= newn) return;
-    // shift [pos, newn-2] up by one, from the top down
-    for (int base = (int)newn - 2; base >= (int)pos; base -= 64) {
-        const int i = base - (int)lane;
-        double ts = 0;
-        uint32_t td = 0;
-        const bool act = i >= (int)pos;
-        if (act) {
-            ts = L.score[i];
-            td = L.doc[i];
-        }
-        __builtin_amdgcn_wave_barrier();
-        if (act) {
-            L.score[i + 1] = ts;
-            L.doc[i + 1] = td;
-        }
-        __builtin_amdgcn_wave_barrier();
-    }
-    if (lane == 0) {
-        L.score[pos] = s;
-        L.doc[pos] = d;
-        L.count = newn;
-    }
-    __builtin_amdgcn_wave_barrier();
-}
-
-// Offer up to 64 candidates (one per lane, `has` marks validity) to the list.
-template <int KMAX>
-__device__ __forceinline__ void topk_offer(TopK<KMAX> &L, uint32_t k, bool has, double s,
-                                           uint32_t d, uint32_t lane) {
-    for (;;) {
-        const uint32_t n = L.count;
-        bool alive = has;
-        if (alive && n >= k) alive = better(s, d, L.score[k - 1], L.doc[k - 1]);
-        const unsigned long long mask = __ballot(alive);
-        if (!mask) break;
-        const int leader = __ffsll((long long)mask) - 1;
-        const double cs = __shfl(s, leader);
-        const uint32_t cd = __shfl(d, leader);
-        topk_insert<KMAX>(L, k, cs, cd, lane);
-        if ((int)lane == leader) has = false;
-    }
-}
-
-// ---------------------------------------------------------------------------
-// Posting scan
-// ---------------------------------------------------------------------------
-template <int KMAX>
-__global__ void __launch_bounds__(WG) scan_many_kernel(DevIndex ix, DevBatch bt) {
-    __shared__ uint32_t s_key[SLOTS];
-    __shared__ double s_val[SLOTS];
-    __shared__ uint16_t s_cand[SLOTS];
-    __shared__ double s_s1[256];
-    __shared__ TopK<KMAX> s_top;
-    __shared__ uint32_t t_cur[MAX_TERMS], t_end[MAX_TERMS], t_quota[MAX_TERMS];
-    __shared__ double t_s0[MAX_TERMS];
-    __shared__ uint32_t s_m, s_hi, s_next_lo, s_cand_cnt, s_dense;
-    __shared__ unsigned long long s_theta, s_sumdf;
-
-    const uint32_t tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const uint32_t k = bt.k;
-    for (int i = tid; i < 256; i += WG) s_s1[i] = ix.s1[i];
-
-    const uint32_t n_items = *bt.n_items;
-    for (uint32_t item = blockIdx.x; item < n_items; item += gridDim.x) {
-        const Item it = bt.items[item];
-        const bool failed = it.m <= (uint32_t)CHAIN_MAX_TERMS && bt.item_failed[item] != 0;
-        if (it.m <= (uint32_t)CHAIN_MAX_TERMS && !failed) continue;  // done by scan_kernel
-        const bool force_dense = failed || (it.m & ITEM_DENSE) != 0;
-        const uint32_t q = it.q, clo = it.doc_lo, chi = it.doc_hi;
-        __syncthreads();  // previous item fully done with LDS
-        if (tid == 0) {
-            // valid terms of the query, ascending (Query::new guarantees sorted keys)
-            uint32_t m = 0;
-            unsigned long long sum = 0;
-            for (uint32_t p = bt.q_off[q]; p < bt.q_off[q + 1]; ++p) {
-                const uint32_t term = bt.term_ids[p];
-                if (term >= ix.n_terms) continue;  // search.rs:59-61
-                if (m < MAX_TERMS) {
-                    t_cur[m] = term;  // resolved below
-                    sum += ix.term_df[term];
-                    ++m;
-                }
-            }
-            s_m = m;
-            s_sumdf = sum;
-            s_top.count = 0;
-            s_dense = (force_dense || m >= (uint32_t)CAP_BLOCKS) ? 1u : 0u;
-        }
-        __syncthreads();
-        const uint32_t m = s_m;
-        const bool dense = s_dense != 0;
-        if (tid < m) {
-            const uint32_t term = t_cur[tid];
-            const uint32_t b0 = ix.term_first_block[term], b1 = ix.term_first_block[term + 1];
-            // first block whose max_doc >= clo
-            uint32_t lo = b0, hi = b1;
-            while (lo < hi) {
-                const uint32_t mid = (lo + hi) >> 1;
-                if (ix.blk_max_doc[mid] < clo) lo = mid + 1; else hi = mid;
-            }
-            t_end[tid] = b1;
-            t_s0[tid] = ix.term_s0[term];
-            const unsigned long long df = ix.term_df[term];
-            const uint32_t share = (uint32_t)(((unsigned long long)(CAP_BLOCKS - (dense ? 0 : (int)m)) * df) / s_sumdf);
-            t_quota[tid] = share > 1 ? share : 1;
-            t_cur[tid] = lo;
-        }
-        __syncthreads();
-
-        uint32_t lo = clo;
-        unsigned long long published = 0;
-        while (lo < chi) {
-            // ---- tile bounds + table reset
-            if (tid == 0) {
-                s_hi = dense ? (chi - lo > (uint32_t)SLOTS ? lo + SLOTS : chi) : chi;
-                s_cand_cnt = 0;
-                s_next_lo = chi;
-                s_theta = __hip_atomic_load(&bt.theta[q], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            }
-            for (int i = tid; i < SLOTS; i += WG) s_key[i] = EMPTY;
-            __syncthreads();
-            if (!dense && tid < m) {
-                const uint32_t j = t_cur[tid] + t_quota[tid];
-                if (j < t_end[tid]) atomicMin(&s_hi, ix.blk_min_doc[j]);
-            }
-            __syncthreads();
-            const uint32_t hi = s_hi;
-
-            // ---- accumulate, one term per phase (ascending key order)
-            for (uint32_t t = 0; t < m; ++t) {
-                const uint32_t jend = t_end[t];
-                const double s0 = t_s0[t];
-                for (uint32_t j = t_cur[t] + wave; j < jend; j += NW) {
-                    const uint4 bm = ix.blk_meta[j];
-                    if (bm.x >= hi) break;
-                    const uint32_t n = bm.w & 0xff, md = (bm.w >> 8) & 0xff, mt = (bm.w >> 16) & 0xff;
-                    const uint8_t *body = ix.blob + 8ull * bm.z;
-                    uint32_t d0, d1, f0, f1;
-                    decode_doc_ids(body, md, n, bm.x, lane, d0, d1);
-                    decode_fields(body + ((payload_bytes(md, n) + 7u) & ~7u), mt, n, lane, f0, f1);
-                    const uchar2 fn = reinterpret_cast<const uchar2 *>(ix.post_fn + 128ull * j)[lane];
-#pragma unroll
-                    for (int e = 0; e < 2; ++e) {
-                        const uint32_t i = 2 * lane + e;
-                        const uint32_t d = e ? d1 : d0;
-                        const uint32_t tfv = e ? f1 : f0;
-                        const uint32_t f = e ? fn.y : fn.x;
-                        if (i < n && d >= lo && d < hi) {
-                            const double tf = (double)tfv;
-                            const double p = (tf * s0) / (tf + s_s1[f]);  // bm25.rs:355-358
-                            const uint32_t key = d - lo;
-                            uint32_t slot = dense ? key : ((key * 0x9E3779B1u) >> (32 - SLOTS_LOG2));
-                            for (;;) {
-                                const uint32_t prev = atomicCAS(&s_key[slot], EMPTY, key);
-                                if (prev == EMPTY) {
-                                    s_val[slot] = p;
-                                    break;
-                                }
-                                if (prev == key) {
-                                    s_val[slot] += p;
-                                    break;
-                                }
-                                slot = (slot + 1) & (SLOTS - 1);
-                            }
-                        }
-                    }
-                }
-                __syncthreads();
-            }
-
-            // ---- candidates of this tile
-            {
-                const unsigned long long theta = s_theta;
-                const uint32_t n = s_top.count;
-                const double ws = n >= k ? s_top.score[k - 1] : 0.0;
-                const uint32_t wd = n >= k ? s_top.doc[k - 1] : 0u;
-                for (int i = tid; i < SLOTS; i += WG) {
-                    const uint32_t key = s_key[i];
-                    if (key == EMPTY) continue;
-                    const double sc = s_val[i];
-                    if ((unsigned long long)__double_as_longlong(sc) < theta) continue;
-                    if (n >= k && !better(sc, lo + key, ws, wd)) continue;
-                    const uint32_t at = atomicAdd(&s_cand_cnt, 1u);
-                    s_cand[at] = (uint16_t)i;
-                }
-            }
-            __syncthreads();
-            if (wave == 0) {
-                const uint32_t cnt = s_cand_cnt;
-                for (uint32_t base = 0; base < cnt; base += 64) {
-                    const bool has = base + lane < cnt;
-                    double sc = 0;
-                    uint32_t d = 0;
-                    if (has) {
-                        const uint32_t slot = s_cand[base + lane];
-                        sc = s_val[slot];
-                        d = lo + s_key[slot];
-                    }
-                    topk_offer<KMAX>(s_top, k, has, sc, d, lane);
-                }
-                if (s_top.count >= k && lane == 0) {
-                    const unsigned long long bits = (unsigned long long)__double_as_longlong(s_top.score[k - 1]);
-                    if (bits > published) {
-                        atomicMax(&bt.theta[q], bits);
-                        published = bits;
-                    }
-                }
-            }
-            // ---- advance cursors; next tile starts at the first remaining posting
-            if (tid < m) {
-                uint32_t j = t_cur[tid];
-                const uint32_t e = t_end[tid];
-                while (j < e && ix.blk_max_doc[j] < hi) ++j;
-                t_cur[tid] = j;
-                if (j < e) atomicMin(&s_next_lo, max(hi, ix.blk_min_doc[j]));
-            }
-            __syncthreads();
-            lo = max(hi, s_next_lo);
-        }
-
-        // ---- chunk result
-        __syncthreads();
-        {
-            const uint32_t n = s_top.count;
-            for (uint32_t i = tid; i < n; i += WG) {
-                bt.res_score[(size_t)item * k + i] = s_top.score[i];
-                bt.res_doc[(size_t)item * k + i] = s_top.doc[i];
-            }
-            if (tid == 0) bt.res_cnt[item] = n;
-        }
-    }
-}
-
-
-// ---------------------------------------------------------------------------
-// Split decode used by scan_kernel: the two dwords that hold a field are fetched early
-// (possibly one tile ahead) and the field is extracted later.  One formula covers every
-// codec of compression.rs:65-136: bit-packed (lane stream words 16 bytes apart), width 32 /
-// bytewidth 4 (raw), byte-packed tails (unaligned little-endian bytes).
-// ---------------------------------------------------------------------------
-struct FieldAddr {
-    uint32_t off0, off1, sh, mask;
-};
-__device__ __forceinline__ FieldAddr field_addr(uint32_t meta, uint32_t n, uint32_t i) {
-    FieldAddr a;
-    const uint32_t width = meta & 127u;
-    if ((meta >> 7) == 0) {
-        if (width == 32) {
-            a.off0 = a.off1 = 4 * i;
-            a.sh = 0;
-            a.mask = 0xffffffffu;
-        } else {
-            const uint32_t l = i & 3, bit = (i >> 2) * width, w = bit >> 5;
-            a.sh = bit & 31;
-            a.off0 = 16 * w + 4 * l;
-            a.off1 = a.off0 + ((a.sh + width > 32) ? 16u : 0u);
-            a.mask = (1u << width) - 1u;  // width 0 -> mask 0 -> field 0
-        }
-    } else {
-        const uint32_t bo = (i < n ? i : 0u) * width;
-        a.off0 = bo & ~3u;
-        a.off1 = a.off0 + 4;
-        a.sh = 8 * (bo & 3u);
-        a.mask = width >= 4 ? 0xffffffffu : (1u << (8 * width)) - 1u;
-    }
-    return a;
-}
-__device__ __forceinline__ uint32_t field_val(uint32_t lo, uint32_t hi, const FieldAddr &a) {
-    return __builtin_amdgcn_alignbit(hi, lo, a.sh) & a.mask;  // ((hi:lo) >> sh), sh < 32
-}
-struct BlockFetch {  // raw dwords of one block for this lane: doc fields 0/1, tf fields 0/1
-    uint32_t dlo0, dhi0, dlo1, dhi1, tlo0, thi0, tlo1, thi1;
-    uint32_t fn;  // two fieldnorm bytes
-};
-// Bit-packed blocks: a lane's two values (indices 2L, 2L+1) sit in adjacent lane streams at the
-// same step, so their words are one aligned 8-byte pair in group w and one in group w+1.
-__device__ __forceinline__ void pair_fetch(const uint8_t *__restrict__ p, uint32_t width, uint32_t lane,
-                                           uint32_t &lo0, uint32_t &hi0, uint32_t &lo1, uint32_t &hi1) {
-    const uint32_t bit = __umul24(lane >> 1, width);   // step t = (2L) >> 2
-    const uint32_t off = 16 * (bit >> 5) + 8 * (lane & 1);  // streams l0 = 2*(L&1), l0 + 1
-    const uint2 a = *reinterpret_cast<const uint2 *>(p + off);
-    const uint2 b = *reinterpret_cast<const uint2 *>(p + off + 16);  // may be the next payload: unused then
-    lo0 = a.x;
-    lo1 = a.y;
-    hi0 = b.x;
-    hi1 = b.y;
-}
-__device__ __forceinline__ void pair_extract(uint32_t width, uint32_t lane, uint32_t lo0, uint32_t hi0,
-                                             uint32_t lo1, uint32_t hi1, uint32_t &v0, uint32_t &v1) {
-    const uint32_t sh = __umul24(lane >> 1, width) & 31;
-    const uint32_t mask = width >= 32 ? 0xffffffffu : (1u << width) - 1u;
-    v0 = __builtin_amdgcn_alignbit(hi0, lo0, sh) & mask;  // ((hi:lo) >> sh), sh < 32
-    v1 = __builtin_amdgcn_alignbit(hi1, lo1, sh) & mask;
-}
-__device__ __forceinline__ void block_fetch(const DevIndex &ix, const uint4 bm, uint32_t j,
-                                            uint32_t lane, BlockFetch &f) {
-    const uint32_t n = bm.w & 0xff, md = (bm.w >> 8) & 0xff, mt = (bm.w >> 16) & 0xff;
-    const uint8_t *body = ix.blob + 8ull * bm.z;
-    const uint8_t *tbody = body + ((payload_bytes(md, n) + 7u) & ~7u);
-    if ((md >> 7) == 0) {  // full block (both streams bit-packed, compression.rs:42-52,99-103)
-        pair_fetch(body, md & 127u, lane, f.dlo0, f.dhi0, f.dlo1, f.dhi1);
-        pair_fetch(tbody, mt & 127u, lane, f.tlo0, f.thi0, f.tlo1, f.thi1);
-    } else {               // tail block: byte-packed, generic addressing
-        const FieldAddr a0 = field_addr(md, n, 2 * lane), a1 = field_addr(md, n, 2 * lane + 1);
-        const FieldAddr b0 = field_addr(mt, n, 2 * lane), b1 = field_addr(mt, n, 2 * lane + 1);
-        f.dlo0 = *reinterpret_cast<const uint32_t *>(body + a0.off0);
-        f.dhi0 = *reinterpret_cast<const uint32_t *>(body + a0.off1);
-        f.dlo1 = *reinterpret_cast<const uint32_t *>(body + a1.off0);
-        f.dhi1 = *reinterpret_cast<const uint32_t *>(body + a1.off1);
-        f.tlo0 = *reinterpret_cast<const uint32_t *>(tbody + b0.off0);
-        f.thi0 = *reinterpret_cast<const uint32_t *>(tbody + b0.off1);
-        f.tlo1 = *reinterpret_cast<const uint32_t *>(tbody + b1.off0);
-        f.thi1 = *reinterpret_cast<const uint32_t *>(tbody + b1.off1);
-    }
-    f.fn = reinterpret_cast<const uint16_t *>(ix.post_fn + 128ull * j)[lane];
-}
-// fields of a fetched block: document-id deltas (or raw ids) and term frequencies
-__device__ __forceinline__ void block_fields(const uint4 bm, uint32_t lane, const BlockFetch &f,
-                                             uint32_t &v0, uint32_t &v1, uint32_t &f0, uint32_t &f1) {
-    const uint32_t n = bm.w & 0xff, md = (bm.w >> 8) & 0xff, mt = (bm.w >> 16) & 0xff;
-    if ((md >> 7) == 0) {
-        pair_extract(md & 127u, lane, f.dlo0, f.dhi0, f.dlo1, f.dhi1, v0, v1);
-        pair_extract(mt & 127u, lane, f.tlo0, f.thi0, f.tlo1, f.thi1, f0, f1);
-    } else {
-        v0 = field_val(f.dlo0, f.dhi0, field_addr(md, n, 2 * lane));
-        v1 = field_val(f.dlo1, f.dhi1, field_addr(md, n, 2 * lane + 1));
-        f0 = field_val(f.tlo0, f.thi0, field_addr(mt, n, 2 * lane));
-        f1 = field_val(f.tlo1, f.thi1, field_addr(mt, n, 2 * lane + 1));
-    }
-}
-
-// Reductions over lanes 0..15 (one DPP row); result valid in lane 15, broadcast with readlane.
-__device__ __forceinline__ uint32_t row16_min_bcast(uint32_t v) {
-    v = min(v, (uint32_t)__builtin_amdgcn_update_dpp(-1, (int)v, 0x111, 0xf, 0xf, false));
-    v = min(v, (uint32_t)__builtin_amdgcn_update_dpp(-1, (int)v, 0x112, 0xf, 0xf, false));
-    v = min(v, (uint32_t)__builtin_amdgcn_update_dpp(-1, (int)v, 0x114, 0xf, 0xf, false));
-    v = min(v, (uint32_t)__builtin_amdgcn_update_dpp(-1, (int)v, 0x118, 0xf, 0xf, false));
-    return (uint32_t)__builtin_amdgcn_readlane((int)v, 15);
-}
-__device__ __forceinline__ uint32_t row16_incl_sum(uint32_t v) {
-    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x111, 0xf, 0xf, false);
-    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x112, 0xf, 0xf, false);
-    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x114, 0xf, 0xf, false);
-    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x118, 0xf, 0xf, false);
-    return v;
-}
-
-__device__ __forceinline__ double readlane_f64(double v, uint32_t src_lane) {  // src_lane uniform
-    const int lo = __builtin_amdgcn_readlane(__double2loint(v), (int)src_lane);
-    const int hi = __builtin_amdgcn_readlane(__double2hiint(v), (int)src_lane);
-    return __hiloint2double(hi, lo);
-}
-__device__ __forceinline__ uint32_t wave_shr1_u32(uint32_t v) {  // lane l gets lane l-1 (lane 0: itself)
-    return (uint32_t)__builtin_amdgcn_update_dpp((int)v, (int)v, 0x138, 0xf, 0xf, false);  // wave_shr:1
-}
-__device__ __forceinline__ double wave_shr1_f64(double v) {
-    const uint32_t lo = wave_shr1_u32((uint32_t)__double2loint(v));
-    const uint32_t hi = wave_shr1_u32((uint32_t)__double2hiint(v));
-    return __hiloint2double((int)hi, (int)lo);
-}
-
-// ---------------------------------------------------------------------------
-// Running top-k of ONE wave held in registers: RK rows of 64 entries, sorted best first, entry e
-// in row e / 64 at lane e % 64.  Insert = ballot/popcount for the position, DPP wave shift,
-// rows chained through lane 63 -> lane 0.  No LDS traffic.
-// ---------------------------------------------------------------------------
-template <int RK>
-struct RegTopK {
-    double score[RK];
-    uint32_t doc[RK];
-    uint32_t cnt;
-    double kth_s;   // k-th entry, uniform copies (valid once cnt == k)
-    uint32_t kth_d;
-    __device__ __forceinline__ void init() {
-#pragma unroll
-        for (int r = 0; r < RK; ++r) {
-            score[r] = 0.0;
-            doc[r] = NONE32;
-        }
-        cnt = 0;
-        kth_s = 0.0;
-        kth_d = 0;
-    }
-    // offer one candidate per lane (`has` marks validity); all 64 lanes call
-    __device__ __forceinline__ void offer(bool has, double sc, uint32_t d, uint32_t k, uint32_t lane) {
-        for (;;) {
-            const bool alive = has && (cnt < k || better(sc, d, kth_s, kth_d));
-            const unsigned long long mask = __ballot(alive);
-            if (!mask) break;
-            const uint32_t leader = (uint32_t)__ffsll((long long)mask) - 1;
-            const double cs = readlane_f64(sc, leader);
-            const uint32_t cd = (uint32_t)__builtin_amdgcn_readlane((int)d, (int)leader);
-            if (lane == leader) has = false;
-            uint32_t pos = 0;  // entries better than the candidate: a prefix of the list
-#pragma unroll
-            for (int r = 0; r < RK; ++r)
-                pos += (uint32_t)__popcll(__ballot(r * 64 + lane < cnt && better(score[r], doc[r], cs, cd)));
-            double carry_s = 0.0;
-            uint32_t carry_d = NONE32;
-#pragma unroll
-            for (int r = 0; r < RK; ++r) {
-                const double us = wave_shr1_f64(score[r]);
-                const uint32_t ud = wave_shr1_u32(doc[r]);
-                const double out_s = readlane_f64(score[r], 63);
-                const uint32_t out_d = (uint32_t)__builtin_amdgcn_readlane((int)doc[r], 63);
-                const uint32_t e = r * 64 + lane;
-                if (e > pos) {
-                    score[r] = lane == 0 ? carry_s : us;
-                    doc[r] = lane == 0 ? carry_d : ud;
-                } else if (e == pos) {
-                    score[r] = cs;
-                    doc[r] = cd;
-                }
-                carry_s = out_s;
-                carry_d = out_d;
-            }
-            cnt = cnt < k ? cnt + 1 : k;
-            if (cnt >= k) {
-#pragma unroll
-                for (int r = 0; r < RK; ++r)
-                    if ((k - 1) / 64 == (uint32_t)r) {
-                        kth_s = readlane_f64(score[r], (k - 1) & 63);
-                        kth_d = (uint32_t)__builtin_amdgcn_readlane((int)doc[r], (int)((k - 1) & 63));
-                    }
-            }
-        }
-    }
-};
-
-
-// Workgroup barrier that orders LDS traffic only.  __syncthreads() also drains vmcnt, i.e. it
-// would wait for every global load in flight (the planner's metadata refills, the threshold
-// poll); all hand-offs inside the tile loop go through LDS.
-__device__ __forceinline__ uint32_t uni(uint32_t v) {  // value is wave-uniform: keep it in an SGPR
-    return (uint32_t)__builtin_amdgcn_readfirstlane((int)v);
-}
-__device__ __forceinline__ uint4 uni4(const uint4 v) {
-    return make_uint4(uni(v.x), uni(v.y), uni(v.z), uni(v.w));
-}
-__device__ __forceinline__ void lds_barrier() {
-    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
-}
-
-#ifdef VBM25_PROFILE
-#define PROF_T(var) const unsigned long long var = __builtin_readcyclecounter()
-#define PROF_ADD(slot, a, b) prof[slot] += (b) - (a)
-#else
-#define PROF_T(var)
-#define PROF_ADD(slot, a, b)
-#endif
-
-// ---------------------------------------------------------------------------
-// Posting scan, tile formulation (scan_kernel): queries with CUR_T < terms <= CHAIN_MAX_TERMS, and every
-// query of at most CHAIN_MAX_TERMS terms when k > REG_K or the cursor kernel is switched off.
-//
-// Per workgroup: CNW worker waves + one planner / merger wave + one joiner wave; C_BLOCKS block slots of
-// staging in LDS (doc id, tf, fieldnorm per posting), split into per-term regions in key order, so that
-// a posting's staging index orders postings by term.  Per doc-range tile [lo, hi), ONE LDS-only barrier:
-//   plan    (planner, one tile ahead) hi = smallest min_doc of the first block that does not fit a term's
-//           region; entries = newly admitted blocks + blocks still resident from earlier tiles
-//           ("carried", decoded once per chunk); block metadata comes from an LDS ring
-//   pass A  (workers, two entries each) decode (unless carried) from words fetched one tile earlier, stage,
-//           mark every posting of [lo, hi) in two independently hashed seen / multi bitmap pairs
-//   pass B  (workers) postings whose multi bit is clear under either hash are whole documents: dropped in
-//           hot tiles (threshold above every token upper bound), else scored and filtered; the others go
-//           to the tile's slow list
-//   join    (joiner, one tile late) exact join of the slow list in registers, sums in key order
-//   merge   (planner) running top-k in registers (k <= REG_K) or LDS; the k-th score is shared through LDS
-//           and, across the chunks of a query, through a 64-bit atomicMax on the score bits
-// ---------------------------------------------------------------------------
-__device__ __forceinline__ uint32_t wave_incl_scan_u32(uint32_t x) {
-    // DPP row shifts inside 16-lane rows, then row broadcasts across rows (gfx9 wave64)
-    x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x111, 0xf, 0xf, false);  // row_shr:1
-    x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x112, 0xf, 0xf, false);  // row_shr:2
-    x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x114, 0xf, 0xf, false);  // row_shr:4
-    x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x118, 0xf, 0xf, false);  // row_shr:8
-    x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x142, 0xa, 0xf, false);  // row_bcast:15
-    x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x143, 0xc, 0xf, false);  // row_bcast:31
-    return x;
-}
-
-
-template <int KMAX>
-__global__ void __launch_bounds__(CWG, 6) scan_kernel(DevIndex ix, DevBatch bt) {
-    constexpr int T = CHAIN_MAX_TERMS;
-    constexpr int RING = 64;              // metadata ring entries (power-of-two ring per term)
-    constexpr uint32_t PLANNER = CNW;     // waves 0..CNW-1 work: entries w and w + CNW of a tile
-    constexpr uint32_t JOINER = CNW + 1;  // exact join of colliding postings, one tile late
-    // staging: decoded postings of the resident blocks (needed again when a block is carried)
-    __shared__ uint32_t st_doc[C_POSTINGS];
-    __shared__ uint32_t st_tf[C_POSTINGS];
-    __shared__ uint8_t st_fn[C_POSTINGS];
-    // two independently hashed bitmap pairs per tile, three tiles in rotation: "some posting hit
-    // this bit" / "a second posting hit it".  A posting is slow only if it collides under BOTH.
-    __shared__ uint32_t bm_seen[3][2][BM_WORDS];
-    __shared__ uint32_t bm_multi[3][2][BM_WORDS];
-    __shared__ uint32_t sl_doc[2][SLOW_CAP];  // slow postings of a tile (copies)
-    __shared__ double sl_p[2][SLOW_CAP];
-    __shared__ uint16_t sl_idx[2][SLOW_CAP];
-    __shared__ double jc_score[2][JC_CAP];    // documents produced by the join, for the merger
-    __shared__ uint32_t jc_doc[2][JC_CAP];
-    __shared__ double c_score[2][CAND_CAP];   // documents of the fast path (overflow: global spill)
-    __shared__ uint32_t c_doc[2][CAND_CAP];
-    __shared__ double s_s1[256];
-    __shared__ TopK<(KMAX > REG_K ? KMAX : 1)> s_top;  // LDS list only for k > REG_K
-    __shared__ uint4 s_ring[RING];
-    __shared__ uint4 e_meta[2][C_BLOCKS];     // entries of a tile: new blocks first, then carried
-    __shared__ uint2 e_aux[2][C_BLOCKS];      // {block index, staging base | term << 16}
-    __shared__ double t_s0[T];
-    // tile header {lo, hi, nent, nnew | done << 16}, per-tile counters, shared filter state
-    __shared__ uint4 s_hdr[2];
-    __shared__ uint32_t s_cand_cnt[2], sl_cnt[2], jc_cnt[2], s_abort;
-    __shared__ unsigned long long s_theta;
-    __shared__ double s_kth_score;
-    __shared__ uint32_t s_top_cnt;
-
-    const uint32_t tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const uint32_t k = bt.k;
-    for (int i = tid; i < 256; i += CWG) s_s1[i] = ix.s1[i];
-    for (int i = tid; i < 6 * BM_WORDS; i += CWG) {
-        (&bm_seen[0][0][0])[i] = 0;
-        (&bm_multi[0][0][0])[i] = 0;
-    }
-    // rarely used overflow areas in HBM, per workgroup: [cand | slow | join][2 bufs][C_POSTINGS][2 words]
-    unsigned long long *spill_s = bt.spill + (size_t)blockIdx.x * 3 * 2 * C_POSTINGS * 2;
-    unsigned long long *spill_l = spill_s + 2 * C_POSTINGS * 2;
-    unsigned long long *spill_j = spill_l + 2 * C_POSTINGS * 2;
-
-#ifdef VBM25_PROFILE
-    unsigned long long prof[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
-    const unsigned long long prof_t0 = __builtin_readcyclecounter();
-#endif
-    const uint32_t n_items = *bt.n_items;
-    for (uint32_t item = blockIdx.x; item < n_items; item += gridDim.x) {
-        const Item it = bt.items[item];
-        if (it.m > (uint32_t)T || it.m < bt.chain_min_terms) continue;  // the other kernels'
-        const uint32_t q = it.q, clo = it.doc_lo, chi = it.doc_hi;
-        __syncthreads();
-        if (tid == 0) s_abort = 0;
-
-        if (wave == PLANNER) {
-            // =====================================================================
-            // Planner / merger wave: lane t owns term t.  Plans one tile ahead (block
-            // metadata only) and owns the running top-k.
-            // =====================================================================
-            uint32_t p_rb = 0, p_re = 0, p_end = 0, p_q = 1, p_rmask = 0, p_roff = 0, p_base = 0,
-                     p_slot = 0;  // p_slot = region slot of block p_rb (p_rb mod p_q, incremental)
-            uint32_t m = 0;
-            unsigned long long ub_bits = 0;  // bits of the largest single-posting score (+ margin)
-            {
-                const uint32_t qb = bt.q_off[q], qe = bt.q_off[q + 1];
-                uint32_t term = NONE32;
-                for (uint32_t p = qb; p < qe; ++p) {  // indexed terms in ascending key order
-                    const uint32_t tt = bt.term_ids[p];
-                    if (tt >= ix.n_terms) continue;  // search.rs:59-61
-                    if (m == lane) term = tt;
-                    ++m;
-                }
-                const bool act = lane < m;
-                unsigned long long df = act ? ix.term_df[term] : 0ull;
-                unsigned long long sum = df, frac = 0;
-#pragma unroll
-                for (int o = 32; o > 0; o >>= 1) sum += __shfl_xor(sum, o);
-                if (act) {
-                    const uint32_t b0 = ix.term_first_block[term], b1 = ix.term_first_block[term + 1];
-                    uint32_t lo_b = b0, hi_b = b1;  // first block whose max_doc >= clo
-                    while (lo_b < hi_b) {
-                        const uint32_t mid = (lo_b + hi_b) >> 1;
-                        if (ix.blk_max_doc[mid] < clo) lo_b = mid + 1; else hi_b = mid;
-                    }
-                    p_rb = p_re = lo_b;
-                    p_end = b1;
-                    p_q = (uint32_t)(((unsigned long long)(C_BLOCKS - m) * df) / sum) + 1;
-                    frac = ((unsigned long long)(C_BLOCKS - m) * df) % sum;
-                    t_s0[lane] = ix.term_s0[term];
-                }
-                {   // Cursor::new, search.rs:363: token_upper_bound = Cache::evaluate(token WAND pair)
-                    double ub = 0.0;
-                    if (act) {
-                        const double wtf = (double)ix.term_wand_tf[term];
-                        ub = (wtf * ix.term_s0[term]) / (wtf + ix.s1[ix.term_wand_fn[term]]);
-                    }
-#pragma unroll
-                    for (int o = 8; o > 0; o >>= 1) ub = fmax(ub, __shfl_xor(ub, o));
-                    // margin: the pair maximises tf() at flush time; Cache::evaluate of another
-                    // posting may round one ulp higher
-                    ub_bits = (unsigned long long)__double_as_longlong(readlane_f64(ub, 0) * (1.0 + 1e-12));
-                }
-                {   // hand the block slots left over by the floor() to the largest remainders
-                    const uint32_t used = row16_incl_sum(act ? p_q : 0u);
-                    const uint32_t left = (uint32_t)C_BLOCKS - (uint32_t)__builtin_amdgcn_readlane((int)used, 15);
-                    uint32_t rank = 0;
-                    for (uint32_t t = 0; t < m; ++t) {
-                        const unsigned long long ft = __shfl(frac, (int)t);
-                        rank += (ft > frac || (ft == frac && t < lane)) ? 1u : 0u;
-                    }
-                    if (act && rank < left) p_q += 1;
-                    uint32_t rs = 2;  // ring holds blocks [rb, rb + 2q]
-                    while (rs < 2 * p_q + 1) rs <<= 1;
-                    p_rmask = rs - 1;
-                }
-                const uint32_t xb = act ? 128 * p_q : 0, xr = act ? p_rmask + 1 : 0;
-                p_base = row16_incl_sum(xb) - xb;
-                p_roff = row16_incl_sum(xr) - xr;
-                if (act) {  // initial fill of the metadata ring: blocks [rb, rb + 2q]
-                    for (uint32_t i = 0; i <= 2 * p_q; ++i) {
-                        const uint32_t j = p_rb + i;
-                        if (j < p_end) s_ring[p_roff + (j & p_rmask)] = ix.blk_meta[j];
-                    }
-                }
-                if (lane == 0) {
-                    s_top.count = 0;
-                    s_cand_cnt[0] = s_cand_cnt[1] = 0;
-                    sl_cnt[0] = sl_cnt[1] = 0;
-                    jc_cnt[0] = jc_cnt[1] = 0;
-                    s_top_cnt = 0;
-                    s_kth_score = 0.0;
-                    s_theta = 0;
-                }
-            }
-            const bool act = lane < m;
-            uint32_t p_hi = clo;  // end of the tile planned last
-            uint4 pf0 = make_uint4(0, 0, 0, 0), pf1 = pf0;
-            uint32_t at0 = NONE32, at1 = NONE32;
-            unsigned long long theta_next = 0;
-
-            // plan the tile after [.., p_hi) into buffer nb (header + entries).  The loads it
-            // starts are consumed by plan_finish(), after the next barrier.
-            auto plan_start = [&](uint32_t nb) {
-                const uint32_t hi_prev = p_hi;
-                uint32_t nrb = p_rb;
-                if (act) {  // 1. drop blocks that end before the previous tile's end
-                    while (nrb < p_re && s_ring[p_roff + (nrb & p_rmask)].y < hi_prev) ++nrb;
-                    p_slot += nrb - p_rb;
-                    while (p_slot >= p_q) p_slot -= p_q;
-                }
-                at0 = at1 = NONE32;
-                if (act) {  // 2. refill the ring towards [nrb, nrb + 2q] (used one tile later)
-                    uint32_t j2 = p_rb + 2 * p_q + 1;
-                    const uint32_t last = min(nrb + 2 * p_q, p_end - 1);
-                    if (j2 <= last) {
-                        pf0 = ix.blk_meta[j2];
-                        at0 = p_roff + (j2 & p_rmask);
-                        ++j2;
-                    }
-                    if (j2 <= last) {
-                        pf1 = ix.blk_meta[j2];
-                        at1 = p_roff + (j2 & p_rmask);
-                        ++j2;
-                    }
-                    for (; j2 <= last; ++j2) s_ring[p_roff + (j2 & p_rmask)] = ix.blk_meta[j2];
-                    p_rb = nrb;
-                }
-                theta_next = __hip_atomic_load(&bt.theta[q], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                // 3. tile range
-                uint32_t lo_c = chi, hi_c = chi;
-                if (act && p_rb < p_end) {
-                    lo_c = max(hi_prev, s_ring[p_roff + (p_rb & p_rmask)].x);
-                    if (p_rb + p_q < p_end) hi_c = s_ring[p_roff + ((p_rb + p_q) & p_rmask)].x;
-                }
-                const uint32_t lo_n = row16_min_bcast(lo_c), hi_n = min(chi, row16_min_bcast(hi_c));
-                // 4. entries: newly admitted blocks first (they cost a decode), then the blocks
-                //    still resident from earlier tiles
-                uint32_t n_car = 0, n_new = 0, re_old = p_re;
-                if (act && lo_n < chi) {
-                    const uint32_t lim = min(p_rb + p_q, p_end);
-                    re_old = max(p_re, p_rb);
-                    uint32_t j = re_old;
-                    while (j < lim && s_ring[p_roff + (j & p_rmask)].x < hi_n) ++j;
-                    n_car = re_old - p_rb;
-                    n_new = j - re_old;
-                    p_re = j;
-                }
-                const uint32_t inc_n = row16_incl_sum(n_new), inc_c = row16_incl_sum(n_car);
-                const uint32_t tot_new = (uint32_t)__builtin_amdgcn_readlane((int)inc_n, 15);
-                const uint32_t tot_car = (uint32_t)__builtin_amdgcn_readlane((int)inc_c, 15);
-                if (act) {
-                    uint32_t slot = p_slot;
-                    uint32_t e_c = tot_new + inc_c - n_car, e_n = inc_n - n_new;
-                    for (uint32_t i = 0; i < n_car + n_new; ++i) {
-                        const uint32_t j = p_rb + i;
-                        const uint32_t e = i < n_car ? e_c++ : e_n++;
-                        e_meta[nb][e] = s_ring[p_roff + (j & p_rmask)];
-                        e_aux[nb][e] = make_uint2(j, (p_base + slot * 128) | (lane << 16));
-                        if (++slot == p_q) slot = 0;
-                    }
-                }
-                const bool fin = lo_n >= chi;
-                // hot tile: the shared threshold already exceeds every single-posting score, so only
-                // documents with two or more postings can still enter the top-k
-                const bool hot = theta_next > ub_bits;
-#ifdef VBM25_PROFILE
-                prof[13] += hot ? 1 : 0;
-#endif
-                if (lane == 0)
-                    s_hdr[nb] = make_uint4(lo_n, hi_n, tot_new + tot_car,
-                                           tot_new | (fin ? 0x10000u : 0u) | (hot ? 0x20000u : 0u));
-                p_hi = hi_n;
-                return fin;
-            };
-            auto plan_finish = [&]() {
-                if (at0 != NONE32) s_ring[at0] = pf0;
-                if (at1 != NONE32) s_ring[at1] = pf1;
-                if (lane == 0) s_theta = theta_next;
-            };
-
-            // running top-k: for k <= REG_K in registers (RegTopK), else a sorted list in LDS
-            constexpr int RK = KMAX <= REG_K ? KMAX / 64 : 1;
-            RegTopK<RK> rtop;
-            rtop.init();
-            auto offer1 = [&](bool has, double sc, uint32_t d) {
-                if constexpr (KMAX <= REG_K) rtop.offer(has, sc, d, k, lane);
-                else topk_offer<(KMAX > REG_K ? KMAX : 1)>(s_top, k, has, sc, d, lane);
-            };
-            auto offer_list = [&](const double *sc_arr, const uint32_t *d_arr, uint32_t cnt) {
-                for (uint32_t base = 0; base < cnt; base += 64) {
-                    const bool has = base + lane < cnt;
-                    offer1(has, has ? sc_arr[base + lane] : 0.0, has ? d_arr[base + lane] : 0u);
-                }
-            };
-            unsigned long long published = 0;
-            auto publish = [&]() {  // new k-th entry -> candidate filters of this and other chunks
-                uint32_t n_now;
-                double ks = 0.0;
-                if constexpr (KMAX <= REG_K) {
-                    n_now = rtop.cnt;
-                    ks = rtop.kth_s;
-                } else {
-                    n_now = s_top.count;
-                    if (n_now >= k) {
-                        ks = s_top.score[k - 1];
-                    }
-                }
-                if (lane == 0) {
-                    s_top_cnt = n_now;
-                    if (n_now >= k) {
-                        s_kth_score = ks;
-                        const unsigned long long bits = (unsigned long long)__double_as_longlong(ks);
-                        if (bits > published) {
-                            atomicMax(&bt.theta[q], bits);
-                            published = bits;
-                        }
-                    }
-                }
-            };
-            // fast-path documents of tile buffer b (LDS part + global spill); also detects a slow
-            // list that did not fit (-> abort the item, it is redone by scan_many_kernel)
-            auto merge_cand = [&](uint32_t b) {
-                const uint32_t cnt = uni(s_cand_cnt[b]);
-                if (uni(sl_cnt[b]) > (uint32_t)SLOW_ABORT && lane == 0) s_abort = 1;
-#ifdef VBM25_PROFILE
-                {
-                    const uint32_t ns = uni(sl_cnt[b]);
-                    if (ns > prof[8]) prof[8] = ns;
-                    prof[9] += ns;
-                    prof[10] += ns > 64 ? 1 : 0;
-                    prof[11] += cnt;
-                    if (cnt > prof[12]) prof[12] = cnt;
-                }
-#endif
-                if (!cnt) return;
-                offer_list(c_score[b], c_doc[b], min(cnt, (uint32_t)CAND_CAP));
-                for (uint32_t base = CAND_CAP; base < cnt; base += 64) {
-                    const bool has = base + lane < cnt;
-                    double sc = 0.0;
-                    uint32_t d = 0;
-                    if (has) {
-                        const unsigned long long *sp = spill_s + ((size_t)b * C_POSTINGS + (base + lane - CAND_CAP)) * 2;
-                        sc = __longlong_as_double((long long)__hip_atomic_load(sp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
-                        d = (uint32_t)__hip_atomic_load(sp + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    }
-                    offer1(has, sc, d);
-                }
-                if (lane == 0) s_cand_cnt[b] = 0;
-                publish();
-            };
-            // documents produced by the joiner for tile buffer b
-            auto merge_jc = [&](uint32_t b) {
-                const uint32_t jcnt = uni(jc_cnt[b]);
-                if (!jcnt) return;
-                offer_list(jc_score[b], jc_doc[b], min(jcnt, (uint32_t)JC_CAP));
-                for (uint32_t base = JC_CAP; base < jcnt; base += 64) {
-                    const bool has = base + lane < jcnt;
-                    double sc = 0.0;
-                    uint32_t d = 0;
-                    if (has) {
-                        const unsigned long long *sp = spill_j + ((size_t)b * C_POSTINGS + (base + lane - JC_CAP)) * 2;
-                        sc = __longlong_as_double((long long)__hip_atomic_load(sp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
-                        d = (uint32_t)__hip_atomic_load(sp + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    }
-                    offer1(has, sc, d);
-                }
-                if (lane == 0) jc_cnt[b] = 0;
-                publish();
-            };
-
-            bool done = plan_start(0);
-            plan_finish();
-            lds_barrier();  // S
-            // tile i: plan i+1, barrier X_i, then merge what is complete: fast path of tile i-1
-            // (its pass B ended before X_i) and the join of tile i-2 (the joiner ran it between
-            // X_{i-1} and X_i); both live in buffer (i-1) & 1 ... (i-2) & 1 respectively
-            for (uint32_t par = 0;; par ^= 1) {
-                if (done) break;
-                const bool next_done = plan_start(par ^ 1);
-                lds_barrier();  // X
-                if (uni(s_abort)) break;
-                plan_finish();
-                merge_cand(par ^ 1);  // fast path of tile i-1: its pass B ended before X_i
-                merge_jc(par);        // join of tile i-2: ran between X_{i-1} and X_i
-#ifdef VBM25_PROFILE
-                prof[7] += 1;
-#endif
-                done = next_done;
-            }
-            __syncthreads();  // E1: every wave left the tile loop; the joiner flushes its list
-            __syncthreads();  // E2
-            const bool failed = uni(s_abort) != 0 || uni(sl_cnt[0]) > (uint32_t)SLOW_ABORT || uni(sl_cnt[1]) > (uint32_t)SLOW_ABORT;
-            merge_cand(0);
-            merge_cand(1);
-            merge_jc(0);
-            merge_jc(1);
-            if (lane == 0) bt.item_failed[item] = failed ? 1u : 0u;
-#ifdef VBM25_PROFILE
-            prof[6] += failed ? 1 : 0;
-#endif
-            if constexpr (KMAX <= REG_K) {  // chunk result straight from the registers
-#pragma unroll
-                for (int r = 0; r < RK; ++r) {
-                    const uint32_t e = r * 64 + lane;
-                    if (e < rtop.cnt) {
-                        bt.res_score[(size_t)item * k + e] = rtop.score[r];
-                        bt.res_doc[(size_t)item * k + e] = rtop.doc[r];
-                    }
-                }
-                if (lane == 0) bt.res_cnt[item] = rtop.cnt;
-            }
-        } else if (wave == JOINER) {
-            // =====================================================================
-            // Joiner wave: exact join of the postings that collided under both hashes.  Each
-            // lane holds one of them and meets all the others through readlane (no LDS traffic);
-            // group leader = smallest staging index = first key.  The list of tile i is complete
-            // at barrier X_{i+1} and is joined before X_{i+2}.
-            // =====================================================================
-            // item e of tile buffer b: the first SLOW_CAP live in LDS, the rest in the global spill
-            auto item_at = [&](uint32_t b, uint32_t e, uint32_t &d, uint32_t &idx, double &p) {
-                if (e < (uint32_t)SLOW_CAP) {
-                    d = sl_doc[b][e];
-                    idx = sl_idx[b][e];
-                    p = sl_p[b][e];
-                } else {
-                    const unsigned long long *sp = spill_l + ((size_t)b * C_POSTINGS + (e - SLOW_CAP)) * 2;
-                    p = __longlong_as_double((long long)__hip_atomic_load(sp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
-                    const unsigned long long w = __hip_atomic_load(sp + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    d = (uint32_t)w;
-                    idx = (uint32_t)(w >> 32);
-                }
-            };
-            auto emit = [&](uint32_t b, bool lead, double score, uint32_t d) {
-                // pre-filter on the score alone, strictly: the merger publishes {count, score, doc} with
-                // separate stores while this wave runs, and a torn (new score, old doc) pair must not
-                // drop a document that ties the k-th score; the merger applies the exact rule
-                if (lead && !(s_top_cnt >= k && score < s_kth_score)) {
-                    const uint32_t at = atomicAdd(&jc_cnt[b], 1u);
-                    if (at < (uint32_t)JC_CAP) {
-                        jc_score[b][at] = score;
-                        jc_doc[b][at] = d;
-                    } else {
-                        unsigned long long *sp = spill_j + ((size_t)b * C_POSTINGS + (at - JC_CAP)) * 2;
-                        __hip_atomic_store(sp, (unsigned long long)__double_as_longlong(score), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                        __hip_atomic_store(sp + 1, (unsigned long long)d, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                    }
-                }
-            };
-            auto join = [&](uint32_t b) {
-                const uint32_t n = uni(sl_cnt[b]);
-                if (n == 0 || n > (uint32_t)SLOW_ABORT) return;  // overflow: the planner aborts the item
-                if (n <= 64) {
-                    const bool v = lane < n;
-                    const uint32_t jd = v ? sl_doc[b][lane] : NONE32;
-                    const uint32_t ji = v ? (uint32_t)sl_idx[b][lane] : NONE32;
-                    const double jp = v ? sl_p[b][lane] : 0.0;
-                    uint32_t same = 0, minidx = ji, mate = 0;
-                    for (uint32_t j = 0; j < n; ++j) {
-                        const uint32_t dj = (uint32_t)__builtin_amdgcn_readlane((int)jd, (int)j);
-                        const uint32_t ij = (uint32_t)__builtin_amdgcn_readlane((int)ji, (int)j);
-                        const bool hit = dj == jd && ij != ji;
-                        same += hit ? 1u : 0u;
-                        mate = hit ? j : mate;
-                        minidx = hit ? min(minidx, ij) : minidx;
-                    }
-                    const bool lead = v && minidx == ji;
-                    double score = jp;
-                    if (__ballot(lead && same >= 1)) {
-                        const double op = __shfl(jp, (int)mate);
-                        if (lead && same == 1) score = jp + op;  // two addends commute
-                    }
-                    if (__ballot(lead && same >= 2)) {
-                        // three or more addends: ascending staging index = key order, one pass
-                        // over the list per addend
-                        double acc = 0.0;
-                        int last = -1;
-                        const bool l3 = lead && same >= 2;
-                        for (;;) {
-                            uint32_t best = NONE32;
-                            double bp = 0.0;
-                            for (uint32_t j = 0; j < n; ++j) {
-                                const uint32_t dj = (uint32_t)__builtin_amdgcn_readlane((int)jd, (int)j);
-                                const uint32_t ij = (uint32_t)__builtin_amdgcn_readlane((int)ji, (int)j);
-                                const double pj = readlane_f64(jp, j);
-                                if (l3 && dj == jd && (int)ij > last && ij < best) {
-                                    best = ij;
-                                    bp = pj;
-                                }
-                            }
-                            if (!__ballot(best != NONE32)) break;
-                            if (best != NONE32) {
-                                acc += bp;
-                                last = (int)best;
-                            }
-                        }
-                        if (l3) score = acc;
-                    }
-                    emit(b, lead, score, jd);
-                } else {
-                    // rare: a long list.  Same join, every lane owns one item per round and reads
-                    // all the others (LDS / spill broadcast reads).
-                    for (uint32_t base = 0; base < n; base += 64) {
-                        const bool v = base + lane < n;
-                        uint32_t jd = NONE32, ji = NONE32;
-                        double jp = 0.0;
-                        if (v) item_at(b, base + lane, jd, ji, jp);
-                        uint32_t same = 0, minidx = ji;
-                        for (uint32_t j = 0; j < n; ++j) {
-                            uint32_t dj, ij;
-                            double pj;
-                            item_at(b, j, dj, ij, pj);
-                            const bool hit = dj == jd && ij != ji;
-                            same += hit ? 1u : 0u;
-                            minidx = hit ? min(minidx, ij) : minidx;
-                        }
-                        const bool lead = v && minidx == ji;
-                        double score = jp;
-                        if (__ballot(lead && same >= 1)) {  // ordered sum over the group
-                            double acc = 0.0;
-                            int last = -1;
-                            const bool l2 = lead && same >= 1;
-                            for (;;) {
-                                uint32_t best = NONE32;
-                                double bp = 0.0;
-                                for (uint32_t j = 0; j < n; ++j) {
-                                    uint32_t dj, ij;
-                                    double pj;
-                                    item_at(b, j, dj, ij, pj);
-                                    if (l2 && dj == jd && (int)ij > last && ij < best) {
-                                        best = ij;
-                                        bp = pj;
-                                    }
-                                }
-                                if (!__ballot(best != NONE32)) break;
-                                if (best != NONE32) {
-                                    acc += bp;
-                                    last = (int)best;
-                                }
-                            }
-                            if (l2) score = acc;
-                        }
-                        emit(b, lead, score, jd);
-                    }
-                }
-                if (lane == 0) sl_cnt[b] = 0;
-            };
-            lds_barrier();  // S
-            for (uint32_t par = 0;; par ^= 1) {
-                if (uni(s_hdr[par].w) & 0x10000u) break;
-                lds_barrier();  // X
-                if (uni(s_abort)) break;
-                join(par ^ 1);  // the previous tile's list
-            }
-            __syncthreads();  // E1
-            join(0);
-            join(1);
-            __syncthreads();  // E2
-        } else {
-            // =====================================================================
-            // Worker waves: entries w and w + CNW of every tile; ONE barrier per tile
-            // =====================================================================
-            BlockFetch fetch[2];
-            uint4 ent_m[2];   // this tile's entries (wave-uniform)
-            uint2 ent_a[2];
-            bool fetched = false;
-            lds_barrier();  // S
-            uint4 hdr = uni4(s_hdr[0]);
-#pragma unroll
-            for (int r = 0; r < 2; ++r) {
-                const uint32_t e = wave + r * CNW;
-                ent_m[r] = uni4(e_meta[0][e < (uint32_t)C_BLOCKS ? e : 0]);
-                const uint2 a = e_aux[0][e < (uint32_t)C_BLOCKS ? e : 0];
-                ent_a[r] = make_uint2(uni(a.x), uni(a.y));
-            }
-            unsigned long long theta = 0;
-            uint32_t ntop = 0;
-            double kscore = 0.0;
-            uint32_t tile = 0;
-            for (uint32_t par = 0;; par ^= 1, ++tile) {
-                if (hdr.w & 0x10000u) break;
-                const uint32_t lo = hdr.x, hi = hdr.y, nent = hdr.z, nnew = hdr.w & 0xffffu;
-                const uint32_t bbuf = tile % 3;
-
-                // ---- pass A.1: decode this wave's new blocks into staging; fetch carried ones
-                uint32_t dd[4], tt[4], fnp[2];  // doc ids, term frequencies, packed fieldnorm pairs
-#pragma unroll
-                for (int r = 0; r < 2; ++r) {
-                    const uint32_t e = wave + r * CNW;
-                    dd[2 * r] = dd[2 * r + 1] = NONE32;
-                    tt[2 * r] = tt[2 * r + 1] = 0;
-                    fnp[r] = 0;
-                    const uint32_t i0 = (ent_a[r].y & 0xffffu) + 2 * lane;
-                    if (e >= nent) continue;
-                    if (e >= nnew) {  // carried over from an earlier tile: already staged
-                        const uint2 v = *reinterpret_cast<const uint2 *>(&st_doc[i0]);
-                        const uint2 w = *reinterpret_cast<const uint2 *>(&st_tf[i0]);
-                        dd[2 * r] = v.x;
-                        dd[2 * r + 1] = v.y;
-                        tt[2 * r] = w.x;
-                        tt[2 * r + 1] = w.y;
-                        fnp[r] = *reinterpret_cast<const uint16_t *>(&st_fn[i0]);
-                        continue;
-                    }
-                    const uint4 bm = ent_m[r];
-                    const uint32_t n = bm.w & 0xff, md = (bm.w >> 8) & 0xff;
-                    if (!fetched) block_fetch(ix, bm, ent_a[r].x, lane, fetch[r]);
-                    const BlockFetch &f = fetch[r];
-                    uint32_t v0, v1, f0, f1;
-                    block_fields(bm, lane, f, v0, v1, f0, f1);
-                    uint32_t d0 = v0, d1 = v1;
-                    const uint32_t width = md & 127u;
-                    if (!((md >> 7) ? (width == 4) : (width == 32))) {  // d1 deltas from min_doc
-                        const uint32_t own = v0 + v1;
-                        const uint32_t incl = wave_incl_scan_u32(own);
-                        d0 = bm.x + (incl - own) + v0;
-                        d1 = d0 + v1;
-                    }
-                    if (2 * lane >= n) d0 = NONE32;
-                    if (2 * lane + 1 >= n) d1 = NONE32;
-                    *reinterpret_cast<uint2 *>(&st_doc[i0]) = make_uint2(d0, d1);
-                    *reinterpret_cast<uint2 *>(&st_tf[i0]) = make_uint2(f0, f1);
-                    *reinterpret_cast<uint16_t *>(&st_fn[i0]) = (uint16_t)f.fn;
-                    dd[2 * r] = d0;
-                    dd[2 * r + 1] = d1;
-                    tt[2 * r] = f0;
-                    tt[2 * r + 1] = f1;
-                    fnp[r] = f.fn;
-                }
-                // ---- pass A.2: mark every posting of [lo, hi) in the hashed bitmaps.  A bit that
-                // was already set means "another posting may belong to the same document".
-                uint32_t inr = 0;  // bit x: posting x is inside [lo, hi)
-#pragma unroll
-                for (int x = 0; x < 4; ++x) {
-                    const uint32_t d = dd[x];
-                    if (d >= lo && d < hi) {  // NONE32 never is
-                        inr |= 1u << x;
-                        const uint32_t h = d & ((1u << BM_BITS_LOG2) - 1u);  // ids of a tile lie in a narrow range
-                        const uint32_t g = (__umul24(d >> BM_BITS_LOG2, 97u) + d) & ((1u << BM_BITS_LOG2) - 1u);  // never equal for two ids that share h
-                        const uint32_t hb = 1u << (h & 31), gb = 1u << (g & 31);
-                        const uint32_t o1 = atomicOr(&bm_seen[bbuf][0][h >> 5], hb);
-                        const uint32_t o2 = atomicOr(&bm_seen[bbuf][1][g >> 5], gb);
-                        if (o1 & hb) atomicOr(&bm_multi[bbuf][0][h >> 5], hb);
-                        if (o2 & gb) atomicOr(&bm_multi[bbuf][1][g >> 5], gb);
-                    }
-                }
-                lds_barrier();  // X: all marks of this tile are in; everybody finished tile - 1
-                if (uni(s_abort)) break;
-
-                // ---- next tile: header, this wave's entries, filter state -- one LDS round trip;
-                // then the loads of its new blocks
-                const uint4 nh = uni4(s_hdr[par ^ 1]);
-                uint4 nm[2];
-                uint2 na[2];
-#pragma unroll
-                for (int r = 0; r < 2; ++r) {
-                    const uint32_t e = wave + r * CNW;
-                    nm[r] = uni4(e_meta[par ^ 1][e < (uint32_t)C_BLOCKS ? e : 0]);
-                    const uint2 a2 = e_aux[par ^ 1][e < (uint32_t)C_BLOCKS ? e : 0];
-                    na[r] = make_uint2(uni(a2.x), uni(a2.y));
-                }
-                theta = s_theta;
-                ntop = s_top_cnt;
-                kscore = s_kth_score;
-                // the bitmaps of the previous tile are free now (next used two tiles from here)
-                {
-                    const uint32_t wb = (tile + 2) % 3;
-                    for (int i = tid; i < 2 * BM_WORDS / 4; i += CNW * 64) {
-                        reinterpret_cast<uint4 *>(&bm_seen[wb][0][0])[i] = make_uint4(0, 0, 0, 0);
-                        reinterpret_cast<uint4 *>(&bm_multi[wb][0][0])[i] = make_uint4(0, 0, 0, 0);
-                    }
-                }
-                // ---- pass B: a document whose bit nobody else hit has a single posting: its
-                // partial score IS its score.  In a hot tile such a document cannot reach the top-k
-                // and no score is computed at all.  The others go to the joiner (with their score).
-                const bool hot = (hdr.w & 0x20000u) != 0;
-#pragma unroll
-                for (int x = 0; x < 4; ++x) {
-                    if (!(inr & (1u << x))) continue;
-                    const uint32_t d = dd[x];
-                    const uint32_t h = d & ((1u << BM_BITS_LOG2) - 1u);  // ids of a tile lie in a narrow range
-                    const uint32_t g = (__umul24(d >> BM_BITS_LOG2, 97u) + d) & ((1u << BM_BITS_LOG2) - 1u);  // never equal for two ids that share h
-                    const bool single = !((bm_multi[bbuf][0][h >> 5] >> (h & 31)) & (bm_multi[bbuf][1][g >> 5] >> (g & 31)) & 1u);
-                    if (single && hot) continue;
-                    // Cache::evaluate, bm25.rs:355-358
-                    const double tf = (double)tt[x];
-                    const double p = (tf * t_s0[ent_a[x >> 1].y >> 16]) / (tf + s_s1[(fnp[x >> 1] >> (8 * (x & 1))) & 0xff]);
-                    if (single) {
-                        if ((unsigned long long)__double_as_longlong(p) < theta) continue;
-                        // score alone, strictly (see the joiner's emit): ties go to the merger
-                        if (ntop >= k && p < kscore) continue;
-                        const uint32_t at = atomicAdd(&s_cand_cnt[par], 1u);
-                        if (at < (uint32_t)CAND_CAP) {
-                            c_score[par][at] = p;
-                            c_doc[par][at] = d;
-                        } else {  // cold tiles: more candidates than the LDS buffer holds
-                            unsigned long long *sp = spill_s + ((size_t)par * C_POSTINGS + (at - CAND_CAP)) * 2;
-                            __hip_atomic_store(sp, (unsigned long long)__double_as_longlong(p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                            __hip_atomic_store(sp + 1, (unsigned long long)d, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // landed before the next barrier
-                        }
-                    } else {
-                        const uint32_t idx = (ent_a[x >> 1].y & 0xffffu) + 2 * lane + (x & 1);  // staging index
-                        const uint32_t at = atomicAdd(&sl_cnt[par], 1u);
-                        if (at < (uint32_t)SLOW_CAP) {
-                            sl_doc[par][at] = d;
-                            sl_p[par][at] = p;
-                            sl_idx[par][at] = (uint16_t)idx;
-                        } else if (at < (uint32_t)SLOW_ABORT) {
-                            unsigned long long *sp = spill_l + ((size_t)par * C_POSTINGS + (at - SLOW_CAP)) * 2;
-                            __hip_atomic_store(sp, (unsigned long long)__double_as_longlong(p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                            __hip_atomic_store(sp + 1, (unsigned long long)d | (unsigned long long)idx << 32, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                        }
-                    }
-                }
-                // ---- loads of the next tile's new blocks (consumed after the next barrier)
-                fetched = false;
-                if (!(nh.w & 0x10000u)) {
-                    const uint32_t nn = nh.w & 0xffffu;
-#pragma unroll
-                    for (int r = 0; r < 2; ++r) {
-                        const uint32_t e = wave + r * CNW;
-                        if (e < nn) block_fetch(ix, nm[r], na[r].x, lane, fetch[r]);
-                    }
-                    fetched = true;
-                }
-                // roll over to the next tile
-                hdr = nh;
-#pragma unroll
-                for (int r = 0; r < 2; ++r) {
-                    ent_m[r] = nm[r];
-                    ent_a[r] = na[r];
-                }
-#ifdef VBM25_PROFILE
-                prof[7] += nent;
-#endif
-            }
-            __syncthreads();  // E1
-            __syncthreads();  // E2
-        }
-
-        __syncthreads();
-        if constexpr (KMAX > REG_K) {
-            const uint32_t n = s_top.count;
-            for (uint32_t i = tid; i < n; i += CWG) {
-                bt.res_score[(size_t)item * k + i] = s_top.score[i];
-                bt.res_doc[(size_t)item * k + i] = s_top.doc[i];
-            }
-            if (tid == 0) bt.res_cnt[item] = n;
-        }
-    }
-#ifdef VBM25_PROFILE
-    if (bt.prof && lane == 0 && (wave == 0 || wave == PLANNER)) {
-        unsigned long long *o = bt.prof + (size_t)blockIdx.x * 33 + (wave == 0 ? 0 : 16);
-        for (int i = 0; i < 16; ++i) o[i] = prof[i];
-        if (wave == 0) bt.prof[(size_t)blockIdx.x * 33 + 32] = __builtin_readcyclecounter() - prof_t0;
-    }
-#endif
-}
-
+#include "device_types.h"
+#include "decode.h"
+#include "plan.h"
+#include "topk_lds.h"
+#include "scan_many.h"
+#include "block_fetch.h"
+#include "topk_reg.h"
+#include "scan_tile.h"
 #include "scan_cursor.h"
-
-// ---------------------------------------------------------------------------
-// Merge of per-chunk lists -> hits
-// ---------------------------------------------------------------------------
-template <int KMAX>
-__global__ void __launch_bounds__(64) merge_kernel(DevIndex ix, DevBatch bt) {
-    __shared__ TopK<(KMAX > REG_K ? KMAX : 1)> s_top;
-    constexpr int RK = KMAX <= REG_K ? KMAX / 64 : 1;
-    RegTopK<RK> rtop;
-    rtop.init();
-    const uint32_t q = blockIdx.x, lane = threadIdx.x, k = bt.k;
-    if (lane == 0) s_top.count = 0;
-    __builtin_amdgcn_wave_barrier();
-    const uint32_t i0 = bt.q_item_base[q], i1 = bt.q_item_base[q + 1];
-    for (uint32_t item = i0; item < i1; ++item) {
-        const uint32_t cnt = uni(bt.res_cnt[item]);
-        for (uint32_t base = 0; base < cnt; base += 64) {
-            const bool has = base + lane < cnt;
-            double sc = 0;
-            uint32_t d = 0;
-            if (has) {
-                sc = bt.res_score[(size_t)item * k + base + lane];
-                d = bt.res_doc[(size_t)item * k + base + lane];
-            }
-            if constexpr (KMAX <= REG_K) rtop.offer(has, sc, d, k, lane);
-            else topk_offer<(KMAX > REG_K ? KMAX : 1)>(s_top, k, has, sc, d, lane);
-        }
-    }
-    __builtin_amdgcn_wave_barrier();
-    auto emit = [&](uint32_t i, double sc, uint32_t d) {
-        // 24-byte record written as three 64-bit words so that padding bytes are zero
-        const uint16_t *pl = ix.doc_payload + 3ull * d;
-        unsigned long long *out = reinterpret_cast<unsigned long long *>(bt.hits + (size_t)q * k + i);
-        out[0] = (unsigned long long)__double_as_longlong(sc);
-        out[1] = (unsigned long long)d | (unsigned long long)pl[0] << 32 | (unsigned long long)pl[1] << 48;
-        out[2] = (unsigned long long)pl[2];
-    };
-    uint32_t n;
-    if constexpr (KMAX <= REG_K) {
-        n = rtop.cnt;
-#pragma unroll
-        for (int r = 0; r < RK; ++r)
-            if (r * 64 + lane < n) emit(r * 64 + lane, rtop.score[r], rtop.doc[r]);
-    } else {
-        n = s_top.count;
-        for (uint32_t i = lane; i < n; i += 64) emit(i, s_top.score[i], s_top.doc[i]);
-    }
-    if (lane == 0) bt.n_hits[q] = n;
-}
+#include "merge.h"
 
 // ---------------------------------------------------------------------------
 // Host objects
