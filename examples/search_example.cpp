@@ -46,6 +46,13 @@ int main(int argc, char **argv) {
                     merged.empty() ? 0 : merged[0].payload[0], merged.empty() ? 0 : merged[0].payload[1],
                     merged.empty() ? 0 : merged[0].payload[2], !merged.empty() && merged[0].score > 0);
     }
+    {   // an empty page store: the page reader reports corruption instead of crashing
+        try {
+            vbm25::Segment::from_pages([](void *, uint32_t) -> const uint8_t * { return nullptr; }, nullptr);
+        } catch (const vbm25::Error &e) {
+            std::printf("from_pages without pages: error %d\n", e.code);
+        }
+    }
     if (host_only) {
         try {
             vbm25::Index ix(desc, 0);

@@ -8,6 +8,7 @@
 //   vbm25::Query         crates/bm25/src/vector.rs:96-134  (sorted unique 16-byte keys)
 //   vbm25::Index::search crates/bm25/src/search.rs:28-36   (bm25::search, filter == true)
 //   vbm25::search_growing, vbm25::merge_growing   crates/bm25/src/search.rs:83-135  (unsealed documents, host side)
+//   vbm25::Segment::from_pages, vbm25::growing_from_pages   the relation's pages -> flat arrays (tape.rs, tuples.rs)
 // Reference panics ("data corruption", "invalid data") and pgrx::error! become vbm25::Error.
 #ifndef VBM25_HPP
 #define VBM25_HPP
@@ -108,6 +109,31 @@ class Index {
     vbm25_index *h_ = nullptr;
 };
 
+// Host copy of a flattened sealed segment (RAII over vbm25_segment).
+class Segment {
+  public:
+    // A bm25 index relation in the reference's on-disk format (PostgreSQL 8 KiB pages): Meta -> Jump ->
+    // documents / tokens / summaries / blocks tapes (the walk of maintain.rs:104-161).
+    static Segment from_pages(vbm25_read_page_fn read_page, void *ctx) {
+        vbm25_segment *h = nullptr;
+        check(vbm25_segment_from_pages(read_page, ctx, &h));
+        return Segment(h);
+    }
+    explicit Segment(vbm25_segment *h) : h_(h) {}
+    Segment(Segment &&o) noexcept : h_(o.h_) { o.h_ = nullptr; }
+    Segment(const Segment &) = delete;
+    Segment &operator=(const Segment &) = delete;
+    ~Segment() { vbm25_segment_free(h_); }
+    vbm25_index_desc desc() const {
+        vbm25_index_desc d;
+        check(vbm25_segment_desc(h_, &d));
+        return d;
+    }
+
+  private:
+    vbm25_segment *h_;
+};
+
 // The growing (unsealed) segment, search.rs:83-135: documents as CSR over their VectorTuple elements.
 struct GrowingDocs {
     std::vector<uint64_t> start{0};      // n + 1 offsets into key / tf
@@ -118,6 +144,26 @@ struct GrowingDocs {
     std::vector<uint8_t> deleted;        // VectorTuple::_0.deleted
     size_t size() const { return start.size() - 1; }
 };
+// The unsealed documents of a relation (vectors tape from Jump.ptr_vectors; VectorTuple _2 / _1 / _0).
+inline GrowingDocs growing_from_pages(vbm25_read_page_fn read_page, void *ctx) {
+    vbm25_growing *g = nullptr;
+    check(vbm25_growing_from_pages(read_page, ctx, &g));
+    vbm25_growing_desc d;
+    const int rc = vbm25_growing_get_desc(g, &d);
+    GrowingDocs out;
+    if (rc == VBM25_OK) {
+        out.start.assign(d.start, d.start + d.n_docs + 1);
+        out.key.resize(d.n_elements);
+        if (d.n_elements) std::memcpy(out.key[0].data(), d.key, 16 * d.n_elements);
+        out.tf.assign(d.tf, d.tf + d.n_elements);
+        out.fieldnorm.assign(d.fieldnorm, d.fieldnorm + d.n_docs);
+        out.payload.assign(d.payload, d.payload + 3ull * d.n_docs);
+        out.deleted.assign(d.deleted, d.deleted + d.n_docs);
+    }
+    vbm25_growing_free(g);
+    check(rc);
+    return out;
+}
 // Scores the unsealed documents with the sealed segment's statistics (host code, as in the reference).
 inline std::vector<Hit> search_growing(const vbm25_index_desc &desc, const Query &query, size_t k,
                                        const GrowingDocs &g) {

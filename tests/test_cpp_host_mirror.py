@@ -26,6 +26,7 @@ def test_cpp_mirror_host_side(tmp_path):
     assert "intern long lexeme: error -4" in out
     assert "segment: 50000 docs, 200 terms" in out
     assert "growing: 1 hit(s), merged 1, payload (1,2,3), score > 0: 1" in out
+    assert "from_pages without pages: error -2" in out
     import torch
     if not torch.cuda.is_available():
         assert "index create without GPU: error -3" in out
