@@ -112,6 +112,7 @@ struct vbm25_batch {
     uint32_t cur_mt = 1;          // most indexed terms among the cursor kernel's queries
     uint32_t target_items = TARGET_ITEMS;
     uint32_t min_chunk = MIN_CHUNK_POSTINGS;
+    uint32_t cur_grid = CUR_GRID;  // persistent workgroups of the cursor kernel for the current queries
     std::vector<std::pair<hipEvent_t, hipEvent_t>> events;
     size_t events_used = 0;
     ~vbm25_batch() {
@@ -421,6 +422,8 @@ static int vbm25_batch_set_queries_impl(vbm25_batch *bt, const uint32_t *term_id
     const char *env = std::getenv("VBM25_DENSE_X1000");
     const unsigned long long dense_x1000 = env ? (unsigned long long)std::atoll(env) : 100ull;
     std::vector<uint8_t> dense(nq, 0);
+    std::vector<unsigned long long> q_postings(nq, 0);
+    unsigned long long total_postings = 0;
     for (uint32_t q = 0; q < nq; ++q) {
         if (q_off[q + 1] < q_off[q]) return set_error(VBM25_ERR_INVALID, "q_off not monotone at query %u", q);
         uint32_t valid = 0;
@@ -431,6 +434,8 @@ static int vbm25_batch_set_queries_impl(vbm25_batch *bt, const uint32_t *term_id
             valid += term_ids[p] < bt->index->n_terms;
             if (term_ids[p] < bt->index->n_terms) postings += bt->index->term_df_host[term_ids[p]];
         }
+        q_postings[q] = postings;
+        total_postings += postings;
         if (postings * 1000ull >= dense_x1000 * bt->index->n_docs) {
             dense[q] = 1;
             many = true;
@@ -452,6 +457,20 @@ static int vbm25_batch_set_queries_impl(vbm25_batch *bt, const uint32_t *term_id
     bt->has_many_terms = many;
     bt->has_mid_terms = mid;
     bt->cur_mt = cur_mt;
+    {   // the number of work items plan_kernel will make (same integer arithmetic): the cursor kernel's
+        // persistent grid need not be larger (a single query is a handful of items, not 6144 workgroups)
+        unsigned long long chunk = (total_postings + bt->target_items - 1) / bt->target_items;
+        if (chunk < bt->min_chunk) chunk = bt->min_chunk;
+        unsigned long long items = 0;
+        for (uint32_t q = 0; q < nq; ++q) {
+            if (!q_postings[q]) continue;
+            unsigned long long c = (q_postings[q] + chunk / 2) / chunk;
+            if (c == 0) c = 1;
+            if (c > bt->index->n_docs) c = bt->index->n_docs;
+            items += c;
+        }
+        bt->cur_grid = uint32_t(std::min<unsigned long long>(std::max<unsigned long long>(items, 1), CUR_GRID));
+    }
     return VBM25_OK;
 }
 
@@ -503,7 +522,7 @@ static int vbm25_batch_run_impl(vbm25_batch *bt, void *hip_stream) {
         if constexpr (KM <= REG_K) {
             if (bt->use_cursor) {
                 // persistent single-wave workgroups; items are handed out through bt.work_ctr
-                scan_cursor_kernel<KM><<<CUR_GRID, 64, 4 * cur_lds_words(bt->cur_mt), st>>>(ix, db, bt->cur_mt);
+                scan_cursor_kernel<KM><<<bt->cur_grid, 64, 4 * cur_lds_words(bt->cur_mt), st>>>(ix, db, bt->cur_mt);
             }
         }
         if (!bt->use_cursor || bt->has_mid_terms) scan_kernel<KM><<<grid, CWG, 0, st>>>(ix, db);
