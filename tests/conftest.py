@@ -8,6 +8,12 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 
+# The library sends batches of fewer than 64 work items to the tile kernel (single-query latency).  The
+# parity tests are small by design, so they switch that rule off: every query of <= 8 terms, k <= 256 goes
+# through the cursor kernel, the one that serves the benchmark.  test_tiny_batches_take_the_tile_kernel
+# covers the rule itself.
+os.environ.setdefault("VBM25_CUR_MIN_ITEMS", "0")
+
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu)")

@@ -68,6 +68,23 @@ def test_kernel_routing_by_term_count(nterms, k):
     check_batch(gix, oix, terms, off, k)
 
 
+def test_tiny_batches_take_the_tile_kernel(monkeypatch):
+    """Default routing: a batch of fewer than 64 work items (a single query) runs on the tile kernel,
+    larger ones on the cursor kernel; same results either way."""
+    c = make_corpus(150_000, 3000, seed=11, length="lognormal", mean_len=60)
+    seg, gix, oix = both(c)
+    terms, off = make_queries(c, 200, 4, seed=6)
+    monkeypatch.setenv("VBM25_CUR_MIN_ITEMS", "64")  # read when a batch object is created
+    for nq in (1, 3, 200):
+        b = vb.Batch(gix, nq, int(off[nq]), 10)
+        b.set_queries(terms[:off[nq]], off[:nq + 1])
+        b.run()
+        hits, nh = b.fetch()
+        for q in range(nq):
+            want = oix.search_brute(terms[off[q]:off[q + 1]], 10)
+            assert_bit_exact(want, hits[q, :nh[q]], what=f"nq={nq} q{q} vs brute")
+
+
 def test_mixed_batch_all_kernels():
     """One batch whose queries are spread over the cursor, tile and many-term kernels, with unknown
     tokens and an empty query in between."""
