@@ -49,6 +49,8 @@ struct DevBatch {
     uint32_t *work_ctr;        // next item of the cursor kernel (reset by plan_kernel)
     uint32_t *hist;            // per query: CUR_HB score buckets, documents accepted by any item
     uint32_t chain_min_terms;  // scan_kernel leaves queries with fewer terms to scan_cursor_kernel
+    uint32_t lpi;              // result lists per item (scan_range_kernel: one per wave; the others use list 0)
+    uint32_t range_max_terms;  // scan_range_kernel takes the sparse queries with at most this many terms (0: off)
 };
 
 constexpr int WG = 256;

@@ -15,9 +15,10 @@ __global__ void __launch_bounds__(64) merge_kernel(DevIndex ix, DevBatch bt) {
     const uint32_t q = blockIdx.x, lane = threadIdx.x, k = bt.k;
     if (lane == 0) s_top.count = 0;
     __builtin_amdgcn_wave_barrier();
-    const uint32_t i0 = bt.q_item_base[q], i1 = bt.q_item_base[q + 1];
-    for (uint32_t item = i0; item < i1; ++item) {
+    const uint32_t i0 = bt.q_item_base[q] * bt.lpi, i1 = bt.q_item_base[q + 1] * bt.lpi;
+    for (uint32_t item = i0; item < i1; ++item) {  // every list of every item of the query
         const uint32_t cnt = uni(bt.res_cnt[item]);
+        if (cnt == 0) continue;
         for (uint32_t base = 0; base < cnt; base += 64) {
             const bool has = base + lane < cnt;
             double sc = 0;

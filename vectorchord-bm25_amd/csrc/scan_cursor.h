@@ -618,11 +618,11 @@ __global__ void __launch_bounds__(64, CUR_MINW_V) scan_cursor_kernel(DevIndex ix
 #pragma unroll
         for (int r = 0; r < RK; ++r)
             if (r * 64 + lane < n) {
-                bt.res_score[(size_t)item * k + r * 64 + lane] = rtop.score[r];
-                bt.res_doc[(size_t)item * k + r * 64 + lane] = rtop.doc[r];
+                bt.res_score[(size_t)item * bt.lpi * k + r * 64 + lane] = rtop.score[r];
+                bt.res_doc[(size_t)item * bt.lpi * k + r * 64 + lane] = rtop.doc[r];
             }
         if (lane == 0) {
-            bt.res_cnt[item] = n;
+            bt.res_cnt[(size_t)item * bt.lpi] = n;
             bt.item_failed[item] = failed ? 1u : 0u;
         }
         __builtin_amdgcn_wave_barrier();

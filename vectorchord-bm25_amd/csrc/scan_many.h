@@ -25,8 +25,9 @@ __global__ void __launch_bounds__(WG) scan_many_kernel(DevIndex ix, DevBatch bt)
     const uint32_t n_items = *bt.n_items;
     for (uint32_t item = blockIdx.x; item < n_items; item += gridDim.x) {
         const Item it = bt.items[item];
-        const bool failed = it.m <= (uint32_t)CHAIN_MAX_TERMS && bt.item_failed[item] != 0;
-        if (it.m <= (uint32_t)CHAIN_MAX_TERMS && !failed) continue;  // done by scan_kernel
+        const uint32_t others_max = max((uint32_t)CHAIN_MAX_TERMS, bt.range_max_terms);  // taken by the other kernels
+        const bool failed = it.m <= others_max && bt.item_failed[item] != 0;
+        if (it.m <= others_max && !failed) continue;
         const bool force_dense = failed || (it.m & ITEM_DENSE) != 0;
         const uint32_t q = it.q, clo = it.doc_lo, chi = it.doc_hi;
         __syncthreads();  // previous item fully done with LDS
@@ -185,10 +186,10 @@ __global__ void __launch_bounds__(WG) scan_many_kernel(DevIndex ix, DevBatch bt)
         {
             const uint32_t n = s_top.count;
             for (uint32_t i = tid; i < n; i += WG) {
-                bt.res_score[(size_t)item * k + i] = s_top.score[i];
-                bt.res_doc[(size_t)item * k + i] = s_top.doc[i];
+                bt.res_score[(size_t)item * bt.lpi * k + i] = s_top.score[i];
+                bt.res_doc[(size_t)item * bt.lpi * k + i] = s_top.doc[i];
             }
-            if (tid == 0) bt.res_cnt[item] = n;
+            if (tid == 0) bt.res_cnt[(size_t)item * bt.lpi] = n;
         }
     }
 }

@@ -1,0 +1,573 @@
+// scan_range.h -- scan_range_kernel: the doc-range formulation (queries of <= RT indexed terms, k <= REG_K).
+// Part of libvbm25's single device translation unit: included by search.hip inside namespace vbm25, after
+// scan_cursor.h.
+//
+// One 8-wave workgroup per work item (query x doc range), persistent, items from an atomic counter.  The
+// item is cut into TILES: a tile is a doc range [tlo, thi) that holds at most R_NBLK posting blocks of the
+// query's ESSENTIAL terms (every block whose min_doc < thi; per-term quotas proportional to df make thi).
+// A tile is three phases separated by two LDS-only barriers:
+//
+//   S1  every wave decodes its <= RB blocks (raw words requested up front: RB blocks x ~3 lines in flight
+//       per wave), keeps the ids in registers, stages them in LDS (one 128-id row per block) and marks
+//       every in-range id in the tile bitmap (exact when the tile is <= 2^17 documents wide, else a 2-hash
+//       Bloom filter over two 2^16-bit halves).  A mark that was already set = a SECOND ARRIVAL: the
+//       document may sit in two lists.  It is de-duplicated through a small hash set and gets a ROW.
+//   S2  lanes = (row, term): binary search of the row's document in the term's staged blocks; a posting
+//       found gets its tf field / fieldnorm byte read, Cache::evaluate (bm25.rs:355-358), the value goes
+//       to contrib[row][term] and a done bit marks the posting.  Wave 0 plans tile n + 2 and polls the
+//       query's shared threshold; all waves wipe the bitmap.
+//   S3  lanes = rows: sum of the row in ascending key order (evaluate.rs:43-72 order; absent terms add
+//       0.0, exact) -> offer.  Then the COLD pass, per wave over its own blocks: a block whose upper bound
+//       (search.rs:377-380) plus the non-essential terms' bounds reaches the threshold has every posting
+//       without a done bit scored on its own; all other blocks never have their tf / fieldnorm bytes read.
+//
+// MaxScore split (search.rs:153-169 is the same test on token upper bounds, one document at a time): terms
+// are ordered by token upper bound; the longest prefix whose bounds sum below the threshold is NON-ESSENTIAL
+// -- no document made only of those terms can enter the top-k, so their blocks are neither planned nor
+// fetched.  Documents that the essential lists produce and whose partial score + non-essential bounds still
+// reaches the threshold are completed by LOOKUPS (NE phase): block located by bisection of blk_max_doc, the
+// block upper bound (search.rs:177-203) refines the bound, surviving (block, row) pairs decode the block once
+// per wave and read the one posting.  This is where posting blocks are skipped.
+//
+// Every wave keeps its own top-k in registers (RegTopK); the k-th scores are shared through LDS, the query's
+// 64-bit atomicMax word and the 256-bucket histogram (as in scan_cursor.h).  Lists go to res_* at
+// item * RNW + wave; merge_kernel merges them.  A tile whose rows overflow hands the item to
+// scan_many_kernel (item_failed).
+
+constexpr int RNW = 8;               // waves per workgroup
+constexpr int RWG = RNW * 64;
+constexpr int RB = 8;                // blocks per wave per tile
+constexpr int R_NBLK = 64;           // blocks per tile = lanes of the planner wave
+constexpr int R_BM_WORDS = 4096;     // 16 KB: one exact 2^17-bit bitmap, or two 2^16-bit Bloom halves
+constexpr uint32_t R_BM_EXACT = 1u << 17;
+constexpr int R_HS_LOG2 = 10;
+constexpr int R_HS = 1 << R_HS_LOG2;  // slots of the second-arrival hash set
+constexpr int R_ROWS = 128;           // rows (documents with a second arrival / NE candidates) per tile
+constexpr uint32_t R_TARGET_ITEMS = 1024;
+constexpr uint32_t R_MIN_CHUNK_POSTINGS = 16384;
+constexpr uint32_t R_GRID = 512;      // persistent workgroups: 256 CUs x 2
+constexpr int R_PLAN_RING = 3;
+
+template <int RT>
+struct RangeLds {
+    uint32_t bm[R_BM_WORDS];
+    uint32_t stage[R_NBLK * 128];
+    uint32_t hkeys[R_HS];
+    double contrib[R_ROWS * RT];
+    uint32_t done[R_NBLK * 4];
+    uint32_t mdoc[2][R_ROWS];
+    uint16_t mslot[2][R_ROWS];
+    uint4 pm[R_PLAN_RING][R_NBLK];     // {min_doc, max_doc, off8, n | md << 8 | mt << 16 | wand_fn << 24}
+    uint2 pa[R_PLAN_RING][R_NBLK];     // {block index, term}
+    double pub[R_PLAN_RING][R_NBLK];   // block upper bound
+    uint4 hdr[R_PLAN_RING];            // {tlo, thi, blocks, first non-essential position in t_order}
+    uint8_t ptb[R_PLAN_RING][RT + 4];  // first plan entry of each term (entries of a term are contiguous)
+    double s1[256];
+    double t_s0[RT];
+    double t_ub[RT];                   // token upper bound x (1 + 1e-12)
+    uint32_t t_b0[RT], t_b1[RT];       // block range of the term
+    double hscale;
+    unsigned long long theta;          // bits of a lower bound of the query's k-th best score
+    uint32_t nmulti[2];
+    uint32_t item, q, lo, hi, mq, fail;
+    uint32_t scratch[64];
+};
+
+template <int KMAX, int RT>
+__global__ void __launch_bounds__(RWG, 4) scan_range_kernel(DevIndex ix, DevBatch bt) {
+    static_assert(KMAX <= REG_K, "register top-k only");
+    static_assert(RT == 8 || RT == 16, "row stride");
+    constexpr int RK = KMAX / 64;
+    constexpr int LRT = RT == 8 ? 3 : 4;
+    __shared__ RangeLds<RT> S;
+
+    const uint32_t tid = threadIdx.x, lane = tid & 63, wave = uni(tid >> 6);
+    const uint32_t k = bt.k;
+    const uint32_t n_items = *bt.n_items;
+    for (uint32_t i = tid; i < 256; i += RWG) S.s1[i] = ix.s1[i];
+
+    // planner state (wave 0 only): lane t = term t, lane s = plan slot s
+    uint32_t p_cur = 0, p_end = 0, p_quota = 0, p_base = 0, p_st = NONE32, p_so = 0;
+
+    for (;;) {
+        __syncthreads();  // previous item fully done with LDS
+        if (tid == 0) S.item = atomicAdd(bt.work_ctr, 1u);
+        for (uint32_t i = tid; i < R_HS; i += RWG) S.hkeys[i] = EMPTY;
+        for (uint32_t i = tid; i < R_BM_WORDS; i += RWG) S.bm[i] = 0;
+        for (uint32_t i = tid; i < R_ROWS * RT; i += RWG) S.contrib[i] = 0.0;
+        if (tid < R_NBLK * 4) S.done[tid] = 0;
+        __syncthreads();
+        const uint32_t item = uni(S.item);
+        if (item >= n_items) break;
+        const Item it = bt.items[item];
+        if (it.m > (uint32_t)RT) {  // more terms or dense: the other kernels'
+            continue;
+        }
+        const uint32_t q = uni(it.q), lo = uni(it.doc_lo), hi = uni(it.doc_hi);
+        uint32_t *hrow = bt.hist + (size_t)q * CUR_HB;
+
+        // ---- threshold poll (wave 0): the query's published k-th score and the histogram of accepted documents
+        unsigned long long pg = 0;
+        uint32_t pc[4] = {0, 0, 0, 0};
+        double hscale = 0.0;
+        auto poll_request = [&]() {
+            pg = __hip_atomic_load(&bt.theta[q], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) pc[i] = __hip_atomic_load(&hrow[4 * lane + i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        };
+        auto poll_consume = [&]() {
+            unsigned long long th = ((unsigned long long)uni((uint32_t)(pg >> 32)) << 32) | uni((uint32_t)pg);
+            const uint32_t own = pc[0] + pc[1] + pc[2] + pc[3];
+            const uint32_t incl = wave_incl_scan_u32(own);
+            const uint32_t total = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
+            const uint32_t above = total - incl;  // documents in the buckets of higher lanes
+            const unsigned long long hit = __ballot(above + own >= k);
+            if (hit) {
+                const uint32_t hl = 63u - (uint32_t)__builtin_clzll(hit);
+                uint32_t a = (uint32_t)__builtin_amdgcn_readlane((int)above, (int)hl), b = 4 * hl;
+                const uint32_t c3 = (uint32_t)__builtin_amdgcn_readlane((int)pc[3], (int)hl);
+                const uint32_t c2 = (uint32_t)__builtin_amdgcn_readlane((int)pc[2], (int)hl);
+                const uint32_t c1 = (uint32_t)__builtin_amdgcn_readlane((int)pc[1], (int)hl);
+                if (a + c3 >= k) b += 3;
+                else if (a + c3 + c2 >= k) b += 2;
+                else if (a + c3 + c2 + c1 >= k) b += 1;
+                // a score lands in bucket b only if score * hscale >= b (up to one rounding)
+                const double edge = ((double)b / hscale) * (1.0 - 1e-12);
+                const unsigned long long eb2 = (unsigned long long)__double_as_longlong(edge);
+                if (eb2 > th) th = eb2;
+            }
+            if (lane == 0) atomicMax(&S.theta, th);
+        };
+
+        // ---- tile planner (wave 0)
+        uint32_t p_tlo = lo;
+        auto plan_tile = [&](uint32_t buf) {
+            const bool alive = lane < uni(S.mq) && p_cur < p_end;
+            uint32_t bnd = NONE32;
+            if (alive && p_cur + p_quota < p_end) bnd = ix.blk_min_doc[p_cur + p_quota];
+            if (!__ballot(alive) || p_tlo >= hi) {
+                if (lane == 0) S.hdr[buf] = make_uint4(p_tlo, p_tlo, 0, 0);
+                return;
+            }
+            const uint32_t thi = min(hi, wave_min_u32(bnd));
+            const uint32_t st = p_st < 64u ? p_st : 0u;
+            const uint32_t cur_s = (uint32_t)__shfl((int)p_cur, (int)st), end_s = (uint32_t)__shfl((int)p_end, (int)st);
+            const uint32_t quo_s = (uint32_t)__shfl((int)p_quota, (int)st);
+            const uint32_t j = cur_s + p_so;
+            const bool valid = p_st != NONE32 && p_so < quo_s && j < end_s;
+            uint4 meta = make_uint4(NONE32, 0, 0, 0);
+            double ub = 0.0;
+            if (valid) {
+                meta = ix.blk_meta[j];
+                ub = ix.blk_ub[j];
+            }
+            const bool in_tile = valid && meta.x < thi;
+            const unsigned long long mask = __ballot(in_tile);
+            const uint32_t pos = __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
+            if (in_tile) {
+                S.pm[buf][pos] = meta;
+                S.pa[buf][pos] = make_uint2(j, p_st);
+                S.pub[buf][pos] = ub;
+            }
+            const unsigned long long cmask = __ballot(in_tile && meta.y < thi);
+            if (lane <= (uint32_t)RT) {  // lane t: entries before term t's slots = first entry of term t
+                const unsigned long long below = p_base >= 64u ? ~0ull : ((1ull << p_base) - 1ull);
+                S.ptb[buf][lane] = (uint8_t)__popcll(mask & below);
+                const unsigned long long qm = p_quota >= 64u ? ~0ull : ((1ull << p_quota) - 1ull);
+                if (p_base < 64u) p_cur += (uint32_t)__popcll((cmask >> p_base) & qm);
+            }
+            if (lane == 0) S.hdr[buf] = make_uint4(p_tlo, thi, (uint32_t)__popcll(mask), 0);
+            p_tlo = thi;
+        };
+
+        // ---- item setup (wave 0): terms, cursors, quotas, slot map; the first two plans
+        if (wave == 0) {
+            poll_request();
+            uint32_t m = 0, term = NONE32;
+            {
+                const uint32_t qb = uni(bt.q_off[q]), qe = uni(bt.q_off[q + 1]);
+                if (qe - qb <= 64) {  // one load per lane, compaction of the indexed terms through LDS
+                    const uint32_t tt = lane < qe - qb ? bt.term_ids[qb + lane] : NONE32;
+                    const bool ok = tt < ix.n_terms;  // search.rs:59-61
+                    const unsigned long long okm = __ballot(ok);
+                    if (ok) S.scratch[__builtin_amdgcn_mbcnt_hi((uint32_t)(okm >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)okm, 0u))] = tt;
+                    __builtin_amdgcn_wave_barrier();
+                    m = (uint32_t)__popcll(okm);
+                    if (lane < m) term = S.scratch[lane];
+                    __builtin_amdgcn_wave_barrier();
+                } else {
+                    for (uint32_t p = qb; p < qe; ++p) {
+                        const uint32_t tt = bt.term_ids[p];
+                        if (tt >= ix.n_terms) continue;
+                        if (m == lane) term = tt;
+                        ++m;
+                    }
+                }
+            }
+            m = uni(m);
+            const bool act = lane < m;
+            double s0 = 0.0, tub = 0.0;
+            uint32_t df = 0, b0 = 0, b1 = 0;
+            p_cur = p_end = 0;
+            if (act) {
+                b0 = ix.term_first_block[term];
+                b1 = ix.term_first_block[term + 1];
+                s0 = ix.term_s0[term];
+                df = ix.term_df[term];
+                const double wtf = (double)ix.term_wand_tf[term];
+                tub = ((wtf * s0) / (wtf + S.s1[ix.term_wand_fn[term]])) * (1.0 + 1e-12);
+                // first block whose max_doc >= lo: guess by interpolation, gallop, then bisect
+                uint32_t lo_b = b0, hi_b = b1;
+                if (lo != 0 && b1 > b0) {
+                    uint32_t g = b0 + (uint32_t)((unsigned long long)(b1 - b0) * lo / ix.n_docs);
+                    if (g >= b1) g = b1 - 1;
+                    if (ix.blk_max_doc[g] < lo) {
+                        lo_b = g + 1;
+                        for (uint32_t step = 1; lo_b < hi_b; step *= 4) {
+                            const uint32_t p = min(lo_b + step - 1, hi_b - 1);
+                            if (ix.blk_max_doc[p] < lo) lo_b = p + 1;
+                            else {
+                                hi_b = p;
+                                break;
+                            }
+                        }
+                    } else {
+                        hi_b = g;
+                        for (uint32_t step = 1; lo_b < hi_b; step *= 4) {
+                            const uint32_t p = hi_b - lo_b >= step ? hi_b - step : lo_b;
+                            if (ix.blk_max_doc[p] >= lo) hi_b = p;
+                            else {
+                                lo_b = p + 1;
+                                break;
+                            }
+                        }
+                    }
+                    while (lo_b < hi_b) {
+                        const uint32_t mid = (lo_b + hi_b) >> 1;
+                        if (ix.blk_max_doc[mid] < lo) lo_b = mid + 1; else hi_b = mid;
+                    }
+                }
+                p_cur = lo_b;
+                p_end = b1;
+                S.t_s0[lane] = s0;
+                S.t_ub[lane] = tub;
+                S.t_b0[lane] = b0;
+                S.t_b1[lane] = b1;
+            }
+            // quotas: R_NBLK - m slots shared in proportion to df, at least one each
+            unsigned long long sumdf = 0;
+            double sums0 = 0.0;
+            for (uint32_t t = 0; t < m; ++t) {
+                sumdf += (uint32_t)__builtin_amdgcn_readlane((int)df, (int)t);
+                sums0 += readlane_f64(s0, t);
+            }
+            p_quota = 0;
+            if (act) {
+                p_quota = (uint32_t)(((unsigned long long)(R_NBLK - m) * df) / sumdf);
+                if (p_quota < 1) p_quota = 1;
+            }
+            {
+                const uint32_t incl = wave_incl_scan_u32(p_quota);
+                p_base = incl - p_quota;  // lanes >= m: total
+            }
+            p_st = NONE32;
+            p_so = 0;
+            for (uint32_t t = 0; t < m; ++t) {
+                const uint32_t bt0 = (uint32_t)__builtin_amdgcn_readlane((int)p_base, (int)t);
+                const uint32_t qt = (uint32_t)__builtin_amdgcn_readlane((int)p_quota, (int)t);
+                if (lane >= bt0 && lane < bt0 + qt) {
+                    p_st = t;
+                    p_so = lane - bt0;
+                }
+            }
+            hscale = (double)CUR_HB / sums0;  // score -> histogram bucket: linear in [0, sum of s0)
+            if (lane == 0) {
+                S.q = q;
+                S.lo = lo;
+                S.hi = hi;
+                S.mq = m;
+                S.fail = 0;
+                S.hscale = hscale;
+                S.theta = 0;
+                S.nmulti[0] = 0;
+                S.nmulti[1] = 0;
+            }
+            __builtin_amdgcn_wave_barrier();
+            poll_consume();
+            p_tlo = lo;
+            plan_tile(0);
+            plan_tile(1);
+        }
+        __syncthreads();
+        const uint32_t mq = uni(S.mq);
+        hscale = S.hscale;
+
+        RegTopK<RK> rtop;
+        rtop.init();
+        unsigned long long published = 0;
+        auto theta_now = [&]() -> unsigned long long {
+            unsigned long long th = S.theta;
+            th = ((unsigned long long)uni((uint32_t)(th >> 32)) << 32) | uni((uint32_t)th);
+            return th;
+        };
+        // offer whole documents to this wave's list; the ones that can enter it are counted in the histogram
+        auto offer = [&](bool has, double sc, uint32_t d) {
+            const unsigned long long th = theta_now();
+            has = has && (unsigned long long)__double_as_longlong(sc) >= th &&
+                  (rtop.cnt < k || better(sc, d, rtop.kth_s, rtop.kth_d));
+            if (!__ballot(has)) return;
+            if (has) {
+                const double hb = sc * hscale;
+                const uint32_t b = hb >= (double)(CUR_HB - 1) ? (uint32_t)(CUR_HB - 1) : (uint32_t)hb;
+                atomicAdd(&hrow[b], 1u);
+            }
+            rtop.offer(has, sc, d, k, lane);
+            if (rtop.cnt >= k) {
+                const unsigned long long kb = (unsigned long long)__double_as_longlong(rtop.kth_s);
+                if (kb > published) {
+                    if (lane == 0) {
+                        atomicMax(&S.theta, kb);
+                        atomicMax(&bt.theta[q], kb);
+                    }
+                    published = kb;
+                }
+            }
+        };
+
+        // =====================================================================
+        // Tile loop
+        // =====================================================================
+        bool failed = false;
+        for (uint32_t tile = 0;; ++tile) {
+            const uint32_t buf = tile % R_PLAN_RING, par = tile & 1u;
+            const uint4 hdr = uni4(S.hdr[buf]);
+            const uint32_t tlo = hdr.x, thi = hdr.y, np = hdr.z;
+            if (np == 0) break;
+            const bool exact = thi - tlo <= R_BM_EXACT;
+
+            // ---- S1: decode, stage, mark
+            uint32_t d0[RB], d1[RB];
+            uint32_t inmask = 0;  // bit 2i / 2i + 1: posting 0 / 1 of entry i is inside [tlo, thi)
+            {
+                uint32_t flo0[RB], fhi0[RB], flo1[RB], fhi1[RB];
+#pragma unroll
+                for (int i = 0; i < RB; ++i) {
+                    const uint32_t e = wave == 0 ? 56u + i : (wave - 1u) + 7u * i;
+                    flo0[i] = fhi0[i] = flo1[i] = fhi1[i] = 0;
+                    if (e < np) {
+                        const uint4 c = S.pm[buf][e];
+                        const uint32_t md = uni((c.w >> 8) & 0xff);
+                        if (md < 32u) pair_fetch(ix.blob + 8ull * uni(c.z), md, lane, flo0[i], fhi0[i], flo1[i], fhi1[i]);
+                    }
+                }
+#pragma unroll
+                for (int i = 0; i < RB; ++i) {
+                    const uint32_t e = wave == 0 ? 56u + i : (wave - 1u) + 7u * i;
+                    d0[i] = d1[i] = NONE32;
+                    if (e < np) {
+                        const uint4 c = uni4(S.pm[buf][e]);
+                        const uint32_t md = (c.w >> 8) & 0xff;
+                        uint32_t a0, a1;
+                        if (md < 32u) {  // bit-packed d1 deltas (compression.rs:65-92)
+                            uint32_t v0, v1;
+                            pair_extract(md, lane, flo0[i], fhi0[i], flo1[i], fhi1[i], v0, v1);
+                            const uint32_t own = v0 + v1;
+                            const uint32_t incl = wave_incl_scan_u32(own);
+                            a0 = c.x + (incl - own) + v0;
+                            a1 = a0 + v1;
+                        } else {  // raw (width 32) or a byte-packed tail block: generic path
+                            const uint32_t n = c.w & 0xff;
+                            decode_doc_ids(ix.blob + 8ull * c.z, md, n, c.x, lane, a0, a1);
+                            if (2 * lane >= n) a0 = NONE32;
+                            if (2 * lane + 1 >= n) a1 = NONE32;
+                        }
+                        d0[i] = a0;
+                        d1[i] = a1;
+                        *reinterpret_cast<uint2 *>(&S.stage[e * 128 + 2 * lane]) = make_uint2(a0, a1);
+                        const bool all_in = c.x >= tlo && c.y < thi;
+                        const bool in0 = a0 != NONE32 && (all_in || (a0 >= tlo && a0 < thi));
+                        const bool in1 = a1 != NONE32 && (all_in || (a1 >= tlo && a1 < thi));
+                        inmask |= (in0 ? 1u : 0u) << (2 * i) | (in1 ? 1u : 0u) << (2 * i + 1);
+                        bool dup0 = false, dup1 = false;
+                        const uint32_t x0 = a0 - tlo, x1 = a1 - tlo;
+                        if (exact) {
+                            if (in0) {
+                                const uint32_t b = 1u << (x0 & 31);
+                                dup0 = (atomicOr(&S.bm[x0 >> 5], b) & b) != 0;
+                            }
+                            if (in1) {
+                                const uint32_t b = 1u << (x1 & 31);
+                                dup1 = (atomicOr(&S.bm[x1 >> 5], b) & b) != 0;
+                            }
+                        } else {
+                            if (in0) {
+                                const uint32_t h = x0 & 0xffffu, g = (__umul24(x0, 40503u) >> 8) & 0xffffu;
+                                const uint32_t hb = 1u << (h & 31), gb = 1u << (g & 31);
+                                const uint32_t o1 = atomicOr(&S.bm[h >> 5], hb), o2 = atomicOr(&S.bm[2048 + (g >> 5)], gb);
+                                dup0 = (o1 & hb) && (o2 & gb);
+                            }
+                            if (in1) {
+                                const uint32_t h = x1 & 0xffffu, g = (__umul24(x1, 40503u) >> 8) & 0xffffu;
+                                const uint32_t hb = 1u << (h & 31), gb = 1u << (g & 31);
+                                const uint32_t o1 = atomicOr(&S.bm[h >> 5], hb), o2 = atomicOr(&S.bm[2048 + (g >> 5)], gb);
+                                dup1 = (o1 & hb) && (o2 & gb);
+                            }
+                        }
+                        if (__ballot(dup0 || dup1)) {  // second arrivals: one row per document
+#pragma unroll
+                            for (int s = 0; s < 2; ++s) {
+                                const bool dup = s ? dup1 : dup0;
+                                const uint32_t d = s ? a1 : a0;
+                                if (dup) {
+                                    uint32_t slot = (d * 0x9E3779B1u) >> (32 - R_HS_LOG2);
+                                    for (;;) {
+                                        if (S.nmulti[par] >= (uint32_t)R_ROWS) {
+                                            S.fail = 1;
+                                            break;
+                                        }
+                                        const uint32_t prev = atomicCAS(&S.hkeys[slot], EMPTY, d);
+                                        if (prev == EMPTY) {
+                                            const uint32_t r = atomicAdd(&S.nmulti[par], 1u);
+                                            if (r < (uint32_t)R_ROWS) {
+                                                S.mdoc[par][r] = d;
+                                                S.mslot[par][r] = (uint16_t)slot;
+                                            } else {
+                                                S.fail = 1;
+                                            }
+                                            break;
+                                        }
+                                        if (prev == d) break;
+                                        slot = (slot + 1) & (R_HS - 1);
+                                    }
+                                }
+                            }
+                        }
+                    }
+                }
+            }
+            lds_barrier();  // ---- A: every mark and every row of the tile is in LDS
+
+            if (uni(S.fail)) {
+                failed = true;
+                break;
+            }
+            const uint32_t nm = min(uni(S.nmulti[par]), (uint32_t)R_ROWS);
+
+            // ---- S2: wipe the bitmap; rows x terms: find the postings, score them; wave 0 plans ahead
+            if (wave == 0) poll_request();
+#pragma unroll
+            for (int i = 0; i < R_BM_WORDS / 4 / RWG; ++i)
+                reinterpret_cast<uint4 *>(S.bm)[tid + i * RWG] = make_uint4(0, 0, 0, 0);
+            if (tid == 0) S.nmulti[par ^ 1u] = 0;
+            if (nm) {
+                for (uint32_t p = tid; p < (nm << LRT); p += RWG) {
+                    const uint32_t r = p >> LRT, t = p & (RT - 1);
+                    const uint32_t d = S.mdoc[par][r];
+                    if (t == 0) S.hkeys[S.mslot[par][r]] = EMPTY;
+                    if (t >= mq) continue;
+                    uint32_t eb = S.ptb[buf][t], len = S.ptb[buf][t + 1] - eb;
+                    if (len == 0) continue;
+                    while (len > 1) {  // last entry of the term with min_doc <= d
+                        const uint32_t half = len >> 1;
+                        if (S.pm[buf][eb + half].x <= d) {
+                            eb += half;
+                            len -= half;
+                        } else {
+                            len = half;
+                        }
+                    }
+                    const uint4 sj = S.pm[buf][eb];
+                    if (d < sj.x || d > sj.y) continue;
+                    const uint32_t *sb = &S.stage[eb * 128];
+                    uint32_t idx = 0;
+#pragma unroll
+                    for (int s = 64; s > 0; s >>= 1)
+                        if (sb[idx + s - 1] < d) idx += s;
+                    if (idx >= 128u || sb[idx] != d) continue;
+                    atomicOr(&S.done[eb * 4 + (idx >> 5)], 1u << (idx & 31));
+                    const uint32_t nj = sj.w & 0xff, mdj = (sj.w >> 8) & 0xff, mtj = (sj.w >> 16) & 0xff;
+                    const uint8_t *tbody = ix.blob + 8ull * sj.z + ((payload_bytes(mdj, nj) + 7u) & ~7u);
+                    const FieldAddr fa = field_addr(mtj, nj, idx);
+                    const uint32_t flo = *reinterpret_cast<const uint32_t *>(tbody + fa.off0);
+                    const uint32_t fhi = *reinterpret_cast<const uint32_t *>(tbody + fa.off1);
+                    const uint32_t fn = ix.post_fn[128ull * S.pa[buf][eb].x + idx];
+                    const double tf = (double)field_val(flo, fhi, fa);
+                    S.contrib[(r << LRT) + t] = (tf * S.t_s0[t]) / (tf + S.s1[fn]);  // Cache::evaluate, bm25.rs:355-358
+                }
+            }
+            if (wave == 0) {
+                poll_consume();
+                plan_tile((tile + 2) % R_PLAN_RING);
+            }
+            lds_barrier();  // ---- B: contributions and done bits complete; bitmap clean
+
+            // ---- S3: rows -> documents (row r: lane r / RNW of wave r % RNW)
+            if (nm) {
+                const uint32_t r = lane * RNW + wave;
+                const bool has = r < nm;
+                double acc = 0.0;
+                uint32_t d = 0;
+                if (has) {
+                    d = S.mdoc[par][r];
+                    for (uint32_t t = 0; t < mq; ++t) {  // ascending key order; absent terms add 0.0
+                        acc += S.contrib[(r << LRT) + t];
+                        S.contrib[(r << LRT) + t] = 0.0;
+                    }
+                }
+                offer(has, acc, d);
+            }
+            // ---- cold pass: blocks whose upper bound reaches the threshold (search.rs:203)
+#pragma unroll
+            for (int i = 0; i < RB; ++i) {
+                const uint32_t e = wave == 0 ? 56u + i : (wave - 1u) + 7u * i;
+                if (e < np) {
+                    uint32_t dw = 0;
+                    if (nm) {
+                        dw = S.done[e * 4 + (lane >> 4)];
+                        __builtin_amdgcn_wave_barrier();
+                        if (lane < 4) S.done[e * 4 + lane] = 0;
+                    }
+                    const unsigned long long ubb = (unsigned long long)__double_as_longlong(S.pub[buf][e]);
+                    const unsigned long long ubu = ((unsigned long long)uni((uint32_t)(ubb >> 32)) << 32) | uni((uint32_t)ubb);
+                    if (theta_now() <= ubu) {
+                        const bool ok0 = ((inmask >> (2 * i)) & 1u) && !((dw >> ((2 * lane) & 31)) & 1u);
+                        const bool ok1 = ((inmask >> (2 * i + 1)) & 1u) && !((dw >> ((2 * lane + 1) & 31)) & 1u);
+                        if (__ballot(ok0 || ok1)) {
+                            const uint4 sj = uni4(S.pm[buf][e]);
+                            const uint2 aux = S.pa[buf][e];
+                            const uint32_t blkj = uni(aux.x), t = uni(aux.y);
+                            const uint32_t nj = sj.w & 0xff, mdj = (sj.w >> 8) & 0xff, mtj = (sj.w >> 16) & 0xff;
+                            const uint8_t *tbody = ix.blob + 8ull * sj.z + ((payload_bytes(mdj, nj) + 7u) & ~7u);
+                            const FieldAddr f0 = field_addr(mtj, nj, 2 * lane), f1 = field_addr(mtj, nj, 2 * lane + 1);
+                            const uint32_t l0 = *reinterpret_cast<const uint32_t *>(tbody + f0.off0);
+                            const uint32_t h0 = *reinterpret_cast<const uint32_t *>(tbody + f0.off1);
+                            const uint32_t l1 = *reinterpret_cast<const uint32_t *>(tbody + f1.off0);
+                            const uint32_t h1 = *reinterpret_cast<const uint32_t *>(tbody + f1.off1);
+                            const uint32_t fnp = reinterpret_cast<const uint16_t *>(ix.post_fn + 128ull * blkj)[lane];
+                            const double s0t = S.t_s0[t];
+                            const double tf0 = (double)field_val(l0, h0, f0), tf1 = (double)field_val(l1, h1, f1);
+                            const double p0 = (tf0 * s0t) / (tf0 + S.s1[fnp & 0xff]);
+                            const double p1 = (tf1 * s0t) / (tf1 + S.s1[fnp >> 8]);
+                            offer(ok0, p0, d0[i]);
+                            offer(ok1, p1, d1[i]);
+                        }
+                    }
+                }
+            }
+        }
+
+        // ---- item result: one list per wave
+        const uint32_t n = failed ? 0u : rtop.cnt;
+        const size_t list = (size_t)item * bt.lpi + wave;
+#pragma unroll
+        for (int r = 0; r < RK; ++r)
+            if (r * 64 + lane < n) {
+                bt.res_score[list * k + r * 64 + lane] = rtop.score[r];
+                bt.res_doc[list * k + r * 64 + lane] = rtop.doc[r];
+            }
+        if (lane == 0) {
+            bt.res_cnt[list] = n;
+            if (wave == 0) bt.item_failed[item] = failed ? 1u : 0u;
+        }
+    }
+}

@@ -383,11 +383,11 @@ __global__ void __launch_bounds__(CWG, 6) scan_kernel(DevIndex ix, DevBatch bt) 
                 for (int r = 0; r < RK; ++r) {
                     const uint32_t e = r * 64 + lane;
                     if (e < rtop.cnt) {
-                        bt.res_score[(size_t)item * k + e] = rtop.score[r];
-                        bt.res_doc[(size_t)item * k + e] = rtop.doc[r];
+                        bt.res_score[(size_t)item * bt.lpi * k + e] = rtop.score[r];
+                        bt.res_doc[(size_t)item * bt.lpi * k + e] = rtop.doc[r];
                     }
                 }
-                if (lane == 0) bt.res_cnt[item] = rtop.cnt;
+                if (lane == 0) bt.res_cnt[(size_t)item * bt.lpi] = rtop.cnt;
             }
         } else if (wave == JOINER) {
             // =====================================================================
@@ -724,10 +724,10 @@ __global__ void __launch_bounds__(CWG, 6) scan_kernel(DevIndex ix, DevBatch bt) 
         if constexpr (KMAX > REG_K) {
             const uint32_t n = s_top.count;
             for (uint32_t i = tid; i < n; i += CWG) {
-                bt.res_score[(size_t)item * k + i] = s_top.score[i];
-                bt.res_doc[(size_t)item * k + i] = s_top.doc[i];
+                bt.res_score[(size_t)item * bt.lpi * k + i] = s_top.score[i];
+                bt.res_doc[(size_t)item * bt.lpi * k + i] = s_top.doc[i];
             }
-            if (tid == 0) bt.res_cnt[item] = n;
+            if (tid == 0) bt.res_cnt[(size_t)item * bt.lpi] = n;
         }
     }
 #ifdef VBM25_PROFILE

@@ -57,6 +57,7 @@ int set_error(int code, const char *fmt, ...) {
 #include "topk_reg.h"
 #include "scan_tile.h"
 #include "scan_cursor.h"
+#include "scan_range.h"
 #include "merge.h"
 
 // ---------------------------------------------------------------------------
@@ -111,6 +112,10 @@ struct vbm25_batch {
     bool run_cursor = false;      // ... for the current queries (tiny batches stay with the tile kernel)
     uint32_t cur_min_items = 64;
     bool has_mid_terms = false;   // some sparse query has CUR_T < terms <= CHAIN_MAX_TERMS
+    bool use_range = false;       // k <= REG_K: sparse queries of <= 16 terms take scan_range_kernel (VBM25_RANGE=0: off)
+    uint32_t range_rt = 0;        // ... with this row stride (8 or 16) for the current queries; 0 = not used
+    uint32_t lpi = 1;             // result lists per work item
+    uint32_t range_grid = R_GRID;
     uint32_t cur_mt = 1;          // most indexed terms among the cursor kernel's queries
     uint32_t target_items = TARGET_ITEMS;
     uint32_t min_chunk = MIN_CHUNK_POSTINGS;
@@ -372,11 +377,17 @@ static int vbm25_batch_create_impl(vbm25_index *ix, uint32_t max_queries, uint32
     {
         const char *env = std::getenv("VBM25_NO_CURSOR");
         bt->use_cursor = k <= (uint32_t)REG_K && !(env && env[0] == '1');
+        const char *rg = std::getenv("VBM25_RANGE");
+        bt->use_range = k <= (uint32_t)REG_K && !(rg && rg[0] == '0');
+        if (bt->use_range) bt->use_cursor = false;
+        bt->lpi = bt->use_range ? (uint32_t)RNW : 1u;
         const char *ti = std::getenv("VBM25_CUR_ITEMS");
-        bt->target_items = bt->use_cursor ? (ti ? (uint32_t)std::atoi(ti) : CUR_TARGET_ITEMS) : TARGET_ITEMS;
-        if (bt->target_items < TARGET_ITEMS) bt->target_items = TARGET_ITEMS;
+        bt->target_items = bt->use_range ? (ti ? (uint32_t)std::atoi(ti) : R_TARGET_ITEMS)
+                           : bt->use_cursor ? (ti ? (uint32_t)std::atoi(ti) : CUR_TARGET_ITEMS) : TARGET_ITEMS;
+        if (bt->target_items < 256) bt->target_items = 256;
         const char *mc = std::getenv("VBM25_CUR_MIN_CHUNK");
-        bt->min_chunk = bt->use_cursor ? (mc ? (uint32_t)std::atoi(mc) : CUR_MIN_CHUNK_POSTINGS) : MIN_CHUNK_POSTINGS;
+        bt->min_chunk = bt->use_range ? (mc ? (uint32_t)std::atoi(mc) : R_MIN_CHUNK_POSTINGS)
+                        : bt->use_cursor ? (mc ? (uint32_t)std::atoi(mc) : CUR_MIN_CHUNK_POSTINGS) : MIN_CHUNK_POSTINGS;
         if (bt->min_chunk < 128) bt->min_chunk = 128;
         const char *mi = std::getenv("VBM25_CUR_MIN_ITEMS");
         if (mi) bt->cur_min_items = (uint32_t)std::atoi(mi);
@@ -388,9 +399,9 @@ static int vbm25_batch_create_impl(vbm25_index *ix, uint32_t max_queries, uint32
         (rc = bt->items.alloc(sizeof(Item) * size_t(bt->max_items))) || (rc = bt->n_items.alloc(4)) ||
         (rc = bt->q_item_base.alloc(4ull * (max_queries + 1))) ||
         (rc = bt->theta.alloc(8ull * max_queries)) ||
-        (rc = bt->res_score.alloc(8ull * bt->max_items * k)) ||
-        (rc = bt->res_doc.alloc(4ull * bt->max_items * k)) ||
-        (rc = bt->res_cnt.alloc(4ull * bt->max_items)) ||
+        (rc = bt->res_score.alloc(8ull * bt->max_items * bt->lpi * k)) ||
+        (rc = bt->res_doc.alloc(4ull * bt->max_items * bt->lpi * k)) ||
+        (rc = bt->res_cnt.alloc(4ull * bt->max_items * bt->lpi)) ||
         (rc = bt->hits.alloc(sizeof(vbm25_hit) * size_t(max_queries) * k)) ||
         (rc = bt->n_hits.alloc(4ull * max_queries)) || (rc = bt->error_flag.alloc(4)) ||
         (rc = bt->q_dense.alloc(max_queries)) ||
@@ -419,7 +430,7 @@ static int vbm25_batch_set_queries_impl(vbm25_batch *bt, const uint32_t *term_id
     if (nq > bt->max_queries) return set_error(VBM25_ERR_INVALID, "%u queries exceed the batch capacity %u", nq, bt->max_queries);
     if (q_off[0] != 0) return set_error(VBM25_ERR_INVALID, "q_off[0] must be 0");
     bool many = false, mid = false;
-    uint32_t cur_mt = 1;
+    uint32_t cur_mt = 1, range_mt = 0;
     // Routing: the chain kernel is built for sparse queries; a query with many postings per
     // document (Zipf head terms) or more than CHAIN_MAX_TERMS indexed terms takes the
     // dense-window kernel.  Tuning knob: VBM25_DENSE_X1000 (postings per 1000 documents).
@@ -444,10 +455,15 @@ static int vbm25_batch_set_queries_impl(vbm25_batch *bt, const uint32_t *term_id
             dense[q] = 1;
             many = true;
         }
-        many |= valid > (uint32_t)CHAIN_MAX_TERMS;
-        if (!dense[q]) {
-            if (valid <= (uint32_t)CUR_T) cur_mt = std::max(cur_mt, valid);
-            else if (valid <= (uint32_t)CHAIN_MAX_TERMS) mid = true;
+        if (bt->use_range) {  // sparse queries of <= 16 terms: scan_range_kernel; the rest: scan_many_kernel
+            many |= valid > 16u;
+            if (!dense[q] && valid <= 16u) range_mt = std::max(range_mt, valid);
+        } else {
+            many |= valid > (uint32_t)CHAIN_MAX_TERMS;
+            if (!dense[q]) {
+                if (valid <= (uint32_t)CUR_T) cur_mt = std::max(cur_mt, valid);
+                else if (valid <= (uint32_t)CHAIN_MAX_TERMS) mid = true;
+            }
         }
         if (valid > MAX_TERMS)
             return set_error(VBM25_ERR_UNSUPPORTED, "query %u has %u indexed terms; the GPU path handles up to %d", q, valid, MAX_TERMS);
@@ -461,6 +477,7 @@ static int vbm25_batch_set_queries_impl(vbm25_batch *bt, const uint32_t *term_id
     bt->has_many_terms = many;
     bt->has_mid_terms = mid;
     bt->cur_mt = cur_mt;
+    bt->range_rt = !bt->use_range || range_mt == 0 ? 0u : (range_mt <= 8u ? 8u : 16u);
     {   // the number of work items plan_kernel will make (same integer arithmetic): the cursor kernel's
         // persistent grid need not be larger (a single query is a handful of items, not 6144 workgroups)
         unsigned long long chunk = (total_postings + bt->target_items - 1) / bt->target_items;
@@ -474,6 +491,7 @@ static int vbm25_batch_set_queries_impl(vbm25_batch *bt, const uint32_t *term_id
             items += c;
         }
         bt->cur_grid = uint32_t(std::min<unsigned long long>(std::max<unsigned long long>(items, 1), CUR_GRID));
+        bt->range_grid = uint32_t(std::min<unsigned long long>(std::max<unsigned long long>(items, 1), R_GRID));
         // A handful of items cannot occupy the GPU with one wave each: the tile kernel puts a whole
         // workgroup (six decoding waves) on an item and answers a single query faster (C2: 0.10 ms vs 0.15 ms)
         bt->run_cursor = bt->use_cursor && items >= bt->cur_min_items;
@@ -509,10 +527,13 @@ static int vbm25_batch_run_impl(vbm25_batch *bt, void *hip_stream) {
     db.work_ctr = bt->work_ctr.as<uint32_t>();
     const bool cursor = bt->run_cursor;
     db.chain_min_terms = cursor ? (uint32_t)CUR_T + 1u : 0u;
+    db.lpi = bt->lpi;
+    db.range_max_terms = bt->use_range ? 16u : 0u;
+    const bool range = bt->use_range;
     const DevIndex &ix = bt->index->dev;
-    if (cursor) HIP_TRY(hipMemsetAsync(bt->hist.p, 0, 4ull * CUR_HB * bt->nq, st));
-    plan_kernel<<<1, PLAN_WG, 0, st>>>(ix, db, bt->max_items, cursor ? bt->target_items : TARGET_ITEMS,
-                                       cursor ? bt->min_chunk : MIN_CHUNK_POSTINGS);
+    if (cursor || range) HIP_TRY(hipMemsetAsync(bt->hist.p, 0, 4ull * CUR_HB * bt->nq, st));
+    plan_kernel<<<1, PLAN_WG, 0, st>>>(ix, db, bt->max_items, cursor || range ? bt->target_items : TARGET_ITEMS,
+                                       cursor || range ? bt->min_chunk : MIN_CHUNK_POSTINGS);
     hipEvent_t e0 = nullptr, e1 = nullptr;
     if (bt->timing) {
         if (bt->events_used == bt->events.size()) {
@@ -529,12 +550,15 @@ static int vbm25_batch_run_impl(vbm25_batch *bt, void *hip_stream) {
     const int rc = dispatch_k(bt->k, [&](auto kmax) {
         constexpr int KM = decltype(kmax)::value;
         if constexpr (KM <= REG_K) {
-            if (cursor) {
+            if (range) {  // persistent 8-wave workgroups; items are handed out through bt.work_ctr
+                if (bt->range_rt == 8) scan_range_kernel<KM, 8><<<bt->range_grid, RWG, 0, st>>>(ix, db);
+                else if (bt->range_rt == 16) scan_range_kernel<KM, 16><<<bt->range_grid, RWG, 0, st>>>(ix, db);
+            } else if (cursor) {
                 // persistent single-wave workgroups; items are handed out through bt.work_ctr
                 scan_cursor_kernel<KM><<<bt->cur_grid, 64, 4 * cur_lds_words(bt->cur_mt), st>>>(ix, db, bt->cur_mt);
             }
         }
-        if (!cursor || bt->has_mid_terms) scan_kernel<KM><<<grid, CWG, 0, st>>>(ix, db);
+        if (!range && (!cursor || bt->has_mid_terms)) scan_kernel<KM><<<grid, CWG, 0, st>>>(ix, db);
         if (bt->timing) HIP_TRY(hipEventRecord(e1, st));
         // many-term / dense queries, and items the chain kernel gave up on (empty launch: 5 us)
         scan_many_kernel<decltype(kmax)::value><<<grid, WG, 0, st>>>(ix, db);
