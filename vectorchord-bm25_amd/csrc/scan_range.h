@@ -4,63 +4,63 @@
 //
 // One 8-wave workgroup per work item (query x doc range), persistent, items from an atomic counter.  The
 // item is cut into TILES: a tile is a doc range [tlo, thi) that holds at most R_NBLK posting blocks of the
-// query's ESSENTIAL terms (every block whose min_doc < thi; per-term quotas proportional to df make thi).
-// A tile is three phases separated by two LDS-only barriers:
+// query's terms (every block whose min_doc < thi; per-term quotas proportional to df make thi).  Wave 0 is
+// the PLANNER (tile n + 1 while the others work on tile n; it also polls the query's shared threshold),
+// waves 1..7 are WORKERS with RB blocks each.  A tile is three phases separated by two LDS-only barriers:
 //
-//   S1  every wave decodes its <= RB blocks (raw words requested up front: RB blocks x ~3 lines in flight
-//       per wave), keeps the ids in registers, stages them in LDS (one 128-id row per block) and marks
-//       every in-range id in the tile bitmap (exact when the tile is <= 2^17 documents wide, else a 2-hash
-//       Bloom filter over two 2^16-bit halves).  A mark that was already set = a SECOND ARRIVAL: the
-//       document may sit in two lists.  It is de-duplicated through a small hash set and gets a ROW.
-//   S2  lanes = (row, term): binary search of the row's document in the term's staged blocks; a posting
-//       found gets its tf field / fieldnorm byte read, Cache::evaluate (bm25.rs:355-358), the value goes
-//       to contrib[row][term] and a done bit marks the posting.  Wave 0 plans tile n + 2 and polls the
-//       query's shared threshold; all waves wipe the bitmap.
-//   S3  lanes = rows: sum of the row in ascending key order (evaluate.rs:43-72 order; absent terms add
-//       0.0, exact) -> offer.  Then the COLD pass, per wave over its own blocks: a block whose upper bound
-//       (search.rs:377-380) plus the non-essential terms' bounds reaches the threshold has every posting
-//       without a done bit scored on its own; all other blocks never have their tf / fieldnorm bytes read.
+//   S1  workers decode their blocks (two ids per lane per block), stage the ids in LDS (one 128-id row per
+//       block) and mark every in-range id in the tile's SEEN filter with ONE 32-bit LDS atomic: word
+//       (x >> 5) mod 4096, bit x mod 32, x = id - tlo -- exact when the tile is <= 2^17 documents wide; wider
+//       tiles add a second, hashed bit in the same word (a blocked Bloom filter: both bits travel in one
+//       atomic, so two postings of a document that race still see each other).  A mark that was already there
+//       = a SECOND ARRIVAL: the document may sit in two lists.  The wave collects those and inserts them in
+//       one pass into a hash set: one ROW per document.
+//   S2  lanes = (row, term): binary search of the row's document in the term's staged blocks; a posting found
+//       gets its tf field / fieldnorm byte read, Cache::evaluate (bm25.rs:355-358) -> contrib[row][term], done
+//       bit.  Few instructions, long LDS chains: the other workgroup of the CU fills the issue slots.
+//   S3  lanes = rows: sum of the row in ascending key order (evaluate.rs:43-72 order; absent terms add 0.0,
+//       exact) -> offer.  Then the COLD pass, per worker over its own blocks: a block whose upper bound
+//       (search.rs:377-380, evaluated once per index) reaches the threshold has every posting without a done
+//       bit scored on its own; all other blocks never have their tf / fieldnorm bytes read.
 //
-// MaxScore split (search.rs:153-169 is the same test on token upper bounds, one document at a time): terms
-// are ordered by token upper bound; the longest prefix whose bounds sum below the threshold is NON-ESSENTIAL
-// -- no document made only of those terms can enter the top-k, so their blocks are neither planned nor
-// fetched.  Documents that the essential lists produce and whose partial score + non-essential bounds still
-// reaches the threshold are completed by LOOKUPS (NE phase): block located by bisection of blk_max_doc, the
-// block upper bound (search.rs:177-203) refines the bound, surviving (block, row) pairs decode the block once
-// per wave and read the one posting.  This is where posting blocks are skipped.
+// The kernel is bound by instruction issue (PMC: the SIMDs issue > 90 % of the time), so the hot path
+// (S1) is written for instruction count: branch-free over the wave's eight blocks, 32-bit filter words,
+// uniform values in SGPRs.
 //
 // Every wave keeps its own top-k in registers (RegTopK); the k-th scores are shared through LDS, the query's
 // 64-bit atomicMax word and the 256-bucket histogram (as in scan_cursor.h).  Lists go to res_* at
-// item * RNW + wave; merge_kernel merges them.  A tile whose rows overflow hands the item to
+// item * lpi + wave; merge_kernel merges them.  A tile whose rows overflow hands the item to
 // scan_many_kernel (item_failed).
 
-constexpr int RNW = 8;               // waves per workgroup
+constexpr int RNW = 8;               // waves per workgroup: planner + 7 workers (16 waves x 4 blocks measured 13 % slower)
 constexpr int RWG = RNW * 64;
-constexpr int RB = 8;                // blocks per wave per tile
-constexpr int R_NBLK = 64;           // blocks per tile = lanes of the planner wave
-constexpr int R_BM_WORDS = 4096;     // 16 KB: one exact 2^17-bit bitmap, or two 2^16-bit Bloom halves
+constexpr int RB = 8;                // blocks per worker per tile
+constexpr int R_NBLK = (RNW - 1) * RB;  // blocks per tile (slots = lanes 0..R_NBLK-1 of the planner wave)
+static_assert(R_NBLK <= 64, "one planner lane per block of a tile");
+constexpr int R_BM_WORDS = 4096;     // 2^17 bits; word R_BM_WORDS is the trash word of out-of-range postings
 constexpr uint32_t R_BM_EXACT = 1u << 17;
 constexpr int R_HS_LOG2 = 10;
 constexpr int R_HS = 1 << R_HS_LOG2;  // slots of the second-arrival hash set
-constexpr int R_ROWS = 128;           // rows (documents with a second arrival / NE candidates) per tile
+constexpr int R_ROWS = 128;           // rows (documents with a second arrival) per tile at RT = 8; 64 at RT = 16
 constexpr uint32_t R_TARGET_ITEMS = 1024;
 constexpr uint32_t R_MIN_CHUNK_POSTINGS = 16384;
-constexpr uint32_t R_GRID = 512;      // persistent workgroups: 256 CUs x 2
+constexpr uint32_t R_GRID = 512;      // persistent workgroups: 256 CUs x 2 (KMAX <= 64; 1 per CU above)
 constexpr int R_PLAN_RING = 3;
+constexpr int R_LIST = 128;           // second arrivals per wave per tile; more than that: scan_many_kernel
 
 template <int RT>
 struct RangeLds {
-    uint32_t bm[R_BM_WORDS];
+    uint32_t bm[R_BM_WORDS + 4];
     uint32_t stage[R_NBLK * 128];
     uint32_t hkeys[R_HS];
-    double contrib[R_ROWS * RT];
+    double contrib[R_ROWS * 8];        // rows x RT
     uint32_t done[R_NBLK * 4];
     uint32_t mdoc[2][R_ROWS];
     uint16_t mslot[2][R_ROWS];
     uint4 pm[R_PLAN_RING][R_NBLK];     // {min_doc, max_doc, off8, n | md << 8 | mt << 16 | wand_fn << 24}
     uint2 pa[R_PLAN_RING][R_NBLK];     // {block index, term}
     double pub[R_PLAN_RING][R_NBLK];   // block upper bound
-    uint4 hdr[R_PLAN_RING];            // {tlo, thi, blocks, first non-essential position in t_order}
+    uint4 hdr[R_PLAN_RING];            // {tlo, thi, blocks, -}
     uint8_t ptb[R_PLAN_RING][RT + 4];  // first plan entry of each term (entries of a term are contiguous)
     double s1[256];
     double t_s0[RT];
@@ -71,6 +71,8 @@ struct RangeLds {
     uint32_t nmulti[2];
     uint32_t item, q, lo, hi, mq, fail;
     uint32_t scratch[64];
+    uint32_t list[RNW][R_LIST];        // per wave: second arrivals of a tile, inserted in one pass
+    uint32_t lcnt[RNW];
 };
 
 template <int KMAX, int RT>
@@ -86,6 +88,10 @@ __global__ void __launch_bounds__(RWG, 4) scan_range_kernel(DevIndex ix, DevBatc
     const uint32_t n_items = *bt.n_items;
     for (uint32_t i = tid; i < 256; i += RWG) S.s1[i] = ix.s1[i];
 
+#ifdef VBM25_PROFILE
+    unsigned long long prof[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    const unsigned long long prof_t0 = __builtin_readcyclecounter();
+#endif
     // planner state (wave 0 only): lane t = term t, lane s = plan slot s
     uint32_t p_cur = 0, p_end = 0, p_quota = 0, p_base = 0, p_st = NONE32, p_so = 0;
 
@@ -93,9 +99,10 @@ __global__ void __launch_bounds__(RWG, 4) scan_range_kernel(DevIndex ix, DevBatc
         __syncthreads();  // previous item fully done with LDS
         if (tid == 0) S.item = atomicAdd(bt.work_ctr, 1u);
         for (uint32_t i = tid; i < R_HS; i += RWG) S.hkeys[i] = EMPTY;
-        for (uint32_t i = tid; i < R_BM_WORDS; i += RWG) S.bm[i] = 0;
-        for (uint32_t i = tid; i < R_ROWS * RT; i += RWG) S.contrib[i] = 0.0;
+        for (uint32_t i = tid; i < R_BM_WORDS + 4; i += RWG) S.bm[i] = 0;
+        for (uint32_t i = tid; i < R_ROWS * 8; i += RWG) S.contrib[i] = 0.0;
         if (tid < R_NBLK * 4) S.done[tid] = 0;
+        if (tid < RNW) S.lcnt[tid] = 0;
         __syncthreads();
         const uint32_t item = uni(S.item);
         if (item >= n_items) break;
@@ -103,6 +110,7 @@ __global__ void __launch_bounds__(RWG, 4) scan_range_kernel(DevIndex ix, DevBatc
         if (it.m > (uint32_t)RT) {  // more terms or dense: the other kernels'
             continue;
         }
+        PROF_T(t_item);
         const uint32_t q = uni(it.q), lo = uni(it.doc_lo), hi = uni(it.doc_hi);
         uint32_t *hrow = bt.hist + (size_t)q * CUR_HB;
 
@@ -296,7 +304,6 @@ __global__ void __launch_bounds__(RWG, 4) scan_range_kernel(DevIndex ix, DevBatc
             poll_consume();
             p_tlo = lo;
             plan_tile(0);
-            plan_tile(1);
         }
         __syncthreads();
         const uint32_t mq = uni(S.mq);
@@ -335,126 +342,183 @@ __global__ void __launch_bounds__(RWG, 4) scan_range_kernel(DevIndex ix, DevBatc
         };
 
         // =====================================================================
-        // Tile loop
+        // Tile loop.  Wave 0 plans (one tile ahead) and polls; waves 1..7 decode RB blocks each.
         // =====================================================================
         bool failed = false;
+        PROF_T(t_loop);
+        PROF_ADD(8, t_item, t_loop);
+        uint32_t par = 0;
+        // one row per document with a second arrival (de-duplicated through the hash set)
+        auto insert_row = [&](uint32_t d) {
+            uint32_t slot = (d * 0x9E3779B1u) >> (32 - R_HS_LOG2);
+            for (;;) {
+                if (S.nmulti[par] >= (uint32_t)(R_ROWS * 8 / RT)) {
+                    S.fail = 1;
+                    break;
+                }
+                const uint32_t prev = atomicCAS(&S.hkeys[slot], EMPTY, d);
+                if (prev == EMPTY) {
+                    const uint32_t r = atomicAdd(&S.nmulti[par], 1u);
+                    if (r < (uint32_t)(R_ROWS * 8 / RT)) {
+                        S.mdoc[par][r] = d;
+                        S.mslot[par][r] = (uint16_t)slot;
+                    } else {
+                        S.fail = 1;
+                    }
+                    break;
+                }
+                if (prev == d) break;
+                slot = (slot + 1) & (R_HS - 1);
+            }
+        };
+
         for (uint32_t tile = 0;; ++tile) {
-            const uint32_t buf = tile % R_PLAN_RING, par = tile & 1u;
+            const uint32_t buf = tile % R_PLAN_RING;
+            par = tile & 1u;
             const uint4 hdr = uni4(S.hdr[buf]);
             const uint32_t tlo = hdr.x, thi = hdr.y, np = hdr.z;
             if (np == 0) break;
-            const bool exact = thi - tlo <= R_BM_EXACT;
+            const uint32_t span = thi - tlo;
+            const bool exact = span <= R_BM_EXACT;
+            PROF_T(t_a);
 
-            // ---- S1: decode, stage, mark
-            uint32_t d0[RB], d1[RB];
-            uint32_t inmask = 0;  // bit 2i / 2i + 1: posting 0 / 1 of entry i is inside [tlo, thi)
-            {
+            uint32_t nv = 0;  // this wave's entries: (wave - 1) + 7 i < np  <=>  i < nv
+            if (wave == 0) {
+                // ---- planner: threshold poll, plan of the next tile (read by the others after barrier A)
+                poll_request();
+                plan_tile((tile + 1) % R_PLAN_RING);
+                poll_consume();
+            } else {
+                // ---- S1: decode, stage, mark
+                asm volatile("; MARK_S1_BEGIN");
+                nv = (np + (RNW - 1) - wave) / (RNW - 1);
+                if (nv > (uint32_t)RB) nv = RB;
+                uint4 c[RB];
+                bool allfast = true;
+#pragma unroll
+                for (int i = 0; i < RB; ++i) c[i] = S.pm[buf][(wave - 1u) + (RNW - 1) * i];
                 uint32_t flo0[RB], fhi0[RB], flo1[RB], fhi1[RB];
 #pragma unroll
                 for (int i = 0; i < RB; ++i) {
-                    const uint32_t e = wave == 0 ? 56u + i : (wave - 1u) + 7u * i;
+                    c[i] = uni4(c[i]);
                     flo0[i] = fhi0[i] = flo1[i] = fhi1[i] = 0;
-                    if (e < np) {
-                        const uint4 c = S.pm[buf][e];
-                        const uint32_t md = uni((c.w >> 8) & 0xff);
-                        if (md < 32u) pair_fetch(ix.blob + 8ull * uni(c.z), md, lane, flo0[i], fhi0[i], flo1[i], fhi1[i]);
-                    }
+                    const uint32_t md = (c[i].w >> 8) & 0xff;
+                    allfast = allfast && ((uint32_t)i >= nv || md < 32u);
+                    if ((uint32_t)i < nv && md < 32u) pair_fetch(ix.blob + 8ull * c[i].z, md, lane, flo0[i], fhi0[i], flo1[i], fhi1[i]);
                 }
+#ifdef VBM25_PROFILE
+                {
+                    const unsigned long long t_a1 = __builtin_readcyclecounter();
+                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                    const unsigned long long t_a2 = __builtin_readcyclecounter();
+                    prof[1] += t_a1 - t_a;
+                    prof[2] += t_a2 - t_a1;
+                }
+#endif
+                asm volatile("; MARK_S1_DECODE");
+                // full bit-packed blocks (compression.rs:65-92), branch-free so that the eight decodes overlap;
+                // entries beyond nv decode zeros and are masked below
+                uint32_t d0[RB], d1[RB];
 #pragma unroll
                 for (int i = 0; i < RB; ++i) {
-                    const uint32_t e = wave == 0 ? 56u + i : (wave - 1u) + 7u * i;
-                    d0[i] = d1[i] = NONE32;
-                    if (e < np) {
-                        const uint4 c = uni4(S.pm[buf][e]);
-                        const uint32_t md = (c.w >> 8) & 0xff;
-                        uint32_t a0, a1;
-                        if (md < 32u) {  // bit-packed d1 deltas (compression.rs:65-92)
-                            uint32_t v0, v1;
-                            pair_extract(md, lane, flo0[i], fhi0[i], flo1[i], fhi1[i], v0, v1);
-                            const uint32_t own = v0 + v1;
-                            const uint32_t incl = wave_incl_scan_u32(own);
-                            a0 = c.x + (incl - own) + v0;
-                            a1 = a0 + v1;
-                        } else {  // raw (width 32) or a byte-packed tail block: generic path
-                            const uint32_t n = c.w & 0xff;
-                            decode_doc_ids(ix.blob + 8ull * c.z, md, n, c.x, lane, a0, a1);
-                            if (2 * lane >= n) a0 = NONE32;
-                            if (2 * lane + 1 >= n) a1 = NONE32;
-                        }
-                        d0[i] = a0;
-                        d1[i] = a1;
-                        *reinterpret_cast<uint2 *>(&S.stage[e * 128 + 2 * lane]) = make_uint2(a0, a1);
-                        const bool all_in = c.x >= tlo && c.y < thi;
-                        const bool in0 = a0 != NONE32 && (all_in || (a0 >= tlo && a0 < thi));
-                        const bool in1 = a1 != NONE32 && (all_in || (a1 >= tlo && a1 < thi));
-                        inmask |= (in0 ? 1u : 0u) << (2 * i) | (in1 ? 1u : 0u) << (2 * i + 1);
-                        bool dup0 = false, dup1 = false;
-                        const uint32_t x0 = a0 - tlo, x1 = a1 - tlo;
-                        if (exact) {
-                            if (in0) {
-                                const uint32_t b = 1u << (x0 & 31);
-                                dup0 = (atomicOr(&S.bm[x0 >> 5], b) & b) != 0;
-                            }
-                            if (in1) {
-                                const uint32_t b = 1u << (x1 & 31);
-                                dup1 = (atomicOr(&S.bm[x1 >> 5], b) & b) != 0;
-                            }
-                        } else {
-                            if (in0) {
-                                const uint32_t h = x0 & 0xffffu, g = (__umul24(x0, 40503u) >> 8) & 0xffffu;
-                                const uint32_t hb = 1u << (h & 31), gb = 1u << (g & 31);
-                                const uint32_t o1 = atomicOr(&S.bm[h >> 5], hb), o2 = atomicOr(&S.bm[2048 + (g >> 5)], gb);
-                                dup0 = (o1 & hb) && (o2 & gb);
-                            }
-                            if (in1) {
-                                const uint32_t h = x1 & 0xffffu, g = (__umul24(x1, 40503u) >> 8) & 0xffffu;
-                                const uint32_t hb = 1u << (h & 31), gb = 1u << (g & 31);
-                                const uint32_t o1 = atomicOr(&S.bm[h >> 5], hb), o2 = atomicOr(&S.bm[2048 + (g >> 5)], gb);
-                                dup1 = (o1 & hb) && (o2 & gb);
-                            }
-                        }
-                        if (__ballot(dup0 || dup1)) {  // second arrivals: one row per document
+                    uint32_t v0, v1;
+                    pair_extract((c[i].w >> 8) & 31u, lane, flo0[i], fhi0[i], flo1[i], fhi1[i], v0, v1);
+                    const uint32_t own = v0 + v1;
+                    const uint32_t incl = wave_incl_scan_u32(own);
+                    d0[i] = c[i].x + (incl - own) + v0;
+                    d1[i] = d0[i] + v1;
+                }
+                if (!allfast) {  // raw (width 32) or byte-packed tail blocks: generic, synchronous decode
+#pragma nounroll
+                    for (uint32_t i = 0; i < nv; ++i) {
+                        const uint4 cc = uni4(S.pm[buf][(wave - 1u) + (RNW - 1) * i]);
+                        const uint32_t md = (cc.w >> 8) & 0xff;
+                        if (md >= 32u) {
+                            const uint32_t n = cc.w & 0xff;
+                            uint32_t a0, a1;
+                            decode_doc_ids(ix.blob + 8ull * cc.z, md, n, cc.x, lane, a0, a1);
+                            a0 = 2 * lane < n ? a0 : NONE32;
+                            a1 = 2 * lane + 1 < n ? a1 : NONE32;
 #pragma unroll
-                            for (int s = 0; s < 2; ++s) {
-                                const bool dup = s ? dup1 : dup0;
-                                const uint32_t d = s ? a1 : a0;
-                                if (dup) {
-                                    uint32_t slot = (d * 0x9E3779B1u) >> (32 - R_HS_LOG2);
-                                    for (;;) {
-                                        if (S.nmulti[par] >= (uint32_t)R_ROWS) {
-                                            S.fail = 1;
-                                            break;
-                                        }
-                                        const uint32_t prev = atomicCAS(&S.hkeys[slot], EMPTY, d);
-                                        if (prev == EMPTY) {
-                                            const uint32_t r = atomicAdd(&S.nmulti[par], 1u);
-                                            if (r < (uint32_t)R_ROWS) {
-                                                S.mdoc[par][r] = d;
-                                                S.mslot[par][r] = (uint16_t)slot;
-                                            } else {
-                                                S.fail = 1;
-                                            }
-                                            break;
-                                        }
-                                        if (prev == d) break;
-                                        slot = (slot + 1) & (R_HS - 1);
-                                    }
-                                }
+                            for (int j = 0; j < RB; ++j) {
+                                d0[j] = i == (uint32_t)j ? a0 : d0[j];
+                                d1[j] = i == (uint32_t)j ? a1 : d1[j];
                             }
                         }
                     }
                 }
+                asm volatile("; MARK_S1_MARKS");
+                // stage + mark.  Out-of-range postings (other tiles' documents, padding, entries beyond nv) mark
+                // nothing.
+                uint32_t o0[RB], o1[RB], m0[RB], m1[RB];
+#pragma unroll
+                for (int i = 0; i < RB; ++i) {
+                    const uint32_t e = (wave - 1u) + (RNW - 1) * i;
+                    *reinterpret_cast<uint2 *>(&S.stage[e * 128 + 2 * lane]) = make_uint2(d0[i], d1[i]);
+                    const uint32_t sp = (uint32_t)i < nv ? span : 0u;
+                    const uint32_t x0 = d0[i] - tlo, x1 = d1[i] - tlo;
+                    m0[i] = 1u << (x0 & 31);
+                    m1[i] = 1u << (x1 & 31);
+                    if (!exact) {  // second bit hashed from the whole offset (aliases 2^17 apart get different bits)
+                        m0[i] |= 1u << ((x0 * 0x9E3779B1u) >> 27);
+                        m1[i] |= 1u << ((x1 * 0x9E3779B1u) >> 27);
+                    }
+                    if (x0 >= sp) m0[i] = 0;  // out of range: the atomic changes nothing
+                    if (x1 >= sp) m1[i] = 0;
+                    o0[i] = atomicOr(&S.bm[(x0 >> 5) & (R_BM_WORDS - 1)], m0[i]);
+                    o1[i] = atomicOr(&S.bm[(x1 >> 5) & (R_BM_WORDS - 1)], m1[i]);
+                }
+                asm volatile("; MARK_S1_DUPS");
+#ifdef VBM25_PROFILE
+                {
+                    const unsigned long long t_m = __builtin_readcyclecounter();
+                    prof[14] += t_m - t_a;
+                }
+#endif
+                uint32_t dupmask = 0;
+#pragma unroll
+                for (int i = 0; i < RB; ++i)
+                    dupmask |= ((m0[i] != 0 && (o0[i] & m0[i]) == m0[i]) ? 1u : 0u) << (2 * i) |
+                               ((m1[i] != 0 && (o1[i] & m1[i]) == m1[i]) ? 1u : 0u) << (2 * i + 1);
+                if (__ballot(dupmask != 0)) {  // second arrivals -> list -> one insert pass
+                    uint32_t mask = dupmask;
+                    while (mask) {
+                        const uint32_t b = (uint32_t)__ffs((int)mask) - 1u;
+                        mask &= mask - 1u;
+                        uint32_t d = d0[0];
+#pragma unroll
+                        for (int j = 0; j < RB; ++j) {
+                            d = b == (uint32_t)(2 * j) ? d0[j] : d;
+                            d = b == (uint32_t)(2 * j + 1) ? d1[j] : d;
+                        }
+                        const uint32_t pos = atomicAdd(&S.lcnt[wave], 1u);
+                        if (pos < (uint32_t)R_LIST) S.list[wave][pos] = d;
+                        else S.fail = 1;
+                    }
+                    __builtin_amdgcn_wave_barrier();
+                    const uint32_t n = min(uni(S.lcnt[wave]), (uint32_t)R_LIST);
+                    for (uint32_t j = lane; j < n; j += 64) insert_row(S.list[wave][j]);
+                    __builtin_amdgcn_wave_barrier();
+                    if (lane == 0) S.lcnt[wave] = 0;
+                }
+#ifdef VBM25_PROFILE
+                prof[0] += 1;
+#endif
             }
-            lds_barrier();  // ---- A: every mark and every row of the tile is in LDS
+            asm volatile("; MARK_S1_END");
+            PROF_T(t_b);
+            PROF_ADD(3, t_a, t_b);
+            lds_barrier();  // ---- A: every mark, staged id and row of the tile is in LDS; the next plan too
+            PROF_T(t_c);
+            PROF_ADD(4, t_b, t_c);
 
             if (uni(S.fail)) {
                 failed = true;
                 break;
             }
-            const uint32_t nm = min(uni(S.nmulti[par]), (uint32_t)R_ROWS);
+            const uint32_t nm = min(uni(S.nmulti[par]), (uint32_t)(R_ROWS * 8 / RT));
 
-            // ---- S2: wipe the bitmap; rows x terms: find the postings, score them; wave 0 plans ahead
-            if (wave == 0) poll_request();
+            // ---- S2: wipe the filter; rows x terms: find the postings, score them
 #pragma unroll
             for (int i = 0; i < R_BM_WORDS / 4 / RWG; ++i)
                 reinterpret_cast<uint4 *>(S.bm)[tid + i * RWG] = make_uint4(0, 0, 0, 0);
@@ -483,7 +547,7 @@ __global__ void __launch_bounds__(RWG, 4) scan_range_kernel(DevIndex ix, DevBatc
 #pragma unroll
                     for (int s = 64; s > 0; s >>= 1)
                         if (sb[idx + s - 1] < d) idx += s;
-                    if (idx >= 128u || sb[idx] != d) continue;
+                    if (sb[idx] != d) continue;
                     atomicOr(&S.done[eb * 4 + (idx >> 5)], 1u << (idx & 31));
                     const uint32_t nj = sj.w & 0xff, mdj = (sj.w >> 8) & 0xff, mtj = (sj.w >> 16) & 0xff;
                     const uint8_t *tbody = ix.blob + 8ull * sj.z + ((payload_bytes(mdj, nj) + 7u) & ~7u);
@@ -495,11 +559,14 @@ __global__ void __launch_bounds__(RWG, 4) scan_range_kernel(DevIndex ix, DevBatc
                     S.contrib[(r << LRT) + t] = (tf * S.t_s0[t]) / (tf + S.s1[fn]);  // Cache::evaluate, bm25.rs:355-358
                 }
             }
-            if (wave == 0) {
-                poll_consume();
-                plan_tile((tile + 2) % R_PLAN_RING);
-            }
-            lds_barrier();  // ---- B: contributions and done bits complete; bitmap clean
+            PROF_T(t_d);
+            PROF_ADD(5, t_c, t_d);
+            lds_barrier();  // ---- B: contributions and done bits complete; filter clean
+            PROF_T(t_e);
+            PROF_ADD(6, t_d, t_e);
+#ifdef VBM25_PROFILE
+            prof[10] += nm;
+#endif
 
             // ---- S3: rows -> documents (row r: lane r / RNW of wave r % RNW)
             if (nm) {
@@ -516,46 +583,74 @@ __global__ void __launch_bounds__(RWG, 4) scan_range_kernel(DevIndex ix, DevBatc
                 }
                 offer(has, acc, d);
             }
+            PROF_T(t_f);
+            PROF_ADD(7, t_e, t_f);
             // ---- cold pass: blocks whose upper bound reaches the threshold (search.rs:203)
+            if (wave != 0) {
+                uint32_t coldmask = 0;
+                {
+                    double ub[RB];
 #pragma unroll
-            for (int i = 0; i < RB; ++i) {
-                const uint32_t e = wave == 0 ? 56u + i : (wave - 1u) + 7u * i;
-                if (e < np) {
-                    uint32_t dw = 0;
+                    for (int i = 0; i < RB; ++i) ub[i] = S.pub[buf][(wave - 1u) + (RNW - 1) * i];
+                    const unsigned long long th = theta_now();
+#pragma unroll
+                    for (int i = 0; i < RB; ++i) {
+                        const unsigned long long ubb = (unsigned long long)__double_as_longlong(ub[i]);
+                        const unsigned long long ubu = ((unsigned long long)uni((uint32_t)(ubb >> 32)) << 32) | uni((uint32_t)ubb);
+                        if ((uint32_t)i < nv && th <= ubu) coldmask |= 1u << i;
+                    }
+                }
+                if (nm) {  // done bits of the entries that are not cold: reset
+#pragma unroll
+                    for (int i = 0; i < RB; ++i)
+                        if (lane < 4 && !((coldmask >> i) & 1u)) S.done[((wave - 1u) + (RNW - 1) * i) * 4 + lane] = 0;
+                }
+                while (coldmask) {
+                    const uint32_t i = (uint32_t)__ffs((int)coldmask) - 1u;
+                    coldmask &= coldmask - 1u;
+                    const uint32_t e = (wave - 1u) + (RNW - 1) * i;
+                    // ids from this wave's own stage row (nobody else writes it)
+                    const uint2 dd = *reinterpret_cast<const uint2 *>(&S.stage[e * 128 + 2 * lane]);
+                    uint32_t dwi = 0;
                     if (nm) {
-                        dw = S.done[e * 4 + (lane >> 4)];
+                        dwi = S.done[e * 4 + (lane >> 4)];
                         __builtin_amdgcn_wave_barrier();
                         if (lane < 4) S.done[e * 4 + lane] = 0;
                     }
-                    const unsigned long long ubb = (unsigned long long)__double_as_longlong(S.pub[buf][e]);
-                    const unsigned long long ubu = ((unsigned long long)uni((uint32_t)(ubb >> 32)) << 32) | uni((uint32_t)ubb);
-                    if (theta_now() <= ubu) {
-                        const bool ok0 = ((inmask >> (2 * i)) & 1u) && !((dw >> ((2 * lane) & 31)) & 1u);
-                        const bool ok1 = ((inmask >> (2 * i + 1)) & 1u) && !((dw >> ((2 * lane + 1) & 31)) & 1u);
-                        if (__ballot(ok0 || ok1)) {
-                            const uint4 sj = uni4(S.pm[buf][e]);
-                            const uint2 aux = S.pa[buf][e];
-                            const uint32_t blkj = uni(aux.x), t = uni(aux.y);
-                            const uint32_t nj = sj.w & 0xff, mdj = (sj.w >> 8) & 0xff, mtj = (sj.w >> 16) & 0xff;
-                            const uint8_t *tbody = ix.blob + 8ull * sj.z + ((payload_bytes(mdj, nj) + 7u) & ~7u);
-                            const FieldAddr f0 = field_addr(mtj, nj, 2 * lane), f1 = field_addr(mtj, nj, 2 * lane + 1);
-                            const uint32_t l0 = *reinterpret_cast<const uint32_t *>(tbody + f0.off0);
-                            const uint32_t h0 = *reinterpret_cast<const uint32_t *>(tbody + f0.off1);
-                            const uint32_t l1 = *reinterpret_cast<const uint32_t *>(tbody + f1.off0);
-                            const uint32_t h1 = *reinterpret_cast<const uint32_t *>(tbody + f1.off1);
-                            const uint32_t fnp = reinterpret_cast<const uint16_t *>(ix.post_fn + 128ull * blkj)[lane];
-                            const double s0t = S.t_s0[t];
-                            const double tf0 = (double)field_val(l0, h0, f0), tf1 = (double)field_val(l1, h1, f1);
-                            const double p0 = (tf0 * s0t) / (tf0 + S.s1[fnp & 0xff]);
-                            const double p1 = (tf1 * s0t) / (tf1 + S.s1[fnp >> 8]);
-                            offer(ok0, p0, d0[i]);
-                            offer(ok1, p1, d1[i]);
-                        }
+                    const bool ok0 = dd.x - tlo < span && !((dwi >> ((2 * lane) & 31)) & 1u);
+                    const bool ok1 = dd.y - tlo < span && !((dwi >> ((2 * lane + 1) & 31)) & 1u);
+                    if (__ballot(ok0 || ok1)) {
+                        const uint4 sj = uni4(S.pm[buf][e]);
+                        const uint2 aux = S.pa[buf][e];
+                        const uint32_t blkj = uni(aux.x), t = uni(aux.y);
+                        const uint32_t nj = sj.w & 0xff, mdj = (sj.w >> 8) & 0xff, mtj = (sj.w >> 16) & 0xff;
+                        const uint8_t *tbody = ix.blob + 8ull * sj.z + ((payload_bytes(mdj, nj) + 7u) & ~7u);
+                        const FieldAddr f0 = field_addr(mtj, nj, 2 * lane), f1 = field_addr(mtj, nj, 2 * lane + 1);
+                        const uint32_t l0 = *reinterpret_cast<const uint32_t *>(tbody + f0.off0);
+                        const uint32_t h0 = *reinterpret_cast<const uint32_t *>(tbody + f0.off1);
+                        const uint32_t l1 = *reinterpret_cast<const uint32_t *>(tbody + f1.off0);
+                        const uint32_t h1 = *reinterpret_cast<const uint32_t *>(tbody + f1.off1);
+                        const uint32_t fnp = reinterpret_cast<const uint16_t *>(ix.post_fn + 128ull * blkj)[lane];
+                        const double s0t = S.t_s0[t];
+                        const double tf0 = (double)field_val(l0, h0, f0), tf1 = (double)field_val(l1, h1, f1);
+                        const double p0 = (tf0 * s0t) / (tf0 + S.s1[fnp & 0xff]);
+                        const double p1 = (tf1 * s0t) / (tf1 + S.s1[fnp >> 8]);
+                        offer(ok0, p0, dd.x);
+                        offer(ok1, p1, dd.y);
+#ifdef VBM25_PROFILE
+                        prof[11] += 1;
+#endif
                     }
                 }
             }
+            PROF_T(t_g);
+            PROF_ADD(13, t_f, t_g);
         }
 
+#ifdef VBM25_PROFILE
+        prof[12] += 1;
+        prof[9] += __builtin_readcyclecounter() - t_loop;
+#endif
         // ---- item result: one list per wave
         const uint32_t n = failed ? 0u : rtop.cnt;
         const size_t list = (size_t)item * bt.lpi + wave;
@@ -570,4 +665,11 @@ __global__ void __launch_bounds__(RWG, 4) scan_range_kernel(DevIndex ix, DevBatc
             if (wave == 0) bt.item_failed[item] = failed ? 1u : 0u;
         }
     }
+#ifdef VBM25_PROFILE
+    if (bt.prof && lane == 0) {
+        unsigned long long *o = bt.prof + ((size_t)blockIdx.x * RNW + wave) * 16;
+        for (int i = 0; i < 16; ++i) o[i] = prof[i];
+        o[15] = __builtin_readcyclecounter() - prof_t0;
+    }
+#endif
 }

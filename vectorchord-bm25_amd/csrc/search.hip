@@ -491,7 +491,9 @@ static int vbm25_batch_set_queries_impl(vbm25_batch *bt, const uint32_t *term_id
             items += c;
         }
         bt->cur_grid = uint32_t(std::min<unsigned long long>(std::max<unsigned long long>(items, 1), CUR_GRID));
-        bt->range_grid = uint32_t(std::min<unsigned long long>(std::max<unsigned long long>(items, 1), R_GRID));
+        const char *rgrid = std::getenv("VBM25_RANGE_GRID");  // tuning knob: persistent workgroups
+        bt->range_grid = uint32_t(std::min<unsigned long long>(std::max<unsigned long long>(items, 1),
+                                                               rgrid ? (unsigned long long)std::atoll(rgrid) : R_GRID));
         // A handful of items cannot occupy the GPU with one wave each: the tile kernel puts a whole
         // workgroup (six decoding waves) on an item and answers a single query faster (C2: 0.10 ms vs 0.15 ms)
         bt->run_cursor = bt->use_cursor && items >= bt->cur_min_items;
