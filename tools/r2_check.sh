@@ -6,4 +6,3 @@ cat gpurun_out/r2/tests.txt
 python bench.py --no-cpu-baseline --steps 50 --cache /tmp/c3.seg > gpurun_out/r2/bench_range.json 2> gpurun_out/r2/bench_range.err
 tail -3 gpurun_out/r2/bench_range.err; python -c "
 import json;d=json.load(open('gpurun_out/r2/bench_range.json'));print(d['value'],d['ms_per_step'],d['roofline']['kernel_ms'],d['roofline']['frac'])"
-python tools/profile_range.py C3 /tmp/c3.seg 2>&1 | tail -32

@@ -41,7 +41,7 @@ constexpr int R_BM_WORDS = 4096;     // 2^17 bits; word R_BM_WORDS is the trash 
 constexpr uint32_t R_BM_EXACT = 1u << 17;
 constexpr int R_HS_LOG2 = 10;
 constexpr int R_HS = 1 << R_HS_LOG2;  // slots of the second-arrival hash set
-constexpr int R_ROWS = 128;           // rows (documents with a second arrival) per tile at RT = 8; 64 at RT = 16
+constexpr int R_ROWS = 192;           // rows (documents with a second arrival) per tile at RT = 8; 96 at RT = 16
 constexpr uint32_t R_TARGET_ITEMS = 1024;
 constexpr uint32_t R_MIN_CHUNK_POSTINGS = 16384;
 constexpr uint32_t R_GRID = 512;      // persistent workgroups: 256 CUs x 2 (KMAX <= 64; 1 per CU above)
@@ -59,7 +59,8 @@ struct RangeLds {
     uint16_t mslot[2][R_ROWS];
     uint4 pm[R_PLAN_RING][R_NBLK];     // {min_doc, max_doc, off8, n | md << 8 | mt << 16 | wand_fn << 24}
     uint2 pa[R_PLAN_RING][R_NBLK];     // {block index, term}
-    double pub[R_PLAN_RING][R_NBLK];   // block upper bound
+    uint32_t coldw[R_PLAN_RING][RNW];  // per worker: its entries whose upper bound reaches the threshold
+    double pub[R_PLAN_RING][R_NBLK];   // block upper bound (read for the entries marked cold only)
     uint4 hdr[R_PLAN_RING];            // {tlo, thi, blocks, -}
     uint8_t ptb[R_PLAN_RING][RT + 4];  // first plan entry of each term (entries of a term are contiguous)
     double s1[256];
@@ -157,7 +158,7 @@ __global__ void __launch_bounds__(RWG, 4) scan_range_kernel(DevIndex ix, DevBatc
                 if (lane == 0) S.hdr[buf] = make_uint4(p_tlo, p_tlo, 0, 0);
                 return;
             }
-            const uint32_t thi = min(hi, wave_min_u32(bnd));
+            uint32_t thi = min(hi, wave_min_u32(bnd));
             const uint32_t st = p_st < 64u ? p_st : 0u;
             const uint32_t cur_s = (uint32_t)__shfl((int)p_cur, (int)st), end_s = (uint32_t)__shfl((int)p_end, (int)st);
             const uint32_t quo_s = (uint32_t)__shfl((int)p_quota, (int)st);
@@ -169,6 +170,16 @@ __global__ void __launch_bounds__(RWG, 4) scan_range_kernel(DevIndex ix, DevBatc
                 meta = ix.blk_meta[j];
                 ub = ix.blk_ub[j];
             }
+            // the 64 candidates (quotas) may hold more than a tile takes: the largest thi with <= R_NBLK blocks
+            if ((uint32_t)__popcll(__ballot(valid && meta.x < thi)) > (uint32_t)R_NBLK) {
+                uint32_t lo_v = p_tlo + 1, hi_v = thi;  // count(lo_v) <= terms <= R_NBLK < count(hi_v)
+                while (hi_v - lo_v > 1) {
+                    const uint32_t mid = lo_v + ((hi_v - lo_v) >> 1);
+                    if ((uint32_t)__popcll(__ballot(valid && meta.x < mid)) <= (uint32_t)R_NBLK) lo_v = mid;
+                    else hi_v = mid;
+                }
+                thi = lo_v;
+            }
             const bool in_tile = valid && meta.x < thi;
             const unsigned long long mask = __ballot(in_tile);
             const uint32_t pos = __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
@@ -177,6 +188,11 @@ __global__ void __launch_bounds__(RWG, 4) scan_range_kernel(DevIndex ix, DevBatc
                 S.pa[buf][pos] = make_uint2(j, p_st);
                 S.pub[buf][pos] = ub;
             }
+            // cold blocks (search.rs:203): upper bound at or above the threshold -- the threshold only rises, so
+            // deciding here, one tile early, errs on the safe side.  Bit i of word w: entry (w - 1) + (RNW - 1) i
+            if (lane < (uint32_t)RNW) S.coldw[buf][lane] = 0;
+            if (in_tile && S.theta <= (unsigned long long)__double_as_longlong(ub))
+                atomicOr(&S.coldw[buf][1u + pos % (RNW - 1)], 1u << (pos / (RNW - 1)));
             const unsigned long long cmask = __ballot(in_tile && meta.y < thi);
             if (lane <= (uint32_t)RT) {  // lane t: entries before term t's slots = first entry of term t
                 const unsigned long long below = p_base >= 64u ? ~0ull : ((1ull << p_base) - 1ull);
@@ -262,7 +278,7 @@ __global__ void __launch_bounds__(RWG, 4) scan_range_kernel(DevIndex ix, DevBatc
                 S.t_b0[lane] = b0;
                 S.t_b1[lane] = b1;
             }
-            // quotas: R_NBLK - m slots shared in proportion to df, at least one each
+            // quotas: the 64 candidate slots (one per planner lane) shared in proportion to df, at least one each
             unsigned long long sumdf = 0;
             double sums0 = 0.0;
             for (uint32_t t = 0; t < m; ++t) {
@@ -271,7 +287,7 @@ __global__ void __launch_bounds__(RWG, 4) scan_range_kernel(DevIndex ix, DevBatc
             }
             p_quota = 0;
             if (act) {
-                p_quota = (uint32_t)(((unsigned long long)(R_NBLK - m) * df) / sumdf);
+                p_quota = (uint32_t)(((unsigned long long)(64 - m) * df) / sumdf);
                 if (p_quota < 1) p_quota = 1;
             }
             {
@@ -385,9 +401,9 @@ __global__ void __launch_bounds__(RWG, 4) scan_range_kernel(DevIndex ix, DevBatc
             uint32_t nv = 0;  // this wave's entries: (wave - 1) + 7 i < np  <=>  i < nv
             if (wave == 0) {
                 // ---- planner: threshold poll, plan of the next tile (read by the others after barrier A)
-                poll_request();
+                poll_consume();  // requested one tile ago
                 plan_tile((tile + 1) % R_PLAN_RING);
-                poll_consume();
+                poll_request();
             } else {
                 // ---- S1: decode, stage, mark
                 asm volatile("; MARK_S1_BEGIN");
@@ -448,6 +464,7 @@ __global__ void __launch_bounds__(RWG, 4) scan_range_kernel(DevIndex ix, DevBatc
                     }
                 }
                 asm volatile("; MARK_S1_MARKS");
+                if (lane < 4 * RB) S.done[((wave - 1u) + (RNW - 1) * (lane >> 2)) * 4 + (lane & 3)] = 0;  // last tile's done bits
                 // stage + mark.  Out-of-range postings (other tiles' documents, padding, entries beyond nv) mark
                 // nothing.
                 uint32_t o0[RB], o1[RB], m0[RB], m1[RB];
@@ -587,36 +604,19 @@ __global__ void __launch_bounds__(RWG, 4) scan_range_kernel(DevIndex ix, DevBatc
             PROF_ADD(7, t_e, t_f);
             // ---- cold pass: blocks whose upper bound reaches the threshold (search.rs:203)
             if (wave != 0) {
-                uint32_t coldmask = 0;
-                {
-                    double ub[RB];
-#pragma unroll
-                    for (int i = 0; i < RB; ++i) ub[i] = S.pub[buf][(wave - 1u) + (RNW - 1) * i];
-                    const unsigned long long th = theta_now();
-#pragma unroll
-                    for (int i = 0; i < RB; ++i) {
-                        const unsigned long long ubb = (unsigned long long)__double_as_longlong(ub[i]);
-                        const unsigned long long ubu = ((unsigned long long)uni((uint32_t)(ubb >> 32)) << 32) | uni((uint32_t)ubb);
-                        if ((uint32_t)i < nv && th <= ubu) coldmask |= 1u << i;
-                    }
-                }
-                if (nm) {  // done bits of the entries that are not cold: reset
-#pragma unroll
-                    for (int i = 0; i < RB; ++i)
-                        if (lane < 4 && !((coldmask >> i) & 1u)) S.done[((wave - 1u) + (RNW - 1) * i) * 4 + lane] = 0;
-                }
+                uint32_t coldmask = uni(S.coldw[buf][wave]);
                 while (coldmask) {
                     const uint32_t i = (uint32_t)__ffs((int)coldmask) - 1u;
                     coldmask &= coldmask - 1u;
                     const uint32_t e = (wave - 1u) + (RNW - 1) * i;
+                    {   // the planner decided one tile early: check against the threshold of now
+                        const unsigned long long ubb = (unsigned long long)__double_as_longlong(S.pub[buf][e]);
+                        const unsigned long long ubu = ((unsigned long long)uni((uint32_t)(ubb >> 32)) << 32) | uni((uint32_t)ubb);
+                        if (theta_now() > ubu) continue;
+                    }
                     // ids from this wave's own stage row (nobody else writes it)
                     const uint2 dd = *reinterpret_cast<const uint2 *>(&S.stage[e * 128 + 2 * lane]);
-                    uint32_t dwi = 0;
-                    if (nm) {
-                        dwi = S.done[e * 4 + (lane >> 4)];
-                        __builtin_amdgcn_wave_barrier();
-                        if (lane < 4) S.done[e * 4 + lane] = 0;
-                    }
+                    const uint32_t dwi = S.done[e * 4 + (lane >> 4)];
                     const bool ok0 = dd.x - tlo < span && !((dwi >> ((2 * lane) & 31)) & 1u);
                     const bool ok1 = dd.y - tlo < span && !((dwi >> ((2 * lane + 1) & 31)) & 1u);
                     if (__ballot(ok0 || ok1)) {
