@@ -26,8 +26,9 @@ __global__ void __launch_bounds__(WG) scan_many_kernel(DevIndex ix, DevBatch bt)
     for (uint32_t item = blockIdx.x; item < n_items; item += gridDim.x) {
         const Item it = bt.items[item];
         const uint32_t others_max = max((uint32_t)CHAIN_MAX_TERMS, bt.range_max_terms);  // taken by the other kernels
-        const bool failed = it.m <= others_max && bt.item_failed[item] != 0;
-        if (it.m <= others_max && !failed) continue;
+        const uint32_t mt_item = bt.range_dense ? (it.m & ~ITEM_DENSE) : it.m;  // dense items: scan_range_kernel's too
+        const bool failed = mt_item <= others_max && bt.item_failed[item] != 0;
+        if (mt_item <= others_max && !failed) continue;
         const bool force_dense = failed || (it.m & ITEM_DENSE) != 0;
         const uint32_t q = it.q, clo = it.doc_lo, chi = it.doc_hi;
         __syncthreads();  // previous item fully done with LDS

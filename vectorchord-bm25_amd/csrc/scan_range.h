@@ -66,6 +66,11 @@ struct RangeLds {
     double s1[256];
     double t_s0[RT];
     double t_ub[RT];                   // token upper bound x (1 + 1e-12)
+    double t_cum[RT + 1];              // sum of the p smallest token upper bounds
+    uint8_t t_rank[RT];                // position of the term in ascending upper-bound order
+    uint8_t t_ord[RT];                 // ... and the term at a position
+    uint8_t t_best[RT + 1];            // largest admissible non-essential prefix <= p
+    uint32_t bhist[CUR_HB];            // bootstrap: histogram of one list's single-term scores
     uint32_t t_b0[RT], t_b1[RT];       // block range of the term
     double hscale;
     unsigned long long theta;          // bits of a lower bound of the query's k-th best score
@@ -75,6 +80,42 @@ struct RangeLds {
     uint32_t list[RNW][R_LIST];        // per wave: second arrivals of a tile, inserted in one pass
     uint32_t lcnt[RNW];
 };
+
+// First block of [b0, b1) whose max_doc >= d (b1 if none): guess by interpolation over the document space,
+// gallop, then bisect (Cursor::seek_block, search.rs:412-431, without walking the summaries one by one).
+__device__ __forceinline__ uint32_t r_first_block_ge(const DevIndex &ix, uint32_t b0, uint32_t b1, uint32_t d) {
+    uint32_t lo_b = b0, hi_b = b1;
+    if (d != 0 && b1 > b0) {
+        uint32_t g = b0 + (uint32_t)((unsigned long long)(b1 - b0) * d / ix.n_docs);
+        if (g >= b1) g = b1 - 1;
+        if (ix.blk_max_doc[g] < d) {
+            lo_b = g + 1;
+            for (uint32_t step = 1; lo_b < hi_b; step *= 4) {
+                const uint32_t p = min(lo_b + step - 1, hi_b - 1);
+                if (ix.blk_max_doc[p] < d) lo_b = p + 1;
+                else {
+                    hi_b = p;
+                    break;
+                }
+            }
+        } else {
+            hi_b = g;
+            for (uint32_t step = 1; lo_b < hi_b; step *= 4) {
+                const uint32_t p = hi_b - lo_b >= step ? hi_b - step : lo_b;
+                if (ix.blk_max_doc[p] >= d) hi_b = p;
+                else {
+                    lo_b = p + 1;
+                    break;
+                }
+            }
+        }
+        while (lo_b < hi_b) {
+            const uint32_t mid = (lo_b + hi_b) >> 1;
+            if (ix.blk_max_doc[mid] < d) lo_b = mid + 1; else hi_b = mid;
+        }
+    }
+    return lo_b;
+}
 
 template <int KMAX, int RT>
 __global__ void __launch_bounds__(RWG, 4) scan_range_kernel(DevIndex ix, DevBatch bt) {
@@ -94,7 +135,7 @@ __global__ void __launch_bounds__(RWG, 4) scan_range_kernel(DevIndex ix, DevBatc
     const unsigned long long prof_t0 = __builtin_readcyclecounter();
 #endif
     // planner state (wave 0 only): lane t = term t, lane s = plan slot s
-    uint32_t p_cur = 0, p_end = 0, p_quota = 0, p_base = 0, p_st = NONE32, p_so = 0;
+    uint32_t p_cur = 0, p_end = 0, p_quota = 0, p_base = 0, p_st = NONE32, p_so = 0, p_df = 0, p_rank = 0, p_ne = 0;
 
     for (;;) {
         __syncthreads();  // previous item fully done with LDS
@@ -104,13 +145,13 @@ __global__ void __launch_bounds__(RWG, 4) scan_range_kernel(DevIndex ix, DevBatc
         for (uint32_t i = tid; i < R_ROWS * 8; i += RWG) S.contrib[i] = 0.0;
         if (tid < R_NBLK * 4) S.done[tid] = 0;
         if (tid < RNW) S.lcnt[tid] = 0;
+        if (tid < CUR_HB) S.bhist[tid] = 0;
         __syncthreads();
         const uint32_t item = uni(S.item);
         if (item >= n_items) break;
         const Item it = bt.items[item];
-        if (it.m > (uint32_t)RT) {  // more terms or dense: the other kernels'
-            continue;
-        }
+        const bool dense_item = (it.m & ITEM_DENSE) != 0;
+        if ((it.m & ~ITEM_DENSE) > (uint32_t)RT || (dense_item && !bt.range_dense)) continue;  // the other kernels'
         PROF_T(t_item);
         const uint32_t q = uni(it.q), lo = uni(it.doc_lo), hi = uni(it.doc_hi);
         uint32_t *hrow = bt.hist + (size_t)q * CUR_HB;
@@ -148,10 +189,64 @@ __global__ void __launch_bounds__(RWG, 4) scan_range_kernel(DevIndex ix, DevBatc
             if (lane == 0) atomicMax(&S.theta, th);
         };
 
+        auto theta_lds = [&]() -> unsigned long long {
+            unsigned long long th = S.theta;
+            return ((unsigned long long)uni((uint32_t)(th >> 32)) << 32) | uni((uint32_t)th);
+        };
         // ---- tile planner (wave 0)
         uint32_t p_tlo = lo;
+        // quotas of the essential terms: the 64 candidate slots (one per planner lane) shared in proportion to df,
+        // at least one each; slot -> (term, offset)
+        auto assign_quotas = [&]() {
+            const uint32_t m = uni(S.mq);
+            const bool ess = lane < m && p_rank >= p_ne;
+            unsigned long long sumdf = 0;
+            uint32_t ne = 0;
+            for (uint32_t t = 0; t < m; ++t) {
+                const uint32_t rk = (uint32_t)__builtin_amdgcn_readlane((int)p_rank, (int)t);
+                if (rk >= p_ne) {
+                    sumdf += (uint32_t)__builtin_amdgcn_readlane((int)p_df, (int)t);
+                    ++ne;
+                }
+            }
+            p_quota = 0;
+            if (ess) {
+                p_quota = (uint32_t)(((unsigned long long)(64 - ne) * p_df) / sumdf);
+                if (p_quota < 1) p_quota = 1;
+            }
+            const uint32_t incl = wave_incl_scan_u32(p_quota);
+            p_base = incl - p_quota;  // lanes >= m: total
+            p_st = NONE32;
+            p_so = 0;
+            for (uint32_t t = 0; t < m; ++t) {
+                const uint32_t bt0 = (uint32_t)__builtin_amdgcn_readlane((int)p_base, (int)t);
+                const uint32_t qt = (uint32_t)__builtin_amdgcn_readlane((int)p_quota, (int)t);
+                if (lane >= bt0 && lane < bt0 + qt) {
+                    p_st = t;
+                    p_so = lane - bt0;
+                }
+            }
+        };
         auto plan_tile = [&](uint32_t buf) {
-            const bool alive = lane < uni(S.mq) && p_cur < p_end;
+            // MaxScore split (search.rs:153-169 is this test, one document at a time): the longest prefix of the
+            // terms in ascending upper-bound order whose bounds sum below the threshold is NON-ESSENTIAL -- a
+            // document made only of those terms cannot enter the top-k.  Their blocks are not planned at all.
+            const uint32_t mqp = uni(S.mq);
+            const double thd = __longlong_as_double((long long)theta_lds());
+            uint32_t p_th = 0;
+            for (uint32_t pp = 1; pp <= mqp; ++pp)
+                if (S.t_cum[pp] < thd) p_th = pp;
+            if (p_th == mqp) {  // no document at all can reach the threshold any more
+                if (lane == 0) S.hdr[buf] = make_uint4(p_tlo, p_tlo, 0, 0);
+                return;
+            }
+            const uint32_t p_new = bt.range_dense ? (uint32_t)S.t_best[p_th] : 0u;
+            if (p_new > p_ne) {
+                p_ne = p_new;
+                assign_quotas();
+            }
+            const double nesum = S.t_cum[p_ne];
+            const bool alive = lane < mqp && p_rank >= p_ne && p_cur < p_end;
             uint32_t bnd = NONE32;
             if (alive && p_cur + p_quota < p_end) bnd = ix.blk_min_doc[p_cur + p_quota];
             if (!__ballot(alive) || p_tlo >= hi) {
@@ -191,7 +286,7 @@ __global__ void __launch_bounds__(RWG, 4) scan_range_kernel(DevIndex ix, DevBatc
             // cold blocks (search.rs:203): upper bound at or above the threshold -- the threshold only rises, so
             // deciding here, one tile early, errs on the safe side.  Bit i of word w: entry (w - 1) + (RNW - 1) i
             if (lane < (uint32_t)RNW) S.coldw[buf][lane] = 0;
-            if (in_tile && S.theta <= (unsigned long long)__double_as_longlong(ub))
+            if (in_tile && thd <= ub + nesum)
                 atomicOr(&S.coldw[buf][1u + pos % (RNW - 1)], 1u << (pos / (RNW - 1)));
             const unsigned long long cmask = __ballot(in_tile && meta.y < thi);
             if (lane <= (uint32_t)RT) {  // lane t: entries before term t's slots = first entry of term t
@@ -200,8 +295,29 @@ __global__ void __launch_bounds__(RWG, 4) scan_range_kernel(DevIndex ix, DevBatc
                 const unsigned long long qm = p_quota >= 64u ? ~0ull : ((1ull << p_quota) - 1ull);
                 if (p_base < 64u) p_cur += (uint32_t)__popcll((cmask >> p_base) & qm);
             }
-            if (lane == 0) S.hdr[buf] = make_uint4(p_tlo, thi, (uint32_t)__popcll(mask), 0);
+            if (lane == 0) S.hdr[buf] = make_uint4(p_tlo, thi, (uint32_t)__popcll(mask), p_ne);
             p_tlo = thi;
+        };
+        // bootstrap tile of a dense item: the first blocks of the rarest term, every one of them cold.  Its
+        // single-term scores are lower bounds of the documents' scores: their k-th best starts the threshold.
+        auto plan_boot = [&](uint32_t buf, uint32_t tr) {
+            const uint32_t cur = (uint32_t)__builtin_amdgcn_readlane((int)p_cur, (int)tr);
+            const uint32_t end = (uint32_t)__builtin_amdgcn_readlane((int)p_end, (int)tr);
+            const uint32_t j = cur + lane;
+            const bool valid = lane < (uint32_t)R_NBLK && j < end;
+            uint4 meta = make_uint4(NONE32, 0, 0, 0);
+            if (valid) meta = ix.blk_meta[j];
+            const bool in_tile = valid && meta.x < hi;
+            const unsigned long long mask = __ballot(in_tile);  // a prefix of the lanes
+            if (in_tile) {
+                S.pm[buf][lane] = meta;
+                S.pa[buf][lane] = make_uint2(j, tr);
+                S.pub[buf][lane] = 1e300;
+            }
+            const uint32_t n = (uint32_t)__popcll(mask);
+            if (lane <= (uint32_t)RT) S.ptb[buf][lane] = (uint8_t)(lane <= tr ? 0u : n);
+            if (lane < (uint32_t)RNW) S.coldw[buf][lane] = (1u << RB) - 1u;
+            if (lane == 0) S.hdr[buf] = make_uint4(lo, hi, n, 0x80000000u);
         };
 
         // ---- item setup (wave 0): terms, cursors, quotas, slot map; the first two plans
@@ -278,32 +394,45 @@ __global__ void __launch_bounds__(RWG, 4) scan_range_kernel(DevIndex ix, DevBatc
                 S.t_b0[lane] = b0;
                 S.t_b1[lane] = b1;
             }
-            // quotas: the 64 candidate slots (one per planner lane) shared in proportion to df, at least one each
-            unsigned long long sumdf = 0;
+            // terms in ascending order of their token upper bound; prefix sums; admissible prefixes
+            p_df = df;
+            p_rank = 0;
             double sums0 = 0.0;
+            unsigned long long sumdf = 0;
             for (uint32_t t = 0; t < m; ++t) {
-                sumdf += (uint32_t)__builtin_amdgcn_readlane((int)df, (int)t);
+                const double ubt = readlane_f64(tub, t);
+                if (act && (ubt < tub || (ubt == tub && t < lane))) ++p_rank;
                 sums0 += readlane_f64(s0, t);
+                sumdf += (uint32_t)__builtin_amdgcn_readlane((int)df, (int)t);
             }
-            p_quota = 0;
-            if (act) {
-                p_quota = (uint32_t)(((unsigned long long)(64 - m) * df) / sumdf);
-                if (p_quota < 1) p_quota = 1;
-            }
+            if (act) S.t_rank[lane] = (uint8_t)p_rank;
             {
-                const uint32_t incl = wave_incl_scan_u32(p_quota);
-                p_base = incl - p_quota;  // lanes >= m: total
-            }
-            p_st = NONE32;
-            p_so = 0;
-            for (uint32_t t = 0; t < m; ++t) {
-                const uint32_t bt0 = (uint32_t)__builtin_amdgcn_readlane((int)p_base, (int)t);
-                const uint32_t qt = (uint32_t)__builtin_amdgcn_readlane((int)p_quota, (int)t);
-                if (lane >= bt0 && lane < bt0 + qt) {
-                    p_st = t;
-                    p_so = lane - bt0;
+                // a prefix of p terms is admissible when its shortest list is still R_NE_RATIO times longer
+                // than all the essential lists together (else the lookups cost more than the scan they save)
+                double cum = 0.0;
+                unsigned long long head = 0;
+                uint32_t best = 0;
+                if (lane == 0) {
+                    S.t_cum[0] = 0.0;
+                    S.t_best[0] = 0;
+                }
+                for (uint32_t pp = 0; pp < m; ++pp) {
+                    const uint32_t owner = (uint32_t)__ffsll((long long)__ballot(act && p_rank == pp)) - 1u;
+                    cum += readlane_f64(tub, owner);
+                    const unsigned long long dfo = (uint32_t)__builtin_amdgcn_readlane((int)df, (int)owner);
+                    head += dfo;
+                    if (pp + 1 < m && dfo >= (unsigned long long)bt.ne_ratio * (sumdf - head)) best = pp + 1;
+                    if (lane == 0) {
+                        S.t_cum[pp + 1] = cum;
+                        S.t_best[pp + 1] = (uint8_t)best;
+                        S.t_ord[pp] = (uint8_t)owner;
+                    }
                 }
             }
+            p_ne = 0;
+            if (lane == 0) S.mq = m;
+            __builtin_amdgcn_wave_barrier();
+            assign_quotas();
             hscale = (double)CUR_HB / sums0;  // score -> histogram bucket: linear in [0, sum of s0)
             if (lane == 0) {
                 S.q = q;
@@ -319,7 +448,19 @@ __global__ void __launch_bounds__(RWG, 4) scan_range_kernel(DevIndex ix, DevBatc
             __builtin_amdgcn_wave_barrier();
             poll_consume();
             p_tlo = lo;
-            plan_tile(0);
+            if (dense_item && theta_lds() == 0) {  // nothing known about the query yet: bootstrap the threshold
+                uint32_t tr = 0, dmin = NONE32;
+                for (uint32_t t = 0; t < m; ++t) {
+                    const uint32_t dft = (uint32_t)__builtin_amdgcn_readlane((int)df, (int)t);
+                    if (dft < dmin) {
+                        dmin = dft;
+                        tr = t;
+                    }
+                }
+                plan_boot(0, tr);
+            } else {
+                plan_tile(0);
+            }
         }
         __syncthreads();
         const uint32_t mq = uni(S.mq);
@@ -393,6 +534,8 @@ __global__ void __launch_bounds__(RWG, 4) scan_range_kernel(DevIndex ix, DevBatc
             par = tile & 1u;
             const uint4 hdr = uni4(S.hdr[buf]);
             const uint32_t tlo = hdr.x, thi = hdr.y, np = hdr.z;
+            const uint32_t pne = hdr.w & 0xffu;       // non-essential terms: positions 0..pne-1 of t_ord
+            const bool boot = (hdr.w >> 31) != 0;      // bootstrap tile: scores feed the threshold only
             if (np == 0) break;
             const uint32_t span = thi - tlo;
             const bool exact = span <= R_BM_EXACT;
@@ -401,9 +544,11 @@ __global__ void __launch_bounds__(RWG, 4) scan_range_kernel(DevIndex ix, DevBatc
             uint32_t nv = 0;  // this wave's entries: (wave - 1) + 7 i < np  <=>  i < nv
             if (wave == 0) {
                 // ---- planner: threshold poll, plan of the next tile (read by the others after barrier A)
-                poll_consume();  // requested one tile ago
-                plan_tile((tile + 1) % R_PLAN_RING);
-                poll_request();
+                if (!boot) {
+                    poll_consume();  // requested one tile ago
+                    plan_tile((tile + 1) % R_PLAN_RING);
+                    poll_request();
+                }
             } else {
                 // ---- S1: decode, stage, mark
                 asm volatile("; MARK_S1_BEGIN");
@@ -585,6 +730,78 @@ __global__ void __launch_bounds__(RWG, 4) scan_range_kernel(DevIndex ix, DevBatc
             prof[10] += nm;
 #endif
 
+            // ---- completion of a candidate by lookups in the non-essential lists (all 64 lanes call; `cand` marks
+            // the lanes that hold one): partial = its score over the essential terms, which come from the row
+            // (row != NONE32) or are the single posting (tself, pself).
+            const double nesum = pne ? S.t_cum[pne] : 0.0;
+            auto complete = [&](bool cand, uint32_t d, uint32_t row, uint32_t tself, double pself, double partial) {
+                const double thd = __longlong_as_double((long long)theta_now());
+                cand = cand && partial + nesum >= thd;
+                if (!__ballot(cand)) return;
+                // pass 1: block upper bounds (search.rs:177-203) instead of the token bounds
+                double bound = partial;
+                for (uint32_t u = 0; u < pne; ++u) {
+                    const uint32_t t = S.t_ord[u];
+                    const uint32_t b1 = S.t_b1[t];
+                    if (cand) {
+                        const uint32_t b = r_first_block_ge(ix, S.t_b0[t], b1, d);
+                        if (b < b1 && ix.blk_min_doc[b] <= d) bound += ix.blk_ub[b];
+                    }
+                }
+                cand = cand && bound * (1.0 + 1e-12) >= thd;
+                if (!__ballot(cand)) return;
+#ifdef VBM25_PROFILE
+                prof[5] += (unsigned long long)__popcll(__ballot(cand)) << 40;
+#endif
+                // pass 2: the exact score, terms in ascending key order (evaluate.rs:43-72)
+                uint32_t *scr = S.list[wave];  // 128 ids of the block being looked into
+                double acc = 0.0;
+                for (uint32_t t = 0; t < mq; ++t) {
+                    double c = 0.0;
+                    if ((uint32_t)S.t_rank[t] >= pne) {
+                        if (cand) c = row != NONE32 ? S.contrib[(row << LRT) + t] : (t == tself ? pself : 0.0);
+                    } else {
+                        const uint32_t b1 = S.t_b1[t];
+                        uint32_t b = NONE32;
+                        bool pend = false;
+                        if (cand) {
+                            b = r_first_block_ge(ix, S.t_b0[t], b1, d);
+                            pend = b < b1 && ix.blk_min_doc[b] <= d;
+                        }
+                        for (;;) {
+                            const unsigned long long pmask = __ballot(pend);
+                            if (!pmask) break;
+                            const uint32_t blk = (uint32_t)__builtin_amdgcn_readlane((int)b, __ffsll((long long)pmask) - 1);
+                            const uint4 bm = uni4(ix.blk_meta[blk]);
+                            const uint32_t n = bm.w & 0xff, md = (bm.w >> 8) & 0xff, mt = (bm.w >> 16) & 0xff;
+                            uint32_t a0, a1;
+                            decode_doc_ids(ix.blob + 8ull * bm.z, md, n, bm.x, lane, a0, a1);
+                            __builtin_amdgcn_wave_barrier();
+                            *reinterpret_cast<uint2 *>(&scr[2 * lane]) = make_uint2(2 * lane < n ? a0 : NONE32, 2 * lane + 1 < n ? a1 : NONE32);
+                            __builtin_amdgcn_wave_barrier();
+                            if (pend && b == blk) {
+                                uint32_t idx = 0;
+#pragma unroll
+                                for (int sft = 64; sft > 0; sft >>= 1)
+                                    if (scr[idx + sft - 1] < d) idx += sft;
+                                if (scr[idx] == d) {
+                                    const uint8_t *tbody = ix.blob + 8ull * bm.z + ((payload_bytes(md, n) + 7u) & ~7u);
+                                    const FieldAddr fa = field_addr(mt, n, idx);
+                                    const uint32_t flo = *reinterpret_cast<const uint32_t *>(tbody + fa.off0);
+                                    const uint32_t fhi = *reinterpret_cast<const uint32_t *>(tbody + fa.off1);
+                                    const uint32_t fn = ix.post_fn[128ull * blk + idx];
+                                    const double tf = (double)field_val(flo, fhi, fa);
+                                    c = (tf * S.t_s0[t]) / (tf + S.s1[fn]);
+                                }
+                                pend = false;
+                            }
+                        }
+                    }
+                    acc += c;
+                }
+                offer(cand, acc, d);
+            };
+
             // ---- S3: rows -> documents (row r: lane r / RNW of wave r % RNW)
             if (nm) {
                 const uint32_t r = lane * RNW + wave;
@@ -593,12 +810,17 @@ __global__ void __launch_bounds__(RWG, 4) scan_range_kernel(DevIndex ix, DevBatc
                 uint32_t d = 0;
                 if (has) {
                     d = S.mdoc[par][r];
-                    for (uint32_t t = 0; t < mq; ++t) {  // ascending key order; absent terms add 0.0
-                        acc += S.contrib[(r << LRT) + t];
-                        S.contrib[(r << LRT) + t] = 0.0;
-                    }
+                    for (uint32_t t = 0; t < mq; ++t) acc += S.contrib[(r << LRT) + t];  // ascending key order; absent terms add 0.0
                 }
-                offer(has, acc, d);
+                if (boot) {
+                    // bootstrap tile: nothing is offered (the scores are partial)
+                } else if (pne == 0) {
+                    offer(has, acc, d);
+                } else {
+                    complete(has, d, has ? r : NONE32, 0, 0.0, acc);
+                }
+                if (has)
+                    for (uint32_t t = 0; t < mq; ++t) S.contrib[(r << LRT) + t] = 0.0;
             }
             PROF_T(t_f);
             PROF_ADD(7, t_e, t_f);
@@ -609,10 +831,11 @@ __global__ void __launch_bounds__(RWG, 4) scan_range_kernel(DevIndex ix, DevBatc
                     const uint32_t i = (uint32_t)__ffs((int)coldmask) - 1u;
                     coldmask &= coldmask - 1u;
                     const uint32_t e = (wave - 1u) + (RNW - 1) * i;
+                    if (e >= np) continue;
                     {   // the planner decided one tile early: check against the threshold of now
                         const unsigned long long ubb = (unsigned long long)__double_as_longlong(S.pub[buf][e]);
                         const unsigned long long ubu = ((unsigned long long)uni((uint32_t)(ubb >> 32)) << 32) | uni((uint32_t)ubb);
-                        if (theta_now() > ubu) continue;
+                        if (__longlong_as_double((long long)theta_now()) > __longlong_as_double((long long)ubu) + nesum) continue;
                     }
                     // ids from this wave's own stage row (nobody else writes it)
                     const uint2 dd = *reinterpret_cast<const uint2 *>(&S.stage[e * 128 + 2 * lane]);
@@ -635,8 +858,16 @@ __global__ void __launch_bounds__(RWG, 4) scan_range_kernel(DevIndex ix, DevBatc
                         const double tf0 = (double)field_val(l0, h0, f0), tf1 = (double)field_val(l1, h1, f1);
                         const double p0 = (tf0 * s0t) / (tf0 + S.s1[fnp & 0xff]);
                         const double p1 = (tf1 * s0t) / (tf1 + S.s1[fnp >> 8]);
-                        offer(ok0, p0, dd.x);
-                        offer(ok1, p1, dd.y);
+                        if (boot) {  // single-term scores: lower bounds of the documents' scores
+                            if (ok0) atomicAdd(&S.bhist[min((uint32_t)(p0 * hscale), (uint32_t)(CUR_HB - 1))], 1u);
+                            if (ok1) atomicAdd(&S.bhist[min((uint32_t)(p1 * hscale), (uint32_t)(CUR_HB - 1))], 1u);
+                        } else if (pne == 0) {
+                            offer(ok0, p0, dd.x);
+                            offer(ok1, p1, dd.y);
+                        } else {
+                            complete(ok0, dd.x, NONE32, t, p0, p0);
+                            complete(ok1, dd.y, NONE32, t, p1, p1);
+                        }
 #ifdef VBM25_PROFILE
                         prof[11] += 1;
 #endif
@@ -645,6 +876,37 @@ __global__ void __launch_bounds__(RWG, 4) scan_range_kernel(DevIndex ix, DevBatc
             }
             PROF_T(t_g);
             PROF_ADD(13, t_f, t_g);
+            if (boot) {  // threshold from the histogram, then the first real plan
+                lds_barrier();
+                if (wave == 0) {
+                    const uint4 cnt4 = *reinterpret_cast<const uint4 *>(&S.bhist[4 * lane]);
+                    const uint32_t own = cnt4.x + cnt4.y + cnt4.z + cnt4.w;
+                    const uint32_t incl = wave_incl_scan_u32(own);
+                    const uint32_t total = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
+                    const uint32_t above = total - incl;
+                    const unsigned long long hit = __ballot(above + own >= k);
+                    if (hit) {
+                        const uint32_t hl = 63u - (uint32_t)__builtin_clzll(hit);
+                        uint32_t a = (uint32_t)__builtin_amdgcn_readlane((int)above, (int)hl), b = 4 * hl;
+                        const uint32_t c3 = (uint32_t)__builtin_amdgcn_readlane((int)cnt4.w, (int)hl);
+                        const uint32_t c2 = (uint32_t)__builtin_amdgcn_readlane((int)cnt4.z, (int)hl);
+                        const uint32_t c1 = (uint32_t)__builtin_amdgcn_readlane((int)cnt4.y, (int)hl);
+                        if (a + c3 >= k) b += 3;
+                        else if (a + c3 + c2 >= k) b += 2;
+                        else if (a + c3 + c2 + c1 >= k) b += 1;
+                        const double edge = ((double)b / hscale) * (1.0 - 1e-12);
+                        const unsigned long long eb2 = (unsigned long long)__double_as_longlong(edge);
+                        if (lane == 0 && b > 0) {
+                            atomicMax(&S.theta, eb2);
+                            atomicMax(&bt.theta[q], eb2);
+                        }
+                    }
+                    __builtin_amdgcn_wave_barrier();
+                    plan_tile((tile + 1) % R_PLAN_RING);
+                    poll_request();
+                }
+                lds_barrier();
+            }
         }
 
 #ifdef VBM25_PROFILE

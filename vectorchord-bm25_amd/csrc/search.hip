@@ -116,6 +116,8 @@ struct vbm25_batch {
     uint32_t range_rt = 0;        // ... with this row stride (8 or 16) for the current queries; 0 = not used
     uint32_t lpi = 1;             // result lists per work item
     uint32_t range_grid = R_GRID;
+    bool range_dense = true;      // dense queries take scan_range_kernel too (VBM25_NE=0: scan_many_kernel)
+    uint32_t ne_ratio = 2;        // VBM25_NE_RATIO
     uint32_t cur_mt = 1;          // most indexed terms among the cursor kernel's queries
     uint32_t target_items = TARGET_ITEMS;
     uint32_t min_chunk = MIN_CHUNK_POSTINGS;
@@ -380,6 +382,10 @@ static int vbm25_batch_create_impl(vbm25_index *ix, uint32_t max_queries, uint32
         const char *rg = std::getenv("VBM25_RANGE");
         bt->use_range = k <= (uint32_t)REG_K && !(rg && rg[0] == '0');
         if (bt->use_range) bt->use_cursor = false;
+        const char *ne = std::getenv("VBM25_NE");
+        bt->range_dense = bt->use_range && !(ne && ne[0] == '0');
+        const char *nr = std::getenv("VBM25_NE_RATIO");
+        if (nr) bt->ne_ratio = (uint32_t)std::max(1, std::atoi(nr));
         bt->lpi = bt->use_range ? (uint32_t)RNW : 1u;
         const char *ti = std::getenv("VBM25_CUR_ITEMS");
         bt->target_items = bt->use_range ? (ti ? (uint32_t)std::atoi(ti) : R_TARGET_ITEMS)
@@ -457,7 +463,7 @@ static int vbm25_batch_set_queries_impl(vbm25_batch *bt, const uint32_t *term_id
         }
         if (bt->use_range) {  // sparse queries of <= 16 terms: scan_range_kernel; the rest: scan_many_kernel
             many |= valid > 16u;
-            if (!dense[q] && valid <= 16u) range_mt = std::max(range_mt, valid);
+            if ((!dense[q] || bt->range_dense) && valid <= 16u) range_mt = std::max(range_mt, valid);
         } else {
             many |= valid > (uint32_t)CHAIN_MAX_TERMS;
             if (!dense[q]) {
@@ -531,6 +537,8 @@ static int vbm25_batch_run_impl(vbm25_batch *bt, void *hip_stream) {
     db.chain_min_terms = cursor ? (uint32_t)CUR_T + 1u : 0u;
     db.lpi = bt->lpi;
     db.range_max_terms = bt->use_range ? 16u : 0u;
+    db.range_dense = bt->range_dense ? 1u : 0u;
+    db.ne_ratio = bt->ne_ratio;
     const bool range = bt->use_range;
     const DevIndex &ix = bt->index->dev;
     if (cursor || range) HIP_TRY(hipMemsetAsync(bt->hist.p, 0, 4ull * CUR_HB * bt->nq, st));
