@@ -61,8 +61,12 @@ def make_queries(seg, vocab, nq, nterms, seed, zipf_s):
         p /= p.sum()
     rows = []
     while len(rows) < nq:
-        toks = (rng.choice(vocab, nterms, replace=False) if zipf_s <= 0 else
-                np.unique(rng.choice(vocab, nterms * 4, p=p))[:nterms])
+        if zipf_s <= 0:
+            toks = rng.choice(vocab, nterms, replace=False)
+        else:  # the first nterms DISTINCT draws, in draw order (np.unique alone would keep the lowest ranks)
+            draws = rng.choice(vocab, nterms * 4, p=p)
+            _, first = np.unique(draws, return_index=True)
+            toks = draws[np.sort(first)[:nterms]]
         ids = seg.token_terms(toks.astype(np.uint32))
         ids = ids[ids != 0xffffffff]
         if len(ids) == nterms:  # queries whose tokens are all present in the vocab

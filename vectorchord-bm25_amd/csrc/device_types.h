@@ -51,7 +51,8 @@ struct DevBatch {
     uint32_t chain_min_terms;  // scan_kernel leaves queries with fewer terms to scan_cursor_kernel
     uint32_t lpi;              // result lists per item (scan_range_kernel: one per wave; the others use list 0)
     uint32_t range_max_terms;  // scan_range_kernel takes the queries with at most this many terms (0: off)
-    uint32_t range_dense;      // ... the dense ones too (MaxScore split + lookups); 0: dense queries go to scan_many_kernel
+    uint32_t range_dense;      // ... the dense ones too; 0: dense queries go to scan_many_kernel
+    uint32_t ne_on;            // MaxScore split in scan_range_kernel (non-essential lists looked up, not scanned)
     uint32_t ne_ratio;         // a non-essential list must be this many times longer than the essential lists together
 };
 

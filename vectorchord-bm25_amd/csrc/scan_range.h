@@ -70,7 +70,8 @@ struct RangeLds {
     uint8_t t_rank[RT];                // position of the term in ascending upper-bound order
     uint8_t t_ord[RT];                 // ... and the term at a position
     uint8_t t_best[RT + 1];            // largest admissible non-essential prefix <= p
-    uint32_t bhist[CUR_HB];            // bootstrap: histogram of one list's single-term scores
+    uint32_t bhist[CUR_HB];            // bootstrap: histogram of one list's single-term scores, then of full scores
+    double boot_edge, boot_nes;
     uint32_t t_b0[RT], t_b1[RT];       // block range of the term
     double hscale;
     unsigned long long theta;          // bits of a lower bound of the query's k-th best score
@@ -135,7 +136,10 @@ __global__ void __launch_bounds__(RWG, 4) scan_range_kernel(DevIndex ix, DevBatc
     const unsigned long long prof_t0 = __builtin_readcyclecounter();
 #endif
     // planner state (wave 0 only): lane t = term t, lane s = plan slot s
-    uint32_t p_cur = 0, p_end = 0, p_quota = 0, p_base = 0, p_st = NONE32, p_so = 0, p_df = 0, p_rank = 0, p_ne = 0;
+    uint32_t p_cur = 0, p_end = 0, p_quota = 0, p_base = 0, p_st = NONE32, p_so = 0, p_df = 0, p_rank = 0, p_ne = 0, p_relax = 0;
+    // blocks a tile may take (halved when a tile overflows its rows, see the retry below) and the planner's state
+    // before its last two plans
+    uint32_t p_cap = R_NBLK, p_good = 0, sv_cur[2] = {0, 0}, sv_tlo[2] = {0, 0};
 
     for (;;) {
         __syncthreads();  // previous item fully done with LDS
@@ -231,6 +235,14 @@ __global__ void __launch_bounds__(RWG, 4) scan_range_kernel(DevIndex ix, DevBatc
             // MaxScore split (search.rs:153-169 is this test, one document at a time): the longest prefix of the
             // terms in ascending upper-bound order whose bounds sum below the threshold is NON-ESSENTIAL -- a
             // document made only of those terms cannot enter the top-k.  Their blocks are not planned at all.
+            sv_cur[0] = sv_cur[1];
+            sv_tlo[0] = sv_tlo[1];
+            sv_cur[1] = p_cur;
+            sv_tlo[1] = p_tlo;
+            if (++p_good >= 8u) {  // eight tiles without an overflow: try larger tiles again
+                p_good = 0;
+                p_cap = min(2 * p_cap, (uint32_t)R_NBLK);
+            }
             const uint32_t mqp = uni(S.mq);
             const double thd = __longlong_as_double((long long)theta_lds());
             uint32_t p_th = 0;
@@ -240,7 +252,9 @@ __global__ void __launch_bounds__(RWG, 4) scan_range_kernel(DevIndex ix, DevBatc
                 if (lane == 0) S.hdr[buf] = make_uint4(p_tlo, p_tlo, 0, 0);
                 return;
             }
-            const uint32_t p_new = bt.range_dense ? (uint32_t)S.t_best[p_th] : 0u;
+            // (p_relax: the essential lists intersect too densely even for the smallest tiles -- every term the
+            // threshold allows becomes non-essential, whatever the lookups cost)
+            const uint32_t p_new = !bt.ne_on ? 0u : p_relax ? p_th : (uint32_t)S.t_best[p_th];
             if (p_new > p_ne) {
                 p_ne = p_new;
                 assign_quotas();
@@ -266,11 +280,11 @@ __global__ void __launch_bounds__(RWG, 4) scan_range_kernel(DevIndex ix, DevBatc
                 ub = ix.blk_ub[j];
             }
             // the 64 candidates (quotas) may hold more than a tile takes: the largest thi with <= R_NBLK blocks
-            if ((uint32_t)__popcll(__ballot(valid && meta.x < thi)) > (uint32_t)R_NBLK) {
-                uint32_t lo_v = p_tlo + 1, hi_v = thi;  // count(lo_v) <= terms <= R_NBLK < count(hi_v)
+            if ((uint32_t)__popcll(__ballot(valid && meta.x < thi)) > p_cap) {
+                uint32_t lo_v = p_tlo + 1, hi_v = thi;  // count(lo_v) <= terms <= p_cap < count(hi_v)
                 while (hi_v - lo_v > 1) {
                     const uint32_t mid = lo_v + ((hi_v - lo_v) >> 1);
-                    if ((uint32_t)__popcll(__ballot(valid && meta.x < mid)) <= (uint32_t)R_NBLK) lo_v = mid;
+                    if ((uint32_t)__popcll(__ballot(valid && meta.x < mid)) <= p_cap) lo_v = mid;
                     else hi_v = mid;
                 }
                 thi = lo_v;
@@ -315,9 +329,11 @@ __global__ void __launch_bounds__(RWG, 4) scan_range_kernel(DevIndex ix, DevBatc
                 S.pub[buf][lane] = 1e300;
             }
             const uint32_t n = (uint32_t)__popcll(mask);
+            // the tile ends with its last block (a narrow tile keeps the seen filter exact for a dense list)
+            const uint32_t last_max = n ? (uint32_t)__builtin_amdgcn_readlane((int)meta.y, (int)(n - 1)) : lo;
             if (lane <= (uint32_t)RT) S.ptb[buf][lane] = (uint8_t)(lane <= tr ? 0u : n);
             if (lane < (uint32_t)RNW) S.coldw[buf][lane] = (1u << RB) - 1u;
-            if (lane == 0) S.hdr[buf] = make_uint4(lo, hi, n, 0x80000000u);
+            if (lane == 0) S.hdr[buf] = make_uint4(lo, min(hi, last_max + 1u), n, 0x80000000u);
         };
 
         // ---- item setup (wave 0): terms, cursors, quotas, slot map; the first two plans
@@ -421,7 +437,7 @@ __global__ void __launch_bounds__(RWG, 4) scan_range_kernel(DevIndex ix, DevBatc
                     cum += readlane_f64(tub, owner);
                     const unsigned long long dfo = (uint32_t)__builtin_amdgcn_readlane((int)df, (int)owner);
                     head += dfo;
-                    if (pp + 1 < m && dfo >= (unsigned long long)bt.ne_ratio * (sumdf - head)) best = pp + 1;
+                    if (pp + 1 < m && (dfo >= (unsigned long long)bt.ne_ratio * (sumdf - head) || dfo * 16ull >= ix.n_docs)) best = pp + 1;
                     if (lane == 0) {
                         S.t_cum[pp + 1] = cum;
                         S.t_best[pp + 1] = (uint8_t)best;
@@ -430,6 +446,9 @@ __global__ void __launch_bounds__(RWG, 4) scan_range_kernel(DevIndex ix, DevBatc
                 }
             }
             p_ne = 0;
+            p_relax = 0;
+            p_cap = R_NBLK;
+            p_good = 0;
             if (lane == 0) S.mq = m;
             __builtin_amdgcn_wave_barrier();
             assign_quotas();
@@ -449,14 +468,21 @@ __global__ void __launch_bounds__(RWG, 4) scan_range_kernel(DevIndex ix, DevBatc
             poll_consume();
             p_tlo = lo;
             if (dense_item && theta_lds() == 0) {  // nothing known about the query yet: bootstrap the threshold
-                uint32_t tr = 0, dmin = NONE32;
+                // the rarest term that is expected to have 4 k postings in the item's range (else the densest)
+                uint32_t tr = 0, dmin = NONE32, tmax = 0, dmax = 0;
+                const unsigned long long need = 4ull * k * ix.n_docs / max(hi - lo, 1u);
                 for (uint32_t t = 0; t < m; ++t) {
                     const uint32_t dft = (uint32_t)__builtin_amdgcn_readlane((int)df, (int)t);
-                    if (dft < dmin) {
+                    if (dft >= need && dft < dmin) {
                         dmin = dft;
                         tr = t;
                     }
+                    if (dft > dmax) {
+                        dmax = dft;
+                        tmax = t;
+                    }
                 }
+                if (dmin == NONE32) tr = tmax;
                 plan_boot(0, tr);
             } else {
                 plan_tile(0);
@@ -531,6 +557,7 @@ __global__ void __launch_bounds__(RWG, 4) scan_range_kernel(DevIndex ix, DevBatc
 
         for (uint32_t tile = 0;; ++tile) {
             const uint32_t buf = tile % R_PLAN_RING;
+        retry_tile:
             par = tile & 1u;
             const uint4 hdr = uni4(S.hdr[buf]);
             const uint32_t tlo = hdr.x, thi = hdr.y, np = hdr.z;
@@ -572,8 +599,6 @@ __global__ void __launch_bounds__(RWG, 4) scan_range_kernel(DevIndex ix, DevBatc
                     const unsigned long long t_a1 = __builtin_readcyclecounter();
                     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                     const unsigned long long t_a2 = __builtin_readcyclecounter();
-                    prof[1] += t_a1 - t_a;
-                    prof[2] += t_a2 - t_a1;
                 }
 #endif
                 asm volatile("; MARK_S1_DECODE");
@@ -634,7 +659,6 @@ __global__ void __launch_bounds__(RWG, 4) scan_range_kernel(DevIndex ix, DevBatc
 #ifdef VBM25_PROFILE
                 {
                     const unsigned long long t_m = __builtin_readcyclecounter();
-                    prof[14] += t_m - t_a;
                 }
 #endif
                 uint32_t dupmask = 0;
@@ -655,7 +679,7 @@ __global__ void __launch_bounds__(RWG, 4) scan_range_kernel(DevIndex ix, DevBatc
                         }
                         const uint32_t pos = atomicAdd(&S.lcnt[wave], 1u);
                         if (pos < (uint32_t)R_LIST) S.list[wave][pos] = d;
-                        else S.fail = 1;
+                        else S.fail = 2;
                     }
                     __builtin_amdgcn_wave_barrier();
                     const uint32_t n = min(uni(S.lcnt[wave]), (uint32_t)R_LIST);
@@ -669,14 +693,44 @@ __global__ void __launch_bounds__(RWG, 4) scan_range_kernel(DevIndex ix, DevBatc
             }
             asm volatile("; MARK_S1_END");
             PROF_T(t_b);
-            PROF_ADD(3, t_a, t_b);
             lds_barrier();  // ---- A: every mark, staged id and row of the tile is in LDS; the next plan too
             PROF_T(t_c);
-            PROF_ADD(4, t_b, t_c);
 
             if (uni(S.fail)) {
-                failed = true;
-                break;
+                // The tile overflowed its rows (or a wave its list of second arrivals): lists that intersect that
+                // densely take smaller tiles.  Undo the tile, re-plan it with half the blocks, run it again; an
+                // item that overflows even at one block per term goes to scan_many_kernel.
+                lds_barrier();  // everybody has seen the flag
+                for (uint32_t i = tid; i < R_HS; i += RWG) S.hkeys[i] = EMPTY;
+                for (uint32_t i = tid; i < R_BM_WORDS; i += RWG) S.bm[i] = 0;
+                if (tid < RNW) S.lcnt[tid] = 0;
+                if (wave == 0) {
+                    bool give_up = boot;
+                    const uint32_t n_ess = uni(S.mq) - p_ne;  // a tile holds at least one block per essential term
+                    if (p_cap <= n_ess) {  // smallest tiles already: relax the admissibility rule once
+                        give_up = give_up || p_relax != 0;
+                        p_relax = 1;
+                    }
+                    if (lane == 0) {
+                        S.fail = give_up ? (0x10u | (boot ? 0x20u : 0u) | S.fail | p_ne << 8 | min(S.nmulti[par], 255u) << 16 | (exact ? 1u << 24 : 0u) | min(np, 127u) << 25) : 0u;
+                        S.nmulti[par] = 0;
+                    }
+                    if (!give_up) {
+                        p_cap = max(p_cap >> 1, n_ess);
+                        p_good = 0;
+                        p_cur = sv_cur[0];
+                        p_tlo = sv_tlo[0];
+                        sv_cur[1] = p_cur;
+                        sv_tlo[1] = p_tlo;
+                        plan_tile(buf);
+                    }
+                }
+                lds_barrier();
+                if (uni(S.fail)) {
+                    failed = true;
+                    break;
+                }
+                goto retry_tile;
             }
             const uint32_t nm = min(uni(S.nmulti[par]), (uint32_t)(R_ROWS * 8 / RT));
 
@@ -734,14 +788,26 @@ __global__ void __launch_bounds__(RWG, 4) scan_range_kernel(DevIndex ix, DevBatc
             // the lanes that hold one): partial = its score over the essential terms, which come from the row
             // (row != NONE32) or are the single posting (tself, pself).
             const double nesum = pne ? S.t_cum[pne] : 0.0;
-            auto complete = [&](bool cand, uint32_t d, uint32_t row, uint32_t tself, double pself, double partial) {
+            uint32_t emask = 0xffffffffu;  // bit t: term t is essential
+            if (pne) {
+                emask = 0;
+                for (uint32_t t = 0; t < mq; ++t) emask |= ((uint32_t)S.t_rank[t] >= pne ? 1u : 0u) << t;
+            }
+            // em: the essential terms (their contributions are known), nes: sum of the other terms' token bounds;
+            // to_hist: the score goes to the bootstrap histogram instead of the top-k
+            auto complete = [&](bool cand, uint32_t d, uint32_t row, uint32_t tself, double pself, double partial,
+                                uint32_t em, double nes, bool to_hist) {
                 const double thd = __longlong_as_double((long long)theta_now());
-                cand = cand && partial + nesum >= thd;
+                cand = cand && partial + nes >= thd;
                 if (!__ballot(cand)) return;
+#ifdef VBM25_PROFILE
+                prof[1] += (unsigned long long)__popcll(__ballot(cand));
+                const unsigned long long t_c0 = __builtin_readcyclecounter();
+#endif
                 // pass 1: block upper bounds (search.rs:177-203) instead of the token bounds
                 double bound = partial;
-                for (uint32_t u = 0; u < pne; ++u) {
-                    const uint32_t t = S.t_ord[u];
+                for (uint32_t t = 0; t < mq; ++t) {
+                    if ((em >> t) & 1u) continue;
                     const uint32_t b1 = S.t_b1[t];
                     if (cand) {
                         const uint32_t b = r_first_block_ge(ix, S.t_b0[t], b1, d);
@@ -751,14 +817,15 @@ __global__ void __launch_bounds__(RWG, 4) scan_range_kernel(DevIndex ix, DevBatc
                 cand = cand && bound * (1.0 + 1e-12) >= thd;
                 if (!__ballot(cand)) return;
 #ifdef VBM25_PROFILE
-                prof[5] += (unsigned long long)__popcll(__ballot(cand)) << 40;
+                prof[2] += (unsigned long long)__popcll(__ballot(cand));
+                const unsigned long long t_c1 = __builtin_readcyclecounter();
 #endif
                 // pass 2: the exact score, terms in ascending key order (evaluate.rs:43-72)
                 uint32_t *scr = S.list[wave];  // 128 ids of the block being looked into
                 double acc = 0.0;
                 for (uint32_t t = 0; t < mq; ++t) {
                     double c = 0.0;
-                    if ((uint32_t)S.t_rank[t] >= pne) {
+                    if ((em >> t) & 1u) {
                         if (cand) c = row != NONE32 ? S.contrib[(row << LRT) + t] : (t == tself ? pself : 0.0);
                     } else {
                         const uint32_t b1 = S.t_b1[t];
@@ -773,6 +840,9 @@ __global__ void __launch_bounds__(RWG, 4) scan_range_kernel(DevIndex ix, DevBatc
                             if (!pmask) break;
                             const uint32_t blk = (uint32_t)__builtin_amdgcn_readlane((int)b, __ffsll((long long)pmask) - 1);
                             const uint4 bm = uni4(ix.blk_meta[blk]);
+#ifdef VBM25_PROFILE
+                            prof[14] += 1;
+#endif
                             const uint32_t n = bm.w & 0xff, md = (bm.w >> 8) & 0xff, mt = (bm.w >> 16) & 0xff;
                             uint32_t a0, a1;
                             decode_doc_ids(ix.blob + 8ull * bm.z, md, n, bm.x, lane, a0, a1);
@@ -799,7 +869,18 @@ __global__ void __launch_bounds__(RWG, 4) scan_range_kernel(DevIndex ix, DevBatc
                     }
                     acc += c;
                 }
-                offer(cand, acc, d);
+#ifdef VBM25_PROFILE
+                {
+                    const unsigned long long t_c2 = __builtin_readcyclecounter();
+                    prof[3] += t_c1 - t_c0;
+                    prof[4] += t_c2 - t_c1;
+                }
+#endif
+                if (to_hist) {
+                    if (cand) atomicAdd(&S.bhist[min((uint32_t)(acc * hscale), (uint32_t)(CUR_HB - 1))], 1u);
+                } else {
+                    offer(cand, acc, d);
+                }
             };
 
             // ---- S3: rows -> documents (row r: lane r / RNW of wave r % RNW)
@@ -817,96 +898,123 @@ __global__ void __launch_bounds__(RWG, 4) scan_range_kernel(DevIndex ix, DevBatc
                 } else if (pne == 0) {
                     offer(has, acc, d);
                 } else {
-                    complete(has, d, has ? r : NONE32, 0, 0.0, acc);
+                    complete(has, d, has ? r : NONE32, 0, 0.0, acc, emask, nesum, false);
                 }
                 if (has)
                     for (uint32_t t = 0; t < mq; ++t) S.contrib[(r << LRT) + t] = 0.0;
             }
             PROF_T(t_f);
             PROF_ADD(7, t_e, t_f);
-            // ---- cold pass: blocks whose upper bound reaches the threshold (search.rs:203)
-            if (wave != 0) {
-                uint32_t coldmask = uni(S.coldw[buf][wave]);
-                while (coldmask) {
-                    const uint32_t i = (uint32_t)__ffs((int)coldmask) - 1u;
-                    coldmask &= coldmask - 1u;
-                    const uint32_t e = (wave - 1u) + (RNW - 1) * i;
-                    if (e >= np) continue;
-                    {   // the planner decided one tile early: check against the threshold of now
-                        const unsigned long long ubb = (unsigned long long)__double_as_longlong(S.pub[buf][e]);
-                        const unsigned long long ubu = ((unsigned long long)uni((uint32_t)(ubb >> 32)) << 32) | uni((uint32_t)ubb);
-                        if (__longlong_as_double((long long)theta_now()) > __longlong_as_double((long long)ubu) + nesum) continue;
-                    }
-                    // ids from this wave's own stage row (nobody else writes it)
-                    const uint2 dd = *reinterpret_cast<const uint2 *>(&S.stage[e * 128 + 2 * lane]);
-                    const uint32_t dwi = S.done[e * 4 + (lane >> 4)];
-                    const bool ok0 = dd.x - tlo < span && !((dwi >> ((2 * lane) & 31)) & 1u);
-                    const bool ok1 = dd.y - tlo < span && !((dwi >> ((2 * lane + 1) & 31)) & 1u);
-                    if (__ballot(ok0 || ok1)) {
-                        const uint4 sj = uni4(S.pm[buf][e]);
-                        const uint2 aux = S.pa[buf][e];
-                        const uint32_t blkj = uni(aux.x), t = uni(aux.y);
-                        const uint32_t nj = sj.w & 0xff, mdj = (sj.w >> 8) & 0xff, mtj = (sj.w >> 16) & 0xff;
-                        const uint8_t *tbody = ix.blob + 8ull * sj.z + ((payload_bytes(mdj, nj) + 7u) & ~7u);
-                        const FieldAddr f0 = field_addr(mtj, nj, 2 * lane), f1 = field_addr(mtj, nj, 2 * lane + 1);
-                        const uint32_t l0 = *reinterpret_cast<const uint32_t *>(tbody + f0.off0);
-                        const uint32_t h0 = *reinterpret_cast<const uint32_t *>(tbody + f0.off1);
-                        const uint32_t l1 = *reinterpret_cast<const uint32_t *>(tbody + f1.off0);
-                        const uint32_t h1 = *reinterpret_cast<const uint32_t *>(tbody + f1.off1);
-                        const uint32_t fnp = reinterpret_cast<const uint16_t *>(ix.post_fn + 128ull * blkj)[lane];
-                        const double s0t = S.t_s0[t];
-                        const double tf0 = (double)field_val(l0, h0, f0), tf1 = (double)field_val(l1, h1, f1);
-                        const double p0 = (tf0 * s0t) / (tf0 + S.s1[fnp & 0xff]);
-                        const double p1 = (tf1 * s0t) / (tf1 + S.s1[fnp >> 8]);
-                        if (boot) {  // single-term scores: lower bounds of the documents' scores
-                            if (ok0) atomicAdd(&S.bhist[min((uint32_t)(p0 * hscale), (uint32_t)(CUR_HB - 1))], 1u);
-                            if (ok1) atomicAdd(&S.bhist[min((uint32_t)(p1 * hscale), (uint32_t)(CUR_HB - 1))], 1u);
-                        } else if (pne == 0) {
-                            offer(ok0, p0, dd.x);
-                            offer(ok1, p1, dd.y);
-                        } else {
-                            complete(ok0, dd.x, NONE32, t, p0, p0);
-                            complete(ok1, dd.y, NONE32, t, p1, p1);
+            // ---- cold pass: blocks whose upper bound reaches the threshold (search.rs:203).  A bootstrap tile runs
+            // it twice: (1) histogram of the single-term scores, (2) the best 2 k of them completed by lookups in
+            // every other list -- exact scores of real documents, whose k-th best starts the threshold.
+            uint32_t cmode = boot ? 1u : 0u;
+            // lower edge of the highest bucket with kk entries at or above it (0 if there is none)
+            auto hist_edge = [&](uint32_t kk) -> double {
+                const uint4 cnt4 = *reinterpret_cast<const uint4 *>(&S.bhist[4 * lane]);
+                __builtin_amdgcn_wave_barrier();
+                *reinterpret_cast<uint4 *>(&S.bhist[4 * lane]) = make_uint4(0, 0, 0, 0);
+                const uint32_t own = cnt4.x + cnt4.y + cnt4.z + cnt4.w;
+                const uint32_t incl = wave_incl_scan_u32(own);
+                const uint32_t total = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
+                const uint32_t above = total - incl;
+                const unsigned long long hit = __ballot(above + own >= kk);
+                if (!hit) return 0.0;
+                const uint32_t hl = 63u - (uint32_t)__builtin_clzll(hit);
+                uint32_t a = (uint32_t)__builtin_amdgcn_readlane((int)above, (int)hl), b = 4 * hl;
+                const uint32_t c3 = (uint32_t)__builtin_amdgcn_readlane((int)cnt4.w, (int)hl);
+                const uint32_t c2 = (uint32_t)__builtin_amdgcn_readlane((int)cnt4.z, (int)hl);
+                const uint32_t c1 = (uint32_t)__builtin_amdgcn_readlane((int)cnt4.y, (int)hl);
+                if (a + c3 >= kk) b += 3;
+                else if (a + c3 + c2 >= kk) b += 2;
+                else if (a + c3 + c2 + c1 >= kk) b += 1;
+                return ((double)b / hscale) * (1.0 - 1e-12);
+            };
+            for (;;) {
+                if (wave != 0) {
+                    uint32_t coldmask = uni(S.coldw[buf][wave]);
+                    while (coldmask) {
+                        const uint32_t i = (uint32_t)__ffs((int)coldmask) - 1u;
+                        coldmask &= coldmask - 1u;
+                        const uint32_t e = (wave - 1u) + (RNW - 1) * i;
+                        if (e >= np) continue;
+                        {   // the planner decided one tile early: check against the threshold of now
+                            const unsigned long long ubb = (unsigned long long)__double_as_longlong(S.pub[buf][e]);
+                            const unsigned long long ubu = ((unsigned long long)uni((uint32_t)(ubb >> 32)) << 32) | uni((uint32_t)ubb);
+                            if (__longlong_as_double((long long)theta_now()) > __longlong_as_double((long long)ubu) + nesum) continue;
                         }
-#ifdef VBM25_PROFILE
-                        prof[11] += 1;
-#endif
+                        // ids from this wave's own stage row (nobody else writes it)
+                        const uint2 dd = *reinterpret_cast<const uint2 *>(&S.stage[e * 128 + 2 * lane]);
+                        const uint32_t dwi = S.done[e * 4 + (lane >> 4)];
+                        const bool ok0 = dd.x - tlo < span && !((dwi >> ((2 * lane) & 31)) & 1u);
+                        const bool ok1 = dd.y - tlo < span && !((dwi >> ((2 * lane + 1) & 31)) & 1u);
+                        if (__ballot(ok0 || ok1)) {
+                            const uint4 sj = uni4(S.pm[buf][e]);
+                            const uint2 aux = S.pa[buf][e];
+                            const uint32_t blkj = uni(aux.x), t = uni(aux.y);
+                            const uint32_t nj = sj.w & 0xff, mdj = (sj.w >> 8) & 0xff, mtj = (sj.w >> 16) & 0xff;
+                            const uint8_t *tbody = ix.blob + 8ull * sj.z + ((payload_bytes(mdj, nj) + 7u) & ~7u);
+                            const FieldAddr f0 = field_addr(mtj, nj, 2 * lane), f1 = field_addr(mtj, nj, 2 * lane + 1);
+                            const uint32_t l0 = *reinterpret_cast<const uint32_t *>(tbody + f0.off0);
+                            const uint32_t h0 = *reinterpret_cast<const uint32_t *>(tbody + f0.off1);
+                            const uint32_t l1 = *reinterpret_cast<const uint32_t *>(tbody + f1.off0);
+                            const uint32_t h1 = *reinterpret_cast<const uint32_t *>(tbody + f1.off1);
+                            const uint32_t fnp = reinterpret_cast<const uint16_t *>(ix.post_fn + 128ull * blkj)[lane];
+                            const double s0t = S.t_s0[t];
+                            const double tf0 = (double)field_val(l0, h0, f0), tf1 = (double)field_val(l1, h1, f1);
+                            const double p0 = (tf0 * s0t) / (tf0 + S.s1[fnp & 0xff]);
+                            const double p1 = (tf1 * s0t) / (tf1 + S.s1[fnp >> 8]);
+                            if (cmode == 1) {  // single-term scores: lower bounds of the documents' scores
+                                if (ok0) atomicAdd(&S.bhist[min((uint32_t)(p0 * hscale), (uint32_t)(CUR_HB - 1))], 1u);
+                                if (ok1) atomicAdd(&S.bhist[min((uint32_t)(p1 * hscale), (uint32_t)(CUR_HB - 1))], 1u);
+                            } else if (cmode == 2) {  // the best of them, completed in every other list
+                                const double edge = S.boot_edge;
+                                complete(ok0 && p0 >= edge, dd.x, NONE32, t, p0, p0, 1u << t, S.boot_nes, true);
+                                complete(ok1 && p1 >= edge, dd.y, NONE32, t, p1, p1, 1u << t, S.boot_nes, true);
+                            } else if (pne == 0) {
+                                offer(ok0, p0, dd.x);
+                                offer(ok1, p1, dd.y);
+                            } else {
+                                complete(ok0, dd.x, NONE32, t, p0, p0, emask, nesum, false);
+                                complete(ok1, dd.y, NONE32, t, p1, p1, emask, nesum, false);
+                            }
+    #ifdef VBM25_PROFILE
+                            prof[11] += 1;
+    #endif
+                        }
                     }
                 }
-            }
-            PROF_T(t_g);
-            PROF_ADD(13, t_f, t_g);
-            if (boot) {  // threshold from the histogram, then the first real plan
+                if (!boot) break;
                 lds_barrier();
                 if (wave == 0) {
-                    const uint4 cnt4 = *reinterpret_cast<const uint4 *>(&S.bhist[4 * lane]);
-                    const uint32_t own = cnt4.x + cnt4.y + cnt4.z + cnt4.w;
-                    const uint32_t incl = wave_incl_scan_u32(own);
-                    const uint32_t total = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
-                    const uint32_t above = total - incl;
-                    const unsigned long long hit = __ballot(above + own >= k);
-                    if (hit) {
-                        const uint32_t hl = 63u - (uint32_t)__builtin_clzll(hit);
-                        uint32_t a = (uint32_t)__builtin_amdgcn_readlane((int)above, (int)hl), b = 4 * hl;
-                        const uint32_t c3 = (uint32_t)__builtin_amdgcn_readlane((int)cnt4.w, (int)hl);
-                        const uint32_t c2 = (uint32_t)__builtin_amdgcn_readlane((int)cnt4.z, (int)hl);
-                        const uint32_t c1 = (uint32_t)__builtin_amdgcn_readlane((int)cnt4.y, (int)hl);
-                        if (a + c3 >= k) b += 3;
-                        else if (a + c3 + c2 >= k) b += 2;
-                        else if (a + c3 + c2 + c1 >= k) b += 1;
-                        const double edge = ((double)b / hscale) * (1.0 - 1e-12);
+                    if (cmode == 1) {
+                        const double edge = hist_edge(2 * k);
+                        const uint32_t tr = S.pa[buf][0].y;
+                        double nes = 0.0;
+                        for (uint32_t t = 0; t < mq; ++t)
+                            if (t != tr) nes += S.t_ub[t];
+                        if (lane == 0) {
+                            S.boot_edge = edge;
+                            S.boot_nes = nes;
+                        }
+                    } else {
+                        const double edge = hist_edge(k);
                         const unsigned long long eb2 = (unsigned long long)__double_as_longlong(edge);
-                        if (lane == 0 && b > 0) {
+                        if (lane == 0 && edge > 0.0) {
                             atomicMax(&S.theta, eb2);
                             atomicMax(&bt.theta[q], eb2);
                         }
+                        __builtin_amdgcn_wave_barrier();
+                        plan_tile((tile + 1) % R_PLAN_RING);
+                        poll_request();
                     }
-                    __builtin_amdgcn_wave_barrier();
-                    plan_tile((tile + 1) % R_PLAN_RING);
-                    poll_request();
                 }
                 lds_barrier();
+                if (cmode == 2) break;
+                cmode = 2;
             }
+            PROF_T(t_g);
+            PROF_ADD(13, t_f, t_g);
         }
 
 #ifdef VBM25_PROFILE
@@ -924,7 +1032,7 @@ __global__ void __launch_bounds__(RWG, 4) scan_range_kernel(DevIndex ix, DevBatc
             }
         if (lane == 0) {
             bt.res_cnt[list] = n;
-            if (wave == 0) bt.item_failed[item] = failed ? 1u : 0u;
+            if (wave == 0) bt.item_failed[item] = failed ? (S.fail | 0x100u) : 0u;
         }
     }
 #ifdef VBM25_PROFILE

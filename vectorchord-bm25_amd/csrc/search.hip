@@ -116,7 +116,8 @@ struct vbm25_batch {
     uint32_t range_rt = 0;        // ... with this row stride (8 or 16) for the current queries; 0 = not used
     uint32_t lpi = 1;             // result lists per work item
     uint32_t range_grid = R_GRID;
-    bool range_dense = true;      // dense queries take scan_range_kernel too (VBM25_NE=0: scan_many_kernel)
+    bool ne_on = true;            // MaxScore split in scan_range_kernel (VBM25_NE=0: off)
+    bool range_dense = false;     // dense queries take scan_range_kernel too (VBM25_RANGE_DENSE=1); default: scan_many_kernel
     uint32_t ne_ratio = 2;        // VBM25_NE_RATIO
     uint32_t cur_mt = 1;          // most indexed terms among the cursor kernel's queries
     uint32_t target_items = TARGET_ITEMS;
@@ -383,7 +384,9 @@ static int vbm25_batch_create_impl(vbm25_index *ix, uint32_t max_queries, uint32
         bt->use_range = k <= (uint32_t)REG_K && !(rg && rg[0] == '0');
         if (bt->use_range) bt->use_cursor = false;
         const char *ne = std::getenv("VBM25_NE");
-        bt->range_dense = bt->use_range && !(ne && ne[0] == '0');
+        bt->ne_on = bt->use_range && !(ne && ne[0] == '0');
+        const char *rd = std::getenv("VBM25_RANGE_DENSE");
+        bt->range_dense = bt->ne_on && rd && rd[0] == '1';
         const char *nr = std::getenv("VBM25_NE_RATIO");
         if (nr) bt->ne_ratio = (uint32_t)std::max(1, std::atoi(nr));
         bt->lpi = bt->use_range ? (uint32_t)RNW : 1u;
@@ -538,6 +541,7 @@ static int vbm25_batch_run_impl(vbm25_batch *bt, void *hip_stream) {
     db.lpi = bt->lpi;
     db.range_max_terms = bt->use_range ? 16u : 0u;
     db.range_dense = bt->range_dense ? 1u : 0u;
+    db.ne_on = bt->ne_on ? 1u : 0u;
     db.ne_ratio = bt->ne_ratio;
     const bool range = bt->use_range;
     const DevIndex &ix = bt->index->dev;
@@ -601,6 +605,31 @@ int vbm25_batch_device_results(vbm25_batch *bt, void **hits, void **n_hits) {
     if (!bt) return set_error(VBM25_ERR_INVALID, "batch is NULL");
     if (hits) *hits = bt->hits.p;
     if (n_hits) *n_hits = bt->n_hits.p;
+    return VBM25_OK;
+}
+
+// tuning / test aid (not declared in include/vbm25.h): work items of the last run and how many of them the
+// first-choice kernel handed to scan_many_kernel
+int vbm25_batch_debug_counts(vbm25_batch *bt, uint32_t *n_items, uint32_t *n_failed) {
+    if (!bt || !n_items || !n_failed) return set_error(VBM25_ERR_INVALID, "NULL argument");
+    if (int rc = use_device(bt->index->device)) return rc;
+    HIP_TRY(hipDeviceSynchronize());
+    HIP_TRY(hipMemcpy(n_items, bt->n_items.p, 4, hipMemcpyDeviceToHost));
+    std::vector<uint32_t> f(*n_items);
+    if (*n_items) HIP_TRY(hipMemcpy(f.data(), bt->item_failed.p, 4ull * *n_items, hipMemcpyDeviceToHost));
+    *n_failed = 0;
+    uint32_t codes[64] = {};
+    int shown = 0;
+    for (uint32_t x : f) {
+        *n_failed += x != 0;
+        if (x) codes[x & 63]++;
+        if (x && std::getenv("VBM25_DEBUG") && shown++ < 24)
+            std::fprintf(stderr, "vbm25: failed item code 0x%x p_ne %u nmulti %u exact %u np %u\n", x & 0xff, (x >> 8) & 0xff,
+                         (x >> 16) & 0xff, (x >> 24) & 1, x >> 25);
+    }
+    if (std::getenv("VBM25_DEBUG"))
+        for (int c = 0; c < 64; ++c)
+            if (codes[c]) std::fprintf(stderr, "vbm25: %u items failed with code 0x%x\n", codes[c], c);
     return VBM25_OK;
 }
 
