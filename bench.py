@@ -1,17 +1,23 @@
 #!/usr/bin/env python3
 """bench.py -- queries/sec of the batched BM25 top-k path on MI355X.
 
-A "step" is one pass of the hot path (plan -> posting scan -> merge) over one batch of
-synthetic queries already resident in HBM.  Default workload = BASELINE.json configs[2]
-("C3"): 10M docs / 30k vocab, 1024 five-term queries, top-10, one MI355X.  With --gpus N
-every rank holds a replica of the index and its own 1024 queries (weak scaling); the only
-collective is the all-gather of the per-rank top-k (RCCL).
+A "step" is one pass of the hot path (plan -> posting scan -> merge) over one batch of synthetic queries
+already resident in HBM.  Default workload = BASELINE.json configs[2] ("C3"): 10M docs / 30k vocab, 1024
+five-term queries, top-10, one MI355X.  --workload C5 is configs[4] (50M docs / 100k vocab Zipf(1) /
+10-term / top-100), C2 the single 3-term query on 1M docs (adds host-inclusive latencies), C1 the plumbing
+case.
+
+With --gpus N (launched by torch.distributed.run, one rank per GPU) the run is BASELINE.json configs[3]
+("C4"): rank 0 makes ONE batch of N x 1024 queries, broadcasts the two descriptor arrays (RCCL), every
+rank keeps its contiguous shard, searches it against its replica of the index, and the hit records are
+gathered to rank 0.  The broadcast is paid once (scatter_ms); the gather is inside every step (gather_ms).
 
 Prints ONE JSON line (rank 0).  See DESIGN.md "Measurement".
 """
 import argparse
 import json
 import os
+import statistics
 import sys
 import time
 
@@ -29,6 +35,7 @@ WORKLOADS = {
     "C3": (10_000_000, 30_000, 100, 1, 0.0, 1024, 5, 10),
     "C5": (50_000_000, 100_000, 100, 1, 1.0, 1024, 10, 100),
 }
+METRIC = "queries/sec top-10 BM25, 10M synthetic docs; achieved HBM GB/s vs peak"
 
 
 class _DevArray:
@@ -54,6 +61,16 @@ def usable_cpus():
     return n
 
 
+def cpu_model():
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                return line.split(":", 1)[1].strip()
+    except Exception:
+        pass
+    return "unknown"
+
+
 def make_queries(seg, vocab, nq, nterms, seed, zipf_s):
     rng = np.random.default_rng(seed)
     if zipf_s > 0:
@@ -76,39 +93,80 @@ def make_queries(seg, vocab, nq, nterms, seed, zipf_s):
     return terms, off
 
 
-def cpu_baseline(seg, terms, off, k, budget_s=20.0):
-    """Faithful C++ restatement of the reference's Block-WAND search (oracle/), one query per
-    thread, on a bounded sample of the same batch.  NOT the Rust binary (no rustc here)."""
+def oracle_index(seg):
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import orc
 
-    oix = orc.OracleIndex.from_arrays(seg.meta(), seg.arrays())
+    return orc.OracleIndex.from_arrays(seg.meta(), seg.arrays())
+
+
+def cpu_baseline(oix, terms, off, k, budget_s=20.0):
+    """Faithful C++ restatement of the reference's Block-WAND search (oracle/), one query per thread
+    (PostgreSQL's execution model), on a bounded sample of the same batch: T = 1 and T = usable cores,
+    median of >= 5 repetitions each, plus the brute-force scorer for context.  NOT the Rust binary (there
+    is no rustc in this image)."""
     cores = usable_cpus()
     nq = len(off) - 1
-    probe = min(nq, 8)
+    probe = min(nq, 4)
     _, _, t_probe = oix.search_batch(terms[:off[probe]], off[:probe + 1], k, mode="wand", threads=1)
     per_q = max(t_probe / probe, 1e-6)
-    sample = int(min(nq, max(cores, budget_s * cores / per_q)))
-    reps = 1
-    if sample == nq:  # whole batch is cheap: repeat it
-        reps = int(max(1, min(50, budget_s * cores / (per_q * nq))))
-    t = 0.0
-    for _ in range(reps):
-        _, _, dt = oix.search_batch(terms[:off[sample]], off[:sample + 1], k, mode="wand", threads=cores)
-        t += dt
-    return {"value": round(sample * reps / t, 2), "unit": "queries/s", "cores": cores, "kind": "port",
-            "sample": f"{sample} of the batch's {nq} queries x{reps}, Block-WAND restatement "
-                      f"(oracle/), one query per thread; 1-thread rate {1.0 / per_q:.1f} q/s"}
+    reps = 5
+    n1 = int(min(nq, max(1, 0.2 * budget_s / (reps * per_q))))
+    nn = int(min(nq, max(cores, 0.6 * budget_s * cores / (reps * per_q))))
+
+    def rate(n, threads, mode):
+        ts = []
+        for _ in range(reps):
+            _, _, dt = oix.search_batch(terms[:off[n]], off[:n + 1], k, mode=mode, threads=threads)
+            ts.append(n / dt)
+        return statistics.median(ts)
+
+    t1 = rate(n1, 1, "wand")
+    tn = rate(nn, cores, "wand")
+    nb = int(min(nq, max(cores, nn // 4)))
+    _, _, dtb = oix.search_batch(terms[:off[nb]], off[:nb + 1], k, mode="brute", threads=cores)
+    return {"value": round(tn, 2), "unit": "queries/s", "cores": cores, "kind": "port",
+            "t1_qps": round(t1, 2), "tn_qps": round(tn, 2), "brute_force_tn_qps": round(nb / dtb, 2),
+            "repetitions": reps, "statistic": "median", "cpu_model": cpu_model(),
+            "compiler_flags": "g++ -O3 -DNDEBUG -march=x86-64-v3 -ffp-contract=off",
+            "sample": f"first {nn} of the batch's {nq} queries at T={cores} ({n1} at T=1), Block-WAND "
+                      f"restatement of search.rs:28-282 over in-memory arrays (oracle/), one query per thread"}
+
+
+class OracleScorer:
+    """CPU stand-in used ONLY by the gloo test of this script's distributed path
+    (VBM25_BENCH_BACKEND=gloo): same interface as the GPU batch, results from the oracle."""
+
+    def __init__(self, oix, nq, k):
+        import torch
+
+        self.oix, self.k, self.nq = oix, k, nq
+        self.words = torch.zeros(nq * k * 3, dtype=torch.int64)
+
+    def set_queries(self, terms, off):
+        self.terms, self.off = terms, off
+
+    def run(self, stream=None):
+        import torch
+
+        hits, nh, _ = self.oix.search_batch(self.terms, self.off, self.k, mode="brute", threads=1)
+        self.hits, self.nh = hits, nh
+        self.words.copy_(torch.from_numpy(np.frombuffer(hits.tobytes(), dtype=np.int64).copy()))
+
+    def fetch(self):
+        return self.hits, self.nh
 
 
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--workload", default="C3", choices=sorted(WORKLOADS))
     ap.add_argument("--queries", type=int, default=0, help="override queries per GPU")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--verify", action="store_true",
+                    help="check every query of the batch bit-exact against the oracle (outside the timed region)")
     ap.add_argument("--build-threads", type=int, default=0)
     ap.add_argument("--cache", default="", help="segment file: load if present, else build and save")
     args = ap.parse_args()
@@ -122,9 +180,12 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run")
-    if not torch.cuda.is_available():
-        raise SystemExit("bench.py needs an MI355X: the HIP path has no CPU fallback")
-    torch.cuda.set_device(local_rank)
+    gloo = os.environ.get("VBM25_BENCH_BACKEND") == "gloo"  # CPU test of the distributed path only
+    if not gloo:
+        if not torch.cuda.is_available():
+            raise SystemExit("bench.py needs an MI355X: the HIP path has no CPU fallback")
+        torch.cuda.set_device(local_rank)
+    dev = "cpu" if gloo else f"cuda:{local_rank}"
     dist = None
     # VBM25_BENCH_FORCE_DIST=1 runs the RCCL code path even with one rank (GPU test of the N>1 path)
     use_dist = world > 1 or os.environ.get("VBM25_BENCH_FORCE_DIST") == "1"
@@ -132,8 +193,14 @@ def main():
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29511")
-        dist.init_process_group("nccl", rank=rank, world_size=world,
-                                device_id=torch.device("cuda", local_rank))
+        if gloo:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+        else:
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+
+    def sync():
+        if not gloo:
+            torch.cuda.synchronize()
 
     n_docs, vocab, mean_len, len_mode, zipf_s, nq, nterms, k = WORKLOADS[args.workload]
     if args.queries:
@@ -169,97 +236,186 @@ def main():
         if use_dist:
             dist.barrier()
     t_build = time.perf_counter() - t0
+    oix = None
     t0 = time.perf_counter()
-    gix = vb.GpuIndex(seg, device=local_rank)
+    gix = None if gloo else vb.GpuIndex(seg, device=local_rank)
     t_upload = time.perf_counter() - t0
-    terms, off = make_queries(seg, vocab, nq, nterms, seed=1 + rank, zipf_s=zipf_s)
-    algo_bytes = sum(seg.query_bytes(terms[off[q]:off[q + 1]], k) for q in range(nq))
 
-    batch = vb.Batch(gix, nq, len(terms), k)
-    batch.set_queries(terms, off)
-    stream = torch.cuda.current_stream()
-    local = None
+    # ---- the batch: rank 0 makes all world x nq queries, broadcasts the descriptors, every rank keeps its shard
+    n_total = world * nq
+    scatter_ms = 0.0
     if use_dist:
-        import ctypes as C
-        hp, nh = C.c_void_p(), C.c_void_p()
-        vb._lib.check(vb.lib().vbm25_batch_device_results(batch.h, C.byref(hp), C.byref(nh)))
-        local = torch.as_tensor(_DevArray(hp.value, nq * k * 3), device=f"cuda:{local_rank}")
+        if rank == 0:
+            terms_all, off_all = make_queries(seg, vocab, n_total, nterms, seed=1, zipf_s=zipf_s)
+        else:
+            terms_all = np.zeros(n_total * nterms, dtype=np.uint32)
+            off_all = np.zeros(n_total + 1, dtype=np.uint32)
+        sync()
+        dist.barrier()
+        t0 = time.perf_counter()
+        tt = torch.from_numpy(terms_all.astype(np.int32)).to(dev)
+        ot = torch.from_numpy(off_all.astype(np.int32)).to(dev)
+        dist.broadcast(tt, 0)
+        dist.broadcast(ot, 0)
+        sync()
+        terms_all = tt.cpu().numpy().astype(np.uint32)
+        off_all = ot.cpu().numpy().astype(np.uint32)
+        terms, off = vb.sharded.shard_queries(terms_all, off_all, world, rank)
+        scatter_ms = 1e3 * (time.perf_counter() - t0)
+    else:
+        terms, off = make_queries(seg, vocab, nq, nterms, seed=1, zipf_s=zipf_s)
+    nq_local = len(off) - 1
+    algo_bytes = sum(seg.query_bytes(terms[off[q]:off[q + 1]], k) for q in range(nq_local))
+
+    if gloo:
+        oix = oracle_index(seg)
+        batch = OracleScorer(oix, nq_local, k)
+        batch.set_queries(terms, off)
+        local = batch.words
+        stream_ptr = None
+    else:
+        batch = vb.Batch(gix, nq_local, len(terms), k)
+        batch.set_queries(terms, off)
+        stream = torch.cuda.current_stream()
+        stream_ptr = stream.cuda_stream
+        local = None
+        if use_dist:
+            import ctypes as C
+            hp, nh = C.c_void_p(), C.c_void_p()
+            vb._lib.check(vb.lib().vbm25_batch_device_results(batch.h, C.byref(hp), C.byref(nh)))
+            local = torch.as_tensor(_DevArray(hp.value, nq_local * k * 3), device=dev)
+
+    gather_s = [0.0]
 
     def step():
-        batch.run(stream.cuda_stream)
-        if use_dist:  # the path's only exchange: every rank gets all top-k lists
-            return vb.sharded.gather_hits(local, world * nq, k)
+        batch.run(stream_ptr)
+        if use_dist:  # the path's only exchange: the top-k records go to rank 0
+            if gloo:
+                t0 = time.perf_counter()
+                out = vb.sharded.gather_to_root(local, n_total, k)
+                gather_s[0] += time.perf_counter() - t0
+                return out
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            out = vb.sharded.gather_to_root(local, n_total, k)
+            e1.record()
+            gather_events.append((e0, e1))
+            return out
 
+    gather_events = []
     for _ in range(args.warmup):
         step()
-    torch.cuda.synchronize()
+    sync()
+    gather_events.clear()
+    gather_s[0] = 0.0
     if use_dist:
         dist.barrier()
-    batch.set_timing(True)
-    torch.cuda.synchronize()
+    if not gloo:
+        batch.set_timing(True)
+    sync()
     t0 = time.perf_counter()
+    gathered = None
     for _ in range(args.steps):
-        step()
-    torch.cuda.synchronize()
+        gathered = step()
+    sync()
     if use_dist:
         dist.barrier()
     elapsed = time.perf_counter() - t0
-    kernel_ms, n_launch = batch.kernel_ms()
-    batch.set_timing(False)
+    kernel_ms, n_launch = (0.0, 0) if gloo else batch.kernel_ms()
+    if not gloo:
+        batch.set_timing(False)
+    gather_ms = 0.0
     if use_dist:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=f"cuda:{local_rank}")
+        gather_ms = (1e3 * gather_s[0] / args.steps if gloo else
+                     sum(a.elapsed_time(b) for a, b in gather_events) / max(1, len(gather_events)))
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
-    # the same batch through the host-buffer boundary (upload queries, run, download hits)
-    t0 = time.perf_counter()
-    for _ in range(5):
-        batch.set_queries(terms, off)
-        batch.run(stream.cuda_stream)
-        hits, n_hits = batch.fetch()
-    pcie_qps = 5 * nq / (time.perf_counter() - t0)
-
-    # sanity: results exist and are sorted (full parity lives in tests/ and smoke())
+    # ---- outside the timed region ----
+    pcie_qps = None
+    if not gloo:  # the same batch through the host-buffer boundary (upload queries, run, download hits)
+        t0 = time.perf_counter()
+        for _ in range(5):
+            batch.set_queries(terms, off)
+            batch.run(stream_ptr)
+            hits, n_hits = batch.fetch()
+        pcie_qps = 5 * nq_local / (time.perf_counter() - t0)
     hits, n_hits = batch.fetch()
     assert (n_hits == k).all() or args.workload in ("C1",), "missing hits"
     s = hits["score"]
     assert (s[:, :-1] >= s[:, 1:]).all()
+    if use_dist and rank == 0 and gathered is not None:  # rank 0's shard sits first in the gathered records
+        got = gathered.cpu().numpy()[:nq_local * k * 3]
+        assert got.tobytes() == np.frombuffer(hits.tobytes(), dtype=np.int64).tobytes(), "gathered records differ"
+
+    verified = None
+    if args.verify:  # full parity of this rank's batch, bit-exact against the oracle's brute force
+        oix = oix or oracle_index(seg)
+        t0 = time.perf_counter()
+        ob, onb, _ = oix.search_batch(terms, off, k, mode="brute", threads=usable_cpus())
+        assert np.array_equal(n_hits, onb), "hit counts differ from the oracle"
+        assert np.array_equal(hits["doc_id"], ob["doc_id"]), "doc ids differ from the oracle"
+        assert np.array_equal(hits["score"].view(np.uint64), ob["score"].view(np.uint64)), "score bits differ"
+        assert np.array_equal(hits["payload"], ob["payload"]), "payloads differ"
+        verified = {"queries": int(nq_local), "seconds": round(time.perf_counter() - t0, 2)}
+
+    latency = None
+    if args.workload == "C2" and not gloo and world == 1:
+        # host-inclusive latency of vbm25_search_batch(nq = 1): 1000 different 3-term queries
+        lt, lo = make_queries(seg, vocab, 1000, nterms, seed=7, zipf_s=zipf_s)
+        one = np.array([0, nterms], dtype=np.uint32)
+        for q in range(20):
+            vb.search_batch(gix, lt[lo[q]:lo[q + 1]], one, k)
+        us = []
+        for q in range(1000):
+            t0 = time.perf_counter()
+            vb.search_batch(gix, lt[lo[q]:lo[q + 1]], one, k)
+            us.append(1e6 * (time.perf_counter() - t0))
+        us.sort()
+        latency = {"search_batch_nq1_us_p50": round(us[500], 1), "search_batch_nq1_us_p99": round(us[990], 1),
+                   "includes": "ctypes call, query upload, plan + scan + merge, hit download"}
 
     result_line = None
     if rank == 0:
         ms_per_step = 1e3 * elapsed / args.steps
+        dense = zipf_s > 0
         out = {
-            "metric": "queries/sec top-10 BM25, 10M synthetic docs; achieved HBM GB/s vs peak",
-            "value": round(world * nq * args.steps / elapsed, 1),
+            "metric": METRIC,
+            "value": round(n_total * args.steps / elapsed, 1),
             "unit": "queries/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(ms_per_step, 4),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f64", "data": "synthetic",
-            "config": {"workload": f"{args.workload}: {n_docs} docs / {vocab} vocab / "
-                                   f"{nq} x {nterms}-term queries per GPU / top-{k}",
+            "config": {"workload": f"{args.workload if world == 1 else 'C4'}: {n_docs} docs / {vocab} vocab / "
+                                   f"{nq_local} x {nterms}-term queries per GPU / top-{k}",
                        "doc_length": "lognormal(ln 80, 0.6) clamp [8,2000]" if len_mode == 1 else f"fixed {mean_len}",
                        "token_distribution": f"zipf({zipf_s})" if zipf_s > 0 else "uniform",
-                       "k1": 1.2, "b": 0.75, "index_hbm_bytes": gix.device_bytes,
+                       "k1": 1.2, "b": 0.75, "index_hbm_bytes": None if gloo else gix.device_bytes,
                        "postings": int(seg.arrays()["term_df"].astype(np.int64).sum()),
-                       "parallelism": f"query-batch data parallel x{world}, index replicated",
+                       "parallelism": f"one {n_total}-query batch sharded over {world} GPU(s), index replicated",
                        "build_s": round(t_build, 2), "upload_s": round(t_upload, 2),
-                       "host_buffer_inclusive_qps_per_gpu": round(pcie_qps, 1)},
+                       "scatter_ms": round(scatter_ms, 3), "gather_ms": round(gather_ms, 4),
+                       "host_buffer_inclusive_qps_per_gpu": None if pcie_qps is None else round(pcie_qps, 1)},
         }
-        achieved = algo_bytes / (kernel_ms * 1e-3) / 1e9 if kernel_ms > 0 else 0.0
-        traffic = None
-        try:  # PMC-derived HBM bytes per launch, collected separately (profiles/)
-            pmc = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))
-            traffic = pmc.get(args.workload, {}).get("hbm_bytes_per_launch")
-        except Exception:
-            pass
-        out["roofline"] = {"bound": "hbm", "kernel": "scan_cursor_kernel", "achieved": round(achieved, 1),
-                           "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                           "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": traffic,
-                           "algorithmic_bytes_per_launch": int(algo_bytes),
-                           "kernel_ms": round(kernel_ms, 4), "launches_timed": n_launch}
-        if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(seg, terms, off, k)
+        if verified:
+            out["config"]["verified_bit_exact_vs_oracle"] = verified
+        if latency:
+            out["config"]["latency"] = latency
+        if not gloo:
+            achieved = algo_bytes / (kernel_ms * 1e-3) / 1e9 if kernel_ms > 0 else 0.0
+            out["roofline"] = {"bound": "hbm", "kernel": "scan_many_kernel" if dense else "scan_range_kernel",
+                               "achieved": round(achieved, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                               "frac": round(achieved / HBM_PEAK_GBPS, 4),
+                               # HBM bytes per launch come from separate rocprofv3 --pmc passes (tools/r2_pmc.sh,
+                               # summaries under profiles/); they are not collected inside this run
+                               "traffic": None,
+                               "algorithmic_bytes_per_launch": int(algo_bytes),
+                               "kernel_ms": round(kernel_ms, 4), "launches_timed": n_launch}
+        if world == 1 and not args.no_cpu_baseline and not gloo:
+            oix = oix or oracle_index(seg)
+            out["cpu_baseline"] = cpu_baseline(oix, terms, off, k)
         result_line = json.dumps(out)
     if use_dist:
         if rank == 0 and not args.cache and cache and os.path.exists(cache):

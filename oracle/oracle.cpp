@@ -801,7 +801,10 @@ uint32_t search_brute(const orc_index *ix, const uint32_t *terms, uint32_t n_ter
                       orc_hit *out) {
     if (k == 0) return 0;
     const double avgdl = ix->avgdl();
-    std::vector<double> acc(ix->n_docs, 0.0);
+    // one accumulator per thread, kept across calls and wiped through the touched list: allocating and
+    // zeroing n_docs doubles per query made a full-batch check on 10 M documents take minutes
+    static thread_local std::vector<double> acc;
+    if (acc.size() < ix->n_docs) acc.assign(ix->n_docs, 0.0);
     std::vector<uint32_t> touched;
     uint32_t docs[128], tfs[128];
     for (uint32_t i = 0; i < n_terms; ++i) {
@@ -831,6 +834,7 @@ uint32_t search_brute(const orc_index *ix, const uint32_t *terms, uint32_t n_ter
         std::memcpy(out[i].payload, ix->doc_payload.data() + 3ull * d, 6);
         out[i]._pad = 0;
     }
+    for (uint32_t d : touched) acc[d] = 0.0;
     return uint32_t(kk);
 }
 

@@ -370,10 +370,12 @@ def test_bench_distributed_code_path_single_rank():
     assert line["n_gpus"] == 1 and line["value"] > 0 and line["roofline"]["frac"] > 0
 
 
-def test_c3_full_size_sample_parity():
-    """BASELINE config C3 at full size (10M docs / 30k vocab, 5-term queries, top-10): a sample of
-    the bench's own queries against both oracles, plus batch invariance at 1024 queries."""
+def test_c3_full_size_full_batch_parity():
+    """BASELINE config C3 at full size (10M docs / 30k vocab, 5-term queries, top-10): ALL 1024 of the
+    bench's own queries bit-exact against the oracle's brute force, a sample against the faithful
+    Block-WAND restatement, plus batch invariance."""
     import sys
+    import time
     sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
     from bench import make_queries as bench_queries, usable_cpus
     seg = vb.Segment.synth(10_000_000, 30000, mean_len=100, len_mode=1, seed=20260925, threads=usable_cpus())
@@ -382,16 +384,75 @@ def test_c3_full_size_sample_parity():
     hits, nh = vb.search_batch(gix, terms, off, 10)
     assert (nh == 10).all()
     oix = orc.OracleIndex.from_arrays(seg.meta(), seg.arrays())
+    t0 = time.perf_counter()
+    ob, onb, _ = oix.search_batch(terms, off, 10, mode="brute", threads=usable_cpus())
+    assert time.perf_counter() - t0 < 60.0, "the full-batch check must stay cheap"
+    assert np.array_equal(nh, onb)
+    for q in range(1024):
+        assert_bit_exact(ob[q, :onb[q]], hits[q, :nh[q]], what=f"q{q} vs brute")
     sample = list(range(0, 1024, 37))
     st = np.concatenate([terms[off[q]:off[q + 1]] for q in sample])
     so = (np.arange(len(sample) + 1) * 5).astype(np.uint32)
-    ob, onb, _ = oix.search_batch(st, so, 10, mode="brute", threads=usable_cpus())
     ow, onw, _ = oix.search_batch(st, so, 10, mode="wand", threads=usable_cpus())
     for i, q in enumerate(sample):
-        assert_bit_exact(ob[i, :onb[i]], hits[q, :nh[q]], what=f"q{q} vs brute")
         assert_same_ranking(ow[i, :onw[i]], hits[q, :nh[q]], ref_ext=oix.search_brute(st[so[i]:so[i + 1]], 300),
                             what=f"q{q} vs wand")
     # the sampled queries alone give the same records as inside the 1024-query batch
     h2, n2 = vb.search_batch(gix, st, so, 10)
     for f in ("score", "doc_id", "payload"):
         assert np.array_equal(h2[f], hits[sample][f]), f
+
+
+@pytest.mark.parametrize("n_docs,vocab,nq,nterms,k", [(300_000, 20_000, 96, 10, 100), (1_000_000, 50_000, 64, 6, 10)])
+def test_maxscore_split_zipf(monkeypatch, n_docs, vocab, nq, nterms, k):
+    """Zipf(1) corpora through scan_range_kernel's MaxScore split (VBM25_RANGE_DENSE=1: threshold bootstrap,
+    non-essential lists looked up instead of scanned, tile retries): same records as the exhaustive
+    scan_many_kernel path (the default for dense queries) and as the oracle."""
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    from bench import make_queries as bench_queries
+    seg = vb.Segment.synth(n_docs, vocab, mean_len=100, len_mode=1, zipf_s=1.0, seed=3)
+    gix = vb.GpuIndex(seg)
+    oix = orc.OracleIndex.from_arrays(seg.meta(), seg.arrays())
+    terms, off = bench_queries(seg, vocab, nq, nterms, seed=5, zipf_s=1.0)
+    h_ex, n_ex = vb.search_batch(gix, terms, off, k)
+    monkeypatch.setenv("VBM25_RANGE_DENSE", "1")  # read when a batch object is created
+    b = vb.Batch(gix, nq, len(terms), k)
+    b.set_queries(terms, off)
+    b.run()
+    h_ne, n_ne = b.fetch()
+    assert h_ne.tobytes() == h_ex.tobytes() and np.array_equal(n_ne, n_ex)
+    ob, onb, _ = oix.search_batch(terms, off, k, mode="brute", threads=8)
+    for q in range(nq):
+        assert_bit_exact(ob[q, :onb[q]], h_ne[q, :n_ne[q]], what=f"q{q} vs brute")
+
+
+def test_c5_full_size_sample_parity(monkeypatch):
+    """BASELINE config C5 at full size (50M docs / 100k vocab Zipf(1), 10-term queries, top-100): the bench's
+    batch of 1024 runs; 32 of its queries bit-exact against the oracle's brute force and ranking-equal to
+    the faithful Block-WAND restatement; the MaxScore-split path gives the same records on 64 of them."""
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    from bench import make_queries as bench_queries, usable_cpus
+    seg = vb.Segment.synth(50_000_000, 100_000, mean_len=100, len_mode=1, zipf_s=1.0, seed=20260925,
+                           threads=usable_cpus())
+    gix = vb.GpuIndex(seg)
+    terms, off = bench_queries(seg, 100_000, 1024, 10, seed=1, zipf_s=1.0)
+    hits, nh = vb.search_batch(gix, terms, off, 100)
+    assert (nh == 100).all()
+    s = hits["score"]
+    assert (s[:, :-1] >= s[:, 1:]).all()
+    oix = orc.OracleIndex.from_arrays(seg.meta(), seg.arrays())
+    ns = 32
+    ob, onb, _ = oix.search_batch(terms[:off[ns]], off[:ns + 1], 100, mode="brute", threads=usable_cpus())
+    ow, onw, _ = oix.search_batch(terms[:off[ns]], off[:ns + 1], 100, mode="wand", threads=usable_cpus())
+    for q in range(ns):
+        assert_bit_exact(ob[q, :onb[q]], hits[q, :nh[q]], what=f"q{q} vs brute")
+        assert_same_ranking(ow[q, :onw[q]], hits[q, :nh[q]], ref_ext=oix.search_brute(terms[off[q]:off[q + 1]], 400),
+                            what=f"q{q} vs wand")
+    monkeypatch.setenv("VBM25_RANGE_DENSE", "1")
+    b = vb.Batch(gix, 64, int(off[64]), 100)
+    b.set_queries(terms[:off[64]], off[:65])
+    b.run()
+    h2, n2 = b.fetch()
+    assert h2.tobytes() == hits[:64].tobytes() and np.array_equal(n2, nh[:64])

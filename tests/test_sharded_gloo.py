@@ -65,3 +65,24 @@ def test_two_rank_gather_equals_single_process(nq):
         b = [vb.sharded.shard_bounds(nq, world, r) for r in range(world)]
         assert b[0][0] == 0 and b[-1][1] == nq and all(b[i][1] == b[i + 1][0] for i in range(world - 1))
         assert max(h - l for l, h in b) - min(h - l for l, h in b) <= 1
+
+
+def test_bench_step_two_ranks_gloo():
+    """bench.py's own distributed step (rank 0 makes the batch, broadcast, shard, search, gather to rank 0)
+    under gloo with the oracle standing in for the GPU (VBM25_BENCH_BACKEND=gloo is a test-only switch)."""
+    import json
+
+    env = dict(os.environ, VBM25_BENCH_BACKEND="gloo")
+    port = 29500 + (os.getpid() + 77) % 1000
+    out = subprocess.run(
+        [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+         "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.join(ROOT, "bench.py"),
+         "--gpus", "2", "--workload", "C1", "--steps", "3", "--warmup", "1", "--verify"],
+        env=env, timeout=600, capture_output=True, text=True)
+    assert out.returncode == 0, out.stderr[-2000:]
+    line = [l for l in out.stdout.splitlines() if l.startswith("{")][-1]
+    d = json.loads(line)
+    assert d["n_gpus"] == 2 and d["steps"] == 3 and d["value"] > 0
+    assert d["config"]["scatter_ms"] > 0 and d["config"]["gather_ms"] > 0
+    assert d["config"]["verified_bit_exact_vs_oracle"]["queries"] == 64
+    assert d["config"]["workload"].startswith("C4")

@@ -573,9 +573,9 @@ static int vbm25_batch_run_impl(vbm25_batch *bt, void *hip_stream) {
             }
         }
         if (!range && (!cursor || bt->has_mid_terms)) scan_kernel<KM><<<grid, CWG, 0, st>>>(ix, db);
-        if (bt->timing) HIP_TRY(hipEventRecord(e1, st));
-        // many-term / dense queries, and items the chain kernel gave up on (empty launch: 5 us)
+        // many-term / dense queries, and items the first-choice kernel gave up on (empty launch: 5 us)
         scan_many_kernel<decltype(kmax)::value><<<grid, WG, 0, st>>>(ix, db);
+        if (bt->timing) HIP_TRY(hipEventRecord(e1, st));  // the events bracket every posting-scan kernel of the step
         merge_kernel<decltype(kmax)::value><<<bt->nq, 64, 0, st>>>(ix, db);
         return int(VBM25_OK);
     });

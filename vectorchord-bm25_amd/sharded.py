@@ -47,3 +47,28 @@ def gather_hits(local_words, n_queries: int, k: int, group=None):
         lo, hi = shard_bounds(n_queries, world, r)
         parts.append(out[r * per:r * per + (hi - lo) * k * 3])
     return torch.cat(parts)
+
+
+def gather_to_root(local_words, n_queries: int, k: int, dst: int = 0, group=None):
+    """Gather the per-rank hit records to rank `dst` only (north_star: "top-k gather"): the all-gather of
+    gather_hits moves world x the bytes anybody needs.  Same padding rule; returns the int64 tensor
+    [n_queries * k * 3] in global query order on `dst`, None elsewhere."""
+    import torch
+    import torch.distributed as dist
+
+    world = dist.get_world_size(group)
+    rank = dist.get_rank(group)
+    per = -(-n_queries // world) * k * 3
+    send = local_words
+    if send.numel() != per:
+        send = torch.zeros(per, dtype=torch.int64, device=local_words.device)
+        send[:local_words.numel()] = local_words
+    bufs = [torch.empty(per, dtype=torch.int64, device=local_words.device) for _ in range(world)] if rank == dst else None
+    dist.gather(send, bufs, dst=dst, group=group)
+    if rank != dst:
+        return None
+    parts = []
+    for r in range(world):
+        lo, hi = shard_bounds(n_queries, world, r)
+        parts.append(bufs[r][:(hi - lo) * k * 3])
+    return torch.cat(parts)
