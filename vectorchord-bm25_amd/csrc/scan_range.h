@@ -39,7 +39,8 @@ constexpr int R_NBLK = (RNW - 1) * RB;  // blocks per tile (slots = lanes 0..R_N
 static_assert(R_NBLK <= 64, "one planner lane per block of a tile");
 constexpr int R_BM_WORDS = 4096;     // 2^17 bits; word R_BM_WORDS is the trash word of out-of-range postings
 constexpr uint32_t R_BM_EXACT = 1u << 17;
-constexpr int R_HS_LOG2 = 10;
+constexpr int R_HS_LOG2 = 10;  // > rows + every lane of the workers inserting at once: the table never fills
+
 constexpr int R_HS = 1 << R_HS_LOG2;  // slots of the second-arrival hash set
 constexpr int R_ROWS = 192;           // rows (documents with a second arrival) per tile at RT = 8; 96 at RT = 16
 constexpr uint32_t R_TARGET_ITEMS = 1024;
@@ -80,6 +81,11 @@ struct RangeLds {
     uint32_t scratch[64];
     uint32_t list[RNW][R_LIST];        // per wave: second arrivals of a tile, inserted in one pass
     uint32_t lcnt[RNW];
+    // planner state (wave 0), kept here between its turns so that the workers do not carry it in registers:
+    // per lane {cur, end, quota, base, slot term, slot offset, df, rank, cur before the last two plans}, then
+    // the uniform words {ne, relax, cap, good, tlo, tlo before the last two plans}
+    uint32_t pl[10][64];
+    uint32_t plu[8];
 };
 
 // First block of [b0, b1) whose max_doc >= d (b1 if none): guess by interpolation over the document space,
@@ -163,7 +169,6 @@ __global__ void __launch_bounds__(RWG, 4) scan_range_kernel(DevIndex ix, DevBatc
         // ---- threshold poll (wave 0): the query's published k-th score and the histogram of accepted documents
         unsigned long long pg = 0;
         uint32_t pc[4] = {0, 0, 0, 0};
-        double hscale = 0.0;
         auto poll_request = [&]() {
             pg = __hip_atomic_load(&bt.theta[q], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 #pragma unroll
@@ -186,7 +191,7 @@ __global__ void __launch_bounds__(RWG, 4) scan_range_kernel(DevIndex ix, DevBatc
                 else if (a + c3 + c2 >= k) b += 2;
                 else if (a + c3 + c2 + c1 >= k) b += 1;
                 // a score lands in bucket b only if score * hscale >= b (up to one rounding)
-                const double edge = ((double)b / hscale) * (1.0 - 1e-12);
+                const double edge = ((double)b / S.hscale) * (1.0 - 1e-12);
                 const unsigned long long eb2 = (unsigned long long)__double_as_longlong(edge);
                 if (eb2 > th) th = eb2;
             }
@@ -199,6 +204,46 @@ __global__ void __launch_bounds__(RWG, 4) scan_range_kernel(DevIndex ix, DevBatc
         };
         // ---- tile planner (wave 0)
         uint32_t p_tlo = lo;
+        auto pl_load = [&]() {
+            p_cur = S.pl[0][lane];
+            p_end = S.pl[1][lane];
+            p_quota = S.pl[2][lane];
+            p_base = S.pl[3][lane];
+            p_st = S.pl[4][lane];
+            p_so = S.pl[5][lane];
+            p_df = S.pl[6][lane];
+            p_rank = S.pl[7][lane];
+            sv_cur[0] = S.pl[8][lane];
+            sv_cur[1] = S.pl[9][lane];
+            p_ne = uni(S.plu[0]);
+            p_relax = uni(S.plu[1]);
+            p_cap = uni(S.plu[2]);
+            p_good = uni(S.plu[3]);
+            p_tlo = uni(S.plu[4]);
+            sv_tlo[0] = uni(S.plu[5]);
+            sv_tlo[1] = uni(S.plu[6]);
+        };
+        auto pl_store = [&]() {
+            S.pl[0][lane] = p_cur;
+            S.pl[1][lane] = p_end;
+            S.pl[2][lane] = p_quota;
+            S.pl[3][lane] = p_base;
+            S.pl[4][lane] = p_st;
+            S.pl[5][lane] = p_so;
+            S.pl[6][lane] = p_df;
+            S.pl[7][lane] = p_rank;
+            S.pl[8][lane] = sv_cur[0];
+            S.pl[9][lane] = sv_cur[1];
+            if (lane == 0) {
+                S.plu[0] = p_ne;
+                S.plu[1] = p_relax;
+                S.plu[2] = p_cap;
+                S.plu[3] = p_good;
+                S.plu[4] = p_tlo;
+                S.plu[5] = sv_tlo[0];
+                S.plu[6] = sv_tlo[1];
+            }
+        };
         // quotas of the essential terms: the 64 candidate slots (one per planner lane) shared in proportion to df,
         // at least one each; slot -> (term, offset)
         auto assign_quotas = [&]() {
@@ -452,7 +497,7 @@ __global__ void __launch_bounds__(RWG, 4) scan_range_kernel(DevIndex ix, DevBatc
             if (lane == 0) S.mq = m;
             __builtin_amdgcn_wave_barrier();
             assign_quotas();
-            hscale = (double)CUR_HB / sums0;  // score -> histogram bucket: linear in [0, sum of s0)
+            const double hscale = (double)CUR_HB / sums0;  // score -> histogram bucket: linear in [0, sum of s0)
             if (lane == 0) {
                 S.q = q;
                 S.lo = lo;
@@ -487,10 +532,10 @@ __global__ void __launch_bounds__(RWG, 4) scan_range_kernel(DevIndex ix, DevBatc
             } else {
                 plan_tile(0);
             }
+            pl_store();
         }
         __syncthreads();
         const uint32_t mq = uni(S.mq);
-        hscale = S.hscale;
 
         RegTopK<RK> rtop;
         rtop.init();
@@ -507,7 +552,7 @@ __global__ void __launch_bounds__(RWG, 4) scan_range_kernel(DevIndex ix, DevBatc
                   (rtop.cnt < k || better(sc, d, rtop.kth_s, rtop.kth_d));
             if (!__ballot(has)) return;
             if (has) {
-                const double hb = sc * hscale;
+                const double hb = sc * S.hscale;
                 const uint32_t b = hb >= (double)(CUR_HB - 1) ? (uint32_t)(CUR_HB - 1) : (uint32_t)hb;
                 atomicAdd(&hrow[b], 1u);
             }
@@ -534,8 +579,8 @@ __global__ void __launch_bounds__(RWG, 4) scan_range_kernel(DevIndex ix, DevBatc
         // one row per document with a second arrival (de-duplicated through the hash set)
         auto insert_row = [&](uint32_t d) {
             uint32_t slot = (d * 0x9E3779B1u) >> (32 - R_HS_LOG2);
-            for (;;) {
-                if (S.nmulti[par] >= (uint32_t)(R_ROWS * 8 / RT)) {
+            for (uint32_t probes = 0;; ++probes) {
+                if (S.nmulti[par] >= (uint32_t)(R_ROWS * 8 / RT) || probes >= (uint32_t)R_HS) {
                     S.fail = 1;
                     break;
                 }
@@ -557,7 +602,6 @@ __global__ void __launch_bounds__(RWG, 4) scan_range_kernel(DevIndex ix, DevBatc
 
         for (uint32_t tile = 0;; ++tile) {
             const uint32_t buf = tile % R_PLAN_RING;
-        retry_tile:
             par = tile & 1u;
             const uint4 hdr = uni4(S.hdr[buf]);
             const uint32_t tlo = hdr.x, thi = hdr.y, np = hdr.z;
@@ -572,9 +616,11 @@ __global__ void __launch_bounds__(RWG, 4) scan_range_kernel(DevIndex ix, DevBatc
             if (wave == 0) {
                 // ---- planner: threshold poll, plan of the next tile (read by the others after barrier A)
                 if (!boot) {
-                    poll_consume();  // requested one tile ago
-                    plan_tile((tile + 1) % R_PLAN_RING);
                     poll_request();
+                    pl_load();
+                    poll_consume();
+                    plan_tile((tile + 1) % R_PLAN_RING);
+                    pl_store();
                 }
             } else {
                 // ---- S1: decode, stage, mark
@@ -698,13 +744,14 @@ __global__ void __launch_bounds__(RWG, 4) scan_range_kernel(DevIndex ix, DevBatc
 
             if (uni(S.fail)) {
                 // The tile overflowed its rows (or a wave its list of second arrivals): lists that intersect that
-                // densely take smaller tiles.  Undo the tile, re-plan it with half the blocks, run it again; an
-                // item that overflows even at one block per term goes to scan_many_kernel.
+                // densely take smaller tiles.  Undo the tile and plan it again with half the blocks as the NEXT
+                // tile; an item that overflows even at one block per term goes to scan_many_kernel.
                 lds_barrier();  // everybody has seen the flag
                 for (uint32_t i = tid; i < R_HS; i += RWG) S.hkeys[i] = EMPTY;
                 for (uint32_t i = tid; i < R_BM_WORDS; i += RWG) S.bm[i] = 0;
                 if (tid < RNW) S.lcnt[tid] = 0;
                 if (wave == 0) {
+                    pl_load();
                     bool give_up = boot;
                     const uint32_t n_ess = uni(S.mq) - p_ne;  // a tile holds at least one block per essential term
                     if (p_cap <= n_ess) {  // smallest tiles already: relax the admissibility rule once
@@ -713,7 +760,8 @@ __global__ void __launch_bounds__(RWG, 4) scan_range_kernel(DevIndex ix, DevBatc
                     }
                     if (lane == 0) {
                         S.fail = give_up ? (0x10u | (boot ? 0x20u : 0u) | S.fail | p_ne << 8 | min(S.nmulti[par], 255u) << 16 | (exact ? 1u << 24 : 0u) | min(np, 127u) << 25) : 0u;
-                        S.nmulti[par] = 0;
+                        S.nmulti[0] = 0;
+                        S.nmulti[1] = 0;
                     }
                     if (!give_up) {
                         p_cap = max(p_cap >> 1, n_ess);
@@ -722,15 +770,16 @@ __global__ void __launch_bounds__(RWG, 4) scan_range_kernel(DevIndex ix, DevBatc
                         p_tlo = sv_tlo[0];
                         sv_cur[1] = p_cur;
                         sv_tlo[1] = p_tlo;
-                        plan_tile(buf);
+                        plan_tile((tile + 1) % R_PLAN_RING);  // replaces the plan made from the failed tile's end
                     }
+                    pl_store();
                 }
                 lds_barrier();
                 if (uni(S.fail)) {
                     failed = true;
                     break;
                 }
-                goto retry_tile;
+                continue;  // the next iteration runs the re-planned tile (a backward goto into this loop cost 20 %)
             }
             const uint32_t nm = min(uni(S.nmulti[par]), (uint32_t)(R_ROWS * 8 / RT));
 
@@ -877,7 +926,7 @@ __global__ void __launch_bounds__(RWG, 4) scan_range_kernel(DevIndex ix, DevBatc
                 }
 #endif
                 if (to_hist) {
-                    if (cand) atomicAdd(&S.bhist[min((uint32_t)(acc * hscale), (uint32_t)(CUR_HB - 1))], 1u);
+                    if (cand) atomicAdd(&S.bhist[min((uint32_t)(acc * S.hscale), (uint32_t)(CUR_HB - 1))], 1u);
                 } else {
                     offer(cand, acc, d);
                 }
@@ -928,7 +977,7 @@ __global__ void __launch_bounds__(RWG, 4) scan_range_kernel(DevIndex ix, DevBatc
                 if (a + c3 >= kk) b += 3;
                 else if (a + c3 + c2 >= kk) b += 2;
                 else if (a + c3 + c2 + c1 >= kk) b += 1;
-                return ((double)b / hscale) * (1.0 - 1e-12);
+                return ((double)b / S.hscale) * (1.0 - 1e-12);
             };
             for (;;) {
                 if (wave != 0) {
@@ -964,19 +1013,20 @@ __global__ void __launch_bounds__(RWG, 4) scan_range_kernel(DevIndex ix, DevBatc
                             const double tf0 = (double)field_val(l0, h0, f0), tf1 = (double)field_val(l1, h1, f1);
                             const double p0 = (tf0 * s0t) / (tf0 + S.s1[fnp & 0xff]);
                             const double p1 = (tf1 * s0t) / (tf1 + S.s1[fnp >> 8]);
-                            if (cmode == 1) {  // single-term scores: lower bounds of the documents' scores
-                                if (ok0) atomicAdd(&S.bhist[min((uint32_t)(p0 * hscale), (uint32_t)(CUR_HB - 1))], 1u);
-                                if (ok1) atomicAdd(&S.bhist[min((uint32_t)(p1 * hscale), (uint32_t)(CUR_HB - 1))], 1u);
-                            } else if (cmode == 2) {  // the best of them, completed in every other list
-                                const double edge = S.boot_edge;
-                                complete(ok0 && p0 >= edge, dd.x, NONE32, t, p0, p0, 1u << t, S.boot_nes, true);
-                                complete(ok1 && p1 >= edge, dd.y, NONE32, t, p1, p1, 1u << t, S.boot_nes, true);
-                            } else if (pne == 0) {
-                                offer(ok0, p0, dd.x);
-                                offer(ok1, p1, dd.y);
-                            } else {
-                                complete(ok0, dd.x, NONE32, t, p0, p0, emask, nesum, false);
-                                complete(ok1, dd.y, NONE32, t, p1, p1, emask, nesum, false);
+#pragma nounroll
+                            for (uint32_t si = 0; si < 2; ++si) {  // the two postings of the lane, one call site each
+                                const bool ok = si ? ok1 : ok0;
+                                const double pp = si ? p1 : p0;
+                                const uint32_t dx = si ? dd.y : dd.x;
+                                if (cmode == 1) {  // single-term scores: lower bounds of the documents' scores
+                                    if (ok) atomicAdd(&S.bhist[min((uint32_t)(pp * S.hscale), (uint32_t)(CUR_HB - 1))], 1u);
+                                } else if (cmode == 0 && pne == 0) {
+                                    offer(ok, pp, dx);
+                                } else {  // cmode 2: the best single-term scores, completed in every other list
+                                    const bool b2 = cmode == 2;
+                                    complete(ok && (!b2 || pp >= S.boot_edge), dx, NONE32, t, pp, pp, b2 ? 1u << t : emask,
+                                             b2 ? S.boot_nes : nesum, b2);
+                                }
                             }
     #ifdef VBM25_PROFILE
                             prof[11] += 1;
@@ -1005,8 +1055,9 @@ __global__ void __launch_bounds__(RWG, 4) scan_range_kernel(DevIndex ix, DevBatc
                             atomicMax(&bt.theta[q], eb2);
                         }
                         __builtin_amdgcn_wave_barrier();
+                        pl_load();
                         plan_tile((tile + 1) % R_PLAN_RING);
-                        poll_request();
+                        pl_store();
                     }
                 }
                 lds_barrier();
