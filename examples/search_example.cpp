@@ -15,7 +15,13 @@ int main(int argc, char **argv) {
     try {
         vbm25::intern("a-lexeme-longer-than-15-bytes");
     } catch (const vbm25::Error &e) {
-        std::printf("intern long lexeme: error %d\n", e.code);
+        std::printf("intern long lexeme without a seed: error %d\n", e.code);
+    }
+    {   // with the index's seed (MetaTuple.seed) the lexeme is keyed by its BLAKE3 keyed hash (vector.rs:26)
+        vbm25::Seed seed{};
+        for (size_t i = 0; i < seed.size(); ++i) seed[i] = uint8_t(i);
+        const vbm25::Key k = vbm25::intern(seed, "a-lexeme-longer-than-15-bytes");
+        std::printf("intern long lexeme with a seed: last byte non-zero: %d\n", k[15] != 0);
     }
     vbm25_synth_params p{};
     p.n_docs = 50000;

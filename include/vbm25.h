@@ -200,6 +200,19 @@ typedef struct vbm25_growing_desc {
     const uint8_t *deleted;    /* n_docs */
 } vbm25_growing_desc;
 int vbm25_growing_from_pages(vbm25_read_page_fn read_page, void *ctx, vbm25_growing **out);
+/* Cache key of the HBM copy of a relation's sealed segment: 32 bytes hashed (BLAKE3) over the Meta and Jump
+ * tuples.  VACUUM replaces the sealed segment by rewriting the Jump tuple (maintain.rs:268-298: new tape
+ * pointers, document count, sum of lengths), REINDEX rewrites Meta (new seed): either changes the fingerprint,
+ * and the shim rebuilds its vbm25_index.  Inserts only append to the vectors tape and leave it unchanged
+ * (the growing segment is read per query). */
+int vbm25_pages_fingerprint(vbm25_read_page_fn read_page, void *ctx, uint8_t *out32);
+/* MetaTuple.seed (tuples.rs:48-57): the key of vbm25_intern's hash for this index. */
+int vbm25_pages_seed(vbm25_read_page_fn read_page, void *ctx, uint8_t *seed32);
+
+/* intern (vector.rs:19-35): a lexeme -> its 16-byte token key.  Shorter than 16 bytes and without NUL: the
+ * bytes, zero padded (seed32 may be NULL).  Otherwise the first 16 bytes of blake3::keyed_hash(seed, lexeme)
+ * (blake3 1.8.4; implemented in csrc/blake3.cpp from the specification), last byte forced non-zero. */
+int vbm25_intern(const uint8_t *seed32, const uint8_t *string, size_t len, uint8_t *key16);
 int vbm25_growing_get_desc(const vbm25_growing *, vbm25_growing_desc *out);
 void vbm25_growing_free(vbm25_growing *);
 

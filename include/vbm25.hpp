@@ -4,7 +4,7 @@
 // The reference is Rust; there is no rustc in the build image, so the host side that a
 // maintainer would write in Rust is mirrored here in C++ with the same
 // names, argument meaning and error behaviour:
-//   vbm25::intern        crates/bm25/src/vector.rs:19-35   (short path; see note)
+//   vbm25::intern        crates/bm25/src/vector.rs:19-35   (incl. the BLAKE3 keyed hash of long lexemes)
 //   vbm25::Query         crates/bm25/src/vector.rs:96-134  (sorted unique 16-byte keys)
 //   vbm25::Index::search crates/bm25/src/search.rs:28-36   (bm25::search, filter == true)
 //   vbm25::search_growing, vbm25::merge_growing   crates/bm25/src/search.rs:83-135  (unsealed documents, host side)
@@ -37,16 +37,20 @@ inline void check(int rc) {
     if (rc != VBM25_OK) throw Error(rc, vbm25_last_error());
 }
 
-// vector.rs:19-35.  Lexemes of 16 bytes or more (or containing NUL) are hashed with
-// blake3::keyed_hash (blake3 1.8.4) in the reference; that dependency is outside the query
-// hot path and not reproduced: such lexemes raise VBM25_ERR_UNSUPPORTED here.
+using Seed = std::array<uint8_t, 32>;  // MetaTuple.seed (tuples.rs:48-57)
+
+// vector.rs:19-35: short lexemes are zero padded; lexemes of 16 bytes or more (or containing NUL) are the
+// first 16 bytes of blake3::keyed_hash(seed, lexeme), last byte forced non-zero.
+inline Key intern(const Seed &seed, std::string_view s) {
+    Key k{};
+    check(vbm25_intern(seed.data(), reinterpret_cast<const uint8_t *>(s.data()), s.size(), k.data()));
+    return k;
+}
+// short path only (no index at hand): a lexeme that needs the hash raises VBM25_ERR_INVALID
 inline Key intern(std::string_view s) {
-    if (s.size() < WIDTH && s.find('\0') == std::string_view::npos) {
-        Key k{};
-        std::memcpy(k.data(), s.data(), s.size());
-        return k;
-    }
-    throw Error(VBM25_ERR_UNSUPPORTED, "intern(): lexemes >= 16 bytes need blake3::keyed_hash");
+    Key k{};
+    check(vbm25_intern(nullptr, reinterpret_cast<const uint8_t *>(s.data()), s.size(), k.data()));
+    return k;
 }
 
 // vector.rs:96-134
@@ -58,9 +62,9 @@ class Query {
     }
     // cast_tsvector_to_query, src/datatype/tsvector.rs:96-105: intern, sort, dedup
     template <class It>
-    static Query from_tokens(It first, It last) {
+    static Query from_tokens(It first, It last, const Seed *seed = nullptr) {
         std::vector<Key> keys;
-        for (; first != last; ++first) keys.push_back(intern(*first));
+        for (; first != last; ++first) keys.push_back(seed ? intern(*seed, *first) : intern(*first));
         std::sort(keys.begin(), keys.end());
         keys.erase(std::unique(keys.begin(), keys.end()), keys.end());
         return Query(std::move(keys));

@@ -55,7 +55,12 @@ def test_no_cpu_fallback_without_device():
 def test_intern_and_query():
     assert vb.intern(b"12345") == b"12345" + b"\0" * 11
     with pytest.raises(vb.Vbm25Error):
-        vb.intern(b"x" * 16)
+        vb.intern(b"x" * 16)  # needs the index's seed
+    seed = bytes(range(32))
+    long_key = vb.intern(b"x" * 16, seed)
+    assert len(long_key) == 16 and long_key[15] != 0 and long_key != vb.intern(b"x" * 17, seed)
+    assert vb.intern(b"a\0b", seed) != b"a\0b" + b"\0" * 13  # a NUL inside takes the hash path too
+    assert vb.intern(b"short", seed) == b"short" + b"\0" * 11
     q = vb.Query.from_tokens([b"9", b"10", b"9"])
     assert q.keys == [vb.intern(b"10"), vb.intern(b"9")]  # bytewise order: "10" < "9"
     with pytest.raises(ValueError):

@@ -23,7 +23,8 @@ def build_example(tmp_path):
 def test_cpp_mirror_host_side(tmp_path):
     out = subprocess.check_output([build_example(tmp_path), "host"], text=True)
     assert "query has 3 keys; first = 10" in out  # sorted bytewise, de-duplicated
-    assert "intern long lexeme: error -4" in out
+    assert "intern long lexeme without a seed: error -1" in out
+    assert "intern long lexeme with a seed: last byte non-zero: 1" in out
     assert "segment: 50000 docs, 200 terms" in out
     assert "growing: 1 hit(s), merged 1, payload (1,2,3), score > 0: 1" in out
     assert "from_pages without pages: error -2" in out

@@ -208,7 +208,8 @@ def test_page_reader_under_asan(tmp_path):
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     exe = str(tmp_path / "fuzz_pages")
     src = [os.path.join(root, p) for p in ("tests/native/fuzz_pages.cpp", "vectorchord-bm25_amd/csrc/pages.cpp",
-                                           "vectorchord-bm25_amd/csrc/segment.cpp", "oracle/oracle.cpp", "oracle/pages.cpp")]
+                                           "vectorchord-bm25_amd/csrc/segment.cpp", "vectorchord-bm25_amd/csrc/blake3.cpp", "oracle/oracle.cpp",
+                                           "oracle/pages.cpp")]
     subprocess.check_call(["g++", "-std=c++17", "-O1", "-g", "-fsanitize=address,undefined", "-fno-omit-frame-pointer",
                            "-pthread", *src, "-o", exe])
     out = subprocess.run([exe], capture_output=True, text=True, timeout=600)

@@ -56,6 +56,9 @@ ABI = {
     "vbm25_growing_from_pages": (i32, [vp, vp, vp]),
     "vbm25_growing_get_desc": (i32, [vp, vp]),
     "vbm25_growing_free": (None, [vp]),
+    "vbm25_pages_fingerprint": (i32, [vp, vp, vp]),
+    "vbm25_pages_seed": (i32, [vp, vp, vp]),
+    "vbm25_intern": (i32, [vp, vp, C.c_size_t, vp]),
     "vbm25_index_create": (i32, [vp, i32, vp]),
     "vbm25_index_destroy": (None, [vp]),
     "vbm25_index_device_bytes": (u64, [vp]),

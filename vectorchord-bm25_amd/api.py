@@ -30,13 +30,16 @@ def _p(a):
     return a.ctypes.data_as(C.c_void_p) if a is not None and a.size else None
 
 
-def intern(string: bytes) -> bytes:
-    """vector.rs:19-35, short path only: strings shorter than 16 bytes without NUL are
-    zero padded.  Longer strings need the BLAKE3 keyed hash (blake3 1.8.4), which is outside
-    the query hot path and not implemented here."""
-    if len(string) < WIDTH and b"\0" not in string:
-        return string + b"\0" * (WIDTH - len(string))
-    raise Vbm25Error(-4, "intern(): lexemes >= 16 bytes need blake3::keyed_hash (not implemented)")
+def intern(string: bytes, seed: bytes = None) -> bytes:
+    """vector.rs:19-35: strings shorter than 16 bytes without NUL are zero padded; the others are the first
+    16 bytes of blake3::keyed_hash(seed, string) with the last byte forced non-zero.  `seed` = MetaTuple.seed
+    of the index (pages_seed())."""
+    string = bytes(string)
+    out = (C.c_uint8 * WIDTH)()
+    if seed is not None and len(seed) != 32:
+        raise ValueError("the seed is 32 bytes")
+    check(lib().vbm25_intern(seed, string, len(string), out))
+    return bytes(out)
 
 
 class Query:
@@ -49,9 +52,9 @@ class Query:
         self.keys = keys
 
     @classmethod
-    def from_tokens(cls, tokens):
+    def from_tokens(cls, tokens, seed=None):
         """cast_tsvector_to_query (src/datatype/tsvector.rs:96-105): intern, sort, dedup."""
-        return cls(sorted({intern(t) for t in tokens}))
+        return cls(sorted({intern(t, seed) for t in tokens}))
 
 
 class Segment:
@@ -314,6 +317,22 @@ def segment_from_pages(pages):
     out = C.c_void_p()
     check(lib().vbm25_segment_from_pages(C.cast(cb, C.c_void_p), None, C.byref(out)))
     return Segment(out)
+
+
+def pages_fingerprint(pages) -> bytes:
+    """vbm25_pages_fingerprint: cache key of the relation's sealed segment (changes on VACUUM / REINDEX)."""
+    cb, keep = _page_reader(pages)
+    out = (C.c_uint8 * 32)()
+    check(lib().vbm25_pages_fingerprint(C.cast(cb, C.c_void_p), None, out))
+    return bytes(out)
+
+
+def pages_seed(pages) -> bytes:
+    """MetaTuple.seed of the relation (the key of intern's hash)."""
+    cb, keep = _page_reader(pages)
+    out = (C.c_uint8 * 32)()
+    check(lib().vbm25_pages_seed(C.cast(cb, C.c_void_p), None, out))
+    return bytes(out)
 
 
 def growing_from_pages(pages):

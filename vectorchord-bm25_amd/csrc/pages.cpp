@@ -207,6 +207,11 @@ int vbm25_segment_from_pages(vbm25_read_page_fn read_page, void *ctx, vbm25_segm
             ++j;
         });
         if (j != sums.size()) throw Corrupt{"fewer blocks than summaries", jump.ptr_blocks};
+        {   // the same structural checks vbm25_index_create makes: a segment handed out is valid or refused
+            vbm25_index_desc d;
+            seg->desc(&d);
+            if (int rc = check_desc(&d)) return rc;
+        }
         *out = seg.release();
         return VBM25_OK;
     } catch (const Corrupt &c) {
@@ -240,6 +245,12 @@ int vbm25_growing_from_pages(vbm25_read_page_fn read_page, void *ctx, vbm25_grow
             if (size < 16) throw Corrupt{"vector tuple too short", page};
             switch (rd<uint64_t>(t)) {
             case 2:  // fieldnorm: starts a document
+                if (open) {  // a _2 while a document is open: the reference overwrites its state (search.rs:94-96),
+                             // i.e. drops the unfinished document (an insert that failed before its _0)
+                    g->fieldnorm.pop_back();
+                    g->key.resize(16 * g->start.back());
+                    g->tf.resize(g->start.back());
+                }
                 g->fieldnorm.push_back(t[8]);
                 open = true;
                 break;
@@ -272,6 +283,53 @@ int vbm25_growing_from_pages(vbm25_read_page_fn read_page, void *ctx, vbm25_grow
         return set_error(VBM25_ERR_NOMEM, "out of host memory while reading the growing segment");
     } catch (const std::exception &e) {
         return set_error(VBM25_ERR_INVALID, "internal error: %s", e.what());
+    }
+}
+
+// Meta and Jump tuple bytes of the relation (the two tuples that change when the sealed segment is replaced)
+static int meta_jump_bytes(vbm25_read_page_fn read_page, void *ctx, uint8_t *meta72, uint8_t *jump64) {
+    const Relation rel{read_page, ctx, {}};
+    uint32_t size = 0;
+    const PageView meta_page = rel.read(0);
+    const uint8_t *m = meta_page.get(1, size);
+    if (size < 72 || std::memcmp(m, "vchordbm", 8) != 0) throw Corrupt{"bad magic number", 0};
+    if (rd<uint64_t>(m + 8) != 1) throw Corrupt{"bad version number: REINDEX needed", 0};
+    std::memcpy(meta72, m, 72);
+    if (jump64) {
+        const uint32_t ptr_jump = rd<uint32_t>(m + 36);
+        const PageView jp = rel.read(ptr_jump);
+        const uint8_t *j = jp.get(1, size);
+        if (size < 64) throw Corrupt{"jump tuple too short", ptr_jump};
+        std::memcpy(jump64, j, 64);
+    }
+    return VBM25_OK;
+}
+
+int vbm25_pages_seed(vbm25_read_page_fn read_page, void *ctx, uint8_t *seed32) {
+    if (!read_page || !seed32) return set_error(VBM25_ERR_INVALID, "NULL argument");
+    try {
+        uint8_t meta[72];
+        meta_jump_bytes(read_page, ctx, meta, nullptr);
+        std::memcpy(seed32, meta + 40, 32);  // MetaTuple.seed, tuples.rs:48-57
+        return VBM25_OK;
+    } catch (const Corrupt &c) {
+        return set_error(VBM25_ERR_CORRUPT, "data corruption: %s (page %u)", c.what, c.page);
+    } catch (...) {
+        return set_error(VBM25_ERR_INVALID, "internal error");
+    }
+}
+
+int vbm25_pages_fingerprint(vbm25_read_page_fn read_page, void *ctx, uint8_t *out32) {
+    if (!read_page || !out32) return set_error(VBM25_ERR_INVALID, "NULL argument");
+    try {
+        uint8_t buf[72 + 64];
+        meta_jump_bytes(read_page, ctx, buf, buf + 72);
+        blake3(nullptr, buf, sizeof buf, out32, 32);
+        return VBM25_OK;
+    } catch (const Corrupt &c) {
+        return set_error(VBM25_ERR_CORRUPT, "data corruption: %s (page %u)", c.what, c.page);
+    } catch (...) {
+        return set_error(VBM25_ERR_INVALID, "internal error");
     }
 }
 

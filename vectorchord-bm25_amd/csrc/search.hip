@@ -92,7 +92,7 @@ using namespace vbm25;
 struct vbm25_index {
     int device = 0;
     DevIndex dev{};
-    uint32_t n_docs = 0, n_terms = 0, n_blocks = 0;
+    uint32_t n_docs = 0, n_terms = 0, n_blocks = 0;  // n_docs == 0: empty sealed segment, every search returns no hit
     std::vector<uint8_t> term_key;  // host copy for vbm25_lookup_terms
     std::vector<uint32_t> term_df_host;  // host copy for query routing
     vbm25_batch *scratch = nullptr;      // batch object re-used by vbm25_search_batch
@@ -103,6 +103,7 @@ struct vbm25_index {
 
 struct vbm25_batch {
     vbm25_index *index = nullptr;
+    int device = 0;  // the index's device ordinal: the batch can be destroyed after its index
     uint32_t max_queries = 0, max_terms = 0, k = 0, nq = 0, max_items = 0;
     DeviceBuffer term_ids, q_off, items, n_items, q_item_base, theta, res_score, res_doc, res_cnt,
         hits, n_hits, error_flag, prof, q_dense, spill, item_failed, work_ctr, hist;
@@ -134,63 +135,6 @@ struct vbm25_batch {
 };
 
 namespace {
-
-int check_desc(const vbm25_index_desc *d) {
-    if (!d) return set_error(VBM25_ERR_INVALID, "desc is NULL");
-    if (!d->n_docs) return set_error(VBM25_ERR_INVALID, "index without documents");
-    if (!(d->k1 >= 1.2 && d->k1 <= 2.0) || !(d->b >= 0.0 && d->b <= 1.0))
-        return set_error(VBM25_ERR_INVALID, "k1 must be in [1.2, 2] and b in [0, 1]");
-    if (d->n_terms && (!d->term_key || !d->term_df || !d->term_first_block || !d->term_wand_tf || !d->term_wand_fn))
-        return set_error(VBM25_ERR_INVALID, "term arrays missing");
-    if (d->n_blocks && (!d->blk_min_doc || !d->blk_max_doc || !d->blk_n || !d->blk_meta_doc ||
-                        !d->blk_meta_tf || !d->blk_off8 || !d->blob))
-        return set_error(VBM25_ERR_INVALID, "block arrays missing");
-    if (!d->doc_fieldnorm || !d->doc_payload)
-        return set_error(VBM25_ERR_INVALID, "document arrays missing");
-    if (d->n_terms) {
-        if (d->term_first_block[0] != 0 || d->term_first_block[d->n_terms] != d->n_blocks)
-            return set_error(VBM25_ERR_CORRUPT, "term_first_block does not cover the blocks");
-        for (uint32_t t = 0; t < d->n_terms; ++t) {
-            uint32_t nb = d->term_first_block[t + 1] - d->term_first_block[t];
-            if (d->term_first_block[t + 1] < d->term_first_block[t] ||
-                nb != (d->term_df[t] + 127) / 128 || d->term_df[t] == 0 || d->term_df[t] > d->n_docs)
-                return set_error(VBM25_ERR_CORRUPT, "term %u: df / block count mismatch", t);
-            if (t && std::memcmp(d->term_key + 16ull * (t - 1), d->term_key + 16ull * t, 16) >= 0)
-                return set_error(VBM25_ERR_CORRUPT, "term keys not strictly ascending at %u", t);
-        }
-    } else if (d->n_blocks) {
-        return set_error(VBM25_ERR_CORRUPT, "blocks without terms");
-    }
-    for (uint32_t t = 0; t < d->n_terms; ++t) {
-        uint32_t b0 = d->term_first_block[t], b1 = d->term_first_block[t + 1];
-        uint64_t cnt = 0;
-        for (uint32_t j = b0; j < b1; ++j) {
-            const uint32_t n = d->blk_n[j];
-            const uint8_t md = d->blk_meta_doc[j], mt = d->blk_meta_tf[j];
-            if (n < 1 || n > 128 || (j + 1 < b1 && n != 128))
-                return set_error(VBM25_ERR_CORRUPT, "block %u: bad posting count %u", j, n);
-            const bool full = n == 128;
-            for (uint8_t mm : {md, mt}) {
-                const uint32_t w = mm & 127;
-                if (full ? ((mm >> 7) != 0 || w > 32) : ((mm >> 7) != 1 || w < 1 || w > 4))
-                    return set_error(VBM25_ERR_CORRUPT, "block %u: bad codec metadata 0x%02x", j, mm);
-            }
-            const uint32_t ld = (md >> 7) ? (md & 127u) * n : 16u * (md & 127u);
-            const uint32_t lt = (mt >> 7) ? (mt & 127u) * n : 16u * (mt & 127u);
-            const uint64_t need = ((ld + 7) / 8) + ((lt + 7) / 8);
-            if (d->blk_off8[j + 1] < d->blk_off8[j] || d->blk_off8[j + 1] - d->blk_off8[j] != need)
-                return set_error(VBM25_ERR_CORRUPT, "block %u: body length mismatch", j);
-            if (d->blk_min_doc[j] > d->blk_max_doc[j] || d->blk_max_doc[j] >= d->n_docs ||
-                (j > b0 && d->blk_min_doc[j] <= d->blk_max_doc[j - 1]))
-                return set_error(VBM25_ERR_CORRUPT, "block %u: document range out of order", j);
-            cnt += n;
-        }
-        if (cnt != d->term_df[t]) return set_error(VBM25_ERR_CORRUPT, "term %u: df mismatch", t);
-    }
-    if (d->n_blocks && 8ull * d->blk_off8[d->n_blocks] > d->blob_bytes)
-        return set_error(VBM25_ERR_CORRUPT, "blob shorter than the block offsets");
-    return VBM25_OK;
-}
 
 int use_device(int device) {
     HIP_TRY(hipSetDevice(device));
@@ -374,6 +318,7 @@ static int vbm25_batch_create_impl(vbm25_index *ix, uint32_t max_queries, uint32
     if (int rc = use_device(ix->device)) return rc;
     auto bt = std::make_unique<vbm25_batch>();
     bt->index = ix;
+    bt->device = ix->device;
     bt->max_queries = max_queries;
     bt->max_terms = max_total_terms;
     bt->k = k;
@@ -429,13 +374,14 @@ static int vbm25_batch_create_impl(vbm25_index *ix, uint32_t max_queries, uint32
 
 void vbm25_batch_destroy(vbm25_batch *bt) {
     if (!bt) return;
-    (void)hipSetDevice(bt->index->device);
+    (void)hipSetDevice(bt->device);
     delete bt;
 }
 
 static int vbm25_batch_set_queries_impl(vbm25_batch *bt, const uint32_t *term_ids, const uint32_t *q_off,
                             uint32_t nq) {
     if (!bt || !q_off) return set_error(VBM25_ERR_INVALID, "NULL argument");
+    if (!term_ids && nq && q_off[nq] != 0) return set_error(VBM25_ERR_INVALID, "term_ids is NULL but the queries have terms");
     if (nq > bt->max_queries) return set_error(VBM25_ERR_INVALID, "%u queries exceed the batch capacity %u", nq, bt->max_queries);
     if (q_off[0] != 0) return set_error(VBM25_ERR_INVALID, "q_off[0] must be 0");
     bool many = false, mid = false;
@@ -515,6 +461,10 @@ static int vbm25_batch_run_impl(vbm25_batch *bt, void *hip_stream) {
     if (!bt->nq) return VBM25_OK;
     if (int rc = use_device(bt->index->device)) return rc;
     hipStream_t st = static_cast<hipStream_t>(hip_stream);
+    if (bt->index->n_docs == 0) {  // empty sealed segment: no hits (the growing segment is the shim's, search.rs:83-135)
+        HIP_TRY(hipMemsetAsync(bt->n_hits.p, 0, 4ull * bt->nq, st));
+        return VBM25_OK;
+    }
     DevBatch db{};
     db.term_ids = bt->term_ids.as<uint32_t>();
     db.q_off = bt->q_off.as<uint32_t>();

@@ -20,6 +20,8 @@
 #include <cmath>
 #include <cstdio>
 #include <cstring>
+#include <exception>
+#include <mutex>
 #include <memory>
 #include <numeric>
 #include <string>
@@ -208,20 +210,38 @@ int resolve_threads(int threads) {
     return hc ? int(hc) : 1;
 }
 
+// Runs fn(task, thread) over a pool.  No exception leaves a worker thread (that would be std::terminate,
+// i.e. the death of the host process -- a PostgreSQL backend): the first one is kept and rethrown on the
+// calling thread after every thread has been joined; thread creation failing is handled the same way.
 template <class F>
 void parallel_tasks(size_t n_tasks, int threads, F &&fn) {
     std::atomic<size_t> next{0};
+    std::exception_ptr first_error;
+    std::mutex error_mutex;
     auto worker = [&](int tid) {
-        for (;;) {
-            size_t i = next.fetch_add(1, std::memory_order_relaxed);
-            if (i >= n_tasks) break;
-            fn(i, tid);
+        try {
+            for (;;) {
+                size_t i = next.fetch_add(1, std::memory_order_relaxed);
+                if (i >= n_tasks) break;
+                fn(i, tid);
+            }
+        } catch (...) {
+            std::lock_guard<std::mutex> g(error_mutex);
+            if (!first_error) first_error = std::current_exception();
+            next.store(n_tasks, std::memory_order_relaxed);  // the others stop at their next task
         }
     };
     std::vector<std::thread> pool;
-    for (int t = 1; t < threads; ++t) pool.emplace_back(worker, t);
+    try {
+        for (int t = 1; t < threads; ++t) pool.emplace_back(worker, t);
+    } catch (...) {  // std::system_error: run with the threads that exist
+        std::lock_guard<std::mutex> g(error_mutex);
+        if (!first_error) first_error = std::current_exception();
+        next.store(n_tasks, std::memory_order_relaxed);
+    }
     worker(0);
     for (auto &th : pool) th.join();
+    if (first_error) std::rethrow_exception(first_error);
 }
 
 void init_encoder(Encoder &enc, const Segment &seg) {
@@ -413,6 +433,70 @@ bool get(FILE *f, std::vector<T> &v, uint64_t file_bytes) {
 }  // namespace
 
 
+namespace vbm25 {
+// Structural validation of a flattened segment (shared by vbm25_index_create and vbm25_segment_from_pages):
+// what the reference would panic on as "data corruption" returns VBM25_ERR_CORRUPT.
+int check_desc(const vbm25_index_desc *d) {
+    if (!d) return set_error(VBM25_ERR_INVALID, "desc is NULL");
+    if (!d->n_docs) {  // valid in the reference: every row is still in the growing segment; search returns nothing
+        if (d->n_terms || d->n_blocks) return set_error(VBM25_ERR_CORRUPT, "terms or blocks without documents");
+        return VBM25_OK;
+    }
+    if (!(d->k1 >= 1.2 && d->k1 <= 2.0) || !(d->b >= 0.0 && d->b <= 1.0))
+        return set_error(VBM25_ERR_INVALID, "k1 must be in [1.2, 2] and b in [0, 1]");
+    if (d->n_terms && (!d->term_key || !d->term_df || !d->term_first_block || !d->term_wand_tf || !d->term_wand_fn))
+        return set_error(VBM25_ERR_INVALID, "term arrays missing");
+    if (d->n_blocks && (!d->blk_min_doc || !d->blk_max_doc || !d->blk_n || !d->blk_meta_doc ||
+                        !d->blk_meta_tf || !d->blk_off8 || !d->blob))
+        return set_error(VBM25_ERR_INVALID, "block arrays missing");
+    if (!d->doc_fieldnorm || !d->doc_payload)
+        return set_error(VBM25_ERR_INVALID, "document arrays missing");
+    if (d->n_terms) {
+        if (d->term_first_block[0] != 0 || d->term_first_block[d->n_terms] != d->n_blocks)
+            return set_error(VBM25_ERR_CORRUPT, "term_first_block does not cover the blocks");
+        for (uint32_t t = 0; t < d->n_terms; ++t) {
+            uint32_t nb = d->term_first_block[t + 1] - d->term_first_block[t];
+            if (d->term_first_block[t + 1] < d->term_first_block[t] ||
+                nb != (d->term_df[t] + 127) / 128 || d->term_df[t] == 0 || d->term_df[t] > d->n_docs)
+                return set_error(VBM25_ERR_CORRUPT, "term %u: df / block count mismatch", t);
+            if (t && std::memcmp(d->term_key + 16ull * (t - 1), d->term_key + 16ull * t, 16) >= 0)
+                return set_error(VBM25_ERR_CORRUPT, "term keys not strictly ascending at %u", t);
+        }
+    } else if (d->n_blocks) {
+        return set_error(VBM25_ERR_CORRUPT, "blocks without terms");
+    }
+    for (uint32_t t = 0; t < d->n_terms; ++t) {
+        uint32_t b0 = d->term_first_block[t], b1 = d->term_first_block[t + 1];
+        uint64_t cnt = 0;
+        for (uint32_t j = b0; j < b1; ++j) {
+            const uint32_t n = d->blk_n[j];
+            const uint8_t md = d->blk_meta_doc[j], mt = d->blk_meta_tf[j];
+            if (n < 1 || n > 128 || (j + 1 < b1 && n != 128))
+                return set_error(VBM25_ERR_CORRUPT, "block %u: bad posting count %u", j, n);
+            const bool full = n == 128;
+            for (uint8_t mm : {md, mt}) {
+                const uint32_t w = mm & 127;
+                if (full ? ((mm >> 7) != 0 || w > 32) : ((mm >> 7) != 1 || w < 1 || w > 4))
+                    return set_error(VBM25_ERR_CORRUPT, "block %u: bad codec metadata 0x%02x", j, mm);
+            }
+            const uint32_t ld = (md >> 7) ? (md & 127u) * n : 16u * (md & 127u);
+            const uint32_t lt = (mt >> 7) ? (mt & 127u) * n : 16u * (mt & 127u);
+            const uint64_t need = ((ld + 7) / 8) + ((lt + 7) / 8);
+            if (d->blk_off8[j + 1] < d->blk_off8[j] || d->blk_off8[j + 1] - d->blk_off8[j] != need)
+                return set_error(VBM25_ERR_CORRUPT, "block %u: body length mismatch", j);
+            if (d->blk_min_doc[j] > d->blk_max_doc[j] || d->blk_max_doc[j] >= d->n_docs ||
+                (j > b0 && d->blk_min_doc[j] <= d->blk_max_doc[j - 1]))
+                return set_error(VBM25_ERR_CORRUPT, "block %u: document range out of order", j);
+            cnt += n;
+        }
+        if (cnt != d->term_df[t]) return set_error(VBM25_ERR_CORRUPT, "term %u: df mismatch", t);
+    }
+    if (d->n_blocks && 8ull * d->blk_off8[d->n_blocks] > d->blob_bytes)
+        return set_error(VBM25_ERR_CORRUPT, "blob shorter than the block offsets");
+    return VBM25_OK;
+}
+}  // namespace vbm25
+
 extern "C" {
 
 int vbm25_segment_build(double k1, double b, uint32_t n_docs, const uint32_t *doc_len,
@@ -472,6 +556,10 @@ int vbm25_segment_build(double k1, double b, uint32_t n_docs, const uint32_t *do
         return VBM25_OK;
     } catch (const std::bad_alloc &) {
         return set_error(VBM25_ERR_NOMEM, "out of host memory while building segment");
+    } catch (const std::exception &e) {  // nothing may unwind across the C ABI (std::system_error from std::thread, ...)
+        return set_error(VBM25_ERR_INVALID, "internal error while building segment: %s", e.what());
+    } catch (...) {
+        return set_error(VBM25_ERR_INVALID, "internal error while building segment");
     }
 }
 
@@ -581,6 +669,10 @@ int vbm25_segment_synth(const vbm25_synth_params *pr, vbm25_segment **out) {
         return VBM25_OK;
     } catch (const std::bad_alloc &) {
         return set_error(VBM25_ERR_NOMEM, "out of host memory while generating corpus");
+    } catch (const std::exception &e) {
+        return set_error(VBM25_ERR_INVALID, "internal error while generating corpus: %s", e.what());
+    } catch (...) {
+        return set_error(VBM25_ERR_INVALID, "internal error while generating corpus");
     }
 }
 

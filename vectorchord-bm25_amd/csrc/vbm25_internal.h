@@ -37,6 +37,10 @@ uint8_t length_to_fieldnorm(uint32_t length);
 void bm25_tables(uint32_t n_docs, uint64_t sum_len, double k1, double b, double *s1_256);
 double bm25_s0(uint32_t n_docs, uint32_t df, double k1);
 
+int check_desc(const vbm25_index_desc *d);
+// BLAKE3 hash (key32 == NULL) or keyed hash of `in`; out_len bytes of output
+void blake3(const uint8_t *key32, const uint8_t *in, size_t len, uint8_t *out, size_t out_len);
+
 // Host copy of a flattened sealed segment (the arrays of vbm25_index_desc).
 struct Segment {
     uint32_t n_docs = 0, n_terms = 0, n_blocks = 0;
