@@ -261,8 +261,16 @@ int vbm25_batch_device_results(vbm25_batch *, void **hits, void **n_hits);
 int vbm25_batch_set_timing(vbm25_batch *, int enabled);
 int vbm25_batch_kernel_ms(vbm25_batch *, double *avg_ms, uint32_t *n_launches);
 
-/* bm25::evaluate-style exact scoring of explicit (document, query) pairs is a
- * "next" row and not part of this ABI yet. */
+/* bm25::evaluate (evaluate.rs:22-74) for n_docs documents against ONE query on the device: the seq-scan
+ * form of `tsvector <&> bm25query` (src/index/operators.rs:22-55), batched.  Everything is in term-id space
+ * (vbm25_lookup_terms): q_terms = the query's ids, strictly ascending; ids >= the index's term count (tokens
+ * that are not in the index) are ignored.  Document i is the elements doc_start[i] .. doc_start[i+1]: term id
+ * (ascending in key order; UINT32_MAX for a key that is not in the index -- it still counts for the document's
+ * length) and term frequency (> 0).  scores[i] = sum of idf * tf in query key order, bit-identical to
+ * vbm25_evaluate / the reference (idf through the host's libm log).  The SQL operator negates the value. */
+int vbm25_evaluate_batch(vbm25_index *, const uint32_t *q_terms, uint32_t n_q_terms, uint32_t n_docs,
+                         const uint64_t *doc_start, const uint32_t *doc_term, const uint32_t *doc_tf,
+                         double *scores);
 
 #ifdef __cplusplus
 }

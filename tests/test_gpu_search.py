@@ -456,3 +456,59 @@ def test_c5_full_size_sample_parity(monkeypatch):
     b.run()
     h2, n2 = b.fetch()
     assert h2.tobytes() == hits[:64].tobytes() and np.array_equal(n2, nh[:64])
+
+
+def test_evaluate_batch_on_the_device_matches_the_oracle_bitwise():
+    """vbm25_evaluate_batch (seq-scan `<&>`, evaluate.rs:22-74, many documents x one query on the device)
+    against the oracle's restatement and the host's single-pair vbm25_evaluate, bit for bit."""
+    c = make_corpus(3000, 400, seed=13, length="lognormal", mean_len=40)
+    seg, gix, oix = both(c)
+    a = seg.arrays()
+    n_terms = seg.meta()["n_terms"]
+    rng = np.random.default_rng(4)
+    for trial in range(4):
+        q_rank = np.sort(rng.choice(n_terms, int(rng.integers(1, 9)), replace=False)).astype(np.uint32)
+        q_ids = q_rank if trial % 2 == 0 else np.sort(np.r_[q_rank, np.uint32(0xFFFFFFFF)])  # an unknown query token
+        docs_t, docs_f, start = [], [], [0]
+        for i in range(500):
+            d_rank = np.sort(rng.choice(n_terms, int(rng.integers(0, 40)), replace=False)).astype(np.uint32)
+            if len(d_rank) and rng.random() < 0.7:
+                d_rank = np.unique(np.r_[d_rank, rng.choice(q_rank, min(3, len(q_rank)), replace=False)]).astype(np.uint32)
+            d_tf = rng.integers(1, 2000 if rng.random() < 0.1 else 6, len(d_rank)).astype(np.uint32)
+            docs_t.append(d_rank)
+            docs_f.append(d_tf)
+            start.append(start[-1] + len(d_rank))
+        got = vb.evaluate_batch(gix, q_ids, np.array(start, dtype=np.uint64), np.concatenate(docs_t), np.concatenate(docs_f))
+        for i in range(500):
+            want = orc.lib().orc_score_to_f64(oix.evaluate(docs_t[i], docs_f[i], q_rank))
+            assert got[i] == want, (trial, i)
+        assert (got > 0).sum() > 100
+    # an element whose key is not in the index still counts for the document's length (vector.rs:77-83)
+    k3 = np.array([3], dtype=np.uint32)
+    s_known = vb.evaluate_batch(gix, k3, np.array([0, 1], dtype=np.uint64), k3, np.array([2], dtype=np.uint32))[0]
+    s_longer = vb.evaluate_batch(gix, k3, np.array([0, 2], dtype=np.uint64), np.array([3, 0xFFFFFFFF], dtype=np.uint32),
+                                 np.array([2, 500], dtype=np.uint32))[0]
+    assert 0 < s_longer < s_known
+    want = vb.evaluate(seg, [a["term_key"][3].tobytes(), b"zzzzzzzzzzzzzzz\0"], [2, 500], vb.Query([a["term_key"][3].tobytes()]))
+    assert s_longer == want
+
+
+def test_empty_sealed_segment_and_abi_holes():
+    """An index over an empty table is valid in the reference (every row still in the growing segment): search
+    returns nothing.  NULL term_ids with terms declared is an argument error; a batch may outlive its index."""
+    import ctypes as C
+    meta = dict(n_docs=0, n_terms=0, n_blocks=0, sum_len=0, k1=1.2, b=0.75)
+    arrays = {k: np.zeros(0, dtype=dt) for k, dt in vb.api._DESC_ARRAYS}
+    arrays["term_first_block"] = np.zeros(1, dtype=np.uint32)
+    arrays["blk_off8"] = np.zeros(1, dtype=np.uint32)
+    desc, keep = vb.api.desc_from_arrays(meta, arrays)
+    gix = vb.GpuIndex(desc)
+    hits, nh = vb.search_batch(gix, np.array([0, 5], dtype=np.uint32), np.array([0, 1, 2], dtype=np.uint32), 10)
+    assert nh.tolist() == [0, 0]
+    c = make_corpus(500, 50, seed=2, length="fixed", mean_len=20)
+    seg, gix2, oix = both(c)
+    b = vb.Batch(gix2, 4, 16, 10)
+    rc = vb.lib().vbm25_batch_set_queries(b.h, None, np.array([0, 2], dtype=np.uint32).ctypes.data_as(C.c_void_p), 1)
+    assert rc == -1
+    del gix2  # vbm25_index_destroy before vbm25_batch_destroy
+    del b

@@ -72,6 +72,7 @@ ABI = {
     "vbm25_batch_device_results": (i32, [vp, vp, vp]),
     "vbm25_batch_set_timing": (i32, [vp, i32]),
     "vbm25_batch_kernel_ms": (i32, [vp, vp, vp]),
+    "vbm25_evaluate_batch": (i32, [vp, vp, u32, u32, vp, vp, vp, vp]),
 }
 
 

@@ -368,3 +368,15 @@ def evaluate(segment_or_desc, doc_keys, doc_tfs, query):
     out = C.c_double()
     check(lib().vbm25_evaluate(C.byref(desc), _p(dk), _p(dt), len(dt), _p(qk), len(query.keys), C.byref(out)))
     return out.value
+
+
+def evaluate_batch(index, q_terms, doc_start, doc_term, doc_tf):
+    """vbm25_evaluate_batch: bm25::evaluate for many documents against one query on the device (term-id space)."""
+    q_terms = np.ascontiguousarray(q_terms, dtype=np.uint32)
+    doc_start = np.ascontiguousarray(doc_start, dtype=np.uint64)
+    doc_term = np.ascontiguousarray(doc_term, dtype=np.uint32)
+    doc_tf = np.ascontiguousarray(doc_tf, dtype=np.uint32)
+    out = np.zeros(len(doc_start) - 1, dtype=np.float64)
+    check(lib().vbm25_evaluate_batch(index.h, _p(q_terms), len(q_terms), len(doc_start) - 1,
+                                     doc_start.ctypes.data_as(C.c_void_p), _p(doc_term), _p(doc_tf), _p(out)))
+    return out

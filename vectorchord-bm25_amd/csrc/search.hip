@@ -19,6 +19,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <cmath>
 #include <cstdarg>
 #include <cstdio>
 #include <cstdlib>
@@ -61,6 +62,53 @@ int set_error(int code, const char *fmt, ...) {
 #include "merge.h"
 
 // ---------------------------------------------------------------------------
+// Batched `<&>`: bm25::evaluate (evaluate.rs:22-74) for many documents against one query -- the seq-scan
+// form of the operator (src/index/operators.rs:22-55).  One thread per document: a merge of the document's
+// elements with the query's terms, both ascending; result = sum of idf * tf in query key order.  idf comes
+// from the host (libm log, bm25.rs:285-289), tf() is bm25.rs:291-295 with the index's s1 table (the same
+// expression), the fieldnorm of the document is length_to_fieldnorm of its saturating sum of tfs.
+// ---------------------------------------------------------------------------
+struct EvalArgs {
+    uint32_t n_docs, n_q, n_terms;
+    const uint32_t *q_terms;     // ascending term ids; ids >= n_terms (unknown tokens) are skipped
+    const uint64_t *doc_start;   // n_docs + 1
+    const uint32_t *doc_term;    // per element: term id, NONE32 when the key is not in the index
+    const uint32_t *doc_tf;
+    const double *term_idf, *s1;
+    const uint32_t *fn_len;      // FIELDNORM_TO_LENGTH, 256 entries
+    double k1p1;
+    double *out;
+};
+__global__ void __launch_bounds__(256) evaluate_kernel(EvalArgs a) {
+    const uint32_t d = blockIdx.x * blockDim.x + threadIdx.x;
+    if (d >= a.n_docs) return;
+    const uint64_t e0 = a.doc_start[d], e1 = a.doc_start[d + 1];
+    unsigned long long length = 0;  // Document::length, vector.rs:77-83: saturating
+    for (uint64_t e = e0; e < e1; ++e) {
+        length += a.doc_tf[e];
+        if (length > 0xffffffffull) length = 0xffffffffull;
+    }
+    uint32_t lo = 0, hi = 256;  // length_to_fieldnorm, bm25.rs:278-283: last entry <= length
+    while (hi - lo > 1) {
+        const uint32_t mid = (lo + hi) >> 1;
+        if (a.fn_len[mid] <= (uint32_t)length) lo = mid; else hi = mid;
+    }
+    const double s1 = a.s1[lo];
+    uint64_t cur = e0;
+    double result = 0.0;
+    for (uint32_t i = 0; i < a.n_q; ++i) {
+        const uint32_t qt = a.q_terms[i];
+        if (qt >= a.n_terms) continue;
+        while (cur < e1 && (a.doc_term[cur] >= a.n_terms || a.doc_term[cur] < qt)) ++cur;
+        if (!(cur < e1 && a.doc_term[cur] == qt)) continue;
+        const double tf = (double)a.doc_tf[cur];
+        const double tfv = (tf * a.k1p1) / (tf + s1);
+        result += a.term_idf[qt] * tfv;
+    }
+    a.out[d] = result;
+}
+
+// ---------------------------------------------------------------------------
 // Host objects
 // ---------------------------------------------------------------------------
 struct DeviceBuffer {
@@ -97,7 +145,8 @@ struct vbm25_index {
     std::vector<uint32_t> term_df_host;  // host copy for query routing
     vbm25_batch *scratch = nullptr;      // batch object re-used by vbm25_search_batch
     DeviceBuffer term_wand_tf, term_wand_fn, term_df, term_first_block, term_s0, blk_min_doc, blk_max_doc, blk_meta, blk_ub, blob,
-        post_fn, doc_payload, s1;
+        post_fn, doc_payload, s1, term_idf, fn_len;
+    double k1 = 1.2;
     uint64_t device_bytes = 0;
 };
 
@@ -273,6 +322,15 @@ static int vbm25_index_create_impl(const vbm25_index_desc *d, int device, vbm25_
     ix->dev.post_fn = ix->post_fn.as<uint8_t>();
     ix->dev.doc_payload = ix->doc_payload.as<uint16_t>();
     ix->dev.s1 = ix->s1.as<double>();
+    {   // for vbm25_evaluate_batch: per-term idf (host libm log, bm25.rs:285-289) and the fieldnorm table
+        std::vector<double> idf(d->n_terms);
+        for (uint32_t t = 0; t < d->n_terms; ++t)
+            idf[t] = std::log((double(d->n_docs) + 1.0) / (double(d->term_df[t]) + 0.5));
+        if ((rc = ix->term_idf.upload(idf.data(), 8ull * d->n_terms)) ||
+            (rc = ix->fn_len.upload(fieldnorm_lengths(), 4ull * 256)))
+            return rc;
+        ix->k1 = d->k1;
+    }
     for (const DeviceBuffer *b : {&ix->term_df, &ix->term_first_block, &ix->term_s0, &ix->blk_min_doc,
                                   &ix->blk_max_doc, &ix->blk_meta, &ix->blk_ub, &ix->blob, &ix->post_fn,
                                   &ix->doc_payload, &ix->s1})
@@ -556,6 +614,61 @@ int vbm25_batch_device_results(vbm25_batch *bt, void **hits, void **n_hits) {
     if (hits) *hits = bt->hits.p;
     if (n_hits) *n_hits = bt->n_hits.p;
     return VBM25_OK;
+}
+
+static int vbm25_evaluate_batch_impl(vbm25_index *ix, const uint32_t *q_terms, uint32_t n_q, uint32_t n_docs,
+                                     const uint64_t *doc_start, const uint32_t *doc_term, const uint32_t *doc_tf,
+                                     double *scores) {
+    if (!ix || (n_q && !q_terms) || !doc_start || (n_docs && !scores)) return set_error(VBM25_ERR_INVALID, "NULL argument");
+    if (n_docs == 0) return VBM25_OK;
+    const uint64_t n_el = doc_start[n_docs];
+    if (n_el && (!doc_term || !doc_tf)) return set_error(VBM25_ERR_INVALID, "NULL argument");
+    for (uint32_t i = 1; i < n_q; ++i)  // Query::checked_new, vector.rs:106-110
+        if (q_terms[i] <= q_terms[i - 1] && q_terms[i] < ix->n_terms)
+            return set_error(VBM25_ERR_INVALID, "query term ids must be strictly ascending");
+    for (uint32_t d = 0; d < n_docs; ++d) {
+        if (doc_start[d + 1] < doc_start[d]) return set_error(VBM25_ERR_INVALID, "doc_start not monotone at document %u", d);
+        uint32_t prev = 0;
+        bool first = true;
+        for (uint64_t e = doc_start[d]; e < doc_start[d + 1]; ++e) {
+            if (doc_tf[e] == 0) return set_error(VBM25_ERR_INVALID, "document %u: term frequency 0", d);  // Document::checked_new
+            if (doc_term[e] >= ix->n_terms) continue;
+            if (!first && doc_term[e] <= prev) return set_error(VBM25_ERR_INVALID, "document %u: keys must be strictly ascending", d);
+            prev = doc_term[e];
+            first = false;
+        }
+    }
+    if (int rc = use_device(ix->device)) return rc;
+    if (ix->n_docs == 0) {  // avgdl is 0 / 0 in the reference: NaN scores; report it instead
+        return set_error(VBM25_ERR_INVALID, "evaluate on an index without sealed documents");
+    }
+    DeviceBuffer dq, ds, dt, df, dout;
+    int rc = 0;
+    if ((rc = dq.upload(q_terms, 4ull * n_q)) || (rc = ds.upload(doc_start, 8ull * (n_docs + 1))) ||
+        (rc = dt.upload(doc_term, 4ull * n_el)) || (rc = df.upload(doc_tf, 4ull * n_el)) || (rc = dout.alloc(8ull * n_docs)))
+        return rc;
+    EvalArgs a{};
+    a.n_docs = n_docs;
+    a.n_q = n_q;
+    a.n_terms = ix->n_terms;
+    a.q_terms = dq.as<uint32_t>();
+    a.doc_start = ds.as<uint64_t>();
+    a.doc_term = dt.as<uint32_t>();
+    a.doc_tf = df.as<uint32_t>();
+    a.term_idf = ix->term_idf.as<double>();
+    a.s1 = ix->dev.s1;
+    a.fn_len = ix->fn_len.as<uint32_t>();
+    a.k1p1 = ix->k1 + 1.0;
+    a.out = dout.as<double>();
+    evaluate_kernel<<<(n_docs + 255) / 256, 256>>>(a);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipMemcpy(scores, dout.p, 8ull * n_docs, hipMemcpyDeviceToHost));
+    return VBM25_OK;
+}
+
+int vbm25_evaluate_batch(vbm25_index *ix, const uint32_t *q_terms, uint32_t n_q, uint32_t n_docs,
+                         const uint64_t *doc_start, const uint32_t *doc_term, const uint32_t *doc_tf, double *scores) {
+    return guarded([&] { return vbm25_evaluate_batch_impl(ix, q_terms, n_q, n_docs, doc_start, doc_term, doc_tf, scores); });
 }
 
 // tuning / test aid (not declared in include/vbm25.h): work items of the last run and how many of them the
