@@ -139,9 +139,9 @@ def test_edge_cases():
     assert e.value.code == -1
     with pytest.raises(vb.Vbm25Error):  # not strictly ascending (Query::new)
         vb.search_batch(gix, np.array([5, 5], dtype=np.uint32), np.array([0, 2], dtype=np.uint32), 5)
-    with pytest.raises(vb.Vbm25Error) as e:
-        vb.search_batch(gix, np.array([5], dtype=np.uint32), np.array([0, 1], dtype=np.uint32), 5000)
-    assert e.value.code == -4
+    with pytest.raises(vb.Vbm25Error) as e:  # beyond bm25.limit's maximum (gucs.rs:37-46)
+        vb.search_batch(gix, np.array([5], dtype=np.uint32), np.array([0, 1], dtype=np.uint32), 65536)
+    assert e.value.code == -1
 
 
 def test_codec_corner_case_index():
@@ -512,3 +512,21 @@ def test_empty_sealed_segment_and_abi_holes():
     assert rc == -1
     del gix2  # vbm25_index_destroy before vbm25_batch_destroy
     del b
+
+
+@pytest.mark.parametrize("k", [1025, 5000, 65535])
+def test_k_up_to_bm25_limit_maximum(k):
+    """bm25.limit goes up to 65535 (gucs.rs:37-46): beyond 1024 the exhaustive per-query path (accumulate per term
+    in key order, stable radix sort of score bits) answers, bit-exact against the oracle's brute force."""
+    c = make_corpus(150_000, 3000, seed=11, length="lognormal", mean_len=60)
+    seg, gix, oix = both(c)
+    terms, off = make_queries(c, 6, 5, seed=5)
+    terms = np.r_[terms, np.uint32(0xFFFFFFFF)]  # a last query with an unknown token only: no hits
+    off = np.r_[off, np.uint32(len(terms))].astype(np.uint32)
+    hits, nh = vb.search_batch(gix, terms, off, k)
+    assert nh[-1] == 0
+    for q in range(len(off) - 1):
+        t = terms[off[q]:off[q + 1]]
+        want = oix.search_brute(t[t != 0xFFFFFFFF], k)
+        assert_bit_exact(want, hits[q, :nh[q]], what=f"k={k} q{q} vs brute")
+    assert nh[:-1].min() > 1024

@@ -17,6 +17,7 @@
 // brute-force evaluation.
 
 #include <hip/hip_runtime.h>
+#include <hipcub/hipcub.hpp>
 
 #include <algorithm>
 #include <cmath>
@@ -68,6 +69,55 @@ int set_error(int code, const char *fmt, ...) {
 // from the host (libm log, bm25.rs:285-289), tf() is bm25.rs:291-295 with the index's s1 table (the same
 // expression), the fieldnorm of the document is length_to_fieldnorm of its saturating sum of tfs.
 // ---------------------------------------------------------------------------
+// ---------------------------------------------------------------------------
+// k > 1024 (bm25.limit goes up to 65535, gucs.rs:37-46): exhaustive path, one query at a time.  acc[d] is the
+// score of document d: one launch per term in ascending key order adds that term's postings (a document has
+// at most one posting per term, so the adds of a launch never collide and the sum order is the key order of
+// evaluate.rs:43-72).  Positive doubles order like their bit patterns (crates/score/src/lib.rs:46-60), so a
+// stable descending radix sort of (bits(acc[d]), d) over all documents gives score descending, ties by
+// ascending id; the first k entries with a non-zero key are the result (Results, search.rs:284-314).
+// ---------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) bigk_accum_kernel(DevIndex ix, uint32_t term, double *acc) {
+    const uint32_t lane = threadIdx.x & 63;
+    const uint32_t j0 = ix.term_first_block[term], j1 = ix.term_first_block[term + 1];
+    const double s0 = ix.term_s0[term];
+    for (uint32_t j = j0 + blockIdx.x * (blockDim.x / 64) + (threadIdx.x >> 6); j < j1; j += gridDim.x * (blockDim.x / 64)) {
+        const uint4 bm = ix.blk_meta[j];
+        const uint32_t n = bm.w & 0xff, md = (bm.w >> 8) & 0xff, mt = (bm.w >> 16) & 0xff;
+        const uint8_t *body = ix.blob + 8ull * bm.z;
+        uint32_t d0, d1, f0, f1;
+        decode_doc_ids(body, md, n, bm.x, lane, d0, d1);
+        decode_fields(body + ((payload_bytes(md, n) + 7u) & ~7u), mt, n, lane, f0, f1);
+        const uchar2 fn = reinterpret_cast<const uchar2 *>(ix.post_fn + 128ull * j)[lane];
+        if (2 * lane < n) {
+            const double tf = (double)f0;
+            acc[d0] = acc[d0] + (tf * s0) / (tf + ix.s1[fn.x]);  // Cache::evaluate, bm25.rs:355-358
+        }
+        if (2 * lane + 1 < n) {
+            const double tf = (double)f1;
+            acc[d1] = acc[d1] + (tf * s0) / (tf + ix.s1[fn.y]);
+        }
+    }
+}
+__global__ void __launch_bounds__(256) bigk_iota_kernel(uint32_t *v, uint32_t n) {
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) v[i] = i;
+}
+__global__ void __launch_bounds__(256) bigk_emit_kernel(DevIndex ix, const unsigned long long *keys, const uint32_t *docs,
+                                                        uint32_t n_docs, uint32_t k, vbm25_hit *hits, uint32_t *n_hits) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i == 0 && (n_docs == 0 || keys[0] == 0)) *n_hits = 0;
+    if (i >= k || i >= n_docs) return;
+    const unsigned long long key = keys[i];
+    if (key == 0) return;
+    const uint32_t d = docs[i];
+    const uint16_t *pl = ix.doc_payload + 3ull * d;
+    unsigned long long *out = reinterpret_cast<unsigned long long *>(hits + i);
+    out[0] = key;
+    out[1] = (unsigned long long)d | (unsigned long long)pl[0] << 32 | (unsigned long long)pl[1] << 48;
+    out[2] = (unsigned long long)pl[2];
+    if (i + 1 == k || i + 1 == n_docs || keys[i + 1] == 0) *n_hits = i + 1;
+}
+
 struct EvalArgs {
     uint32_t n_docs, n_q, n_terms;
     const uint32_t *q_terms;     // ascending term ids; ids >= n_terms (unknown tokens) are skipped
@@ -156,6 +206,10 @@ struct vbm25_batch {
     uint32_t max_queries = 0, max_terms = 0, k = 0, nq = 0, max_items = 0;
     DeviceBuffer term_ids, q_off, items, n_items, q_item_base, theta, res_score, res_doc, res_cnt,
         hits, n_hits, error_flag, prof, q_dense, spill, item_failed, work_ctr, hist;
+    bool bigk = false;            // k > 1024: exhaustive path, one query at a time
+    DeviceBuffer bk_acc, bk_keys, bk_iota, bk_docs, bk_tmp;
+    size_t bk_tmp_bytes = 0;
+    std::vector<uint32_t> h_terms, h_off;  // host copy of the queries (bigk launches per term)
     bool timing = false;
     bool has_many_terms = false;  // some query has more than CHAIN_MAX_TERMS indexed terms
     bool use_cursor = false;      // k <= REG_K: queries with at most CUR_T terms take scan_cursor_kernel
@@ -370,8 +424,6 @@ static int vbm25_batch_create_impl(vbm25_index *ix, uint32_t max_queries, uint32
     if (!ix) return set_error(VBM25_ERR_INVALID, "index is NULL");
     if (k == 0) return set_error(VBM25_ERR_INVALID, "number of needed rows is set to 0");  // default.rs:114-116
     if (k > 65535) return set_error(VBM25_ERR_INVALID, "k exceeds bm25.limit's maximum of 65535");
-    if (k > 1024)
-        return set_error(VBM25_ERR_UNSUPPORTED, "k = %u: the GPU path currently keeps at most 1024 hits per query", k);
     if (!max_queries) return set_error(VBM25_ERR_INVALID, "max_queries is 0");
     if (int rc = use_device(ix->device)) return rc;
     auto bt = std::make_unique<vbm25_batch>();
@@ -406,6 +458,23 @@ static int vbm25_batch_create_impl(vbm25_index *ix, uint32_t max_queries, uint32
     }
     bt->max_items = max_queries + bt->target_items;
     int rc = 0;
+    if (k > 1024) {  // exhaustive path: query buffers, results and an accumulator per document
+        bt->bigk = true;
+        bt->use_range = bt->use_cursor = false;
+        const size_t n = ix->n_docs ? ix->n_docs : 1;
+        hipcub::DeviceRadixSort::SortPairsDescending(nullptr, bt->bk_tmp_bytes, (const unsigned long long *)nullptr,
+                                                     (unsigned long long *)nullptr, (const uint32_t *)nullptr,
+                                                     (uint32_t *)nullptr, (int)n);
+        if ((rc = bt->hits.alloc(sizeof(vbm25_hit) * size_t(max_queries) * k)) || (rc = bt->n_hits.alloc(4ull * max_queries)) ||
+            (rc = bt->error_flag.alloc(4)) || (rc = bt->bk_acc.alloc(8 * n)) || (rc = bt->bk_keys.alloc(8 * n)) ||
+            (rc = bt->bk_iota.alloc(4 * n)) || (rc = bt->bk_docs.alloc(4 * n)) || (rc = bt->bk_tmp.alloc(bt->bk_tmp_bytes)))
+            return rc;
+        HIP_TRY(hipMemset(bt->error_flag.p, 0, 4));
+        bigk_iota_kernel<<<1024, 256>>>(bt->bk_iota.as<uint32_t>(), (uint32_t)n);
+        HIP_TRY(hipGetLastError());
+        *out = bt.release();
+        return VBM25_OK;
+    }
     if ((rc = bt->term_ids.alloc(4ull * max_total_terms)) ||
         (rc = bt->q_off.alloc(4ull * (max_queries + 1))) ||
         (rc = bt->items.alloc(sizeof(Item) * size_t(bt->max_items))) || (rc = bt->n_items.alloc(4)) ||
@@ -483,6 +552,12 @@ static int vbm25_batch_set_queries_impl(vbm25_batch *bt, const uint32_t *term_id
     }
     if (q_off[nq] > bt->max_terms) return set_error(VBM25_ERR_INVALID, "%u terms exceed the batch capacity %u", q_off[nq], bt->max_terms);
     if (int rc = use_device(bt->index->device)) return rc;
+    if (bt->bigk) {
+        bt->h_terms.assign(term_ids, term_ids + q_off[nq]);
+        bt->h_off.assign(q_off, q_off + nq + 1);
+        bt->nq = nq;
+        return VBM25_OK;
+    }
     if (q_off[nq]) HIP_TRY(hipMemcpy(bt->term_ids.p, term_ids, 4ull * q_off[nq], hipMemcpyHostToDevice));
     HIP_TRY(hipMemcpy(bt->q_off.p, q_off, 4ull * (nq + 1), hipMemcpyHostToDevice));
     if (nq) HIP_TRY(hipMemcpy(bt->q_dense.p, dense.data(), nq, hipMemcpyHostToDevice));
@@ -521,6 +596,28 @@ static int vbm25_batch_run_impl(vbm25_batch *bt, void *hip_stream) {
     hipStream_t st = static_cast<hipStream_t>(hip_stream);
     if (bt->index->n_docs == 0) {  // empty sealed segment: no hits (the growing segment is the shim's, search.rs:83-135)
         HIP_TRY(hipMemsetAsync(bt->n_hits.p, 0, 4ull * bt->nq, st));
+        return VBM25_OK;
+    }
+    if (bt->bigk) {
+        const DevIndex &dix = bt->index->dev;
+        const uint32_t n = bt->index->n_docs;
+        for (uint32_t q = 0; q < bt->nq; ++q) {
+            HIP_TRY(hipMemsetAsync(bt->bk_acc.p, 0, 8ull * n, st));
+            for (uint32_t p = bt->h_off[q]; p < bt->h_off[q + 1]; ++p) {
+                const uint32_t t = bt->h_terms[p];
+                if (t >= bt->index->n_terms) continue;  // search.rs:59-61
+                const uint32_t nb = (bt->index->term_df_host[t] + 127) / 128;
+                bigk_accum_kernel<<<std::min<uint32_t>((nb + 3) / 4, 4096u), 256, 0, st>>>(dix, t, bt->bk_acc.as<double>());
+            }
+            size_t tmp = bt->bk_tmp_bytes;
+            HIP_TRY(hipcub::DeviceRadixSort::SortPairsDescending(bt->bk_tmp.p, tmp, bt->bk_acc.as<unsigned long long>(),
+                                                                  bt->bk_keys.as<unsigned long long>(), bt->bk_iota.as<uint32_t>(),
+                                                                  bt->bk_docs.as<uint32_t>(), (int)n, 0, 64, st));
+            bigk_emit_kernel<<<(bt->k + 255) / 256, 256, 0, st>>>(dix, bt->bk_keys.as<unsigned long long>(), bt->bk_docs.as<uint32_t>(), n,
+                                                                  bt->k, bt->hits.as<vbm25_hit>() + size_t(q) * bt->k,
+                                                                  bt->n_hits.as<uint32_t>() + q);
+        }
+        HIP_TRY(hipGetLastError());
         return VBM25_OK;
     }
     DevBatch db{};
