@@ -88,6 +88,14 @@ int vbm25_segment_build(double k1, double b, uint32_t n_docs, const uint32_t *do
                         const uint64_t *term_start, const uint32_t *post_doc,
                         const uint32_t *post_tf, int threads, vbm25_segment **out);
 
+/* The same construction on the device (csrc/flush.hip): one wave per 128-posting block (bit
+ * width = OR of the deltas, 4-lane vertical packing, first-maximiser WAND pairs).  Same arguments, same
+ * vbm25_segment, byte for byte; needs a gfx950 device (VBM25_ERR_DEVICE otherwise -- no silent fallback). */
+int vbm25_segment_build_device(int device, double k1, double b, uint32_t n_docs, const uint32_t *doc_len,
+                               const uint16_t *doc_payload, uint32_t n_terms, const uint8_t *term_key,
+                               const uint64_t *term_start, const uint32_t *post_doc,
+                               const uint32_t *post_tf, vbm25_segment **out);
+
 /* Synthetic corpus of SURVEY section 8(d), generated per token so that 10M-50M
  * documents stream: every document is `len` i.i.d. token draws (uniform, or
  * Zipf(s) over token rank when zipf_s > 0); token t's key is its ASCII decimal,

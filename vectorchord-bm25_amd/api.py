@@ -80,6 +80,21 @@ class Segment:
         return cls(out)
 
     @classmethod
+    def build_device(cls, k1, b, doc_len, doc_payload, term_key, term_start, post_doc, post_tf, device=0):
+        """vbm25_segment_build_device: the same segment, encoded by the GPU (csrc/flush.hip)."""
+        doc_len = np.ascontiguousarray(doc_len, dtype=np.uint32)
+        doc_payload = np.ascontiguousarray(doc_payload, dtype=np.uint16)
+        term_key = np.ascontiguousarray(term_key, dtype=np.uint8)
+        term_start = np.ascontiguousarray(term_start, dtype=np.uint64)
+        post_doc = np.ascontiguousarray(post_doc, dtype=np.uint32)
+        post_tf = np.ascontiguousarray(post_tf, dtype=np.uint32)
+        out = C.c_void_p()
+        check(lib().vbm25_segment_build_device(device, k1, b, len(doc_len), _p(doc_len), _p(doc_payload),
+                                               len(term_start) - 1, _p(term_key), _p(term_start),
+                                               _p(post_doc), _p(post_tf), C.byref(out)))
+        return cls(out)
+
+    @classmethod
     def synth(cls, n_docs, vocab, mean_len=100, len_mode=1, zipf_s=0.0, k1=1.2, b=0.75,
               seed=20260925, threads=0):
         p = SynthParams(n_docs, vocab, mean_len, len_mode, zipf_s, k1, b, seed, threads, 0)

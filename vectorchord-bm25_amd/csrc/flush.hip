@@ -1,0 +1,451 @@
+// flush.hip -- sealed-segment construction on the device: the encode side of the posting
+// blocks, /root/reference/crates/bm25/src/flush.rs:40-158 with compression.rs:36-63,94-110 (bit width = OR
+// of the deltas, 4-lane vertical packing, byte-packed tails) and the WAND pairs of bm25.rs:297-332 (first
+// maximiser under strict '<', per block and per token).  Output: the same vbm25_segment the host builder
+// (segment.cpp) makes, byte for byte -- tests/test_gpu_flush.py compares every array.
+//
+// One wave per 128-posting block, two postings per lane:
+//   block_stats_kernel  deltas (DPP neighbour), OR-reduce -> widths, body length, min / max, block WAND pair
+//                       (f64 tf() of bm25.rs:291-295 per posting, wave arg-max that keeps the FIRST maximum),
+//                       input validation (ids < n_docs, strictly increasing inside a term, tf > 0)
+//   (exclusive scan of the body lengths -> blk_off8, hipcub)
+//   block_pack_kernel   fields OR-ed into an LDS image of the body (a field may straddle two words of its lane
+//                       stream), copied out coalesced; tails and width-32 blocks byte / word copies
+//   term_wand_kernel    Wand::extend over a token's blocks in order (first maximum again)
+//   doc_kernel          fieldnorm code of every document (length_to_fieldnorm) and the sum of lengths
+// Host memory in, host memory out; the HBM copies live for the duration of the call.
+#include <hip/hip_runtime.h>
+#include <hipcub/hipcub.hpp>
+
+#include <algorithm>
+#include <cstring>
+#include <memory>
+#include <vector>
+
+#include "vbm25_internal.h"
+
+namespace {
+
+using namespace vbm25;
+
+#define FL_TRY(expr)                                                                                              \
+    do {                                                                                                          \
+        hipError_t e_ = (expr);                                                                                   \
+        if (e_ != hipSuccess)                                                                                     \
+            return set_error(VBM25_ERR_DEVICE, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_), __FILE__, __LINE__); \
+    } while (0)
+
+struct DBuf {
+    void *p = nullptr;
+    ~DBuf() {
+        if (p) (void)hipFree(p);
+    }
+    hipError_t alloc(size_t n) { return hipMalloc(&p, n ? n : 16); }
+    template <class T>
+    T *as() const {
+        return static_cast<T *>(p);
+    }
+};
+
+struct FlushArgs {
+    uint32_t n_docs, n_terms, n_blocks;
+    const uint64_t *term_start;         // n_terms + 1
+    const uint32_t *term_first_block;   // n_terms + 1
+    const uint32_t *post_doc, *post_tf;
+    const uint8_t *fieldnorm;           // per document
+    const double *denom;                // 256: k1 * (1 - b + b * len(f) / avgdl)
+    double kp1;
+    // per block
+    uint32_t *min_doc, *max_doc, *wand_tf, *len8, *off8;
+    uint8_t *n, *wand_fn, *meta_doc, *meta_tf;
+    double *wand_val;
+    uint8_t *blob;
+    uint32_t *error_flag;
+};
+
+__device__ __forceinline__ uint32_t wave_or_u32(uint32_t v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v |= __shfl_xor(v, o);
+    return v;
+}
+__device__ __forceinline__ uint32_t width_of_dev(uint32_t ored) { return ored ? 32u - (uint32_t)__clz(ored) : 0u; }
+
+// term of block j: term_first_block[t] <= j < term_first_block[t + 1]
+__device__ __forceinline__ uint32_t term_of_block(const uint32_t *tfb, uint32_t n_terms, uint32_t j) {
+    uint32_t lo = 0, hi = n_terms;
+    while (hi - lo > 1) {
+        const uint32_t mid = (lo + hi) >> 1;
+        if (tfb[mid] <= j) lo = mid; else hi = mid;
+    }
+    return lo;
+}
+
+// the block's postings, two per lane (indices 2 lane, 2 lane + 1), and the id before the block's first one
+struct BlockIn {
+    uint32_t n, d0, d1, t0, t1, delta0, delta1, prev;  // prev: the id before d0 (lane - 1's second id)
+    bool has0, has1;
+};
+__device__ __forceinline__ BlockIn load_block(const FlushArgs &a, uint32_t j, uint32_t lane, uint32_t &term) {
+    term = term_of_block(a.term_first_block, a.n_terms, j);
+    const uint64_t p0 = a.term_start[term] + 128ull * (j - a.term_first_block[term]);
+    const uint64_t pe = a.term_start[term + 1];
+    BlockIn b;
+    b.n = (uint32_t)min((uint64_t)128, pe - p0);
+    b.has0 = 2 * lane < b.n;
+    b.has1 = 2 * lane + 1 < b.n;
+    b.d0 = b.has0 ? a.post_doc[p0 + 2 * lane] : 0u;
+    b.d1 = b.has1 ? a.post_doc[p0 + 2 * lane + 1] : 0u;
+    b.t0 = b.has0 ? a.post_tf[p0 + 2 * lane] : 0u;
+    b.t1 = b.has1 ? a.post_tf[p0 + 2 * lane + 1] : 0u;
+    b.prev = __shfl_up(b.d1, 1);
+    b.delta0 = b.has0 ? (lane == 0 ? 0u : b.d0 - b.prev) : 0u;  // the first delta is against the block's own first id
+    b.delta1 = b.has1 ? b.d1 - b.d0 : 0u;
+    return b;
+}
+
+__global__ void __launch_bounds__(256) block_stats_kernel(FlushArgs a) {
+    const uint32_t lane = threadIdx.x & 63;
+    const uint32_t j = blockIdx.x * (blockDim.x / 64) + (threadIdx.x >> 6);
+    if (j >= a.n_blocks) return;
+    uint32_t term;
+    const BlockIn b = load_block(a, j, lane, term);
+    // validation (segment.rs:19-50 invariants the host builder checks too)
+    bool bad = false;
+    if (b.has0) bad |= b.d0 >= a.n_docs || b.t0 == 0 || (lane > 0 && b.d0 <= b.prev);
+    if (b.has1) bad |= b.d1 >= a.n_docs || b.t1 == 0 || b.d1 <= b.d0;
+    if (lane == 0 && j > a.term_first_block[term]) {  // across blocks of a term
+        const uint64_t p0 = a.term_start[term] + 128ull * (j - a.term_first_block[term]);
+        bad |= a.post_doc[p0 - 1] >= b.d0;
+    }
+    if (bad) atomicOr(a.error_flag, 1u);
+    const uint32_t bd = width_of_dev(wave_or_u32(b.delta0 | b.delta1)), bt = width_of_dev(wave_or_u32(b.t0 | b.t1));
+    uint32_t meta_d, meta_t, len_d, len_t;
+    if (b.n == 128) {
+        meta_d = bd;
+        meta_t = bt;
+        len_d = 16 * bd;
+        len_t = 16 * bt;
+    } else {
+        const uint32_t wd = max(1u, (bd + 7) / 8), wt = max(1u, (bt + 7) / 8);
+        meta_d = 0x80u | wd;
+        meta_t = 0x80u | wt;
+        len_d = wd * b.n;
+        len_t = wt * b.n;
+    }
+    // block WAND pair: first maximiser, strict '<' (bm25.rs:311-318)
+    double v = 0.0;
+    uint32_t vi = 0xffffffffu, vfn = 255, vtf = 0;
+    if (b.has0) {
+        const uint32_t f = a.fieldnorm[min(b.d0, a.n_docs - 1)];
+        const double t = (double)b.t0, x = (t * a.kp1) / (t + a.denom[f]);
+        if (v < x) {
+            v = x;
+            vi = 2 * lane;
+            vfn = f;
+            vtf = b.t0;
+        }
+    }
+    if (b.has1) {
+        const uint32_t f = a.fieldnorm[min(b.d1, a.n_docs - 1)];
+        const double t = (double)b.t1, x = (t * a.kp1) / (t + a.denom[f]);
+        if (v < x) {
+            v = x;
+            vi = 2 * lane + 1;
+            vfn = f;
+            vtf = b.t1;
+        }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        const double ov = __shfl_xor(v, o);
+        const uint32_t oi = __shfl_xor(vi, o), ofn = __shfl_xor(vfn, o), otf = __shfl_xor(vtf, o);
+        if (ov > v || (ov == v && oi < vi)) {
+            v = ov;
+            vi = oi;
+            vfn = ofn;
+            vtf = otf;
+        }
+    }
+    if (lane == 0) {
+        a.min_doc[j] = b.d0;
+        a.n[j] = (uint8_t)b.n;
+        a.wand_fn[j] = (uint8_t)vfn;
+        a.wand_tf[j] = vtf;
+        a.wand_val[j] = v;
+        a.meta_doc[j] = (uint8_t)meta_d;
+        a.meta_tf[j] = (uint8_t)meta_t;
+        a.len8[j] = (((len_d + 7) & ~7u) + ((len_t + 7) & ~7u)) / 8;
+    }
+    const uint32_t last = b.n - 1;
+    if (lane == last / 2) a.max_doc[j] = (last & 1) ? b.d1 : b.d0;
+}
+
+// value index i = 2 lane + e: lane stream i % 4, step i / 4 (crates/simd/src/bitpacking.rs:58-98)
+__device__ __forceinline__ void or_field(uint32_t *img, uint32_t i, uint32_t v, uint32_t b) {
+    const uint32_t l = i & 3, bit = (i >> 2) * b, w = bit >> 5, sh = bit & 31;
+    atomicOr(&img[4 * w + l], v << sh);
+    if (sh + b > 32) atomicOr(&img[4 * (w + 1) + l], v >> (32 - sh));
+}
+
+__global__ void __launch_bounds__(256) block_pack_kernel(FlushArgs a) {
+    __shared__ uint32_t s_img[4][2][128];  // per wave: doc-id body and tf body, up to 512 bytes each
+    const uint32_t lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const uint32_t j = blockIdx.x * (blockDim.x / 64) + wv;
+    if (j >= a.n_blocks) return;
+    uint32_t term;
+    const BlockIn b = load_block(a, j, lane, term);
+    const uint32_t md = a.meta_doc[j], mt = a.meta_tf[j];
+    uint32_t *imd = s_img[wv][0], *imt = s_img[wv][1];
+    imd[lane] = imd[lane + 64] = imt[lane] = imt[lane + 64] = 0;
+    __builtin_amdgcn_wave_barrier();
+    uint32_t len_d, len_t;
+    if (b.n == 128) {
+        len_d = 16 * md;
+        len_t = 16 * mt;
+        if (md == 32) {  // raw absolute ids
+            imd[2 * lane] = b.d0;
+            imd[2 * lane + 1] = b.d1;
+        } else if (md) {
+            or_field(imd, 2 * lane, b.delta0, md);
+            or_field(imd, 2 * lane + 1, b.delta1, md);
+        }
+        if (mt == 32) {
+            imt[2 * lane] = b.t0;
+            imt[2 * lane + 1] = b.t1;
+        } else if (mt) {
+            or_field(imt, 2 * lane, b.t0, mt);
+            or_field(imt, 2 * lane + 1, b.t1, mt);
+        }
+    } else {  // tail: byte-packed (compression.rs:53-62), width-4 document ids are absolute
+        const uint32_t wd = md & 127u, wt = mt & 127u;
+        len_d = wd * b.n;
+        len_t = wt * b.n;
+        uint8_t *bd8 = reinterpret_cast<uint8_t *>(imd), *bt8 = reinterpret_cast<uint8_t *>(imt);
+#pragma unroll
+        for (int e = 0; e < 2; ++e) {
+            const uint32_t i = 2 * lane + e;
+            if (i < b.n) {
+                const uint32_t v = wd == 4 ? (e ? b.d1 : b.d0) : (e ? b.delta1 : b.delta0);
+                const uint32_t t = e ? b.t1 : b.t0;
+                for (uint32_t q = 0; q < wd; ++q) bd8[i * wd + q] = (uint8_t)(v >> (8 * q));
+                for (uint32_t q = 0; q < wt; ++q) bt8[i * wt + q] = (uint8_t)(t >> (8 * q));
+            }
+        }
+    }
+    __builtin_amdgcn_wave_barrier();
+    // copy out: doc bytes, zero pad to 8, tf bytes, zero pad to 8 (the image is zero beyond the payload)
+    uint32_t *dst = reinterpret_cast<uint32_t *>(a.blob + 8ull * a.off8[j]);
+    const uint32_t wd4 = ((len_d + 7) & ~7u) / 4, wt4 = ((len_t + 7) & ~7u) / 4;
+    for (uint32_t i = lane; i < wd4; i += 64) dst[i] = imd[i];
+    for (uint32_t i = lane; i < wt4; i += 64) dst[wd4 + i] = imt[i];
+}
+
+__global__ void __launch_bounds__(64) term_wand_kernel(FlushArgs a, uint8_t *term_wand_fn, uint32_t *term_wand_tf, uint32_t *term_df) {
+    const uint32_t t = blockIdx.x, lane = threadIdx.x;
+    const uint32_t j0 = a.term_first_block[t], j1 = a.term_first_block[t + 1];
+    double v = 0.0;
+    uint32_t vi = 0xffffffffu;
+    for (uint32_t j = j0 + lane; j < j1; j += 64) {  // Wand::extend, bm25.rs:319-325: strict '<' keeps the first
+        const double x = a.wand_val[j];
+        if (v < x) {
+            v = x;
+            vi = j;
+        }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        const double ov = __shfl_xor(v, o);
+        const uint32_t oi = __shfl_xor(vi, o);
+        if (ov > v || (ov == v && oi < vi)) {
+            v = ov;
+            vi = oi;
+        }
+    }
+    if (lane == 0) {
+        term_wand_fn[t] = vi == 0xffffffffu ? 255 : a.wand_fn[vi];
+        term_wand_tf[t] = vi == 0xffffffffu ? 0 : a.wand_tf[vi];
+        term_df[t] = (uint32_t)(a.term_start[t + 1] - a.term_start[t]);
+    }
+}
+
+__global__ void __launch_bounds__(256) doc_kernel(uint32_t n_docs, const uint32_t *doc_len, const uint32_t *fn_len, uint8_t *fieldnorm,
+                                                  unsigned long long *sum_len) {
+    unsigned long long local = 0;
+    for (uint32_t d = blockIdx.x * blockDim.x + threadIdx.x; d < n_docs; d += gridDim.x * blockDim.x) {
+        const uint32_t len = doc_len[d];
+        uint32_t lo = 0, hi = 256;  // length_to_fieldnorm, bm25.rs:278-283
+        while (hi - lo > 1) {
+            const uint32_t mid = (lo + hi) >> 1;
+            if (fn_len[mid] <= len) lo = mid; else hi = mid;
+        }
+        fieldnorm[d] = (uint8_t)lo;
+        local += len;
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) local += __shfl_xor(local, o);
+    if ((threadIdx.x & 63) == 0) atomicAdd(sum_len, local);
+}
+
+int build_device_impl(int device, double k1, double b, uint32_t n_docs, const uint32_t *doc_len, const uint16_t *doc_payload,
+                      uint32_t n_terms, const uint8_t *term_key, const uint64_t *term_start, const uint32_t *post_doc,
+                      const uint32_t *post_tf, vbm25_segment **out) {
+    if (!out) return set_error(VBM25_ERR_INVALID, "out is NULL");
+    *out = nullptr;
+    if (!doc_len || !doc_payload || !term_start || (n_terms && (!term_key || !post_doc || !post_tf)))
+        return set_error(VBM25_ERR_INVALID, "NULL argument");
+    if (!n_docs) return set_error(VBM25_ERR_INVALID, "segment without documents");
+    if (!(k1 >= 1.2 && k1 <= 2.0) || !(b >= 0.0 && b <= 1.0))  // types.rs:18-45
+        return set_error(VBM25_ERR_INVALID, "k1 must be in [1.2, 2] and b in [0, 1]");
+    for (uint32_t t = 0; t + 1 < n_terms; ++t)
+        if (std::memcmp(term_key + 16ull * t, term_key + 16ull * (t + 1), 16) >= 0)
+            return set_error(VBM25_ERR_INVALID, "term keys must be strictly ascending");
+    int n_dev = 0;
+    if (hipGetDeviceCount(&n_dev) != hipSuccess || n_dev == 0)
+        return set_error(VBM25_ERR_DEVICE, "no HIP device: the device builder has no CPU fallback (vbm25_segment_build is the host builder)");
+    if (device < 0 || device >= n_dev) return set_error(VBM25_ERR_INVALID, "device %d out of range (%d devices)", device, n_dev);
+    FL_TRY(hipSetDevice(device));
+
+    auto seg = std::make_unique<vbm25_segment>();
+    seg->k1 = k1;
+    seg->b = b;
+    seg->n_docs = n_docs;
+    seg->n_terms = n_terms;
+    seg->term_key.assign(term_key, term_key + 16ull * n_terms);
+    seg->doc_payload.assign(doc_payload, doc_payload + 3ull * n_docs);
+    seg->term_first_block.resize(size_t(n_terms) + 1);
+    uint64_t nb = 0;
+    for (uint32_t t = 0; t < n_terms; ++t) {
+        if (term_start[t + 1] <= term_start[t]) return set_error(VBM25_ERR_INVALID, "term %u has no postings", t);
+        seg->term_first_block[t] = uint32_t(nb);
+        nb += (term_start[t + 1] - term_start[t] + 127) / 128;
+        if (nb > 0xfffffff0ull) return set_error(VBM25_ERR_UNSUPPORTED, "more than 2^32 blocks");
+    }
+    seg->term_first_block[n_terms] = uint32_t(nb);
+    const uint32_t n_blocks = seg->n_blocks = uint32_t(nb);
+    const uint64_t n_post = n_terms ? term_start[n_terms] : 0;
+
+    DBuf d_len, d_fnlen, d_fn, d_sum, d_ts, d_tfb, d_pd, d_pt, d_denom, d_err;
+    DBuf b_min, b_max, b_wtf, b_len8, b_off8, b_n, b_wfn, b_md, b_mt, b_wval, t_wfn, t_wtf, t_df, d_tmp, d_blob;
+    FL_TRY(d_len.alloc(4ull * n_docs));
+    FL_TRY(d_fnlen.alloc(4 * 256));
+    FL_TRY(d_fn.alloc(n_docs));
+    FL_TRY(d_sum.alloc(8));
+    FL_TRY(d_err.alloc(4));
+    FL_TRY(hipMemcpy(d_len.p, doc_len, 4ull * n_docs, hipMemcpyHostToDevice));
+    FL_TRY(hipMemcpy(d_fnlen.p, fieldnorm_lengths(), 4 * 256, hipMemcpyHostToDevice));
+    FL_TRY(hipMemset(d_sum.p, 0, 8));
+    FL_TRY(hipMemset(d_err.p, 0, 4));
+    doc_kernel<<<1024, 256>>>(n_docs, d_len.as<uint32_t>(), d_fnlen.as<uint32_t>(), d_fn.as<uint8_t>(), d_sum.as<unsigned long long>());
+    FL_TRY(hipGetLastError());
+    unsigned long long sum_len = 0;
+    FL_TRY(hipMemcpy(&sum_len, d_sum.p, 8, hipMemcpyDeviceToHost));
+    seg->sum_len = sum_len;
+    seg->doc_fieldnorm.resize(n_docs);
+    FL_TRY(hipMemcpy(seg->doc_fieldnorm.data(), d_fn.p, n_docs, hipMemcpyDeviceToHost));
+    double denom[256];
+    bm25_tables(n_docs, sum_len, k1, b, denom);
+
+    FL_TRY(d_ts.alloc(8ull * (n_terms + 1)));
+    FL_TRY(d_tfb.alloc(4ull * (n_terms + 1)));
+    FL_TRY(d_pd.alloc(4ull * n_post));
+    FL_TRY(d_pt.alloc(4ull * n_post));
+    FL_TRY(d_denom.alloc(8 * 256));
+    FL_TRY(hipMemcpy(d_ts.p, term_start, 8ull * (n_terms + 1), hipMemcpyHostToDevice));
+    FL_TRY(hipMemcpy(d_tfb.p, seg->term_first_block.data(), 4ull * (n_terms + 1), hipMemcpyHostToDevice));
+    if (n_post) {
+        FL_TRY(hipMemcpy(d_pd.p, post_doc, 4ull * n_post, hipMemcpyHostToDevice));
+        FL_TRY(hipMemcpy(d_pt.p, post_tf, 4ull * n_post, hipMemcpyHostToDevice));
+    }
+    FL_TRY(hipMemcpy(d_denom.p, denom, 8 * 256, hipMemcpyHostToDevice));
+    FL_TRY(b_min.alloc(4ull * n_blocks));
+    FL_TRY(b_max.alloc(4ull * n_blocks));
+    FL_TRY(b_wtf.alloc(4ull * n_blocks));
+    FL_TRY(b_len8.alloc(4ull * (n_blocks + 1)));
+    FL_TRY(b_off8.alloc(4ull * (n_blocks + 1)));
+    FL_TRY(b_n.alloc(n_blocks));
+    FL_TRY(b_wfn.alloc(n_blocks));
+    FL_TRY(b_md.alloc(n_blocks));
+    FL_TRY(b_mt.alloc(n_blocks));
+    FL_TRY(b_wval.alloc(8ull * n_blocks));
+    FL_TRY(t_wfn.alloc(n_terms));
+    FL_TRY(t_wtf.alloc(4ull * n_terms));
+    FL_TRY(t_df.alloc(4ull * n_terms));
+    FlushArgs a{};
+    a.n_docs = n_docs;
+    a.n_terms = n_terms;
+    a.n_blocks = n_blocks;
+    a.term_start = d_ts.as<uint64_t>();
+    a.term_first_block = d_tfb.as<uint32_t>();
+    a.post_doc = d_pd.as<uint32_t>();
+    a.post_tf = d_pt.as<uint32_t>();
+    a.fieldnorm = d_fn.as<uint8_t>();
+    a.denom = d_denom.as<double>();
+    a.kp1 = k1 + 1.0;
+    a.min_doc = b_min.as<uint32_t>();
+    a.max_doc = b_max.as<uint32_t>();
+    a.wand_tf = b_wtf.as<uint32_t>();
+    a.len8 = b_len8.as<uint32_t>();
+    a.off8 = b_off8.as<uint32_t>();
+    a.n = b_n.as<uint8_t>();
+    a.wand_fn = b_wfn.as<uint8_t>();
+    a.meta_doc = b_md.as<uint8_t>();
+    a.meta_tf = b_mt.as<uint8_t>();
+    a.wand_val = b_wval.as<double>();
+    a.error_flag = d_err.as<uint32_t>();
+    seg->blk_off8.assign(size_t(n_blocks) + 1, 0);
+    if (n_blocks) {
+        FL_TRY(hipMemset(b_len8.p, 0, 4ull * (n_blocks + 1)));
+        block_stats_kernel<<<(n_blocks + 3) / 4, 256>>>(a);
+        FL_TRY(hipGetLastError());
+        size_t tmp_bytes = 0;
+        FL_TRY(hipcub::DeviceScan::ExclusiveSum(nullptr, tmp_bytes, a.len8, a.off8, (int)(n_blocks + 1)));
+        FL_TRY(d_tmp.alloc(tmp_bytes));
+        FL_TRY(hipcub::DeviceScan::ExclusiveSum(d_tmp.p, tmp_bytes, a.len8, a.off8, (int)(n_blocks + 1)));
+        FL_TRY(hipMemcpy(seg->blk_off8.data(), b_off8.p, 4ull * (n_blocks + 1), hipMemcpyDeviceToHost));
+        uint32_t flag = 0;
+        FL_TRY(hipMemcpy(&flag, d_err.p, 4, hipMemcpyDeviceToHost));
+        if (flag) return set_error(VBM25_ERR_INVALID, "mappings must be sorted by (token, document), ids < n_docs, tf > 0");
+        // total body length: the scan would wrap silently beyond 2^32 units of 8 bytes
+        std::vector<uint32_t> len8(n_blocks);
+        FL_TRY(hipMemcpy(len8.data(), b_len8.p, 4ull * n_blocks, hipMemcpyDeviceToHost));
+        uint64_t total8 = 0;
+        for (uint32_t x : len8) total8 += x;
+        if (total8 > 0xffffffffull) return set_error(VBM25_ERR_UNSUPPORTED, "block bodies exceed 32 GiB");
+        const size_t blob_bytes = 8ull * total8;
+        FL_TRY(d_blob.alloc(blob_bytes));
+        a.blob = d_blob.as<uint8_t>();
+        block_pack_kernel<<<(n_blocks + 3) / 4, 256>>>(a);
+        FL_TRY(hipGetLastError());
+        term_wand_kernel<<<n_terms, 64>>>(a, t_wfn.as<uint8_t>(), t_wtf.as<uint32_t>(), t_df.as<uint32_t>());
+        FL_TRY(hipGetLastError());
+        seg->blob.resize(blob_bytes);
+        FL_TRY(hipMemcpy(seg->blob.data(), d_blob.p, blob_bytes, hipMemcpyDeviceToHost));
+    }
+    auto fetch = [&](auto &vec, const DBuf &src, size_t n) -> hipError_t {
+        vec.resize(n);
+        return n ? hipMemcpy(vec.data(), src.p, n * sizeof(vec[0]), hipMemcpyDeviceToHost) : hipSuccess;
+    };
+    FL_TRY(fetch(seg->blk_min_doc, b_min, n_blocks));
+    FL_TRY(fetch(seg->blk_max_doc, b_max, n_blocks));
+    FL_TRY(fetch(seg->blk_wand_tf, b_wtf, n_blocks));
+    FL_TRY(fetch(seg->blk_n, b_n, n_blocks));
+    FL_TRY(fetch(seg->blk_wand_fn, b_wfn, n_blocks));
+    FL_TRY(fetch(seg->blk_meta_doc, b_md, n_blocks));
+    FL_TRY(fetch(seg->blk_meta_tf, b_mt, n_blocks));
+    FL_TRY(fetch(seg->term_wand_fn, t_wfn, n_terms));
+    FL_TRY(fetch(seg->term_wand_tf, t_wtf, n_terms));
+    FL_TRY(fetch(seg->term_df, t_df, n_terms));
+    *out = seg.release();
+    return VBM25_OK;
+}
+
+}  // namespace
+
+extern "C" int vbm25_segment_build_device(int device, double k1, double b, uint32_t n_docs, const uint32_t *doc_len,
+                                          const uint16_t *doc_payload, uint32_t n_terms, const uint8_t *term_key,
+                                          const uint64_t *term_start, const uint32_t *post_doc, const uint32_t *post_tf,
+                                          vbm25_segment **out) {
+    return vbm25::guarded([&] {
+        return build_device_impl(device, k1, b, n_docs, doc_len, doc_payload, n_terms, term_key, term_start, post_doc, post_tf, out);
+    });
+}
