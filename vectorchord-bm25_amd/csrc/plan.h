@@ -117,14 +117,19 @@ __global__ void __launch_bounds__(PLAN_WG) plan_kernel(DevIndex ix, DevBatch bt,
         }
         return t;
     };
-    unsigned long long local = 0;
-    for (uint32_t q = q0; q < q1; ++q) local += postings_of(q);
+    // a thread usually owns one query (nq <= PLAN_WG): its posting count is read once and kept -- every
+    // evaluation is a chain of three dependent global loads, which is what a small batch's plan costs
+    const bool one = q1 - q0 == 1;
+    const unsigned long long own_postings = one ? postings_of(q0) : 0ull;
+    unsigned long long local = own_postings;
+    if (!one)
+        for (uint32_t q = q0; q < q1; ++q) local += postings_of(q);
     unsigned long long total = 0;
     plan_incl_scan(local, s_wave, total);
     unsigned long long chunk = (total + target_items - 1) / target_items;
     if (chunk < min_chunk) chunk = min_chunk;
     auto chunks_of = [&](uint32_t q) -> uint32_t {
-        unsigned long long t = postings_of(q);
+        unsigned long long t = one ? own_postings : postings_of(q);
         if (t == 0) return 0u;
         // nearest, not ceil: a batch of similar queries gets the same count for all of them, i.e. the
         // item count lands on the target (a multiple of the resident waves) instead of ~8 % above it

@@ -229,7 +229,15 @@ struct vbm25_batch {
     uint32_t cur_grid = CUR_GRID;  // persistent workgroups of the cursor kernel for the current queries
     std::vector<std::pair<hipEvent_t, hipEvent_t>> events;
     size_t events_used = 0;
+    // vbm25_search_batch's low-latency route: pinned staging buffers and a private stream -- queries go up and
+    // hits come down with asynchronous copies and ONE stream synchronisation
+    hipStream_t lat_stream = nullptr;
+    uint8_t *pin_in = nullptr, *pin_out = nullptr;
+    size_t pin_in_bytes = 0, pin_out_bytes = 0;
     ~vbm25_batch() {
+        if (lat_stream) (void)hipStreamDestroy(lat_stream);
+        if (pin_in) (void)hipHostFree(pin_in);
+        if (pin_out) (void)hipHostFree(pin_out);
         for (auto &e : events) {
             (void)hipEventDestroy(e.first);
             (void)hipEventDestroy(e.second);
@@ -506,7 +514,7 @@ void vbm25_batch_destroy(vbm25_batch *bt) {
 }
 
 static int vbm25_batch_set_queries_impl(vbm25_batch *bt, const uint32_t *term_ids, const uint32_t *q_off,
-                            uint32_t nq) {
+                            uint32_t nq, bool fast = false) {
     if (!bt || !q_off) return set_error(VBM25_ERR_INVALID, "NULL argument");
     if (!term_ids && nq && q_off[nq] != 0) return set_error(VBM25_ERR_INVALID, "term_ids is NULL but the queries have terms");
     if (nq > bt->max_queries) return set_error(VBM25_ERR_INVALID, "%u queries exceed the batch capacity %u", nq, bt->max_queries);
@@ -558,9 +566,26 @@ static int vbm25_batch_set_queries_impl(vbm25_batch *bt, const uint32_t *term_id
         bt->nq = nq;
         return VBM25_OK;
     }
-    if (q_off[nq]) HIP_TRY(hipMemcpy(bt->term_ids.p, term_ids, 4ull * q_off[nq], hipMemcpyHostToDevice));
-    HIP_TRY(hipMemcpy(bt->q_off.p, q_off, 4ull * (nq + 1), hipMemcpyHostToDevice));
-    if (nq) HIP_TRY(hipMemcpy(bt->q_dense.p, dense.data(), nq, hipMemcpyHostToDevice));
+    if (fast && !bt->bigk) {  // staged in pinned memory, copied on the batch's own stream, nothing waits here
+        const size_t nt = 4ull * q_off[nq], no = 4ull * (nq + 1);
+        if (nt + no + nq > bt->pin_in_bytes) {
+            if (bt->pin_in) HIP_TRY(hipHostFree(bt->pin_in));
+            bt->pin_in = nullptr;
+            bt->pin_in_bytes = 2 * (nt + no + nq) + 256;
+            HIP_TRY(hipHostMalloc(reinterpret_cast<void **>(&bt->pin_in), bt->pin_in_bytes, hipHostMallocDefault));
+        }
+        if (!bt->lat_stream) HIP_TRY(hipStreamCreateWithFlags(&bt->lat_stream, hipStreamNonBlocking));
+        if (nt) std::memcpy(bt->pin_in, term_ids, nt);
+        std::memcpy(bt->pin_in + nt, q_off, no);
+        if (nq) std::memcpy(bt->pin_in + nt + no, dense.data(), nq);
+        if (nt) HIP_TRY(hipMemcpyAsync(bt->term_ids.p, bt->pin_in, nt, hipMemcpyHostToDevice, bt->lat_stream));
+        HIP_TRY(hipMemcpyAsync(bt->q_off.p, bt->pin_in + nt, no, hipMemcpyHostToDevice, bt->lat_stream));
+        if (nq) HIP_TRY(hipMemcpyAsync(bt->q_dense.p, bt->pin_in + nt + no, nq, hipMemcpyHostToDevice, bt->lat_stream));
+    } else {
+        if (q_off[nq]) HIP_TRY(hipMemcpy(bt->term_ids.p, term_ids, 4ull * q_off[nq], hipMemcpyHostToDevice));
+        HIP_TRY(hipMemcpy(bt->q_off.p, q_off, 4ull * (nq + 1), hipMemcpyHostToDevice));
+        if (nq) HIP_TRY(hipMemcpy(bt->q_dense.p, dense.data(), nq, hipMemcpyHostToDevice));
+    }
     bt->nq = nq;
     bt->has_many_terms = many;
     bt->has_mid_terms = mid;
@@ -689,9 +714,35 @@ static int vbm25_batch_run_impl(vbm25_batch *bt, void *hip_stream) {
     return VBM25_OK;
 }
 
-static int vbm25_batch_fetch_impl(vbm25_batch *bt, vbm25_hit *hits, uint32_t *n_hits) {
+static int vbm25_batch_fetch_impl(vbm25_batch *bt, vbm25_hit *hits, uint32_t *n_hits, bool fast = false) {
     if (!bt || (!hits && bt->nq) || (!n_hits && bt->nq)) return set_error(VBM25_ERR_INVALID, "NULL argument");
     if (int rc = use_device(bt->index->device)) return rc;
+    if (fast && bt->lat_stream) {  // flag, counts and hits come down asynchronously; one synchronisation
+        const size_t nh = sizeof(vbm25_hit) * size_t(bt->nq) * bt->k, nc = 4ull * bt->nq;
+        if (8 + nc + nh > bt->pin_out_bytes) {
+            if (bt->pin_out) HIP_TRY(hipHostFree(bt->pin_out));
+            bt->pin_out = nullptr;
+            bt->pin_out_bytes = 2 * (8 + nc + nh) + 256;
+            HIP_TRY(hipHostMalloc(reinterpret_cast<void **>(&bt->pin_out), bt->pin_out_bytes, hipHostMallocDefault));
+        }
+        HIP_TRY(hipMemcpyAsync(bt->pin_out, bt->error_flag.p, 4, hipMemcpyDeviceToHost, bt->lat_stream));
+        if (bt->nq) {
+            HIP_TRY(hipMemcpyAsync(bt->pin_out + 8, bt->n_hits.p, nc, hipMemcpyDeviceToHost, bt->lat_stream));
+            HIP_TRY(hipMemcpyAsync(bt->pin_out + 8 + nc, bt->hits.p, nh, hipMemcpyDeviceToHost, bt->lat_stream));
+        }
+        HIP_TRY(hipStreamSynchronize(bt->lat_stream));
+        uint32_t flag = 0;
+        std::memcpy(&flag, bt->pin_out, 4);
+        if (flag) {
+            HIP_TRY(hipMemset(bt->error_flag.p, 0, 4));
+            return set_error(VBM25_ERR_DEVICE, "device-side planner overflow (flag %u)", flag);
+        }
+        if (bt->nq) {
+            std::memcpy(n_hits, bt->pin_out + 8, nc);
+            std::memcpy(hits, bt->pin_out + 8 + nc, nh);
+        }
+        return VBM25_OK;
+    }
     HIP_TRY(hipDeviceSynchronize());
     uint32_t flag = 0;
     HIP_TRY(hipMemcpy(&flag, bt->error_flag.p, 4, hipMemcpyDeviceToHost));
@@ -844,9 +895,10 @@ static int vbm25_search_batch_impl(vbm25_index *ix, const uint32_t *term_ids, co
         if (int rc = vbm25_batch_create(ix, std::max(nq, 16u), std::max(n_terms, 256u), k, &bt)) return rc;
         ix->scratch = bt;
     }
-    int rc = vbm25_batch_set_queries(bt, term_ids, q_off, nq);
-    if (!rc) rc = vbm25_batch_run(bt, nullptr);
-    if (!rc) rc = vbm25_batch_fetch(bt, hits, n_hits);
+    const bool fast = !bt->bigk;
+    int rc = vbm25_batch_set_queries_impl(bt, term_ids, q_off, nq, fast);
+    if (!rc) rc = vbm25_batch_run_impl(bt, fast ? bt->lat_stream : nullptr);
+    if (!rc) rc = vbm25_batch_fetch_impl(bt, hits, n_hits, fast);
     return rc;
 }
 
