@@ -54,12 +54,12 @@ int set_error(int code, const char *fmt, ...) {
 #include "decode.h"
 #include "plan.h"
 #include "topk_lds.h"
-#include "scan_many.h"
 #include "block_fetch.h"
 #include "topk_reg.h"
 #include "scan_tile.h"
 #include "scan_cursor.h"
 #include "scan_range.h"
+#include "scan_many.h"
 #include "merge.h"
 
 // ---------------------------------------------------------------------------
