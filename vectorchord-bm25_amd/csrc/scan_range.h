@@ -48,11 +48,12 @@ constexpr uint32_t R_MIN_CHUNK_POSTINGS = 16384;
 constexpr uint32_t R_GRID = 512;      // persistent workgroups: 256 CUs x 2 (KMAX <= 64; 1 per CU above)
 constexpr int R_PLAN_RING = 3;
 constexpr int R_LIST = 128;           // second arrivals per wave per tile; more than that: scan_many_kernel
+constexpr int R_STAGE_STRIDE = 130;   // words between staged rows: 128 would put the same column of every row on one LDS bank (S2 probes columns)
 
 template <int RT>
 struct RangeLds {
     uint32_t bm[R_BM_WORDS + 4];
-    uint32_t stage[R_NBLK * 128];
+    uint32_t stage[R_NBLK * R_STAGE_STRIDE];  // one row of 128 ids per block
     uint32_t hkeys[R_HS];
     double contrib[R_ROWS * 8];        // rows x RT
     uint32_t done[R_NBLK * 4];
@@ -687,7 +688,7 @@ __global__ void __launch_bounds__(RWG, 4) scan_range_kernel(DevIndex ix, DevBatc
 #pragma unroll
                 for (int i = 0; i < RB; ++i) {
                     const uint32_t e = (wave - 1u) + (RNW - 1) * i;
-                    *reinterpret_cast<uint2 *>(&S.stage[e * 128 + 2 * lane]) = make_uint2(d0[i], d1[i]);
+                    *reinterpret_cast<uint2 *>(&S.stage[e * R_STAGE_STRIDE + 2 * lane]) = make_uint2(d0[i], d1[i]);
                     const uint32_t sp = (uint32_t)i < nv ? span : 0u;
                     const uint32_t x0 = d0[i] - tlo, x1 = d1[i] - tlo;
                     m0[i] = 1u << (x0 & 31);
@@ -789,11 +790,12 @@ __global__ void __launch_bounds__(RWG, 4) scan_range_kernel(DevIndex ix, DevBatc
                 reinterpret_cast<uint4 *>(S.bm)[tid + i * RWG] = make_uint4(0, 0, 0, 0);
             if (tid == 0) S.nmulti[par ^ 1u] = 0;
             if (nm) {
-                for (uint32_t p = tid; p < (nm << LRT); p += RWG) {
-                    const uint32_t r = p >> LRT, t = p & (RT - 1);
+                // tasks = rows x the query's terms, packed: waves beyond nm * mq tasks skip the phase
+                const uint32_t inv_mq = (65536u + mq - 1u) / mq;  // p / mq == (p * inv_mq) >> 16 for p < 4096
+                for (uint32_t p = tid; p < nm * mq; p += RWG) {
+                    const uint32_t r = (p * inv_mq) >> 16, t = p - r * mq;
                     const uint32_t d = S.mdoc[par][r];
                     if (t == 0) S.hkeys[S.mslot[par][r]] = EMPTY;
-                    if (t >= mq) continue;
                     uint32_t eb = S.ptb[buf][t], len = S.ptb[buf][t + 1] - eb;
                     if (len == 0) continue;
                     while (len > 1) {  // last entry of the term with min_doc <= d
@@ -807,7 +809,7 @@ __global__ void __launch_bounds__(RWG, 4) scan_range_kernel(DevIndex ix, DevBatc
                     }
                     const uint4 sj = S.pm[buf][eb];
                     if (d < sj.x || d > sj.y) continue;
-                    const uint32_t *sb = &S.stage[eb * 128];
+                    const uint32_t *sb = &S.stage[eb * R_STAGE_STRIDE];
                     uint32_t idx = 0;
 #pragma unroll
                     for (int s = 64; s > 0; s >>= 1)
@@ -932,10 +934,13 @@ __global__ void __launch_bounds__(RWG, 4) scan_range_kernel(DevIndex ix, DevBatc
                 }
             };
 
-            // ---- S3: rows -> documents (row r: lane r / RNW of wave r % RNW)
-            if (nm) {
-                const uint32_t r = lane * RNW + wave;
-                const bool has = r < nm;
+            // ---- S3: rows -> documents.  Wave w takes the rows [w R, (w + 1) R): consecutive lanes read consecutive
+            // rows of contrib (a row stride of RNW rows put every lane on the same LDS banks), and the waves
+            // beyond the last row skip the phase
+            constexpr uint32_t RPW = (uint32_t)(R_ROWS * 8 / RT) / RNW;
+            if (nm > wave * RPW) {
+                const uint32_t r = wave * RPW + lane;
+                const bool has = lane < RPW && r < nm;
                 double acc = 0.0;
                 uint32_t d = 0;
                 if (has) {
@@ -993,7 +998,7 @@ __global__ void __launch_bounds__(RWG, 4) scan_range_kernel(DevIndex ix, DevBatc
                             if (__longlong_as_double((long long)theta_now()) > __longlong_as_double((long long)ubu) + nesum) continue;
                         }
                         // ids from this wave's own stage row (nobody else writes it)
-                        const uint2 dd = *reinterpret_cast<const uint2 *>(&S.stage[e * 128 + 2 * lane]);
+                        const uint2 dd = *reinterpret_cast<const uint2 *>(&S.stage[e * R_STAGE_STRIDE + 2 * lane]);
                         const uint32_t dwi = S.done[e * 4 + (lane >> 4)];
                         const bool ok0 = dd.x - tlo < span && !((dwi >> ((2 * lane) & 31)) & 1u);
                         const bool ok1 = dd.y - tlo < span && !((dwi >> ((2 * lane + 1) & 31)) & 1u);
