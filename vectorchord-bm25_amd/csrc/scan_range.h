@@ -718,12 +718,8 @@ __global__ void __launch_bounds__(RWG, 4) scan_range_kernel(DevIndex ix, DevBatc
                     while (mask) {
                         const uint32_t b = (uint32_t)__ffs((int)mask) - 1u;
                         mask &= mask - 1u;
-                        uint32_t d = d0[0];
-#pragma unroll
-                        for (int j = 0; j < RB; ++j) {
-                            d = b == (uint32_t)(2 * j) ? d0[j] : d;
-                            d = b == (uint32_t)(2 * j + 1) ? d1[j] : d;
-                        }
+                        // the id comes back from the wave's own stage row (one LDS read instead of a 16-way select)
+                        const uint32_t d = S.stage[((wave - 1u) + (RNW - 1) * (b >> 1)) * R_STAGE_STRIDE + 2 * lane + (b & 1u)];
                         const uint32_t pos = atomicAdd(&S.lcnt[wave], 1u);
                         if (pos < (uint32_t)R_LIST) S.list[wave][pos] = d;
                         else S.fail = 2;
