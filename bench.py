@@ -405,7 +405,7 @@ def main():
             out["config"]["latency"] = latency
         if not gloo:
             achieved = algo_bytes / (kernel_ms * 1e-3) / 1e9 if kernel_ms > 0 else 0.0
-            out["roofline"] = {"bound": "hbm", "kernel": "scan_many_kernel" if dense else "scan_range_kernel",
+            out["roofline"] = {"bound": "hbm", "kernel": "scan_dense_kernel" if dense else "scan_range_kernel",
                                "achieved": round(achieved, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                                "frac": round(achieved / HBM_PEAK_GBPS, 4),
                                # HBM bytes per launch come from separate rocprofv3 --pmc passes (tools/r2_pmc.sh,

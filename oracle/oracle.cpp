@@ -19,6 +19,7 @@
 #include <chrono>
 #include <cmath>
 #include <cstring>
+#include <limits>
 #include <memory>
 #include <thread>
 #include <vector>
@@ -838,6 +839,8 @@ uint32_t search_brute(const orc_index *ix, const uint32_t *terms, uint32_t n_ter
     return uint32_t(kk);
 }
 
+#include "dense_model.inc"
+
 }  // namespace
 
 // ---------------------------------------------------------------------------
@@ -1041,6 +1044,15 @@ uint64_t orc_query_bytes(const orc_index *ix, const uint32_t *terms, uint32_t n_
         bytes += ix->term_df[t];               // one fieldnorm byte per posting
     }
     return bytes + 14ull * k;
+}
+
+/* model of the device's dense-window kernel (dense_model.inc): a test aid, not an oracle */
+uint32_t orc_dense_model(const orc_index *ix, const uint32_t *terms, uint32_t n_terms, uint32_t k, uint32_t wmax,
+                         uint32_t w0, uint32_t lo, uint32_t hi, int ne_on, orc_hit *out, uint64_t *stats8) {
+    DenseModelStats st;
+    const uint32_t n = dense_model(ix, terms, n_terms, k, wmax, w0, lo, hi, ne_on, out, &st);
+    std::memcpy(stats8, &st, sizeof st);
+    return n;
 }
 
 }  // extern "C"

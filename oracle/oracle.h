@@ -150,6 +150,12 @@ const uint8_t *orc_pages_get(const orc_pages *, uint32_t page_id);
 uint8_t *orc_pages_get_mut(orc_pages *, uint32_t page_id);
 void orc_pages_free(orc_pages *);
 
+/* Scalar model of the device's dense-window kernel (dense_model.inc): windows [lo, hi) of at most wmax documents
+ * (first window w0, doubling), order-free f32 upper-bound sums, MaxScore split + block-level skip of non-essential
+ * blocks (ne_on), candidates re-scored exactly.  A test aid for the kernel's bounds, not an oracle.
+ * stats8: windows, blocks, essential blocks, non-essential blocks tested / skipped, candidates, lookups, -. */
+uint32_t orc_dense_model(const orc_index *, const uint32_t *terms, uint32_t n_terms, uint32_t k, uint32_t wmax,
+                         uint32_t w0, uint32_t lo, uint32_t hi, int ne_on, orc_hit *out, uint64_t *stats8);
 /* Algorithmic bytes of one query per SURVEY section 8(d). */
 uint64_t orc_query_bytes(const orc_index *, const uint32_t *terms, uint32_t n_terms, uint32_t k);
 

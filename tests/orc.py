@@ -42,8 +42,8 @@ class IndexView(C.Structure):
 
 
 def build_oracle():
-    if not os.path.exists(_SO) or os.path.getmtime(_SO) < os.path.getmtime(
-            os.path.join(ROOT, "oracle", "oracle.cpp")):
+    srcs = [os.path.join(ROOT, "oracle", f) for f in ("oracle.cpp", "dense_model.inc", "pages.cpp", "oracle.h")]
+    if not os.path.exists(_SO) or os.path.getmtime(_SO) < max(os.path.getmtime(f) for f in srcs):
         subprocess.check_call(["make", "-s", "-C", os.path.join(ROOT, "oracle")])
     return _SO
 
@@ -104,6 +104,9 @@ def lib():
     L.orc_evaluate.argtypes = [vp, vp, vp, C.c_uint32, vp, C.c_uint32]
     L.orc_query_bytes.restype = C.c_uint64
     L.orc_query_bytes.argtypes = [vp, vp, C.c_uint32, C.c_uint32]
+    L.orc_dense_model.restype = C.c_uint32
+    L.orc_dense_model.argtypes = [vp, vp, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32,
+                                  C.c_int, vp, vp]
     L.orc_pages_build.restype = vp
     L.orc_pages_build.argtypes = [vp, vp]
     L.orc_pages_insert.restype = None
@@ -204,6 +207,16 @@ class OracleIndex:
 
     def search_brute(self, terms, k):
         return self._search(lib().orc_search_brute, terms, k)
+
+    def dense_model(self, terms, k, wmax=8192, w0=256, lo=0, hi=None, ne_on=True):
+        """model of the device's dense-window kernel (oracle/dense_model.inc): hits + statistics"""
+        terms = np.ascontiguousarray(terms, dtype=np.uint32)
+        out = np.zeros(max(k, 1), dtype=HIT_DTYPE)
+        st = np.zeros(8, dtype=np.uint64)
+        hi = self.n_docs if hi is None else hi
+        n = lib().orc_dense_model(self.h, _p(terms), len(terms), k, wmax, w0, lo, hi, int(ne_on), _p(out), _p(st))
+        names = ("windows", "blocks", "ess_blocks", "ne_tested", "ne_skipped", "candidates", "lookups", "_")
+        return out[:n], dict(zip(names, (int(x) for x in st)))
 
     def search_batch(self, terms, q_off, k, mode="wand", threads=1):
         terms = np.ascontiguousarray(terms, dtype=np.uint32)

@@ -251,6 +251,16 @@ class Batch:
         check(lib().vbm25_batch_kernel_ms(self.h, C.byref(ms), C.byref(n)))
         return ms.value, n.value
 
+    def debug_counts(self):
+        """tuning / test aid (not in include/vbm25.h): (work items of the last run, items the first-choice
+        kernel handed to scan_many_kernel)"""
+        f = lib().vbm25_batch_debug_counts
+        f.restype = C.c_int
+        f.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
+        ni, nf = C.c_uint32(), C.c_uint32()
+        check(f(self.h, C.byref(ni), C.byref(nf)))
+        return ni.value, nf.value
+
 
 def search_batch(index, term_ids, q_off, k):
     """vbm25_search_batch: nq queries (CSR of ascending term ids) -> (hits[nq,k], n_hits[nq])."""

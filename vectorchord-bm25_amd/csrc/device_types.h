@@ -46,7 +46,7 @@ struct DevBatch {
     unsigned long long *spill; // per scan workgroup: candidates that did not fit the LDS buffer
     uint32_t *item_failed;     // per item: 1 = the chain kernel gave up (dense tile), redo it
     unsigned long long *prof;  // VBM25_PROFILE builds: 33 counters per workgroup
-    uint32_t *work_ctr;        // next item of the cursor kernel (reset by plan_kernel)
+    uint32_t *work_ctr;        // [0] next item of the cursor / range kernel, [1] of the dense kernel (reset by plan_kernel)
     uint32_t *hist;            // per query: CUR_HB score buckets, documents accepted by any item
     uint32_t chain_min_terms;  // scan_kernel leaves queries with fewer terms to scan_cursor_kernel
     uint32_t lpi;              // result lists per item (scan_range_kernel: one per wave; the others use list 0)
@@ -54,6 +54,7 @@ struct DevBatch {
     uint32_t range_dense;      // ... the dense ones too; 0: dense queries go to scan_many_kernel
     uint32_t ne_on;            // MaxScore split in scan_range_kernel (non-essential lists looked up, not scanned)
     uint32_t ne_ratio;         // a non-essential list must be this many times longer than the essential lists together
+    uint32_t dense_on;         // dense queries of <= D_T terms take scan_dense_kernel (its items come from work_ctr[1])
 };
 
 constexpr int WG = 256;

@@ -107,7 +107,10 @@ __global__ void __launch_bounds__(PLAN_WG) plan_kernel(DevIndex ix, DevBatch bt,
     for (uint32_t i = tid; i < max_items; i += PLAN_WG) bt.item_failed[i] = 0;
     if (bt.lpi > 1)  // lists a kernel does not write must read as empty
         for (uint32_t i = tid; i < max_items * bt.lpi; i += PLAN_WG) bt.res_cnt[i] = 0;
-    if (tid == 0) *bt.work_ctr = 0;
+    if (tid == 0) {
+        bt.work_ctr[0] = 0;
+        bt.work_ctr[1] = 0;
+    }
 
     auto postings_of = [&](uint32_t q) {
         unsigned long long t = 0;

@@ -26,7 +26,7 @@ __global__ void __launch_bounds__(WG) scan_many_kernel(DevIndex ix, DevBatch bt)
     for (uint32_t item = blockIdx.x; item < n_items; item += gridDim.x) {
         const Item it = bt.items[item];
         const uint32_t others_max = max((uint32_t)CHAIN_MAX_TERMS, bt.range_max_terms);  // taken by the other kernels
-        const uint32_t mt_item = bt.range_dense ? (it.m & ~ITEM_DENSE) : it.m;  // dense items: scan_range_kernel's too
+        const uint32_t mt_item = (bt.range_dense || bt.dense_on) ? (it.m & ~ITEM_DENSE) : it.m;  // dense items: scan_dense_kernel's / scan_range_kernel's
         const bool failed = mt_item <= others_max && bt.item_failed[item] != 0;
         if (mt_item <= others_max && !failed) continue;
         const bool force_dense = failed || (it.m & ITEM_DENSE) != 0;

@@ -162,7 +162,7 @@ __global__ void __launch_bounds__(RWG, 4) scan_range_kernel(DevIndex ix, DevBatc
         if (item >= n_items) break;
         const Item it = bt.items[item];
         const bool dense_item = (it.m & ITEM_DENSE) != 0;
-        if ((it.m & ~ITEM_DENSE) > (uint32_t)RT || (dense_item && !bt.range_dense)) continue;  // the other kernels'
+        if ((it.m & ~ITEM_DENSE) > (uint32_t)RT || (dense_item && (!bt.range_dense || bt.dense_on))) continue;  // the other kernels'
         PROF_T(t_item);
         const uint32_t q = uni(it.q), lo = uni(it.doc_lo), hi = uni(it.doc_hi);
         uint32_t *hrow = bt.hist + (size_t)q * CUR_HB;

@@ -6,7 +6,9 @@
 //   scan_cursor.h  scan_cursor_kernel: queries of <= 8 terms, k <= 256 -- one wave per item, cursors
 //                  processed in min_doc order (the dominant kernel)
 //   scan_tile.h    scan_kernel: 9..12 terms or k > 256 -- workgroup per item, doc-range tiles
-//   scan_many.h    scan_many_kernel: many terms, many postings per document, items the others gave up
+//   scan_range.h   scan_range_kernel: sparse queries of <= 16 terms, k <= 256 (the dominant kernel)
+//   scan_dense.h   scan_dense_kernel: queries with many postings per document (Zipf head terms), <= 16 terms, k <= 256
+//   scan_many.h    scan_many_kernel: many terms, k > 256 dense queries, items the others gave up
 //   merge.h        merge_kernel: per-item top-k lists -> hits with payloads
 //   decode.h / block_fetch.h / topk_lds.h / topk_reg.h / device_types.h   shared pieces
 // This file: error text, host objects (index, batch) and the C ABI of include/vbm25.h.  DESIGN.md has
@@ -59,6 +61,7 @@ int set_error(int code, const char *fmt, ...) {
 #include "scan_tile.h"
 #include "scan_cursor.h"
 #include "scan_range.h"
+#include "scan_dense.h"
 #include "scan_many.h"
 #include "merge.h"
 
@@ -223,6 +226,10 @@ struct vbm25_batch {
     bool ne_on = true;            // MaxScore split in scan_range_kernel (VBM25_NE=0: off)
     bool range_dense = false;     // dense queries take scan_range_kernel too (VBM25_RANGE_DENSE=1); default: scan_many_kernel
     uint32_t ne_ratio = 2;        // VBM25_NE_RATIO
+    bool use_dense = false;       // k <= REG_K: dense queries of <= D_T terms take scan_dense_kernel (VBM25_DENSE=0: scan_many_kernel)
+    bool has_dense = false;       // ... and the current queries have such a query
+    uint32_t dense_target = D_TARGET_ITEMS;  // work items of a batch with dense queries (VBM25_DENSE_ITEMS)
+    uint32_t dense_grid = D_GRID;
     uint32_t cur_mt = 1;          // most indexed terms among the cursor kernel's queries
     uint32_t target_items = TARGET_ITEMS;
     uint32_t min_chunk = MIN_CHUNK_POSTINGS;
@@ -453,6 +460,10 @@ static int vbm25_batch_create_impl(vbm25_index *ix, uint32_t max_queries, uint32
         const char *nr = std::getenv("VBM25_NE_RATIO");
         if (nr) bt->ne_ratio = (uint32_t)std::max(1, std::atoi(nr));
         bt->lpi = bt->use_range ? (uint32_t)RNW : 1u;
+        const char *dn = std::getenv("VBM25_DENSE");
+        bt->use_dense = bt->use_range && !bt->range_dense && !(dn && dn[0] == '0');
+        const char *di = std::getenv("VBM25_DENSE_ITEMS");
+        if (di) bt->dense_target = (uint32_t)std::max(256, std::atoi(di));
         const char *ti = std::getenv("VBM25_CUR_ITEMS");
         bt->target_items = bt->use_range ? (ti ? (uint32_t)std::atoi(ti) : R_TARGET_ITEMS)
                            : bt->use_cursor ? (ti ? (uint32_t)std::atoi(ti) : CUR_TARGET_ITEMS) : TARGET_ITEMS;
@@ -464,7 +475,7 @@ static int vbm25_batch_create_impl(vbm25_index *ix, uint32_t max_queries, uint32
         const char *mi = std::getenv("VBM25_CUR_MIN_ITEMS");
         if (mi) bt->cur_min_items = (uint32_t)std::atoi(mi);
     }
-    bt->max_items = max_queries + bt->target_items;
+    bt->max_items = max_queries + std::max(bt->target_items, bt->use_dense ? bt->dense_target : 0u);
     int rc = 0;
     if (k > 1024) {  // exhaustive path: query buffers, results and an accumulator per document
         bt->bigk = true;
@@ -495,7 +506,7 @@ static int vbm25_batch_create_impl(vbm25_index *ix, uint32_t max_queries, uint32
         (rc = bt->n_hits.alloc(4ull * max_queries)) || (rc = bt->error_flag.alloc(4)) ||
         (rc = bt->q_dense.alloc(max_queries)) ||
         (rc = bt->spill.alloc(size_t(TARGET_ITEMS) * 3 * 2 * C_POSTINGS * 16)) ||
-        (rc = bt->item_failed.alloc(4ull * bt->max_items)) || (rc = bt->work_ctr.alloc(4)) ||
+        (rc = bt->item_failed.alloc(4ull * bt->max_items)) || (rc = bt->work_ctr.alloc(8)) ||
         (rc = bt->hist.alloc(4ull * CUR_HB * max_queries)))
         return rc;
     HIP_TRY(hipMemset(bt->error_flag.p, 0, 4));
@@ -519,7 +530,7 @@ static int vbm25_batch_set_queries_impl(vbm25_batch *bt, const uint32_t *term_id
     if (!term_ids && nq && q_off[nq] != 0) return set_error(VBM25_ERR_INVALID, "term_ids is NULL but the queries have terms");
     if (nq > bt->max_queries) return set_error(VBM25_ERR_INVALID, "%u queries exceed the batch capacity %u", nq, bt->max_queries);
     if (q_off[0] != 0) return set_error(VBM25_ERR_INVALID, "q_off[0] must be 0");
-    bool many = false, mid = false;
+    bool many = false, mid = false, has_dense = false;
     uint32_t cur_mt = 1, range_mt = 0;
     // Routing: the chain kernel is built for sparse queries; a query with many postings per
     // document (Zipf head terms) or more than CHAIN_MAX_TERMS indexed terms takes the
@@ -545,8 +556,9 @@ static int vbm25_batch_set_queries_impl(vbm25_batch *bt, const uint32_t *term_id
             dense[q] = 1;
             many = true;
         }
-        if (bt->use_range) {  // sparse queries of <= 16 terms: scan_range_kernel; the rest: scan_many_kernel
+        if (bt->use_range) {  // sparse queries of <= 16 terms: scan_range_kernel; dense ones: scan_dense_kernel; the rest: scan_many_kernel
             many |= valid > 16u;
+            has_dense |= bt->use_dense && dense[q] && valid <= (uint32_t)D_T;
             if ((!dense[q] || bt->range_dense) && valid <= 16u) range_mt = std::max(range_mt, valid);
         } else {
             many |= valid > (uint32_t)CHAIN_MAX_TERMS;
@@ -588,12 +600,14 @@ static int vbm25_batch_set_queries_impl(vbm25_batch *bt, const uint32_t *term_id
     }
     bt->nq = nq;
     bt->has_many_terms = many;
+    bt->has_dense = has_dense;
     bt->has_mid_terms = mid;
     bt->cur_mt = cur_mt;
     bt->range_rt = !bt->use_range || range_mt == 0 ? 0u : (range_mt <= 8u ? 8u : 16u);
     {   // the number of work items plan_kernel will make (same integer arithmetic): the cursor kernel's
         // persistent grid need not be larger (a single query is a handful of items, not 6144 workgroups)
-        unsigned long long chunk = (total_postings + bt->target_items - 1) / bt->target_items;
+        const uint32_t target = has_dense ? std::max(bt->target_items, bt->dense_target) : bt->target_items;
+        unsigned long long chunk = (total_postings + target - 1) / target;
         if (chunk < bt->min_chunk) chunk = bt->min_chunk;
         unsigned long long items = 0;
         for (uint32_t q = 0; q < nq; ++q) {
@@ -610,6 +624,9 @@ static int vbm25_batch_set_queries_impl(vbm25_batch *bt, const uint32_t *term_id
         // A handful of items cannot occupy the GPU with one wave each: the tile kernel puts a whole
         // workgroup (six decoding waves) on an item and answers a single query faster (C2: 0.10 ms vs 0.15 ms)
         bt->run_cursor = bt->use_cursor && items >= bt->cur_min_items;
+        const char *dgrid = std::getenv("VBM25_DENSE_GRID");
+        bt->dense_grid = uint32_t(std::min<unsigned long long>(std::max<unsigned long long>(items, 1),
+                                                               dgrid ? (unsigned long long)std::atoll(dgrid) : D_GRID));
     }
     return VBM25_OK;
 }
@@ -673,10 +690,12 @@ static int vbm25_batch_run_impl(vbm25_batch *bt, void *hip_stream) {
     db.range_dense = bt->range_dense ? 1u : 0u;
     db.ne_on = bt->ne_on ? 1u : 0u;
     db.ne_ratio = bt->ne_ratio;
+    db.dense_on = bt->use_dense ? 1u : 0u;
     const bool range = bt->use_range;
     const DevIndex &ix = bt->index->dev;
     if (cursor || range) HIP_TRY(hipMemsetAsync(bt->hist.p, 0, 4ull * CUR_HB * bt->nq, st));
-    plan_kernel<<<1, PLAN_WG, 0, st>>>(ix, db, bt->max_items, cursor || range ? bt->target_items : TARGET_ITEMS,
+    const uint32_t target = bt->has_dense ? std::max(bt->target_items, bt->dense_target) : bt->target_items;
+    plan_kernel<<<1, PLAN_WG, 0, st>>>(ix, db, bt->max_items, cursor || range ? target : TARGET_ITEMS,
                                        cursor || range ? bt->min_chunk : MIN_CHUNK_POSTINGS);
     hipEvent_t e0 = nullptr, e1 = nullptr;
     if (bt->timing) {
@@ -701,6 +720,9 @@ static int vbm25_batch_run_impl(vbm25_batch *bt, void *hip_stream) {
                 // persistent single-wave workgroups; items are handed out through bt.work_ctr
                 scan_cursor_kernel<KM><<<bt->cur_grid, 64, 4 * cur_lds_words(bt->cur_mt), st>>>(ix, db, bt->cur_mt);
             }
+        }
+        if constexpr (KM <= REG_K) {
+            if (bt->has_dense) scan_dense_kernel<KM><<<bt->dense_grid, DWG, 0, st>>>(ix, db);
         }
         if (!range && (!cursor || bt->has_mid_terms)) scan_kernel<KM><<<grid, CWG, 0, st>>>(ix, db);
         // many-term / dense queries, and items the first-choice kernel gave up on (empty launch: 5 us)
