@@ -13,6 +13,11 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 import vectorchord_bm25_amd as vb
+from vectorchord_bm25_amd import _lib
+
+if os.environ.get("VBM25_SO"):  # a variant build of the library (tuning experiments)
+    _lib._SO = os.path.join(ROOT, "vectorchord-bm25_amd", "csrc", os.environ["VBM25_SO"])
+    _lib._lib = None
 from bench import make_queries, usable_cpus
 
 n_docs, vocab, nq, nterms, k = (int(x) for x in sys.argv[1:6])

@@ -3,63 +3,80 @@
 // search.hip inside namespace vbm25, after scan_range.h (whose helpers it uses).
 //
 // One 8-wave workgroup per work item (query x doc range), persistent, items from bt.work_ctr[1].  The item is
-// cut into WINDOWS of <= D_W consecutive documents with one f32 accumulator per document in LDS.  A window is
+// cut into WINDOWS of <= D_W consecutive documents with one 32-bit FIXED-POINT accumulator per document in LDS
+// (integer LDS atomics run at full rate on gfx950; float LDS atomics measured three times slower than the
+// whole rest of a window).  A window is
 //
 //   P0  enumerate: the blocks of every term that start below the window's end (one lane per block: 16-byte
 //       metadata + block upper bound), laid out as TASKS in descending order of the terms' token upper bounds.
 //   P1  ESSENTIAL terms (search.rs:153-169: the MaxScore split on token upper bounds against the threshold):
 //       every task decoded -- ids, term frequencies, fieldnorm bytes -- and an UPPER BOUND of each posting's
-//       score (f32, rounded up) added to its document's accumulator with an LDS float atomic, in any order:
+//       score (f32 rounded up, scaled to an integer, + 1) added to its document's accumulator, in any order:
 //       no barrier between terms, all eight waves busy, four blocks per wave in flight.
 //   P2  NON-ESSENTIAL terms, one phase per term in descending order of upper bound.  A block is fetched only
 //       if some document of its span can still reach the threshold: max accumulator over the span + the bounds
 //       of the terms not yet complete, with the block's own upper bound for its term (search.rs:177-203: the
 //       block-max test).  Every other block is SKIPPED: no id, tf or fieldnorm byte of it is read.
-//   P3  candidates: documents whose accumulated bound reaches the threshold (a handful per window once the
-//       threshold has settled); accumulators wiped in the same pass.
-//   P4  candidates re-scored EXACTLY: per (candidate, term) the block is found among the window's tasks, decoded
-//       by one wave, the posting's f64 Cache::evaluate (bm25.rs:355-358) taken; sum in ascending key order
-//       (evaluate.rs:43-72) -> the register top-k of wave 0 -> the query's shared threshold.
+//   P3  candidates: documents whose accumulated bound reaches the threshold go to the item's candidate buffer
+//       (document, bound) and -- by the LOWER bound of their score that the accumulator also implies -- into the
+//       query's 256-bucket histogram (bt.hist, shared by all items of the query, as in scan_range.h): k documents
+//       in buckets >= b put the final k-th score at or above the lower edge of b.  The threshold therefore rises
+//       from approximate sums alone, across items, without any exact score.  Accumulators wiped in the same pass.
 //
-// The f32 sums only SELECT; every score that is compared, kept or returned is the exact f64 sum, so results are
-// bit-identical to the other kernels'.  Bounds: s0 is rounded up and carries a factor 1 + 2^-19 (five f32
-// roundings + v_rcp_f32's 1 ulp < 2^-21 relative), s1 is rounded down, and every comparison of an f32 sum with
-// the threshold (rounded down to f32) carries a factor 1 + 2^-17 (<= 128 order-free f32 additions).
-// oracle/dense_model.inc is a scalar CPU model of exactly this scheme (tests/test_dense_model.py).
+// FLUSH (buffer half full after dropping the entries the threshold has overtaken; always at the item's end):
+// the surviving candidates are re-scored EXACTLY -- block located by interpolation + gallop + bisection of
+// blk_max_doc, block upper bounds first (search.rs:177-203), then the block decoded by the wave and the one
+// posting's f64 Cache::evaluate (bm25.rs:355-358) taken, sum in ascending key order (evaluate.rs:43-72) -> the
+// wave's register top-k -> the query's shared threshold.  Most candidates of the warm-up are never re-scored.
+//
+// The integer sums only SELECT; every score that is compared, kept or returned is the exact f64 sum, so results
+// are bit-identical to the other kernels'.  Bounds: s0 is rounded up to f32 and carries a factor 1 + 2^-19
+// (five f32 roundings + v_rcp_f32's 1 ulp < 2^-21 relative), s1 is rounded down; the scale is a power of two with
+// scale x (sum of the token upper bounds) < 2^31; truncation to an integer is covered by the + 1; the integer sum is
+// exact.  So  acc >= scale x score  and  score >= (acc - m) / (scale (1 + 2^-18)).
+// oracle/dense_model.inc is a scalar CPU model of this scheme (tests/test_dense_model.py).
 //
 // The first window of a query whose threshold is still 0 is 256 documents wide and the width doubles from
 // there: the number of candidates per window stays near k ln 2 while the threshold warms up.
 
 constexpr int DNW = 8;
+static_assert(DNW == RNW, "one result list per wave: bt.lpi is scan_range_kernel's");
 constexpr int DWG = DNW * 64;
 constexpr int D_W = 8192;                // documents per window
 constexpr int D_W0 = 256;                // first window while the threshold is 0
 constexpr int D_T = 16;                  // indexed terms per query
 constexpr int D_SEG = D_W / 128 + 4;     // blocks of one term that can start below a window's end (full blocks span >= 128 documents; + straddlers + the tail block)
 constexpr int D_TCAP = D_T * D_SEG;
-constexpr int D_CCAP = 64;               // candidates re-scored per round
-constexpr int D_UN = 4;                  // tasks per wave in flight
-constexpr uint32_t D_MAX_ROUNDS = 32;    // candidate rounds per window; beyond (masses of equal scores): scan_many_kernel
+constexpr int D_WCB = 128;               // candidate buffer entries per wave
+#ifndef D_UN_V
+#define D_UN_V 4
+#endif
+constexpr int D_UN = D_UN_V;                  // tasks per wave in flight
+constexpr uint32_t D_MAX_RESOLVED = 16384;  // exact re-scorings per item; beyond (masses of equal scores): scan_many_kernel
 constexpr uint32_t D_SPAN_TEST = 512;    // widest block span the skip test reads (8 accumulators per lane)
 constexpr uint32_t D_GRID = 512;         // persistent workgroups: 256 CUs x 2
 constexpr uint32_t D_TARGET_ITEMS = 4096;
 
 struct DenseLds {
-    float acc[D_W];
+    uint32_t acc[D_W];        // fixed point: scale x (upper bound of the document's score)
+    uint32_t bmax[D_W / 64];  // largest accumulator of every 64 documents, kept current by the adds
     uint4 tmeta[D_TCAP];      // {min_doc, max_doc, off8, n | md << 8 | mt << 16 | wand_fn << 24}
     uint32_t tblk[D_TCAP];    // block index
-    float tub[D_TCAP];        // block upper bound, rounded up
+    uint32_t tub[D_TCAP];     // block upper bound, scaled, rounded up
     uint8_t tterm[D_TCAP];
-    double contrib[D_CCAP * D_T];
-    uint32_t cand[D_CCAP];    // document - window start
+    uint32_t cdoc[DNW][D_WCB], cval[DNW][D_WCB];  // per wave: candidate buffer (document, accumulator)
+    uint32_t scr[DNW][128];   // per wave: ids of the block being looked into
     double s1[256];
     float s1f[256];           // rounded down
     double t_s0[D_T], t_ub[D_T], t_cum[D_T + 1];
-    float t_s0f[D_T];         // rounded up x (1 + 2^-19)
-    uint32_t t_cur[D_T], t_end[D_T], t_cnt[D_T], t_base[D_T], t_fin[D_T];
+    float t_s0i[D_T];         // scale x s0, rounded up, x (1 + 2^-19)
+    uint32_t t_cur[D_T], t_end[D_T], t_b0[D_T], t_cnt[D_T], t_base[D_T];
     uint8_t t_rank[D_T], t_ord[D_T];
+    uint8_t t_cls[D_T];       // document-frequency class: 2 = df >= N / 2, 1 = df >= N / 8, 0 = rarer
+    uint32_t t_rem[D_T];      // non-essential term: scaled bounds of the OTHER terms that are incomplete during its phase
+    double scale, hscale;
     unsigned long long theta; // bits of a lower bound of the query's k-th best score
-    uint32_t ncand, item, m, fail, p_ne;
+    uint32_t cover, cflag, item, m, fail, p_ne, h_ne, resolved;
     uint32_t scratch[64];
 };
 
@@ -67,7 +84,6 @@ template <int KMAX>
 __global__ void __launch_bounds__(DWG, 4) scan_dense_kernel(DevIndex ix, DevBatch bt) {
     static_assert(KMAX <= REG_K, "register top-k only");
     constexpr int RK = KMAX / 64;
-    constexpr float SLACK = 1.0f + 1.0f / 131072.0f;
     __shared__ DenseLds S;
 
     const uint32_t tid = threadIdx.x, lane = tid & 63, wave = uni(tid >> 6);
@@ -78,14 +94,23 @@ __global__ void __launch_bounds__(DWG, 4) scan_dense_kernel(DevIndex ix, DevBatc
         S.s1[i] = v;
         S.s1f[i] = __double2float_rd(v);
     }
-    for (uint32_t i = tid; i < (uint32_t)D_W; i += DWG) S.acc[i] = 0.0f;
+    for (uint32_t i = tid; i < (uint32_t)D_W; i += DWG) S.acc[i] = 0u;
+    if (tid < (uint32_t)D_W / 64) S.bmax[tid] = 0u;
+#ifdef VBM25_PROFILE
+    // per wave: 0 windows, 1 P0, 2 P1, 3 P2, 4 wait before P3, 5 P3, 6 flush: filter, 7 flush: exact re-scoring, 8 item setup,
+    // 9 window loops, 10 candidates buffered, 11 candidates re-scored, 12 items, 13 tasks fetched, 14 tasks skipped, 15 lifetime
+    unsigned long long prof[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    const unsigned long long prof_t0 = __builtin_readcyclecounter();
+#endif
 
     for (;;) {
         __syncthreads();  // previous item fully done with LDS
         if (tid == 0) {
             S.item = atomicAdd(&bt.work_ctr[1], 1u);
-            S.ncand = 0;
+            S.cover = 0;
+            S.cflag = 0;
             S.fail = 0;
+            S.resolved = 0;
         }
         __syncthreads();
         const uint32_t item = uni(S.item);
@@ -93,9 +118,44 @@ __global__ void __launch_bounds__(DWG, 4) scan_dense_kernel(DevIndex ix, DevBatc
         const Item it = bt.items[item];
         if (!(it.m & ITEM_DENSE) || (it.m & ~ITEM_DENSE) > (uint32_t)D_T) continue;  // the other kernels'
         const uint32_t q = uni(it.q), lo = uni(it.doc_lo), hi = uni(it.doc_hi);
+        uint32_t *hrow = bt.hist + (size_t)q * CUR_HB;
+        PROF_T(t_item);
 
-        // ---- item setup (wave 0, lane t = term t): block ranges, first block at or after lo, bounds, order
+        // ---- threshold poll (wave 0): the query's published k-th score and the histogram of the candidates' lower bounds
+        unsigned long long pg = 0;
+        uint32_t pc[4] = {0, 0, 0, 0};
+        auto poll_request = [&]() {
+            pg = __hip_atomic_load(&bt.theta[q], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) pc[i] = __hip_atomic_load(&hrow[4 * lane + i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        };
+        auto poll_consume = [&]() {
+            unsigned long long th = ((unsigned long long)uni((uint32_t)(pg >> 32)) << 32) | uni((uint32_t)pg);
+            const uint32_t own = pc[0] + pc[1] + pc[2] + pc[3];
+            const uint32_t incl = wave_incl_scan_u32(own);
+            const uint32_t total = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
+            const uint32_t above = total - incl;  // documents in the buckets of higher lanes
+            const unsigned long long hit = __ballot(above + own >= k);
+            if (hit) {
+                const uint32_t hl = 63u - (uint32_t)__builtin_clzll(hit);
+                uint32_t a = (uint32_t)__builtin_amdgcn_readlane((int)above, (int)hl), b = 4 * hl;
+                const uint32_t c3 = (uint32_t)__builtin_amdgcn_readlane((int)pc[3], (int)hl);
+                const uint32_t c2 = (uint32_t)__builtin_amdgcn_readlane((int)pc[2], (int)hl);
+                const uint32_t c1 = (uint32_t)__builtin_amdgcn_readlane((int)pc[1], (int)hl);
+                if (a + c3 >= k) b += 3;
+                else if (a + c3 + c2 >= k) b += 2;
+                else if (a + c3 + c2 + c1 >= k) b += 1;
+                // a document lands in bucket b only if (a lower bound of) its score x hscale >= b (up to one rounding)
+                const double edge = ((double)b / S.hscale) * (1.0 - 1e-12);
+                const unsigned long long eb2 = (unsigned long long)__double_as_longlong(edge);
+                if (eb2 > th) th = eb2;
+            }
+            if (lane == 0) atomicMax(&S.theta, th);
+        };
+
+        // ---- item setup (wave 0, lane t = term t): block ranges, first block at or after lo, bounds, order, scale
         if (wave == 0) {
+            poll_request();
             uint32_t m = 0, term = NONE32;
             {
                 const uint32_t qb = uni(bt.q_off[q]), qe = uni(bt.q_off[q + 1]);
@@ -120,15 +180,19 @@ __global__ void __launch_bounds__(DWG, 4) scan_dense_kernel(DevIndex ix, DevBatc
                 const double wtf = (double)ix.term_wand_tf[term];
                 tub = ((wtf * s0) / (wtf + S.s1[ix.term_wand_fn[term]])) * (1.0 + 1e-12);
                 S.t_cur[lane] = r_first_block_ge(ix, b0, b1, lo);
+                S.t_b0[lane] = b0;
                 S.t_end[lane] = b1;
                 S.t_s0[lane] = s0;
-                S.t_s0f[lane] = __double2float_ru(s0) * (1.0f + 1.0f / 524288.0f);
                 S.t_ub[lane] = tub;
+                const uint32_t df = ix.term_df[term];
+                S.t_cls[lane] = (uint8_t)(df >= ix.n_docs / 2 ? 2 : df >= ix.n_docs / 8 ? 1 : 0);
             }
             uint32_t rank = 0;  // position in ascending order of the token upper bounds
+            double sums0 = 0.0;
             for (uint32_t t = 0; t < m; ++t) {
                 const double ubt = readlane_f64(tub, t);
                 if (act && (ubt < tub || (ubt == tub && t < lane))) ++rank;
+                sums0 += readlane_f64(s0, t);
             }
             if (act) {
                 S.t_rank[lane] = (uint8_t)rank;
@@ -141,13 +205,28 @@ __global__ void __launch_bounds__(DWG, 4) scan_dense_kernel(DevIndex ix, DevBatc
                 cum += readlane_f64(tub, owner);
                 if (lane == 0) S.t_cum[pp + 1] = cum;
             }
+            // power-of-two scale with scale x (sum of all token bounds) < 2^31: no sum of postings can wrap
+            int e = 30 - ilogb(cum > 0.0 ? cum : 1.0);
+            e = e > 60 ? 60 : (e < -60 ? -60 : e);
+            const double scale = ldexp(1.0, e);
+            if (act) S.t_s0i[lane] = (__double2float_ru(s0) * (1.0f + 1.0f / 524288.0f)) * (float)scale;
             if (lane == 0) {
                 S.m = m;
-                S.theta = __hip_atomic_load(&bt.theta[q], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                S.scale = scale;
+                S.hscale = (double)CUR_HB / sums0;  // score -> histogram bucket: linear in [0, sum of s0), as scan_range.h
+                S.theta = 0;
             }
+            __builtin_amdgcn_wave_barrier();
+            poll_consume();
         }
         __syncthreads();
         const uint32_t m = uni(S.m);
+        const double scale = S.scale;
+        // threshold -> fixed point, rounded down (an accumulator >= this may belong to a document at or above the threshold)
+        auto theta_fix = [&](unsigned long long th) -> uint32_t {
+            const double x = __longlong_as_double((long long)th) * scale;
+            return x >= 4294967295.0 ? 0xffffffffu : (uint32_t)x;
+        };
 
         RegTopK<RK> rtop;
         rtop.init();
@@ -155,6 +234,23 @@ __global__ void __launch_bounds__(DWG, 4) scan_dense_kernel(DevIndex ix, DevBatc
         auto theta_now = [&]() -> unsigned long long {
             const unsigned long long th = S.theta;
             return ((unsigned long long)uni((uint32_t)(th >> 32)) << 32) | uni((uint32_t)th);
+        };
+        auto offer = [&](bool has, double sc, uint32_t d) {
+            const unsigned long long th = theta_now();
+            has = has && (unsigned long long)__double_as_longlong(sc) >= th &&
+                  (rtop.cnt < k || better(sc, d, rtop.kth_s, rtop.kth_d));
+            if (!__ballot(has)) return;
+            rtop.offer(has, sc, d, k, lane);
+            if (rtop.cnt >= k) {
+                const unsigned long long kb = (unsigned long long)__double_as_longlong(rtop.kth_s);
+                if (kb > published) {
+                    if (lane == 0) {
+                        atomicMax(&S.theta, kb);
+                        atomicMax(&bt.theta[q], kb);
+                    }
+                    published = kb;
+                }
+            }
         };
 
         // ---- one task: decode the block, add the postings' upper bounds to their documents' accumulators
@@ -172,13 +268,14 @@ __global__ void __launch_bounds__(DWG, 4) scan_dense_kernel(DevIndex ix, DevBatc
         };
         auto add_pair = [&](uint32_t t, uint32_t d0, uint32_t d1, uint32_t f0, uint32_t f1, uint32_t fn, bool in0, bool in1,
                             uint32_t wlo, uint32_t wspan) {
-            const float s0f = S.t_s0f[t];
+            const float s0i = S.t_s0i[t];
             const uint32_t x0 = d0 - wlo, x1 = d1 - wlo;
             const float tf0 = (float)f0, tf1 = (float)f1;
-            const float p0 = (tf0 * s0f) * __builtin_amdgcn_rcpf(tf0 + S.s1f[fn & 0xff]);
-            const float p1 = (tf1 * s0f) * __builtin_amdgcn_rcpf(tf1 + S.s1f[fn >> 8]);
-            if (in0 && x0 < wspan) atomicAdd(&S.acc[x0], p0);
-            if (in1 && x1 < wspan) atomicAdd(&S.acc[x1], p1);
+            const uint32_t p0 = (uint32_t)((tf0 * s0i) * __builtin_amdgcn_rcpf(tf0 + S.s1f[fn & 0xff])) + 1u;
+            const uint32_t p1 = (uint32_t)((tf1 * s0i) * __builtin_amdgcn_rcpf(tf1 + S.s1f[fn >> 8])) + 1u;
+            // the add that comes last in an accumulator's order sees the final sum: the bucket maximum is never below it
+            if (in0 && x0 < wspan) atomicMax(&S.bmax[x0 >> 6], atomicAdd(&S.acc[x0], p0) + p0);
+            if (in1 && x1 < wspan) atomicMax(&S.bmax[x1 >> 6], atomicAdd(&S.acc[x1], p1) + p1);
         };
         auto task_accumulate = [&](const uint4 c, uint32_t t, const Raw &r, uint32_t wlo, uint32_t wspan) {
             const uint32_t md = (c.w >> 8) & 0xff, mt = (c.w >> 16) & 0xff;
@@ -202,105 +299,290 @@ __global__ void __launch_bounds__(DWG, 4) scan_dense_kernel(DevIndex ix, DevBatc
             const uint32_t fn = reinterpret_cast<const uint16_t *>(ix.post_fn + 128ull * j)[lane];
             add_pair(t, d0, d1, f0, f1, fn, 2 * lane < n, 2 * lane + 1 < n, wlo, wspan);
         };
-        // tasks [first, first + cnt), strided over the waves, D_UN per wave in flight.  test: skip a block when no
-        // document of its span can reach the threshold (rem_f: bounds of the other terms not yet complete).
-        auto run_tasks = [&](uint32_t first, uint32_t cnt, bool test, float rem_f, float theta_f, uint32_t wlo, uint32_t wspan) {
+        // up to D_UN tasks of this wave (entries e[0 .. nv) of the task list), all of them in flight together
+        auto run_group = [&](const uint32_t (&e)[D_UN], uint32_t nv, uint32_t wlo, uint32_t wspan) {
+            uint4 c[D_UN];
+            uint32_t j[D_UN], t[D_UN];
+            bool fast[D_UN];
+            Raw r[D_UN];
+#pragma unroll
+            for (int i = 0; i < D_UN; ++i) {
+                const uint32_t ee = (uint32_t)i < nv ? e[i] : e[0];
+                c[i] = uni4(S.tmeta[ee]);
+                j[i] = uni(S.tblk[ee]);
+                t[i] = uni((uint32_t)S.tterm[ee]);
+                fast[i] = ((c[i].w >> 8) & 0xff) < 32u && ((c[i].w >> 16) & 0xff) < 32u;
+            }
+#pragma unroll
+            for (int i = 0; i < D_UN; ++i)
+                if ((uint32_t)i < nv && fast[i]) task_fetch(c[i], j[i], r[i]);
+            uint32_t slow = 0;
+#pragma unroll
+            for (int i = 0; i < D_UN; ++i) {
+                if ((uint32_t)i < nv && fast[i]) task_accumulate(c[i], t[i], r[i], wlo, wspan);
+                __builtin_amdgcn_sched_barrier(0);  // one decode at a time: the scheduler otherwise interleaves them all (registers)
+                if ((uint32_t)i < nv && !fast[i]) slow |= 1u << i;
+            }
+            while (slow) {
+                const uint32_t i = (uint32_t)__ffs((int)slow) - 1u;
+                slow &= slow - 1u;
+                uint32_t ee = e[0];
+#pragma unroll
+                for (int x = 1; x < D_UN; ++x) ee = i == (uint32_t)x ? e[x] : ee;
+                task_slow(ee, wlo, wspan);
+            }
+#ifdef VBM25_PROFILE
+            prof[13] += nv;
+#endif
+        };
+        // essential tasks [0, cnt): strided over the waves, every one of them fetched
+        auto run_all = [&](uint32_t cnt, uint32_t wlo, uint32_t wspan) {
             for (uint32_t base = wave; base < cnt; base += DNW * D_UN) {
-                uint4 c[D_UN];
-                uint32_t j[D_UN], t[D_UN];
-                bool alive[D_UN], fast[D_UN];
-                Raw r[D_UN];
+                uint32_t e[D_UN];
+                uint32_t nv = 0;
 #pragma unroll
                 for (int i = 0; i < D_UN; ++i) {
-                    const uint32_t o = base + DNW * i;
-                    alive[i] = o < cnt;
-                    const uint32_t e = first + (alive[i] ? o : 0u);
-                    c[i] = uni4(S.tmeta[e]);
-                    j[i] = uni(S.tblk[e]);
-                    t[i] = uni((uint32_t)S.tterm[e]);
-                    fast[i] = ((c[i].w >> 8) & 0xff) < 32u && ((c[i].w >> 16) & 0xff) < 32u;
-                    if (test && alive[i]) {
-                        const uint32_t a = max(c[i].x, wlo) - wlo, b = min(c[i].y - wlo, wspan - 1u);
-                        if (b - a < D_SPAN_TEST) {
-                            float mx = 0.0f;
-                            for (uint32_t x = a + lane; x <= b; x += 64) mx = fmaxf(mx, S.acc[x]);
-                            const float bound = (mx + (rem_f + S.tub[e])) * SLACK;
-                            alive[i] = __ballot(bound >= theta_f) != 0ull;
-                        }
-                    }
+                    e[i] = base + DNW * i;
+                    nv += e[i] < cnt ? 1u : 0u;  // a prefix
                 }
-#pragma unroll
-                for (int i = 0; i < D_UN; ++i)
-                    if (alive[i] && fast[i]) task_fetch(c[i], j[i], r[i]);
-                uint32_t slow = 0;
-#pragma unroll
-                for (int i = 0; i < D_UN; ++i) {
-                    if (alive[i] && fast[i]) task_accumulate(c[i], t[i], r[i], wlo, wspan);
-                    if (alive[i] && !fast[i]) slow |= 1u << i;
-                }
-                while (slow) {
-                    const uint32_t i = (uint32_t)__ffs((int)slow) - 1u;
-                    slow &= slow - 1u;
-                    task_slow(first + base + DNW * i, wlo, wspan);
+                run_group(e, nv, wlo, wspan);
+            }
+        };
+        // non-essential tasks [first, first + cnt) of one term, a contiguous share per wave: one lane per task tests
+        // whether any document of the block's span can still reach the threshold (largest accumulator of the
+        // 64-document buckets the span touches + rem_i, the scaled bounds of the terms not yet complete, + the
+        // block's own bound); the blocks that pass are fetched, the others never touched.
+        auto run_tested = [&](uint32_t first, uint32_t cnt, uint32_t theta_i, uint32_t wlo, uint32_t wspan) {
+            const uint32_t share = (cnt + DNW - 1) / DNW;
+          for (uint32_t o0 = 0; o0 < share; o0 += 64) {  // (a share above 64: phases of many terms)
+            const uint32_t o = wave * share + o0 + lane;
+            bool alive = false;
+            if (o0 + lane < share && o < cnt) {
+                const uint2 mm = *reinterpret_cast<const uint2 *>(&S.tmeta[first + o]);
+                const uint32_t a = (max(mm.x, wlo) - wlo) >> 6, b = min(mm.y - wlo, wspan - 1u) >> 6;
+                alive = true;
+                if (b - a < D_SPAN_TEST / 64) {
+                    uint32_t mx = 0;
+                    for (uint32_t x = a; x <= b; ++x) mx = max(mx, S.bmax[x]);
+                    alive = mx + (S.t_rem[S.tterm[first + o]] + S.tub[first + o]) >= theta_i;  // every addend < 2^31: no wrap
                 }
             }
+            unsigned long long mask = __ballot(alive);
+#ifdef VBM25_PROFILE
+            prof[14] += (uint32_t)__popcll(__ballot(o0 + lane < share && o < cnt)) - (uint32_t)__popcll(mask);
+#endif
+            while (mask) {
+                uint32_t e[D_UN];
+                uint32_t nv = 0;
+#pragma unroll
+                for (int i = 0; i < D_UN; ++i) {
+                    e[i] = first;
+                    if (mask) {
+                        e[i] = first + wave * share + o0 + (uint32_t)__ffsll((long long)mask) - 1u;
+                        mask &= mask - 1ull;
+                        ++nv;
+                    }
+                }
+                run_group(e, nv, wlo, wspan);
+            }
+          }
+        };
+
+        // ---- exact score of one candidate per lane (all 64 lanes call; `cand` marks the lanes that hold one)
+        auto resolve = [&](bool cand, uint32_t d) {
+            const double thd = __longlong_as_double((long long)theta_now());
+            // pass 1: block upper bounds (search.rs:177-203)
+            double bound = 0.0;
+            for (uint32_t t = 0; t < m; ++t) {
+                const uint32_t b1 = S.t_end[t];
+                if (cand) {
+                    const uint32_t b = r_first_block_ge(ix, S.t_b0[t], b1, d);
+                    if (b < b1 && ix.blk_min_doc[b] <= d) bound += ix.blk_ub[b];
+                }
+            }
+            cand = cand && bound * (1.0 + 1e-12) >= thd;
+            if (!__ballot(cand)) return;
+#ifdef VBM25_PROFILE
+            prof[11] += (unsigned long long)__popcll(__ballot(cand));
+#endif
+            // pass 2: the exact score, terms in ascending key order (evaluate.rs:43-72)
+            uint32_t *scr = S.scr[wave];
+            double acc = 0.0;
+            for (uint32_t t = 0; t < m; ++t) {
+                double c = 0.0;
+                const uint32_t b1 = S.t_end[t];
+                uint32_t b = NONE32;
+                bool pend = false;
+                if (cand) {
+                    b = r_first_block_ge(ix, S.t_b0[t], b1, d);
+                    pend = b < b1 && ix.blk_min_doc[b] <= d;
+                }
+                for (;;) {
+                    const unsigned long long pmask = __ballot(pend);
+                    if (!pmask) break;
+                    const uint32_t blk = (uint32_t)__builtin_amdgcn_readlane((int)b, __ffsll((long long)pmask) - 1);
+                    const uint4 bm = uni4(ix.blk_meta[blk]);
+                    const uint32_t n = bm.w & 0xff, md = (bm.w >> 8) & 0xff, mt = (bm.w >> 16) & 0xff;
+                    uint32_t a0, a1;
+                    decode_doc_ids(ix.blob + 8ull * bm.z, md, n, bm.x, lane, a0, a1);
+                    __builtin_amdgcn_wave_barrier();
+                    *reinterpret_cast<uint2 *>(&scr[2 * lane]) = make_uint2(2 * lane < n ? a0 : NONE32, 2 * lane + 1 < n ? a1 : NONE32);
+                    __builtin_amdgcn_wave_barrier();
+                    if (pend && b == blk) {  // every lane whose document lies in this block
+                        uint32_t idx = 0;
+#pragma unroll
+                        for (int sft = 64; sft > 0; sft >>= 1)
+                            if (scr[idx + sft - 1] < d) idx += sft;
+                        if (scr[idx] == d) {
+                            const uint8_t *tbody = ix.blob + 8ull * bm.z + ((payload_bytes(md, n) + 7u) & ~7u);
+                            const FieldAddr fa = field_addr(mt, n, idx);
+                            const uint32_t flo = *reinterpret_cast<const uint32_t *>(tbody + fa.off0);
+                            const uint32_t fhi = *reinterpret_cast<const uint32_t *>(tbody + fa.off1);
+                            const uint32_t fn = ix.post_fn[128ull * blk + idx];
+                            const double tf = (double)field_val(flo, fhi, fa);
+                            c = (tf * S.t_s0[t]) / (tf + S.s1[fn]);  // Cache::evaluate, bm25.rs:355-358
+                        }
+                        pend = false;
+                    }
+                }
+                acc += c;  // absent terms add 0.0 (exact)
+            }
+            offer(cand, acc, d);
+        };
+        // ---- flush of the candidate buffers (all waves, each on its own buffer): drop what the threshold has
+        // overtaken, re-score the rest exactly.  No barrier inside: buffer, scratch and top-k are the wave's own.
+        uint32_t cn = 0;  // entries in this wave's candidate buffer (uniform)
+        auto flush = [&]() {
+            PROF_T(t_fa);
+            const uint32_t thi = theta_fix(theta_now());
+            uint32_t w = 0;
+            for (uint32_t base = 0; base < cn; base += 64) {  // in-place compaction (writes never pass the reads)
+                const bool has = base + lane < cn;
+                const uint32_t d = has ? S.cdoc[wave][base + lane] : 0u, v = has ? S.cval[wave][base + lane] : 0u;
+                const bool keep = has && v >= thi;
+                const unsigned long long km = __ballot(keep);
+                const uint32_t pos = w + __builtin_amdgcn_mbcnt_hi((uint32_t)(km >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)km, 0u));
+                __builtin_amdgcn_wave_barrier();
+                if (keep) {
+                    S.cdoc[wave][pos] = d;
+                    S.cval[wave][pos] = v;
+                }
+                w += (uint32_t)__popcll(km);
+            }
+            __builtin_amdgcn_wave_barrier();
+            PROF_T(t_fb);
+            PROF_ADD(6, t_fa, t_fb);
+            for (uint32_t base = 0; base < w; base += 64) {
+                const bool has = base + lane < w;
+                resolve(has, has ? S.cdoc[wave][base + lane] : 0u);
+            }
+            if (lane == 0 && w) atomicAdd(&S.resolved, w);
+            cn = 0;
+            PROF_T(t_fc);
+            PROF_ADD(7, t_fb, t_fc);
         };
 
         // =====================================================================
-        // Window loop
+        // Window loop.  The metadata of window n + 1 is requested before P3 of window n (enum_request) and
+        // consumed at the top of window n + 1: the round trip hides behind P3, the flag barrier and a flush.
+        // Wave w owns the cursors of the terms w and w + 8 (registers).
         // =====================================================================
         uint32_t W = theta_now() == 0ull ? (uint32_t)D_W0 : (uint32_t)D_W;
         bool failed = false;
+        uint32_t ocur[2] = {0, 0}, oend[2] = {0, 0};
+        bool odense[2] = {false, false};
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+            const uint32_t t = wave + DNW * s;
+            if (t < m) {
+                ocur[s] = uni(S.t_cur[t]);
+                oend[s] = uni(S.t_end[t]);
+                odense[s] = uni((uint32_t)S.t_cls[t]) == 2u;
+            }
+        }
+        uint4 em[2][2];
+        double eub[2][2];
+        // lane i = block cur + i of the term (chunk 1: cur + 64 + i, requested only for the dense terms: a full
+        // block spans at least 128 documents, so a window holds more than 64 blocks of a term only if df > N / 2)
+        auto enum_request = [&]() {
+            if (wave == 0) poll_request();
+#pragma unroll
+            for (int s = 0; s < 2; ++s)
+#pragma unroll
+                for (int ch = 0; ch < 2; ++ch) {
+                    em[s][ch] = make_uint4(NONE32, 0, 0, 0);
+                    eub[s][ch] = 0.0;
+                    const uint32_t jj = ocur[s] + 64u * ch + lane;
+                    if (wave + DNW * s < m && jj < oend[s] && (ch == 0 || odense[s])) {
+                        em[s][ch] = ix.blk_meta[jj];
+                        eub[s][ch] = ix.blk_ub[jj];
+                    }
+                }
+        };
+        PROF_T(t_loop);
+        PROF_ADD(8, t_item, t_loop);
+        enum_request();
         for (uint32_t wlo = lo; wlo < hi;) {
             const uint32_t whi = hi - wlo > W ? wlo + W : hi;
             const uint32_t wspan = whi - wlo;
+            PROF_T(t_a);
 
-            // ---- P0: enumerate.  Wave w takes the terms w and w + 8: lane i = block cur + i (two chunks of 64).
-            if (tid == 0) {
-                const unsigned long long g = __hip_atomic_load(&bt.theta[q], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                unsigned long long th = S.theta;
-                if (g > th) {
-                    th = g;
-                    S.theta = g;
-                }
-                // MaxScore split: the longest prefix of the terms in ascending upper-bound order whose bounds sum
-                // below the threshold is non-essential
-                const double thd = __longlong_as_double((long long)th);
-                uint32_t p = 0;
-                for (uint32_t pp = 1; pp <= m; ++pp)
-                    if (S.t_cum[pp] < thd) p = pp;
-                S.p_ne = bt.ne_on ? p : 0u;
-            }
-            uint4 em[2][2];
-            double eub[2][2];
+            // ---- P0: the window's blocks = the blocks that start below its end
             uint32_t ecnt[2] = {0, 0}, ecur[2] = {0, 0};
 #pragma unroll
             for (int s = 0; s < 2; ++s) {
                 const uint32_t t = wave + DNW * s;
                 if (t < m) {
-                    const uint32_t cur = uni(S.t_cur[t]), end = uni(S.t_end[t]);
-                    ecur[s] = cur;
+                    ecur[s] = ocur[s];
                     uint32_t cnt = 0, fin = 0;
 #pragma unroll
                     for (int ch = 0; ch < 2; ++ch) {
-                        em[s][ch] = make_uint4(NONE32, 0, 0, 0);
-                        eub[s][ch] = 0.0;
-                        if (ch == 1 && cnt < 64u) continue;  // the first chunk was not full
-                        const uint32_t jj = cur + 64u * ch + lane;
-                        if (jj < end) {
-                            em[s][ch] = ix.blk_meta[jj];
-                            eub[s][ch] = ix.blk_ub[jj];
+                        const uint32_t jj = ocur[s] + 64u * ch + lane;
+                        if (ch == 1) {
+                            if (cnt < 64u) {  // the first chunk was not full: nothing of the second belongs to the window
+                                em[s][1] = make_uint4(NONE32, 0, 0, 0);
+                            } else if (!odense[s] && jj < oend[s]) {  // not requested ahead (a term just below N / 2 at a dense spot)
+                                em[s][1] = ix.blk_meta[jj];
+                                eub[s][1] = ix.blk_ub[jj];
+                            }
                         }
-                        const bool in = jj < end && em[s][ch].x < whi;  // a prefix of the lanes
+                        const bool in = jj < oend[s] && em[s][ch].x < whi;  // a prefix of the lanes
                         cnt += (uint32_t)__popcll(__ballot(in));
                         fin += (uint32_t)__popcll(__ballot(in && em[s][ch].y < whi));
                     }
                     ecnt[s] = cnt;
+                    ocur[s] += fin;  // blocks that end below the window's end are done
                     if (lane == 0) {
                         S.t_cnt[t] = cnt;
-                        S.t_fin[t] = fin;
                         if (cnt > (uint32_t)D_SEG) S.fail = 1;
                     }
+                }
+            }
+            if (wave == 0) {
+                poll_consume();
+                __builtin_amdgcn_wave_barrier();
+                // MaxScore split (search.rs:153-169): the longest prefix of the terms in ascending upper-bound order
+                // whose bounds sum below the threshold is non-essential.  Of those, the HEAD terms (df >= N / 2, the
+                // lowest positions) are tested block by block in one phase after everything else; the other
+                // non-essential terms are fetched with the essential ones: a phase per term would fetch 23 % of the
+                // blocks of a Zipf(1) query instead of 39 % (oracle/dense_model.inc) but costs a barrier and a
+                // memory round trip per term.  Lane p = position p.
+                const double thd = __longlong_as_double((long long)S.theta);
+                const bool below = lane < m && S.t_cum[lane + 1u] < thd;  // a prefix of the lanes (t_cum ascends)
+                uint32_t pn = (uint32_t)__popcll(__ballot(below));
+                if (!bt.ne_on && pn < m) pn = 0;
+                const bool head = lane < pn && pn < m && S.t_cls[S.t_ord[lane]] == 2;
+                const unsigned long long hm = __ballot(head);
+                const uint32_t h = (uint32_t)__ffsll((long long)~hm) - 1u;  // heads below the first other term
+                if (lane < h) {
+                    // bounds of the other heads (the subtraction's rounding is far below one unit; + 2 covers it and
+                    // the ceiling)
+                    const uint32_t t = S.t_ord[lane];
+                    S.t_rem[t] = __double2uint_ru((S.t_cum[h] - S.t_ub[t]) * scale) + 2u;
+                }
+                if (lane == 0) {
+                    S.p_ne = pn;
+                    S.h_ne = h;
                 }
             }
             lds_barrier();  // counts of every term known
@@ -321,7 +603,7 @@ __global__ void __launch_bounds__(DWG, 4) scan_dense_kernel(DevIndex ix, DevBatc
                                 if (i < ecnt[s]) {
                                     S.tmeta[before + i] = em[s][ch];
                                     S.tblk[before + i] = ecur[s] + i;
-                                    S.tub[before + i] = __double2float_ru(eub[s][ch]);
+                                    S.tub[before + i] = __double2uint_ru(eub[s][ch] * scale) + 1u;
                                     S.tterm[before + i] = (uint8_t)t;
                                 }
                             }
@@ -334,150 +616,123 @@ __global__ void __launch_bounds__(DWG, 4) scan_dense_kernel(DevIndex ix, DevBatc
                 failed = true;
                 break;
             }
-            const uint32_t p_ne = uni(S.p_ne);
+            const uint32_t p_ne = uni(S.p_ne), h_ne = uni(S.h_ne);
             if (p_ne >= m) break;  // no document can reach the threshold any more (search.rs:153-169 with every term)
-            const float theta_f = __double2float_rd(__longlong_as_double((long long)theta_now()));
+            const uint32_t theta_i = theta_fix(theta_now());
+            PROF_T(t_b);
+            PROF_ADD(1, t_a, t_b);
 
-            // ---- P1: essential terms = ranks >= p_ne = the first tasks
-            uint32_t ess_cnt;
+            // ---- P1: every term but the heads = the ranks >= h_ne = the first tasks
+            uint32_t cnt1, cnt_all;
             {
                 const uint32_t cu = lane < m ? S.t_cnt[lane] : 0u, ru = lane < m ? (uint32_t)S.t_rank[lane] : 0u;
-                ess_cnt = (uint32_t)__builtin_amdgcn_readlane((int)wave_incl_scan_u32(lane < m && ru >= p_ne ? cu : 0u), 63);
+                cnt1 = (uint32_t)__builtin_amdgcn_readlane((int)wave_incl_scan_u32(lane < m && ru >= h_ne ? cu : 0u), 63);
+                cnt_all = (uint32_t)__builtin_amdgcn_readlane((int)wave_incl_scan_u32(cu), 63);
             }
-            run_tasks(0, ess_cnt, false, 0.0f, theta_f, wlo, wspan);
-            // ---- P2: non-essential terms, one phase per term, descending upper bound
-            if (p_ne) {
+            run_all(cnt1, wlo, wspan);
+            PROF_T(t_c);
+            PROF_ADD(2, t_b, t_c);
+            // ---- P2: the head terms, every block tested
+            if (cnt_all > cnt1) {
                 lds_barrier();
-                for (uint32_t p = p_ne; p-- > 0;) {
-                    const uint32_t t = uni((uint32_t)S.t_ord[p]);
-                    const uint32_t cnt = uni(S.t_cnt[t]);
-                    if (cnt == 0) continue;
-                    // bounds of the terms below this one (they are complete only after their own phases)
-                    run_tasks(uni(S.t_base[t]), cnt, true, __double2float_ru(S.t_cum[p]), theta_f, wlo, wspan);
-                    if (p) lds_barrier();
-                }
+                run_tested(cnt1, cnt_all - cnt1, theta_i, wlo, wspan);
             }
+            PROF_T(t_d);
+            PROF_ADD(3, t_c, t_d);
             lds_barrier();  // every accumulator of the window complete
+            PROF_T(t_e);
+            PROF_ADD(4, t_d, t_e);
+#ifdef VBM25_PROFILE
+            prof[0] += 1;
+#endif
+            if (whi < hi) enum_request();  // the next window's metadata: in flight during P3
 
-            // ---- P3 / P4: candidates, D_CCAP at a time
-            if (tid < m) S.t_cur[tid] += S.t_fin[tid];
-            for (uint32_t rounds = 0;;) {
-                const float thf = __double2float_rd(__longlong_as_double((long long)theta_now()));
-                for (uint32_t i = tid; i < wspan; i += DWG) {
-                    const float v = S.acc[i];
-                    if (v == 0.0f) continue;
-                    if (v * SLACK >= thf) {
-                        const uint32_t pos = atomicAdd(&S.ncand, 1u);
-                        if (pos < (uint32_t)D_CCAP) {
-                            S.cand[pos] = i;
-                            S.acc[i] = 0.0f;
-                        }  // else: stays for the next round
-                    } else {
-                        S.acc[i] = 0.0f;
+            // ---- P3: candidates -> the wave's buffer + the query's histogram; wipe.  Wave w owns the documents
+            // [1024 w, 1024 (w + 1)) of the window = the buckets 16 w .. 16 w + 15: candidates only where the bucket
+            // maximum reaches the threshold.
+            for (;;) {
+                PROF_T(t_f);
+                constexpr uint32_t BPW = D_W / 64 / DNW;  // buckets per wave
+                const double inv = (1.0 / scale) * (1.0 - 1.0 / 131072.0) * S.hscale;  // accumulator -> bucket of the score's lower bound
+                const uint32_t bmv = lane < BPW ? S.bmax[wave * BPW + lane] : 0u;
+                uint32_t hot = (uint32_t)__ballot(bmv >= theta_i && bmv != 0u), left = 0;
+                while (hot) {
+                    const uint32_t bk = (uint32_t)__ffs((int)hot) - 1u;
+                    hot &= hot - 1u;
+                    const uint32_t i = (wave * BPW + bk) * 64u + lane;
+                    const uint32_t v = S.acc[i];
+                    const bool cand = v >= theta_i && v != 0u;
+                    const unsigned long long cm = __ballot(cand);
+                    const uint32_t c = (uint32_t)__popcll(cm);
+                    if (cn + c > (uint32_t)D_WCB) {  // the bucket stays whole for the next pass
+                        left |= 1u << bk;
+                        continue;
                     }
+                    if (cand) {
+                        const uint32_t pos = cn + __builtin_amdgcn_mbcnt_hi((uint32_t)(cm >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)cm, 0u));
+                        S.cdoc[wave][pos] = wlo + i;
+                        S.cval[wave][pos] = v;
+                        const double hb = (double)(v > m ? v - m : 0u) * inv;
+                        atomicAdd(&hrow[hb >= (double)(CUR_HB - 1) ? (uint32_t)(CUR_HB - 1) : (uint32_t)hb], 1u);
+                    }
+                    cn += c;
+#ifdef VBM25_PROFILE
+                    prof[10] += c;
+#endif
                 }
+                if (left == 0u) {  // wipe the wave's 1024 accumulators and its bucket maxima
+#pragma unroll
+                    for (int x = 0; x < (int)(BPW * 64 / 256); ++x)
+                        *reinterpret_cast<uint4 *>(&S.acc[wave * BPW * 64u + 256u * x + 4u * lane]) = make_uint4(0, 0, 0, 0);
+                    if (lane < BPW) S.bmax[wave * BPW + lane] = 0u;
+                } else {
+                    for (uint32_t bk = 0; bk < BPW; ++bk)
+                        if (!((left >> bk) & 1u)) {
+                            S.acc[(wave * BPW + bk) * 64u + lane] = 0u;
+                            if (lane == 0) S.bmax[wave * BPW + bk] = 0u;
+                        }
+                    if (lane == 0) S.cover = 1;
+                }
+                if (cn >= (uint32_t)D_WCB / 2 && lane == 0) S.cflag = 1;
                 lds_barrier();
-                const uint32_t nc_all = uni(S.ncand);
-                if (nc_all == 0) break;
-                const uint32_t nc = min(nc_all, (uint32_t)D_CCAP);
-                // pairs (candidate, term): one wave each
-                for (uint32_t p = wave; p < nc * m; p += DNW) {
-                    const uint32_t c = p / m, t = p - c * m;
-                    const uint32_t d = wlo + uni(S.cand[c]);
-                    const uint32_t tb = uni(S.t_base[t]), tc = uni(S.t_cnt[t]);
-                    uint32_t e = NONE32;
-                    for (uint32_t o = 0; o < tc; o += 64) {
-                        bool hit = false;
-                        if (o + lane < tc) {
-                            const uint4 mm = S.tmeta[tb + o + lane];
-                            hit = mm.x <= d && d <= mm.y;
-                        }
-                        const unsigned long long hm = __ballot(hit);
-                        if (hm) {
-                            e = tb + o + (uint32_t)__ffsll((long long)hm) - 1u;
-                            break;
-                        }
+                PROF_T(t_g);
+                PROF_ADD(5, t_f, t_g);
+                const bool over = uni(S.cover) != 0;
+                if (over || uni(S.cflag)) {
+                    flush();
+                    lds_barrier();  // everybody has read the flags (and counted its re-scorings)
+                    if (tid == 0) {
+                        S.cover = 0;
+                        S.cflag = 0;
                     }
-                    double val = 0.0;
-                    if (e != NONE32) {
-                        const uint4 bm = uni4(S.tmeta[e]);
-                        const uint32_t j = uni(S.tblk[e]);
-                        const uint32_t n = bm.w & 0xff, md = (bm.w >> 8) & 0xff, mt = (bm.w >> 16) & 0xff;
-                        const uint8_t *body = ix.blob + 8ull * bm.z;
-                        const uint8_t *tbody = body + ((payload_bytes(md, n) + 7u) & ~7u);
-                        uint32_t d0, d1, f0, f1;
-                        const uint32_t fn = reinterpret_cast<const uint16_t *>(ix.post_fn + 128ull * j)[lane];
-                        if (md < 32u && mt < 32u) {
-                            uint32_t a0, a1, a2, a3, b0, b1, b2, b3, v0, v1;
-                            pair_fetch(body, md, lane, a0, a1, a2, a3);
-                            pair_fetch(tbody, mt, lane, b0, b1, b2, b3);
-                            pair_extract(md, lane, a0, a1, a2, a3, v0, v1);
-                            pair_extract(mt, lane, b0, b1, b2, b3, f0, f1);
-                            const uint32_t own = v0 + v1;
-                            const uint32_t incl = wave_incl_scan_u32(own);
-                            d0 = bm.x + (incl - own) + v0;
-                            d1 = d0 + v1;
-                        } else {
-                            decode_doc_ids(body, md, n, bm.x, lane, d0, d1);
-                            decode_fields(tbody, mt, n, lane, f0, f1);
-                        }
-                        const bool m0 = 2 * lane < n && d0 == d, m1 = 2 * lane + 1 < n && d1 == d;
-                        if (m0 || m1) {
-                            const double tf = (double)(m0 ? f0 : f1);
-                            val = (tf * S.t_s0[t]) / (tf + S.s1[m0 ? (fn & 0xff) : (fn >> 8)]);  // Cache::evaluate, bm25.rs:355-358
-                        }
-                        const unsigned long long mm = __ballot(m0 || m1);
-                        val = mm ? readlane_f64(val, (uint32_t)__ffsll((long long)mm) - 1u) : 0.0;
+                    const bool too_many = uni(S.resolved) > D_MAX_RESOLVED;
+                    lds_barrier();
+                    if (too_many) {  // the sums cannot tell masses of equal scores apart: exhaustive kernel
+                        failed = true;
+                        break;
                     }
-                    if (lane == 0) S.contrib[c * D_T + t] = val;
                 }
-                lds_barrier();
-                if (wave == 0) {
-                    const bool has0 = lane < nc;
-                    double sc = 0.0;
-                    uint32_t d = 0;
-                    if (has0) {
-                        d = wlo + S.cand[lane];
-                        for (uint32_t t = 0; t < m; ++t) sc += S.contrib[lane * D_T + t];  // ascending key order; absent terms add 0.0
-                    }
-                    const unsigned long long th = theta_now();
-                    const bool has = has0 && (unsigned long long)__double_as_longlong(sc) >= th &&
-                                     (rtop.cnt < k || better(sc, d, rtop.kth_s, rtop.kth_d));
-                    if (__ballot(has)) {
-                        rtop.offer(has, sc, d, k, lane);
-                        if (rtop.cnt >= k) {
-                            const unsigned long long kb = (unsigned long long)__double_as_longlong(rtop.kth_s);
-                            if (kb > published) {
-                                if (lane == 0) {
-                                    if (kb > S.theta) S.theta = kb;
-                                    atomicMax(&bt.theta[q], kb);
-                                }
-                                published = kb;
-                            }
-                        }
-                    }
-                    if (lane == 0) S.ncand = 0;
-                }
-                lds_barrier();
-                if (nc_all <= (uint32_t)D_CCAP) break;  // every candidate of the window taken (and its accumulator wiped)
-                if (++rounds >= D_MAX_ROUNDS) {  // the approximate sums cannot tell equal scores apart: exhaustive kernel
-                    failed = true;
-                    break;
-                }
+                if (!over) break;
             }
             if (failed) break;
             wlo = whi;
             W = min(2u * W, (uint32_t)D_W);
         }
+        if (!failed) flush();
+#ifdef VBM25_PROFILE
+        prof[12] += 1;
+        prof[9] += __builtin_readcyclecounter() - t_loop;
+#endif
         if (failed) {  // hand the item to scan_many_kernel; leave LDS clean
             __syncthreads();
-            for (uint32_t i = tid; i < (uint32_t)D_W; i += DWG) S.acc[i] = 0.0f;
+            for (uint32_t i = tid; i < (uint32_t)D_W; i += DWG) S.acc[i] = 0u;
+            if (tid < (uint32_t)D_W / 64) S.bmax[tid] = 0u;
         }
 
-        // ---- item result: wave 0's list
-        if (wave == 0) {
+        // ---- item result: one list per wave
+        {
             const uint32_t n = failed ? 0u : rtop.cnt;
-            const size_t list = (size_t)item * bt.lpi;
+            const size_t list = (size_t)item * bt.lpi + wave;
 #pragma unroll
             for (int r = 0; r < RK; ++r)
                 if (r * 64 + lane < n) {
@@ -486,8 +741,15 @@ __global__ void __launch_bounds__(DWG, 4) scan_dense_kernel(DevIndex ix, DevBatc
                 }
             if (lane == 0) {
                 bt.res_cnt[list] = n;
-                bt.item_failed[item] = failed ? 0x140u : 0u;
+                if (wave == 0) bt.item_failed[item] = failed ? 0x140u : 0u;
             }
         }
     }
+#ifdef VBM25_PROFILE
+    if (bt.prof && lane == 0) {
+        unsigned long long *o = bt.prof + ((size_t)blockIdx.x * DNW + wave) * 16;
+        for (int i = 0; i < 15; ++i) o[i] = prof[i];
+        o[15] = __builtin_readcyclecounter() - prof_t0;
+    }
+#endif
 }
