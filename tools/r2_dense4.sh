@@ -8,6 +8,6 @@ if [ $rc -eq 137 ]; then echo "HANG in the small test; stopping"; exit 1; fi
 timeout -s KILL 600 python -m pytest tests/test_gpu_dense.py -q > $O/pytest_dense.log 2>&1
 rc=$?; tail -30 $O/pytest_dense.log; echo "dense rc=$rc"
 if [ $rc -eq 137 ]; then echo "HANG in the dense tests; stopping"; exit 1; fi
-DENSE_SAMPLE=16 timeout -s KILL 400 python tools/dense_check.py 5000000 100000 256 10 100 /tmp/z5.seg > $O/dense_5m.log 2>&1
+DENSE_SAMPLE=16 timeout -s KILL 400 python tools/dense_check.py 10000000 100000 512 10 100 /tmp/z10.seg > $O/dense_5m.log 2>&1
 tail -12 $O/dense_5m.log
-timeout -s KILL 300 python tools/profile_dense.py 5000000 100000 256 10 100 /tmp/z5.seg 2>&1 | grep -v "^--\|waves" | head -30 > $O/prof_5m.log; cat $O/prof_5m.log
+timeout -s KILL 300 python tools/profile_dense.py 10000000 100000 512 10 100 /tmp/z10.seg 2>&1 | grep -v "^--\|waves" | head -30 > $O/prof_5m.log; cat $O/prof_5m.log

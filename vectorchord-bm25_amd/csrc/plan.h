@@ -96,8 +96,10 @@ __device__ __forceinline__ unsigned long long plan_incl_scan(unsigned long long 
     return v + before;
 }
 
+// dense_c != 0: every dense query (q_dense) is cut into dense_c items of equal document counts -- the dense-window kernel's
+// work per item goes with its windows, not with its postings -- and does not count towards the other queries' chunk size.
 __global__ void __launch_bounds__(PLAN_WG) plan_kernel(DevIndex ix, DevBatch bt, uint32_t max_items,
-                                                       uint32_t target_items, uint32_t min_chunk) {
+                                                       uint32_t target_items, uint32_t min_chunk, uint32_t dense_c) {
     __shared__ unsigned long long s_wave[PLAN_WG / 64];
     const uint32_t tid = threadIdx.x;
     const uint32_t per = (bt.nq + PLAN_WG - 1) / PLAN_WG;
@@ -124,9 +126,11 @@ __global__ void __launch_bounds__(PLAN_WG) plan_kernel(DevIndex ix, DevBatch bt,
     // evaluation is a chain of three dependent global loads, which is what a small batch's plan costs
     const bool one = q1 - q0 == 1;
     const unsigned long long own_postings = one ? postings_of(q0) : 0ull;
-    unsigned long long local = own_postings;
+    auto is_dense = [&](uint32_t q) { return dense_c != 0 && bt.q_dense[q] != 0; };
+    unsigned long long local = one && !is_dense(q0) ? own_postings : 0ull;
     if (!one)
-        for (uint32_t q = q0; q < q1; ++q) local += postings_of(q);
+        for (uint32_t q = q0; q < q1; ++q)
+            if (!is_dense(q)) local += postings_of(q);
     unsigned long long total = 0;
     plan_incl_scan(local, s_wave, total);
     unsigned long long chunk = (total + target_items - 1) / target_items;
@@ -134,6 +138,7 @@ __global__ void __launch_bounds__(PLAN_WG) plan_kernel(DevIndex ix, DevBatch bt,
     auto chunks_of = [&](uint32_t q) -> uint32_t {
         unsigned long long t = one ? own_postings : postings_of(q);
         if (t == 0) return 0u;
+        if (is_dense(q)) return min(dense_c, ix.n_docs);
         // nearest, not ceil: a batch of similar queries gets the same count for all of them, i.e. the
         // item count lands on the target (a multiple of the resident waves) instead of ~8 % above it
         unsigned long long c = (t + chunk / 2) / chunk;

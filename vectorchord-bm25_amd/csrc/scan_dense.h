@@ -42,11 +42,11 @@
 constexpr int DNW = 8;
 static_assert(DNW == RNW, "one result list per wave: bt.lpi is scan_range_kernel's");
 constexpr int DWG = DNW * 64;
-constexpr int D_W = 8192;                // documents per window
+constexpr int D_W = 16384;               // documents per window (at most; an item of very dense terms takes narrower ones)
 constexpr int D_W0 = 256;                // first window while the threshold is 0
 constexpr int D_T = 16;                  // indexed terms per query
-constexpr int D_SEG = D_W / 128 + 4;     // blocks of one term that can start below a window's end (full blocks span >= 128 documents; + straddlers + the tail block)
-constexpr int D_TCAP = D_T * D_SEG;
+constexpr int D_SEG = 128;               // blocks of one term per window: two chunks of 64 lanes (a full block spans >= 128 documents)
+constexpr int D_TCAP = 1024;             // blocks of all terms per window; an item's window width is chosen for 80 % of it
 constexpr int D_WCB = 128;               // candidate buffer entries per wave
 #ifndef D_UN_V
 #define D_UN_V 4
@@ -58,7 +58,7 @@ constexpr uint32_t D_GRID = 512;         // persistent workgroups: 256 CUs x 2
 constexpr uint32_t D_TARGET_ITEMS = 4096;
 
 struct DenseLds {
-    uint32_t acc[D_W];        // fixed point: scale x (upper bound of the document's score)
+    uint32_t acc[D_W / 2];    // 16-bit fixed point, two documents per word: scale x (upper bound of the document's score) < 2^16
     uint32_t bmax[D_W / 64];  // largest accumulator of every 64 documents, kept current by the adds
     uint4 tmeta[D_TCAP];      // {min_doc, max_doc, off8, n | md << 8 | mt << 16 | wand_fn << 24}
     uint32_t tblk[D_TCAP];    // block index
@@ -76,7 +76,7 @@ struct DenseLds {
     uint32_t t_rem[D_T];      // non-essential term: scaled bounds of the OTHER terms that are incomplete during its phase
     double scale, hscale;
     unsigned long long theta; // bits of a lower bound of the query's k-th best score
-    uint32_t cover, cflag, item, m, fail, p_ne, h_ne, resolved;
+    uint32_t cover, cflag, item, m, fail, p_ne, h_ne, resolved, ntask, wmax;
     uint32_t scratch[64];
 };
 
@@ -94,7 +94,7 @@ __global__ void __launch_bounds__(DWG, 4) scan_dense_kernel(DevIndex ix, DevBatc
         S.s1[i] = v;
         S.s1f[i] = __double2float_rd(v);
     }
-    for (uint32_t i = tid; i < (uint32_t)D_W; i += DWG) S.acc[i] = 0u;
+    for (uint32_t i = tid; i < (uint32_t)D_W / 2; i += DWG) S.acc[i] = 0u;
     if (tid < (uint32_t)D_W / 64) S.bmax[tid] = 0u;
 #ifdef VBM25_PROFILE
     // per wave: 0 windows, 1 P0, 2 P1, 3 P2, 4 wait before P3, 5 P3, 6 flush: filter, 7 flush: exact re-scoring, 8 item setup,
@@ -110,6 +110,7 @@ __global__ void __launch_bounds__(DWG, 4) scan_dense_kernel(DevIndex ix, DevBatc
             S.cover = 0;
             S.cflag = 0;
             S.fail = 0;
+            S.ntask = 0;
             S.resolved = 0;
         }
         __syncthreads();
@@ -205,13 +206,27 @@ __global__ void __launch_bounds__(DWG, 4) scan_dense_kernel(DevIndex ix, DevBatc
                 cum += readlane_f64(tub, owner);
                 if (lane == 0) S.t_cum[pp + 1] = cum;
             }
-            // power-of-two scale with scale x (sum of all token bounds) < 2^31: no sum of postings can wrap
-            int e = 30 - ilogb(cum > 0.0 ? cum : 1.0);
+            // power-of-two scale with scale x (sum of all token bounds) < 2^15: a document's sum (+ 1 per posting, + 2^-18
+            // relative) stays below 2^16
+            int e = 14 - ilogb(cum > 0.0 ? cum : 1.0);
             e = e > 60 ? 60 : (e < -60 ? -60 : e);
             const double scale = ldexp(1.0, e);
             if (act) S.t_s0i[lane] = (__double2float_ru(s0) * (1.0f + 1.0f / 524288.0f)) * (float)scale;
+            // window width: the expected number of blocks per window (sum of df / 128 per document) within 80 % of the task
+            // list, no term above 120 blocks (chunks of 64 lanes: 128)
+            unsigned long long sumdf = 0;
+            uint32_t maxdf = 1;
+            for (uint32_t t = 0; t < m; ++t) {
+                const uint32_t dft = (uint32_t)__builtin_amdgcn_readlane((int)(act ? ix.term_df[term] : 0u), (int)t);
+                sumdf += dft;
+                maxdf = max(maxdf, dft);
+            }
+            unsigned long long wfit = (unsigned long long)(D_TCAP * 4 / 5) * 128ull * ix.n_docs / max(sumdf, 1ull);
+            wfit = min(wfit, 120ull * 128ull * ix.n_docs / maxdf);
+            const uint32_t wmax_item = (uint32_t)min((unsigned long long)D_W, max(wfit & ~1023ull, 1024ull));
             if (lane == 0) {
                 S.m = m;
+                S.wmax = wmax_item;
                 S.scale = scale;
                 S.hscale = (double)CUR_HB / sums0;  // score -> histogram bucket: linear in [0, sum of s0), as scan_range.h
                 S.theta = 0;
@@ -274,8 +289,9 @@ __global__ void __launch_bounds__(DWG, 4) scan_dense_kernel(DevIndex ix, DevBatc
             const uint32_t p0 = (uint32_t)((tf0 * s0i) * __builtin_amdgcn_rcpf(tf0 + S.s1f[fn & 0xff])) + 1u;
             const uint32_t p1 = (uint32_t)((tf1 * s0i) * __builtin_amdgcn_rcpf(tf1 + S.s1f[fn >> 8])) + 1u;
             // the add that comes last in an accumulator's order sees the final sum: the bucket maximum is never below it
-            if (in0 && x0 < wspan) atomicMax(&S.bmax[x0 >> 6], atomicAdd(&S.acc[x0], p0) + p0);
-            if (in1 && x1 < wspan) atomicMax(&S.bmax[x1 >> 6], atomicAdd(&S.acc[x1], p1) + p1);
+            // (no carry between the halves of a word: every document's sum stays below 2^16)
+            if (in0 && x0 < wspan) atomicMax(&S.bmax[x0 >> 6], ((atomicAdd(&S.acc[x0 >> 1], p0 << (16u * (x0 & 1u))) >> (16u * (x0 & 1u))) & 0xffffu) + p0);
+            if (in1 && x1 < wspan) atomicMax(&S.bmax[x1 >> 6], ((atomicAdd(&S.acc[x1 >> 1], p1 << (16u * (x1 & 1u))) >> (16u * (x1 & 1u))) & 0xffffu) + p1);
         };
         auto task_accumulate = [&](const uint4 c, uint32_t t, const Raw &r, uint32_t wlo, uint32_t wspan) {
             const uint32_t md = (c.w >> 8) & 0xff, mt = (c.w >> 16) & 0xff;
@@ -487,7 +503,8 @@ __global__ void __launch_bounds__(DWG, 4) scan_dense_kernel(DevIndex ix, DevBatc
         // consumed at the top of window n + 1: the round trip hides behind P3, the flag barrier and a flush.
         // Wave w owns the cursors of the terms w and w + 8 (registers).
         // =====================================================================
-        uint32_t W = theta_now() == 0ull ? (uint32_t)D_W0 : (uint32_t)D_W;
+        const uint32_t wmax = uni(S.wmax);
+        uint32_t W = theta_now() == 0ull ? (uint32_t)D_W0 : wmax;
         bool failed = false;
         uint32_t ocur[2] = {0, 0}, oend[2] = {0, 0};
         bool odense[2] = {false, false};
@@ -554,7 +571,8 @@ __global__ void __launch_bounds__(DWG, 4) scan_dense_kernel(DevIndex ix, DevBatc
                     ocur[s] += fin;  // blocks that end below the window's end are done
                     if (lane == 0) {
                         S.t_cnt[t] = cnt;
-                        if (cnt > (uint32_t)D_SEG) S.fail = 1;
+                        if (cnt >= (uint32_t)D_SEG) S.fail = 1;  // (128 enumerated: more may follow)
+                        if (atomicAdd(&S.ntask, cnt) + cnt > (uint32_t)D_TCAP) S.fail = 1;
                     }
                 }
             }
@@ -617,6 +635,7 @@ __global__ void __launch_bounds__(DWG, 4) scan_dense_kernel(DevIndex ix, DevBatc
                 break;
             }
             const uint32_t p_ne = uni(S.p_ne), h_ne = uni(S.h_ne);
+            if (tid == 0) S.ntask = 0;  // (read by nobody until the next window's counts)
             if (p_ne >= m) break;  // no document can reach the threshold any more (search.rs:153-169 with every term)
             const uint32_t theta_i = theta_fix(theta_now());
             PROF_T(t_b);
@@ -648,7 +667,7 @@ __global__ void __launch_bounds__(DWG, 4) scan_dense_kernel(DevIndex ix, DevBatc
             if (whi < hi) enum_request();  // the next window's metadata: in flight during P3
 
             // ---- P3: candidates -> the wave's buffer + the query's histogram; wipe.  Wave w owns the documents
-            // [1024 w, 1024 (w + 1)) of the window = the buckets 16 w .. 16 w + 15: candidates only where the bucket
+            // [2048 w, 2048 (w + 1)) of the window = the buckets 32 w .. 32 w + 31: candidates only where the bucket
             // maximum reaches the threshold.
             for (;;) {
                 PROF_T(t_f);
@@ -660,7 +679,7 @@ __global__ void __launch_bounds__(DWG, 4) scan_dense_kernel(DevIndex ix, DevBatc
                     const uint32_t bk = (uint32_t)__ffs((int)hot) - 1u;
                     hot &= hot - 1u;
                     const uint32_t i = (wave * BPW + bk) * 64u + lane;
-                    const uint32_t v = S.acc[i];
+                    const uint32_t v = (S.acc[i >> 1] >> (16u * (i & 1u))) & 0xffffu;
                     const bool cand = v >= theta_i && v != 0u;
                     const unsigned long long cm = __ballot(cand);
                     const uint32_t c = (uint32_t)__popcll(cm);
@@ -680,15 +699,15 @@ __global__ void __launch_bounds__(DWG, 4) scan_dense_kernel(DevIndex ix, DevBatc
                     prof[10] += c;
 #endif
                 }
-                if (left == 0u) {  // wipe the wave's 1024 accumulators and its bucket maxima
+                if (left == 0u) {  // wipe the wave's accumulators and its bucket maxima
 #pragma unroll
-                    for (int x = 0; x < (int)(BPW * 64 / 256); ++x)
-                        *reinterpret_cast<uint4 *>(&S.acc[wave * BPW * 64u + 256u * x + 4u * lane]) = make_uint4(0, 0, 0, 0);
+                    for (int x = 0; x < (int)(BPW * 32 / 256); ++x)
+                        *reinterpret_cast<uint4 *>(&S.acc[wave * BPW * 32u + 256u * x + 4u * lane]) = make_uint4(0, 0, 0, 0);
                     if (lane < BPW) S.bmax[wave * BPW + lane] = 0u;
                 } else {
                     for (uint32_t bk = 0; bk < BPW; ++bk)
                         if (!((left >> bk) & 1u)) {
-                            S.acc[(wave * BPW + bk) * 64u + lane] = 0u;
+                            if (lane < 32u) S.acc[(wave * BPW + bk) * 32u + lane] = 0u;
                             if (lane == 0) S.bmax[wave * BPW + bk] = 0u;
                         }
                     if (lane == 0) S.cover = 1;
@@ -716,7 +735,7 @@ __global__ void __launch_bounds__(DWG, 4) scan_dense_kernel(DevIndex ix, DevBatc
             }
             if (failed) break;
             wlo = whi;
-            W = min(2u * W, (uint32_t)D_W);
+            W = min(2u * W, wmax);
         }
         if (!failed) flush();
 #ifdef VBM25_PROFILE
@@ -725,7 +744,7 @@ __global__ void __launch_bounds__(DWG, 4) scan_dense_kernel(DevIndex ix, DevBatc
 #endif
         if (failed) {  // hand the item to scan_many_kernel; leave LDS clean
             __syncthreads();
-            for (uint32_t i = tid; i < (uint32_t)D_W; i += DWG) S.acc[i] = 0u;
+            for (uint32_t i = tid; i < (uint32_t)D_W / 2; i += DWG) S.acc[i] = 0u;
             if (tid < (uint32_t)D_W / 64) S.bmax[tid] = 0u;
         }
 

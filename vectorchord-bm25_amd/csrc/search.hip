@@ -230,6 +230,7 @@ struct vbm25_batch {
     bool has_dense = false;       // ... and the current queries have such a query
     uint32_t dense_target = D_TARGET_ITEMS;  // work items of a batch with dense queries (VBM25_DENSE_ITEMS)
     uint32_t dense_grid = D_GRID;
+    uint32_t dense_c = 0;         // items per dense query of the current queries (0: chunks by postings, as the other queries)
     uint32_t cur_mt = 1;          // most indexed terms among the cursor kernel's queries
     uint32_t target_items = TARGET_ITEMS;
     uint32_t min_chunk = MIN_CHUNK_POSTINGS;
@@ -475,7 +476,7 @@ static int vbm25_batch_create_impl(vbm25_index *ix, uint32_t max_queries, uint32
         const char *mi = std::getenv("VBM25_CUR_MIN_ITEMS");
         if (mi) bt->cur_min_items = (uint32_t)std::atoi(mi);
     }
-    bt->max_items = max_queries + std::max(bt->target_items, bt->use_dense ? bt->dense_target : 0u);
+    bt->max_items = max_queries + bt->target_items + (bt->use_dense ? bt->dense_target : 0u);
     int rc = 0;
     if (k > 1024) {  // exhaustive path: query buffers, results and an accumulator per document
         bt->bigk = true;
@@ -531,6 +532,7 @@ static int vbm25_batch_set_queries_impl(vbm25_batch *bt, const uint32_t *term_id
     if (nq > bt->max_queries) return set_error(VBM25_ERR_INVALID, "%u queries exceed the batch capacity %u", nq, bt->max_queries);
     if (q_off[0] != 0) return set_error(VBM25_ERR_INVALID, "q_off[0] must be 0");
     bool many = false, mid = false, has_dense = false;
+    uint32_t n_dense = 0;
     uint32_t cur_mt = 1, range_mt = 0;
     // Routing: the chain kernel is built for sparse queries; a query with many postings per
     // document (Zipf head terms) or more than CHAIN_MAX_TERMS indexed terms takes the
@@ -555,6 +557,7 @@ static int vbm25_batch_set_queries_impl(vbm25_batch *bt, const uint32_t *term_id
         if (postings * 1000ull >= dense_x1000 * bt->index->n_docs) {
             dense[q] = 1;
             many = true;
+            n_dense += postings != 0;
         }
         if (bt->use_range) {  // sparse queries of <= 16 terms: scan_range_kernel; dense ones: scan_dense_kernel; the rest: scan_many_kernel
             many |= valid > 16u;
@@ -606,12 +609,20 @@ static int vbm25_batch_set_queries_impl(vbm25_batch *bt, const uint32_t *term_id
     bt->range_rt = !bt->use_range || range_mt == 0 ? 0u : (range_mt <= 8u ? 8u : 16u);
     {   // the number of work items plan_kernel will make (same integer arithmetic): the cursor kernel's
         // persistent grid need not be larger (a single query is a handful of items, not 6144 workgroups)
-        const uint32_t target = has_dense ? std::max(bt->target_items, bt->dense_target) : bt->target_items;
-        unsigned long long chunk = (total_postings + target - 1) / target;
+        // with the dense-window kernel every dense query gets the same number of items (equal document counts)
+        bt->dense_c = has_dense ? std::max(1u, (bt->dense_target + n_dense / 2) / std::max(n_dense, 1u)) : 0u;
+        unsigned long long sparse_postings = 0;
+        for (uint32_t q = 0; q < nq; ++q)
+            if (!(bt->dense_c && dense[q])) sparse_postings += q_postings[q];
+        unsigned long long chunk = (sparse_postings + bt->target_items - 1) / bt->target_items;
         if (chunk < bt->min_chunk) chunk = bt->min_chunk;
         unsigned long long items = 0;
         for (uint32_t q = 0; q < nq; ++q) {
             if (!q_postings[q]) continue;
+            if (bt->dense_c && dense[q]) {
+                items += std::min(bt->dense_c, bt->index->n_docs);
+                continue;
+            }
             unsigned long long c = (q_postings[q] + chunk / 2) / chunk;
             if (c == 0) c = 1;
             if (c > bt->index->n_docs) c = bt->index->n_docs;
@@ -694,9 +705,8 @@ static int vbm25_batch_run_impl(vbm25_batch *bt, void *hip_stream) {
     const bool range = bt->use_range;
     const DevIndex &ix = bt->index->dev;
     if (cursor || range) HIP_TRY(hipMemsetAsync(bt->hist.p, 0, 4ull * CUR_HB * bt->nq, st));
-    const uint32_t target = bt->has_dense ? std::max(bt->target_items, bt->dense_target) : bt->target_items;
-    plan_kernel<<<1, PLAN_WG, 0, st>>>(ix, db, bt->max_items, cursor || range ? target : TARGET_ITEMS,
-                                       cursor || range ? bt->min_chunk : MIN_CHUNK_POSTINGS);
+    plan_kernel<<<1, PLAN_WG, 0, st>>>(ix, db, bt->max_items, cursor || range ? bt->target_items : TARGET_ITEMS,
+                                       cursor || range ? bt->min_chunk : MIN_CHUNK_POSTINGS, bt->dense_c);
     hipEvent_t e0 = nullptr, e1 = nullptr;
     if (bt->timing) {
         if (bt->events_used == bt->events.size()) {
