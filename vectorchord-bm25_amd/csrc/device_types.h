@@ -55,6 +55,8 @@ struct DevBatch {
     uint32_t ne_on;            // MaxScore split in scan_range_kernel (non-essential lists looked up, not scanned)
     uint32_t ne_ratio;         // a non-essential list must be this many times longer than the essential lists together
     uint32_t dense_on;         // dense queries of <= D_T terms take scan_dense_kernel (its items come from work_ctr[1])
+    uint32_t fused_g;          // scan_range_kernel alone: items per query made in the kernel, lists merged by the query's last workgroup (0: off)
+    uint32_t *fused_state;     // [0] workgroups that left, [1 + q] finished items of query q; zero between launches
 };
 
 constexpr int WG = 256;

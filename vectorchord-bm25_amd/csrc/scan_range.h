@@ -125,7 +125,7 @@ __device__ __forceinline__ uint32_t r_first_block_ge(const DevIndex &ix, uint32_
     return lo_b;
 }
 
-template <int KMAX, int RT>
+template <int KMAX, int RT, bool FUSED = false>
 __global__ void __launch_bounds__(RWG, 4) scan_range_kernel(DevIndex ix, DevBatch bt) {
     static_assert(KMAX <= REG_K, "register top-k only");
     static_assert(RT == 8 || RT == 16, "row stride");
@@ -135,7 +135,11 @@ __global__ void __launch_bounds__(RWG, 4) scan_range_kernel(DevIndex ix, DevBatc
 
     const uint32_t tid = threadIdx.x, lane = tid & 63, wave = uni(tid >> 6);
     const uint32_t k = bt.k;
-    const uint32_t n_items = *bt.n_items;
+    // bt.fused_g != 0 (a handful of queries through vbm25_search_batch): no plan_kernel and no merge_kernel -- every query is
+    // cut into fused_g equal document ranges right here, the last workgroup to finish a query merges its lists into the
+    // hits and leaves the per-launch state (threshold, histogram, counters) clean for the next launch.
+    const uint32_t fused_g = FUSED ? bt.fused_g : 0u;
+    const uint32_t n_items = fused_g ? bt.nq * fused_g : *bt.n_items;
     for (uint32_t i = tid; i < 256; i += RWG) S.s1[i] = ix.s1[i];
 
 #ifdef VBM25_PROFILE
@@ -160,7 +164,16 @@ __global__ void __launch_bounds__(RWG, 4) scan_range_kernel(DevIndex ix, DevBatc
         __syncthreads();
         const uint32_t item = uni(S.item);
         if (item >= n_items) break;
-        const Item it = bt.items[item];
+        Item it;
+        if (FUSED) {
+            it.q = item / fused_g;
+            const uint32_t part = item - it.q * fused_g;
+            it.doc_lo = (uint32_t)((unsigned long long)ix.n_docs * part / fused_g);
+            it.doc_hi = (uint32_t)((unsigned long long)ix.n_docs * (part + 1) / fused_g);
+            it.m = 0;  // the host sends only sparse queries of <= RT indexed terms this way
+        } else {
+            it = bt.items[item];
+        }
         const bool dense_item = (it.m & ITEM_DENSE) != 0;
         if ((it.m & ~ITEM_DENSE) > (uint32_t)RT || (dense_item && (!bt.range_dense || bt.dense_on))) continue;  // the other kernels'
         PROF_T(t_item);
@@ -1085,6 +1098,64 @@ __global__ void __launch_bounds__(RWG, 4) scan_range_kernel(DevIndex ix, DevBatc
         if (lane == 0) {
             bt.res_cnt[list] = n;
             if (wave == 0) bt.item_failed[item] = failed ? (S.fail | 0x100u) : 0u;
+        }
+        if constexpr (FUSED) {
+            // ---- the last workgroup of the query merges (merge.h's loop over the lists; loads that bypass this CU's
+            // vector cache: the lists were written by other CUs during this launch)
+            __threadfence();
+            __syncthreads();
+            if (tid == 0) S.scratch[0] = atomicAdd(&bt.fused_state[1 + q], 1u);
+            __syncthreads();
+            if (uni(S.scratch[0]) == fused_g - 1u && wave == 0) {
+                __threadfence();
+                rtop.init();
+                uint32_t any_failed = 0;
+                const uint32_t i0 = q * fused_g;
+                for (uint32_t li = i0 * bt.lpi; li < (i0 + fused_g) * bt.lpi; ++li) {
+                    const uint32_t cnt = uni(__hip_atomic_load(&bt.res_cnt[li], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+                    for (uint32_t base = 0; base < cnt; base += 64) {
+                        const bool has = base + lane < cnt;
+                        double sc = 0;
+                        uint32_t d = 0;
+                        if (has) {
+                            sc = __longlong_as_double((long long)__hip_atomic_load(
+                                reinterpret_cast<unsigned long long *>(&bt.res_score[(size_t)li * k + base + lane]), __ATOMIC_RELAXED,
+                                __HIP_MEMORY_SCOPE_AGENT));
+                            d = __hip_atomic_load(&bt.res_doc[(size_t)li * k + base + lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        }
+                        rtop.offer(has, sc, d, k, lane);
+                    }
+                }
+                for (uint32_t i = lane; i < fused_g; i += 64)
+                    any_failed |= __hip_atomic_load(&bt.item_failed[i0 + i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                const uint32_t nh = rtop.cnt;
+                const bool failed_any = __ballot(any_failed != 0) != 0ull;
+#pragma unroll
+                for (int r = 0; r < RK; ++r)
+                    if (r * 64 + lane < nh) {
+                        const uint32_t d = rtop.doc[r];
+                        const uint16_t *pl = ix.doc_payload + 3ull * d;
+                        unsigned long long *out = reinterpret_cast<unsigned long long *>(bt.hits + (size_t)q * k + r * 64 + lane);
+                        out[0] = (unsigned long long)__double_as_longlong(rtop.score[r]);
+                        out[1] = (unsigned long long)d | (unsigned long long)pl[0] << 32 | (unsigned long long)pl[1] << 48;
+                        out[2] = (unsigned long long)pl[2];
+                    }
+#pragma unroll
+                for (int i = 0; i < 4; ++i) hrow[4 * lane + i] = 0;
+                if (lane == 0) {
+                    bt.n_hits[q] = failed_any ? NONE32 : nh;  // NONE32: an item needs scan_many_kernel -- the host re-runs the batch on the general route
+                    bt.theta[q] = 0;
+                    bt.fused_state[1 + q] = 0;
+                }
+            }
+        }
+    }
+    if constexpr (FUSED) {  // the last workgroup to leave resets the item counter
+        __threadfence();
+        __syncthreads();
+        if (tid == 0 && atomicAdd(&bt.fused_state[0], 1u) == gridDim.x - 1u) {
+            *bt.work_ctr = 0;
+            bt.fused_state[0] = 0;
         }
     }
 #ifdef VBM25_PROFILE

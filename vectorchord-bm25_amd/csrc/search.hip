@@ -208,7 +208,7 @@ struct vbm25_batch {
     int device = 0;  // the index's device ordinal: the batch can be destroyed after its index
     uint32_t max_queries = 0, max_terms = 0, k = 0, nq = 0, max_items = 0;
     DeviceBuffer term_ids, q_off, items, n_items, q_item_base, theta, res_score, res_doc, res_cnt,
-        hits, n_hits, error_flag, prof, q_dense, spill, item_failed, work_ctr, hist;
+        hits, n_hits, error_flag, prof, q_dense, spill, item_failed, work_ctr, hist, fused_state;
     bool bigk = false;            // k > 1024: exhaustive path, one query at a time
     DeviceBuffer bk_acc, bk_keys, bk_iota, bk_docs, bk_tmp;
     size_t bk_tmp_bytes = 0;
@@ -231,6 +231,10 @@ struct vbm25_batch {
     uint32_t dense_target = D_TARGET_ITEMS;  // work items of a batch with dense queries (VBM25_DENSE_ITEMS)
     uint32_t dense_grid = D_GRID;
     uint32_t dense_c = 0;         // items per dense query of the current queries (0: chunks by postings, as the other queries)
+    // vbm25_search_batch with a handful of sparse queries: ONE launch (scan_range_kernel plans, scans and merges)
+    uint32_t fused_g = 0;         // items per query of the current queries on that route (0: general route)
+    bool use_fused = true;        // VBM25_FUSED=0: off
+    bool state_clean = false;     // threshold / histogram / counters are zero (the fused route leaves them so; the general one does not)
     uint32_t cur_mt = 1;          // most indexed terms among the cursor kernel's queries
     uint32_t target_items = TARGET_ITEMS;
     uint32_t min_chunk = MIN_CHUNK_POSTINGS;
@@ -241,7 +245,7 @@ struct vbm25_batch {
     // hits come down with asynchronous copies and ONE stream synchronisation
     hipStream_t lat_stream = nullptr;
     uint8_t *pin_in = nullptr, *pin_out = nullptr;
-    size_t pin_in_bytes = 0, pin_out_bytes = 0;
+    size_t pin_in_bytes = 0, pin_out_bytes = 0, pin_nt = 0;
     ~vbm25_batch() {
         if (lat_stream) (void)hipStreamDestroy(lat_stream);
         if (pin_in) (void)hipHostFree(pin_in);
@@ -254,6 +258,8 @@ struct vbm25_batch {
 };
 
 namespace {
+
+constexpr int VBM25_RETRY_GENERAL = 1000;  // internal: never leaves this file
 
 int use_device(int device) {
     HIP_TRY(hipSetDevice(device));
@@ -508,8 +514,12 @@ static int vbm25_batch_create_impl(vbm25_index *ix, uint32_t max_queries, uint32
         (rc = bt->q_dense.alloc(max_queries)) ||
         (rc = bt->spill.alloc(size_t(TARGET_ITEMS) * 3 * 2 * C_POSTINGS * 16)) ||
         (rc = bt->item_failed.alloc(4ull * bt->max_items)) || (rc = bt->work_ctr.alloc(8)) ||
-        (rc = bt->hist.alloc(4ull * CUR_HB * max_queries)))
+        (rc = bt->hist.alloc(4ull * CUR_HB * max_queries)) || (rc = bt->fused_state.alloc(4ull * (max_queries + 1))))
         return rc;
+    {
+        const char *fz = std::getenv("VBM25_FUSED");
+        bt->use_fused = bt->use_range && !(fz && fz[0] == '0');
+    }
     HIP_TRY(hipMemset(bt->error_flag.p, 0, 4));
 #ifdef VBM25_PROFILE
     if (int rc2 = bt->prof.alloc(8ull * 33 * CUR_GRID)) return rc2;
@@ -523,6 +533,15 @@ void vbm25_batch_destroy(vbm25_batch *bt) {
     if (!bt) return;
     (void)hipSetDevice(bt->device);
     delete bt;
+}
+
+// queries staged in the pinned buffer (term ids | offsets | dense flags) -> device, on the batch's own stream
+static int upload_staged(vbm25_batch *bt) {
+    const size_t nt = bt->pin_nt, no = 4ull * (bt->nq + 1);
+    if (nt) HIP_TRY(hipMemcpyAsync(bt->term_ids.p, bt->pin_in, nt, hipMemcpyHostToDevice, bt->lat_stream));
+    HIP_TRY(hipMemcpyAsync(bt->q_off.p, bt->pin_in + nt, no, hipMemcpyHostToDevice, bt->lat_stream));
+    if (bt->nq) HIP_TRY(hipMemcpyAsync(bt->q_dense.p, bt->pin_in + nt + no, bt->nq, hipMemcpyHostToDevice, bt->lat_stream));
+    return VBM25_OK;
 }
 
 static int vbm25_batch_set_queries_impl(vbm25_batch *bt, const uint32_t *term_ids, const uint32_t *q_off,
@@ -581,7 +600,24 @@ static int vbm25_batch_set_queries_impl(vbm25_batch *bt, const uint32_t *term_id
         bt->nq = nq;
         return VBM25_OK;
     }
-    if (fast && !bt->bigk) {  // staged in pinned memory, copied on the batch's own stream, nothing waits here
+    bt->nq = nq;
+    bt->fused_g = 0;
+    if (fast && bt->use_fused && nq <= 8 && !many && !has_dense && range_mt != 0 && !bt->timing) {  // every query sparse, <= 16 indexed terms
+        unsigned long long most = 0;
+        bool all = true;
+        for (uint32_t q = 0; q < nq; ++q) {
+            most = std::max(most, q_postings[q]);
+            all = all && q_postings[q] != 0 && !dense[q];
+        }
+        if (all) {
+            const unsigned long long g = (most + bt->min_chunk / 2) / bt->min_chunk;
+            bt->fused_g = uint32_t(std::min<unsigned long long>(std::max<unsigned long long>(g, 1), std::min<unsigned long long>(64, bt->index->n_docs)));
+        }
+    }
+    if (fast && !bt->bigk) {
+        // staged in pinned memory.  One-launch route (fused_g): the kernel reads the queries from there and writes the hits
+        // into the pinned output buffer -- no copy is enqueued at all.  General route: copied on the batch's own stream,
+        // nothing waits here.
         const size_t nt = 4ull * q_off[nq], no = 4ull * (nq + 1);
         if (nt + no + nq > bt->pin_in_bytes) {
             if (bt->pin_in) HIP_TRY(hipHostFree(bt->pin_in));
@@ -589,19 +625,25 @@ static int vbm25_batch_set_queries_impl(vbm25_batch *bt, const uint32_t *term_id
             bt->pin_in_bytes = 2 * (nt + no + nq) + 256;
             HIP_TRY(hipHostMalloc(reinterpret_cast<void **>(&bt->pin_in), bt->pin_in_bytes, hipHostMallocDefault));
         }
+        const size_t nh = sizeof(vbm25_hit) * size_t(nq) * bt->k, nc = (4ull * nq + 7) & ~size_t(7);
+        if (8 + nc + nh > bt->pin_out_bytes) {
+            if (bt->pin_out) HIP_TRY(hipHostFree(bt->pin_out));
+            bt->pin_out = nullptr;
+            bt->pin_out_bytes = 2 * (8 + nc + nh) + 256;
+            HIP_TRY(hipHostMalloc(reinterpret_cast<void **>(&bt->pin_out), bt->pin_out_bytes, hipHostMallocDefault));
+        }
         if (!bt->lat_stream) HIP_TRY(hipStreamCreateWithFlags(&bt->lat_stream, hipStreamNonBlocking));
         if (nt) std::memcpy(bt->pin_in, term_ids, nt);
         std::memcpy(bt->pin_in + nt, q_off, no);
         if (nq) std::memcpy(bt->pin_in + nt + no, dense.data(), nq);
-        if (nt) HIP_TRY(hipMemcpyAsync(bt->term_ids.p, bt->pin_in, nt, hipMemcpyHostToDevice, bt->lat_stream));
-        HIP_TRY(hipMemcpyAsync(bt->q_off.p, bt->pin_in + nt, no, hipMemcpyHostToDevice, bt->lat_stream));
-        if (nq) HIP_TRY(hipMemcpyAsync(bt->q_dense.p, bt->pin_in + nt + no, nq, hipMemcpyHostToDevice, bt->lat_stream));
+        bt->pin_nt = nt;
+        if (!bt->fused_g)
+            if (int rc = upload_staged(bt)) return rc;
     } else {
         if (q_off[nq]) HIP_TRY(hipMemcpy(bt->term_ids.p, term_ids, 4ull * q_off[nq], hipMemcpyHostToDevice));
         HIP_TRY(hipMemcpy(bt->q_off.p, q_off, 4ull * (nq + 1), hipMemcpyHostToDevice));
         if (nq) HIP_TRY(hipMemcpy(bt->q_dense.p, dense.data(), nq, hipMemcpyHostToDevice));
     }
-    bt->nq = nq;
     bt->has_many_terms = many;
     bt->has_dense = has_dense;
     bt->has_mid_terms = mid;
@@ -704,6 +746,37 @@ static int vbm25_batch_run_impl(vbm25_batch *bt, void *hip_stream) {
     db.dense_on = bt->use_dense ? 1u : 0u;
     const bool range = bt->use_range;
     const DevIndex &ix = bt->index->dev;
+    db.fused_state = bt->fused_state.as<uint32_t>();
+    db.fused_g = 0;
+    if (bt->fused_g && bt->range_rt && !bt->timing) {
+        if (!bt->state_clean) {
+            HIP_TRY(hipMemsetAsync(bt->hist.p, 0, 4ull * CUR_HB * bt->max_queries, st));
+            HIP_TRY(hipMemsetAsync(bt->theta.p, 0, 8ull * bt->max_queries, st));
+            HIP_TRY(hipMemsetAsync(bt->work_ctr.p, 0, 8, st));
+            HIP_TRY(hipMemsetAsync(bt->fused_state.p, 0, 4ull * (bt->max_queries + 1), st));
+            bt->state_clean = true;
+        }
+        db.fused_g = bt->fused_g;
+        db.dense_on = 0;
+        const size_t nc = (4ull * bt->nq + 7) & ~size_t(7);
+        db.term_ids = reinterpret_cast<const uint32_t *>(bt->pin_in);
+        db.q_off = reinterpret_cast<const uint32_t *>(bt->pin_in + bt->pin_nt);
+        db.n_hits = reinterpret_cast<uint32_t *>(bt->pin_out + 8);
+        db.hits = reinterpret_cast<vbm25_hit *>(bt->pin_out + 8 + nc);
+        const uint32_t grid = std::min<uint32_t>(bt->nq * bt->fused_g, R_GRID);
+        const int rcf = dispatch_k(bt->k, [&](auto kmax) {
+            constexpr int KM = decltype(kmax)::value;
+            if constexpr (KM <= REG_K) {
+                if (bt->range_rt == 8) scan_range_kernel<KM, 8, true><<<grid, RWG, 0, st>>>(ix, db);
+                else scan_range_kernel<KM, 16, true><<<grid, RWG, 0, st>>>(ix, db);
+            }
+            return int(VBM25_OK);
+        });
+        if (rcf) return rcf;
+        HIP_TRY(hipGetLastError());
+        return VBM25_OK;
+    }
+    bt->state_clean = false;
     if (cursor || range) HIP_TRY(hipMemsetAsync(bt->hist.p, 0, 4ull * CUR_HB * bt->nq, st));
     plan_kernel<<<1, PLAN_WG, 0, st>>>(ix, db, bt->max_items, cursor || range ? bt->target_items : TARGET_ITEMS,
                                        cursor || range ? bt->min_chunk : MIN_CHUNK_POSTINGS, bt->dense_c);
@@ -749,6 +822,16 @@ static int vbm25_batch_run_impl(vbm25_batch *bt, void *hip_stream) {
 static int vbm25_batch_fetch_impl(vbm25_batch *bt, vbm25_hit *hits, uint32_t *n_hits, bool fast = false) {
     if (!bt || (!hits && bt->nq) || (!n_hits && bt->nq)) return set_error(VBM25_ERR_INVALID, "NULL argument");
     if (int rc = use_device(bt->index->device)) return rc;
+    if (fast && bt->lat_stream && bt->fused_g) {  // the kernel wrote counts and hits into the pinned buffer: one synchronisation
+        const size_t nh = sizeof(vbm25_hit) * size_t(bt->nq) * bt->k, nc = (4ull * bt->nq + 7) & ~size_t(7);
+        HIP_TRY(hipStreamSynchronize(bt->lat_stream));
+        const uint32_t *cnt = reinterpret_cast<const uint32_t *>(bt->pin_out + 8);
+        for (uint32_t q = 0; q < bt->nq; ++q)
+            if (cnt[q] == UINT32_MAX) return VBM25_RETRY_GENERAL;  // an item needs scan_many_kernel
+        std::memcpy(n_hits, cnt, 4ull * bt->nq);
+        std::memcpy(hits, bt->pin_out + 8 + nc, nh);
+        return VBM25_OK;
+    }
     if (fast && bt->lat_stream) {  // flag, counts and hits come down asynchronously; one synchronisation
         const size_t nh = sizeof(vbm25_hit) * size_t(bt->nq) * bt->k, nc = 4ull * bt->nq;
         if (8 + nc + nh > bt->pin_out_bytes) {
@@ -931,6 +1014,12 @@ static int vbm25_search_batch_impl(vbm25_index *ix, const uint32_t *term_ids, co
     int rc = vbm25_batch_set_queries_impl(bt, term_ids, q_off, nq, fast);
     if (!rc) rc = vbm25_batch_run_impl(bt, fast ? bt->lat_stream : nullptr);
     if (!rc) rc = vbm25_batch_fetch_impl(bt, hits, n_hits, fast);
+    if (rc == VBM25_RETRY_GENERAL) {  // the one-launch route met an item it cannot finish: general route
+        bt->fused_g = 0;
+        rc = upload_staged(bt);
+        if (!rc) rc = vbm25_batch_run_impl(bt, bt->lat_stream);
+        if (!rc) rc = vbm25_batch_fetch_impl(bt, hits, n_hits, fast);
+    }
     return rc;
 }
 
