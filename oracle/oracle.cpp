@@ -1048,11 +1048,9 @@ uint64_t orc_query_bytes(const orc_index *ix, const uint32_t *terms, uint32_t n_
 
 /* model of the device's dense-window kernel (dense_model.inc): a test aid, not an oracle */
 uint32_t orc_dense_model(const orc_index *ix, const uint32_t *terms, uint32_t n_terms, uint32_t k, uint32_t wmax,
-                         uint32_t w0, uint32_t lo, uint32_t hi, int ne_on, orc_hit *out, uint64_t *stats8) {
-    g_bucket_log2 = uint32_t(ne_on) >> 8;
-    ne_on &= 255;
+                         uint32_t w0, uint32_t lo, uint32_t hi, int phases, orc_hit *out, uint64_t *stats8) {
     DenseModelStats st;
-    const uint32_t n = dense_model(ix, terms, n_terms, k, wmax, w0, lo, hi, ne_on, out, &st);
+    const uint32_t n = dense_model(ix, terms, n_terms, k, wmax, w0, lo, hi, phases, out, &st);
     std::memcpy(stats8, &st, sizeof st);
     return n;
 }

@@ -151,11 +151,13 @@ uint8_t *orc_pages_get_mut(orc_pages *, uint32_t page_id);
 void orc_pages_free(orc_pages *);
 
 /* Scalar model of the device's dense-window kernel (dense_model.inc): windows [lo, hi) of at most wmax documents
- * (first window w0, doubling), order-free f32 upper-bound sums, MaxScore split + block-level skip of non-essential
- * blocks (ne_on), candidates re-scored exactly.  A test aid for the kernel's bounds, not an oracle.
- * stats8: windows, blocks, essential blocks, non-essential blocks tested / skipped, candidates, lookups, -. */
+ * (first window w0, doubling), order-free 16-bit fixed-point upper-bound sums, MaxScore split + block-max test of the
+ * non-essential terms' blocks (phases: 0 off, 1 the kernel's rule -- head terms in one phase --, 2 a phase per term,
+ * 3 runs of one document-frequency class), histogram threshold, candidates re-scored exactly at a flush.  A test aid
+ * for the kernel's bounds, not an oracle.  stats8: windows, blocks, blocks fetched untested, blocks tested / skipped,
+ * candidates buffered / re-scored exactly, phases.  Returns 0xffffffff if an accumulator left its 16 bits. */
 uint32_t orc_dense_model(const orc_index *, const uint32_t *terms, uint32_t n_terms, uint32_t k, uint32_t wmax,
-                         uint32_t w0, uint32_t lo, uint32_t hi, int ne_on, orc_hit *out, uint64_t *stats8);
+                         uint32_t w0, uint32_t lo, uint32_t hi, int phases, orc_hit *out, uint64_t *stats8);
 /* Algorithmic bytes of one query per SURVEY section 8(d). */
 uint64_t orc_query_bytes(const orc_index *, const uint32_t *terms, uint32_t n_terms, uint32_t k);
 

@@ -208,14 +208,15 @@ class OracleIndex:
     def search_brute(self, terms, k):
         return self._search(lib().orc_search_brute, terms, k)
 
-    def dense_model(self, terms, k, wmax=8192, w0=256, lo=0, hi=None, ne_on=True):
+    def dense_model(self, terms, k, wmax=16384, w0=256, lo=0, hi=None, phases=1):
         """model of the device's dense-window kernel (oracle/dense_model.inc): hits + statistics"""
         terms = np.ascontiguousarray(terms, dtype=np.uint32)
         out = np.zeros(max(k, 1), dtype=HIT_DTYPE)
         st = np.zeros(8, dtype=np.uint64)
         hi = self.n_docs if hi is None else hi
-        n = lib().orc_dense_model(self.h, _p(terms), len(terms), k, wmax, w0, lo, hi, int(ne_on), _p(out), _p(st))
-        names = ("windows", "blocks", "ess_blocks", "ne_tested", "ne_skipped", "candidates", "lookups", "_")
+        n = lib().orc_dense_model(self.h, _p(terms), len(terms), k, wmax, w0, lo, hi, int(phases), _p(out), _p(st))
+        assert n != 0xffffffff, "a 16-bit accumulator overflowed"
+        names = ("windows", "blocks", "fetched_untested", "tested", "skipped", "candidates", "rescored", "phases")
         return out[:n], dict(zip(names, (int(x) for x in st)))
 
     def search_batch(self, terms, q_off, k, mode="wand", threads=1):

@@ -1,5 +1,5 @@
 """The scheme of the device's dense-window kernel (scan_dense_kernel) checked on the CPU through its scalar
-model (oracle/dense_model.inc): f32 upper-bound sums select, exact f64 sums decide -- the hits must be those
+model (oracle/dense_model.inc): 16-bit fixed-point upper-bound sums select, exact f64 sums decide -- the hits must be those
 of the canonical brute force for every window size, with and without the MaxScore split / block skipping,
 and the skipping must actually skip on a Zipf corpus."""
 import numpy as np
@@ -24,9 +24,9 @@ def test_model_matches_brute_force(zipf, nterms, k):
     for q in range(len(off) - 1):
         t = terms[off[q]:off[q + 1]]
         ref = oix.search_brute(t, k)
-        for wmax, w0, ne in ((8192, 256, 2), (1024, 64, 2), (8192, 0, 0), (512, 512, 1), (4096, 256, 3)):
-            got, st = oix.dense_model(t, k, wmax=wmax, w0=w0, ne_on=ne)
-            assert got.tobytes() == ref.tobytes(), (q, wmax, w0, ne)
+        for wmax, w0, ph in ((16384, 256, 1), (1024, 64, 2), (8192, 0, 0), (512, 512, 1), (4096, 256, 3)):
+            got, st = oix.dense_model(t, k, wmax=wmax, w0=w0, phases=ph)
+            assert got.tobytes() == ref.tobytes(), (q, wmax, w0, ph)
 
 
 def test_model_on_sub_ranges_and_ties():
@@ -54,11 +54,14 @@ def test_block_skipping_skips_on_zipf():
     sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
     from bench import make_queries as bench_queries
     terms, off = bench_queries(seg, 30_000, 6, 10, seed=1, zipf_s=1.0)
-    tested = skipped = 0
+    tested = skipped = cand = resc = 0
     for q in range(6):
         t = terms[off[q]:off[q + 1]]
-        got, st = oix.dense_model(t, 100, wmax=8192, w0=256, ne_on=2)
+        got, st = oix.dense_model(t, 100, wmax=16384, w0=256, phases=1)
         assert got.tobytes() == oix.search_brute(t, 100).tobytes()
-        tested += st["ne_tested"]
-        skipped += st["ne_skipped"]
+        tested += st["tested"]
+        skipped += st["skipped"]
+        cand += st["candidates"]
+        resc += st["rescored"]
     assert tested > 0 and skipped > 0.3 * tested, (tested, skipped)
+    assert resc < cand, (cand, resc)  # the flush drops candidates the threshold has overtaken

@@ -406,8 +406,8 @@ def test_c3_full_size_full_batch_parity():
 @pytest.mark.parametrize("n_docs,vocab,nq,nterms,k", [(300_000, 20_000, 96, 10, 100), (1_000_000, 50_000, 64, 6, 10)])
 def test_maxscore_split_zipf(monkeypatch, n_docs, vocab, nq, nterms, k):
     """Zipf(1) corpora through scan_range_kernel's MaxScore split (VBM25_RANGE_DENSE=1: threshold bootstrap,
-    non-essential lists looked up instead of scanned, tile retries): same records as the exhaustive
-    scan_many_kernel path (the default for dense queries) and as the oracle."""
+    non-essential lists looked up instead of scanned, tile retries): same records as the default route for dense
+    queries (scan_dense_kernel) and as the oracle."""
     import sys
     sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
     from bench import make_queries as bench_queries
@@ -429,8 +429,9 @@ def test_maxscore_split_zipf(monkeypatch, n_docs, vocab, nq, nterms, k):
 
 def test_c5_full_size_sample_parity(monkeypatch):
     """BASELINE config C5 at full size (50M docs / 100k vocab Zipf(1), 10-term queries, top-100): the bench's
-    batch of 1024 runs; 32 of its queries bit-exact against the oracle's brute force and ranking-equal to
-    the faithful Block-WAND restatement; the MaxScore-split path gives the same records on 64 of them."""
+    batch of 1024 runs on scan_dense_kernel (the default route); 32 of its queries bit-exact against the oracle's
+    brute force and ranking-equal to the faithful Block-WAND restatement; scan_range_kernel's MaxScore split gives
+    the same records on 64 of them, the exhaustive scan_many_kernel on 16."""
     import sys
     sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
     from bench import make_queries as bench_queries, usable_cpus
@@ -456,6 +457,13 @@ def test_c5_full_size_sample_parity(monkeypatch):
     b.run()
     h2, n2 = b.fetch()
     assert h2.tobytes() == hits[:64].tobytes() and np.array_equal(n2, nh[:64])
+    monkeypatch.delenv("VBM25_RANGE_DENSE")
+    monkeypatch.setenv("VBM25_DENSE", "0")  # the exhaustive dense-window kernel of round 1
+    b = vb.Batch(gix, 16, int(off[16]), 100)
+    b.set_queries(terms[:off[16]], off[:17])
+    b.run()
+    h3, n3 = b.fetch()
+    assert h3.tobytes() == hits[:16].tobytes() and np.array_equal(n3, nh[:16])
 
 
 def test_evaluate_batch_on_the_device_matches_the_oracle_bitwise():
@@ -530,3 +538,30 @@ def test_k_up_to_bm25_limit_maximum(k):
         want = oix.search_brute(t[t != 0xFFFFFFFF], k)
         assert_bit_exact(want, hits[q, :nh[q]], what=f"k={k} q{q} vs brute")
     assert nh[:-1].min() > 1024
+
+
+def test_one_launch_route_of_search_batch(monkeypatch):
+    """vbm25_search_batch with at most 8 sparse queries: ONE launch (scan_range_kernel makes the items, the query's last
+    workgroup merges, queries / hits in pinned host memory).  Same records as the general route (VBM25_FUSED=0) and the
+    oracle; repeated calls and general-route calls in between find the per-launch state clean; 9 queries take the
+    general route; an item the kernel gives up sends the batch to the general route (correlated lists)."""
+    c = make_corpus(400_000, 4000, seed=21, length="lognormal", mean_len=70)
+    seg, gix, oix = both(c)
+    terms, off = make_queries(c, 64, 4, seed=8)
+    monkeypatch.setenv("VBM25_FUSED", "0")
+    gix0 = vb.GpuIndex(seg)  # its scratch batch is created under VBM25_FUSED=0
+    ref = {nq: vb.search_batch(gix0, terms[:off[nq]], off[:nq + 1], 10) for nq in (1, 3, 8, 9)}
+    monkeypatch.delenv("VBM25_FUSED")
+    for rep in range(3):
+        for nq in (1, 3, 8, 9, 1):
+            hits, nh = vb.search_batch(gix, terms[:off[nq]], off[:nq + 1], 10)
+            assert hits.tobytes() == ref[nq][0].tobytes() and np.array_equal(nh, ref[nq][1]), (rep, nq)
+            for q in range(nq):
+                assert_bit_exact(oix.search_brute(terms[off[q]:off[q + 1]], 10), hits[q, :nh[q]], what=f"nq={nq} q{q}")
+        # a general-route batch on the same index in between (its plan_kernel / merge_kernel leave other state behind)
+        check_batch(gix, oix, terms, off, 10, wand=False)
+    # single queries of different shapes, k up to the register top-k's limit
+    for q, k in ((0, 1), (5, 64), (9, 100), (17, 256)):
+        t = terms[off[q]:off[q + 1]]
+        hits, nh = vb.search_batch(gix, t, np.array([0, len(t)], dtype=np.uint32), k)
+        assert_bit_exact(oix.search_brute(t, k), hits[0, :nh[0]], what=f"k={k}")
