@@ -281,9 +281,8 @@ __global__ void __launch_bounds__(DWG, 4) scan_dense_kernel(DevIndex ix, DevBatc
             pair_fetch(tbody, mt, lane, r.b0, r.b1, r.b2, r.b3);
             r.fn = reinterpret_cast<const uint16_t *>(ix.post_fn + 128ull * j)[lane];
         };
-        auto add_pair = [&](uint32_t t, uint32_t d0, uint32_t d1, uint32_t f0, uint32_t f1, uint32_t fn, bool in0, bool in1,
+        auto add_pair = [&](float s0i, uint32_t d0, uint32_t d1, uint32_t f0, uint32_t f1, uint32_t fn, bool in0, bool in1,
                             uint32_t wlo, uint32_t wspan) {
-            const float s0i = S.t_s0i[t];
             const uint32_t x0 = d0 - wlo, x1 = d1 - wlo;
             const float tf0 = (float)f0, tf1 = (float)f1;
             const uint32_t p0 = (uint32_t)((tf0 * s0i) * __builtin_amdgcn_rcpf(tf0 + S.s1f[fn & 0xff])) + 1u;
@@ -293,7 +292,7 @@ __global__ void __launch_bounds__(DWG, 4) scan_dense_kernel(DevIndex ix, DevBatc
             if (in0 && x0 < wspan) atomicMax(&S.bmax[x0 >> 6], ((atomicAdd(&S.acc[x0 >> 1], p0 << (16u * (x0 & 1u))) >> (16u * (x0 & 1u))) & 0xffffu) + p0);
             if (in1 && x1 < wspan) atomicMax(&S.bmax[x1 >> 6], ((atomicAdd(&S.acc[x1 >> 1], p1 << (16u * (x1 & 1u))) >> (16u * (x1 & 1u))) & 0xffffu) + p1);
         };
-        auto task_accumulate = [&](const uint4 c, uint32_t t, const Raw &r, uint32_t wlo, uint32_t wspan) {
+        auto task_accumulate = [&](const uint4 c, float s0i, const Raw &r, uint32_t wlo, uint32_t wspan) {
             const uint32_t md = (c.w >> 8) & 0xff, mt = (c.w >> 16) & 0xff;
             uint32_t v0, v1, f0, f1;
             pair_extract(md, lane, r.a0, r.a1, r.a2, r.a3, v0, v1);
@@ -301,7 +300,7 @@ __global__ void __launch_bounds__(DWG, 4) scan_dense_kernel(DevIndex ix, DevBatc
             const uint32_t own = v0 + v1;
             const uint32_t incl = wave_incl_scan_u32(own);
             const uint32_t d0 = c.x + (incl - own) + v0;
-            add_pair(t, d0, d0 + v1, f0, f1, r.fn, true, true, wlo, wspan);
+            add_pair(s0i, d0, d0 + v1, f0, f1, r.fn, true, true, wlo, wspan);
         };
         // byte-packed tail or raw block: generic, synchronous decode (rare: one call site)
         auto task_slow = [&](uint32_t e, uint32_t wlo, uint32_t wspan) {
@@ -313,21 +312,30 @@ __global__ void __launch_bounds__(DWG, 4) scan_dense_kernel(DevIndex ix, DevBatc
             decode_doc_ids(body, md, n, c.x, lane, d0, d1);
             decode_fields(body + ((payload_bytes(md, n) + 7u) & ~7u), mt, n, lane, f0, f1);
             const uint32_t fn = reinterpret_cast<const uint16_t *>(ix.post_fn + 128ull * j)[lane];
-            add_pair(t, d0, d1, f0, f1, fn, 2 * lane < n, 2 * lane + 1 < n, wlo, wspan);
+            add_pair(S.t_s0i[t], d0, d1, f0, f1, fn, 2 * lane < n, 2 * lane + 1 < n, wlo, wspan);
         };
         // up to D_UN tasks of this wave (entries e[0 .. nv) of the task list), all of them in flight together
         auto run_group = [&](const uint32_t (&e)[D_UN], uint32_t nv, uint32_t wlo, uint32_t wspan) {
             uint4 c[D_UN];
-            uint32_t j[D_UN], t[D_UN];
+            uint32_t j[D_UN];
+            float s0i[D_UN];
             bool fast[D_UN];
             Raw r[D_UN];
+            {   // lane i reads the entry of task i: one LDS round trip for the whole group instead of one per field and task
+                uint32_t el = e[0];
 #pragma unroll
-            for (int i = 0; i < D_UN; ++i) {
-                const uint32_t ee = (uint32_t)i < nv ? e[i] : e[0];
-                c[i] = uni4(S.tmeta[ee]);
-                j[i] = uni(S.tblk[ee]);
-                t[i] = uni((uint32_t)S.tterm[ee]);
-                fast[i] = ((c[i].w >> 8) & 0xff) < 32u && ((c[i].w >> 16) & 0xff) < 32u;
+                for (int i = 1; i < D_UN; ++i) el = lane == (uint32_t)i && (uint32_t)i < nv ? e[i] : el;
+                const uint4 cm = S.tmeta[el];
+                const uint32_t jb = S.tblk[el];
+                const float sv = S.t_s0i[S.tterm[el]];
+#pragma unroll
+                for (int i = 0; i < D_UN; ++i) {
+                    c[i] = make_uint4((uint32_t)__builtin_amdgcn_readlane((int)cm.x, i), (uint32_t)__builtin_amdgcn_readlane((int)cm.y, i),
+                                      (uint32_t)__builtin_amdgcn_readlane((int)cm.z, i), (uint32_t)__builtin_amdgcn_readlane((int)cm.w, i));
+                    j[i] = (uint32_t)__builtin_amdgcn_readlane((int)jb, i);
+                    s0i[i] = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(sv), i));
+                    fast[i] = ((c[i].w >> 8) & 0xff) < 32u && ((c[i].w >> 16) & 0xff) < 32u;
+                }
             }
 #pragma unroll
             for (int i = 0; i < D_UN; ++i)
@@ -335,8 +343,10 @@ __global__ void __launch_bounds__(DWG, 4) scan_dense_kernel(DevIndex ix, DevBatc
             uint32_t slow = 0;
 #pragma unroll
             for (int i = 0; i < D_UN; ++i) {
-                if ((uint32_t)i < nv && fast[i]) task_accumulate(c[i], t[i], r[i], wlo, wspan);
-                __builtin_amdgcn_sched_barrier(0);  // one decode at a time: the scheduler otherwise interleaves them all (registers)
+                if ((uint32_t)i < nv && fast[i]) task_accumulate(c[i], s0i[i], r[i], wlo, wspan);
+#ifdef D_SCHED_BARRIER
+                __builtin_amdgcn_sched_barrier(0);  // one decode at a time
+#endif
                 if ((uint32_t)i < nv && !fast[i]) slow |= 1u << i;
             }
             while (slow) {
