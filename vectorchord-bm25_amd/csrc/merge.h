@@ -16,16 +16,20 @@ __global__ void __launch_bounds__(64) merge_kernel(DevIndex ix, DevBatch bt) {
     if (lane == 0) s_top.count = 0;
     __builtin_amdgcn_wave_barrier();
     const uint32_t i0 = bt.q_item_base[q] * bt.lpi, i1 = bt.q_item_base[q + 1] * bt.lpi;
+    // the query's threshold is a lower bound of its k-th best score: entries below it cannot be among the hits (a
+    // dense query's 32 lists of 100 entries mostly are)
+    const unsigned long long theta = bt.theta[q];
     for (uint32_t item = i0; item < i1; ++item) {  // every list of every item of the query
         const uint32_t cnt = uni(bt.res_cnt[item]);
         if (cnt == 0) continue;
         for (uint32_t base = 0; base < cnt; base += 64) {
-            const bool has = base + lane < cnt;
+            bool has = base + lane < cnt;
             double sc = 0;
             uint32_t d = 0;
             if (has) {
                 sc = bt.res_score[(size_t)item * k + base + lane];
                 d = bt.res_doc[(size_t)item * k + base + lane];
+                has = (unsigned long long)__double_as_longlong(sc) >= theta;
             }
             if constexpr (KMAX <= REG_K) rtop.offer(has, sc, d, k, lane);
             else topk_offer<(KMAX > REG_K ? KMAX : 1)>(s_top, k, has, sc, d, lane);

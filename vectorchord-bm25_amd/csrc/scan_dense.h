@@ -123,7 +123,7 @@ __global__ void __launch_bounds__(DWG, 4) scan_dense_kernel(DevIndex ix, DevBatc
         PROF_T(t_item);
 
         // ---- threshold poll (wave 0): the query's published k-th score and the histogram of the candidates' lower bounds
-        unsigned long long pg = 0;
+        unsigned long long pg = 0, hist_published = 0;
         uint32_t pc[4] = {0, 0, 0, 0};
         auto poll_request = [&]() {
             pg = __hip_atomic_load(&bt.theta[q], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -151,7 +151,13 @@ __global__ void __launch_bounds__(DWG, 4) scan_dense_kernel(DevIndex ix, DevBatc
                 const unsigned long long eb2 = (unsigned long long)__double_as_longlong(edge);
                 if (eb2 > th) th = eb2;
             }
-            if (lane == 0) atomicMax(&S.theta, th);
+            if (lane == 0) {
+                atomicMax(&S.theta, th);
+                if (th > hist_published) {  // for merge_kernel: entries below the threshold need no merging
+                    atomicMax(&bt.theta[q], th);
+                    hist_published = th;
+                }
+            }
         };
 
         // ---- item setup (wave 0, lane t = term t): block ranges, first block at or after lo, bounds, order, scale
