@@ -116,6 +116,13 @@ def test_fuzz_shape_100_term_queries_top100():
     seg, gix, oix = both(c)
     terms, off = make_queries(c, 16, 100, seed=5)
     check_batch(gix, oix, terms, off, 100)
+    # 250-term queries (the GPU path's limit is 256 indexed terms), and the error beyond it
+    terms, off = make_queries(c, 4, 250, seed=6)
+    check_batch(gix, oix, terms, off, 20, wand=False)
+    with pytest.raises(vb.Vbm25Error) as e:
+        t = np.arange(300, dtype=np.uint32)
+        vb.search_batch(gix, t, np.array([0, 300], dtype=np.uint32), 5)
+    assert e.value.code == -4  # VBM25_ERR_UNSUPPORTED
 
 
 def test_edge_cases():

@@ -64,7 +64,7 @@ constexpr int NW = WG / 64;
 constexpr int SLOTS_LOG2 = 12;
 constexpr int SLOTS = 1 << SLOTS_LOG2;  // hash table slots per workgroup
 constexpr int CAP_BLOCKS = SLOTS / 2 / 128;  // blocks admitted per tile in hash mode
-constexpr int MAX_TERMS = 128;         // terms per query handled on the GPU
+constexpr int MAX_TERMS = 256;         // terms per query handled on the GPU (scan_many_kernel: one thread per term, WG = 256)
 constexpr uint32_t EMPTY = 0xffffffffu;
 constexpr uint32_t TARGET_ITEMS = 1536;  // 2 x (256 CUs x 3 resident workgroups): measured best of 768..3072
 constexpr uint32_t MIN_CHUNK_POSTINGS = 8192;

@@ -35,7 +35,7 @@ __device__ __forceinline__ uint32_t wave_incl_scan_u32(uint32_t x) {
 
 
 template <int KMAX>
-__global__ void __launch_bounds__(CWG, 6) scan_kernel(DevIndex ix, DevBatch bt) {
+__global__ void __launch_bounds__(CWG, KMAX > REG_K ? 4 : 6) scan_kernel(DevIndex ix, DevBatch bt) {  // (the LDS top-k of k > 256 leaves room for 4)
     constexpr int T = CHAIN_MAX_TERMS;
     constexpr int RING = 64;              // metadata ring entries (power-of-two ring per term)
     constexpr uint32_t PLANNER = CNW;     // waves 0..CNW-1 work: entries w and w + CNW of a tile
