@@ -57,6 +57,7 @@ struct DevBatch {
     uint32_t dense_on;         // dense queries of <= D_T terms take scan_dense_kernel (its items come from work_ctr[1])
     uint32_t fused_g;          // scan_range_kernel alone: items per query made in the kernel, lists merged by the query's last workgroup (0: off)
     uint32_t *fused_state;     // [0] workgroups that left, [1 + q] finished items of query q; zero between launches
+    uint32_t merge_marked;     // merge_kernel: only the queries whose n_hits is NONE32
 };
 
 constexpr int WG = 256;

@@ -13,6 +13,9 @@ __global__ void __launch_bounds__(64) merge_kernel(DevIndex ix, DevBatch bt) {
     RegTopK<RK> rtop;
     rtop.init();
     const uint32_t q = blockIdx.x, lane = threadIdx.x, k = bt.k;
+    // after scan_range_kernel<..., FUSED> (which merges in the kernel): only the queries it marked -- one of their items
+    // went to scan_many_kernel
+    if (bt.merge_marked && bt.n_hits[q] != NONE32) return;
     if (lane == 0) s_top.count = 0;
     __builtin_amdgcn_wave_barrier();
     const uint32_t i0 = bt.q_item_base[q] * bt.lpi, i1 = bt.q_item_base[q + 1] * bt.lpi;
@@ -54,5 +57,8 @@ __global__ void __launch_bounds__(64) merge_kernel(DevIndex ix, DevBatch bt) {
         n = s_top.count;
         for (uint32_t i = lane; i < n; i += 64) emit(i, s_top.score[i], s_top.doc[i]);
     }
-    if (lane == 0) bt.n_hits[q] = n;
+    if (lane == 0) {
+        bt.n_hits[q] = n;
+        if (bt.merge_marked) bt.theta[q] = 0;  // the one-launch route keeps the per-launch state clean
+    }
 }

@@ -513,6 +513,19 @@ __global__ void __launch_bounds__(RWG, 4) scan_range_kernel(DevIndex ix, DevBatc
             assign_quotas();
             const double hscale = (double)CUR_HB / sums0;  // score -> histogram bucket: linear in [0, sum of s0)
             if (lane == 0) {
+                if constexpr (FUSED) {
+                    // the records plan_kernel would have made: scan_many_kernel (items this kernel gives up) and merge_kernel
+                    // (queries with such an item) of the general route read them
+                    Item rec;
+                    rec.q = q;
+                    rec.doc_lo = lo;
+                    rec.doc_hi = hi;
+                    rec.m = m;
+                    bt.items[item] = rec;
+                    if (item == 0) *bt.n_items = n_items;
+                    if (item % fused_g == 0) bt.q_item_base[q] = item;
+                    if (item + 1 == n_items) bt.q_item_base[q + 1] = n_items;
+                }
                 S.q = q;
                 S.lo = lo;
                 S.hi = hi;
@@ -1100,34 +1113,78 @@ __global__ void __launch_bounds__(RWG, 4) scan_range_kernel(DevIndex ix, DevBatc
             if (wave == 0) bt.item_failed[item] = failed ? (S.fail | 0x100u) : 0u;
         }
         if constexpr (FUSED) {
-            // ---- the last workgroup of the query merges (merge.h's loop over the lists; loads that bypass this CU's
-            // vector cache: the lists were written by other CUs during this launch)
-            __threadfence();
-            __syncthreads();
-            if (tid == 0) S.scratch[0] = atomicAdd(&bt.fused_state[1 + q], 1u);
-            __syncthreads();
-            if (uni(S.scratch[0]) == fused_g - 1u && wave == 0) {
+            // ---- the last workgroup of the query merges its lists (merge.h's job) and leaves the per-launch state clean.
+            // One item per query: the eight lists are this workgroup's own and travel through LDS.  Several items: an
+            // atomic counter per query finds the last workgroup; the other workgroups' lists are read with loads that
+            // bypass this CU's vector cache, all entries of 16 lists at a time (one round trip, not one per list).
+            uint32_t *tmp = S.stage;  // (free between items)
+            bool last = true;
+            if (fused_g == 1u) {
+                __syncthreads();  // every wave is done with its stage rows (the cold pass of the last tile reads them)
+                const uint32_t base = wave * 3u * (uint32_t)KMAX;
+#pragma unroll
+                for (int r = 0; r < RK; ++r)
+                    if (r * 64 + lane < n) {
+                        tmp[base + r * 64 + lane] = (uint32_t)__double2loint(rtop.score[r]);
+                        tmp[base + KMAX + r * 64 + lane] = (uint32_t)__double2hiint(rtop.score[r]);
+                        tmp[base + 2 * KMAX + r * 64 + lane] = rtop.doc[r];
+                    }
+                if (lane == 0) S.lcnt[wave] = n;
+                __syncthreads();
+            } else {
                 __threadfence();
+                __syncthreads();
+                if (tid == 0) S.scratch[0] = atomicAdd(&bt.fused_state[1 + q], 1u);
+                __syncthreads();
+                last = uni(S.scratch[0]) == fused_g - 1u;
+            }
+            if (last && wave == 0) {
                 rtop.init();
-                uint32_t any_failed = 0;
+                uint32_t any_failed = failed ? 1u : 0u;
                 const uint32_t i0 = q * fused_g;
-                for (uint32_t li = i0 * bt.lpi; li < (i0 + fused_g) * bt.lpi; ++li) {
-                    const uint32_t cnt = uni(__hip_atomic_load(&bt.res_cnt[li], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
-                    for (uint32_t base = 0; base < cnt; base += 64) {
-                        const bool has = base + lane < cnt;
-                        double sc = 0;
-                        uint32_t d = 0;
-                        if (has) {
-                            sc = __longlong_as_double((long long)__hip_atomic_load(
-                                reinterpret_cast<unsigned long long *>(&bt.res_score[(size_t)li * k + base + lane]), __ATOMIC_RELAXED,
-                                __HIP_MEMORY_SCOPE_AGENT));
-                            d = __hip_atomic_load(&bt.res_doc[(size_t)li * k + base + lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (fused_g == 1u) {
+                    for (uint32_t w = 0; w < (uint32_t)RNW; ++w) {
+                        const uint32_t cnt = uni(S.lcnt[w]), base = w * 3u * (uint32_t)KMAX;
+                        for (uint32_t e0 = 0; e0 < cnt; e0 += 64) {
+                            const bool has = e0 + lane < cnt;
+                            double sc = 0;
+                            uint32_t d = 0;
+                            if (has) {
+                                sc = __hiloint2double((int)tmp[base + KMAX + e0 + lane], (int)tmp[base + e0 + lane]);
+                                d = tmp[base + 2 * KMAX + e0 + lane];
+                            }
+                            rtop.offer(has, sc, d, k, lane);
                         }
-                        rtop.offer(has, sc, d, k, lane);
+                    }
+                } else {
+                    __threadfence();
+                    const uint32_t L0 = i0 * bt.lpi, NL = fused_g * bt.lpi;
+                    for (uint32_t lb = 0; lb < NL; lb += 16) {
+                        uint32_t cnt = 0;
+                        if (lane < 16u && lb + lane < NL) cnt = min(__hip_atomic_load(&bt.res_cnt[L0 + lb + lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT), k);
+                        const uint32_t incl = wave_incl_scan_u32(cnt), excl = incl - cnt;
+                        const uint32_t total = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);  // <= 16 k <= 4096 words of the stage
+                        for (uint32_t j = 0; j < cnt; ++j) tmp[excl + j] = lane << 16 | j;
+                        __builtin_amdgcn_wave_barrier();
+                        for (uint32_t e0 = 0; e0 < total; e0 += 64) {
+                            const bool has = e0 + lane < total;
+                            double sc = 0;
+                            uint32_t d = 0;
+                            if (has) {
+                                const uint32_t ds = tmp[e0 + lane];
+                                const size_t at = (size_t)(L0 + lb + (ds >> 16)) * k + (ds & 0xffffu);
+                                sc = __longlong_as_double((long long)__hip_atomic_load(
+                                    reinterpret_cast<unsigned long long *>(&bt.res_score[at]), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+                                d = __hip_atomic_load(&bt.res_doc[at], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                            }
+                            rtop.offer(has, sc, d, k, lane);
+                        }
+                        __builtin_amdgcn_wave_barrier();
                     }
                 }
-                for (uint32_t i = lane; i < fused_g; i += 64)
-                    any_failed |= __hip_atomic_load(&bt.item_failed[i0 + i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (fused_g != 1u)
+                    for (uint32_t i = lane; i < fused_g; i += 64)
+                        any_failed |= __hip_atomic_load(&bt.item_failed[i0 + i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 const uint32_t nh = rtop.cnt;
                 const bool failed_any = __ballot(any_failed != 0) != 0ull;
 #pragma unroll
@@ -1145,7 +1202,7 @@ __global__ void __launch_bounds__(RWG, 4) scan_range_kernel(DevIndex ix, DevBatc
                 if (lane == 0) {
                     bt.n_hits[q] = failed_any ? NONE32 : nh;  // NONE32: an item needs scan_many_kernel -- the host re-runs the batch on the general route
                     bt.theta[q] = 0;
-                    bt.fused_state[1 + q] = 0;
+                    if (fused_g != 1u) bt.fused_state[1 + q] = 0;
                 }
             }
         }
