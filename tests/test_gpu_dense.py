@@ -1,5 +1,6 @@
-"""scan_dense_kernel (dense doc windows: f32 upper-bound sums select, exact f64 sums decide; MaxScore split with
-block-level skipping) through the C ABI against the CPU oracle.  -m gpu only.
+"""scan_dense_kernel (dense doc windows: 16-bit fixed-point upper-bound sums select, exact f64 sums decide; MaxScore
+split with block-max skipping; k <= 128 -- dense queries with a larger k take scan_many_kernel) through the C ABI
+against the CPU oracle.  -m gpu only.
 
 VBM25_DENSE_X1000=0 declares every query dense, which sends the whole range of corpora of the other parity
 tests -- sparse lists, tail blocks, raw width-32 blocks, unknown terms, ties -- through this kernel; the batch's
@@ -46,7 +47,7 @@ def check_dense(gix, oix, terms, off, k, expect_failed=0):
 
 
 @pytest.mark.parametrize("n_docs,vocab,nq,nterms,k", [(300_000, 20_000, 96, 10, 100), (1_000_000, 50_000, 64, 6, 10),
-                                                      (200_000, 5_000, 32, 16, 256)])
+                                                      (200_000, 5_000, 32, 16, 128), (200_000, 5_000, 16, 12, 256)])
 def test_zipf_corpora(monkeypatch, n_docs, vocab, nq, nterms, k):
     sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
     from bench import make_queries as bench_queries
@@ -68,7 +69,7 @@ def test_zipf_corpora(monkeypatch, n_docs, vocab, nq, nterms, k):
 
 @pytest.mark.parametrize("length,zipf,nterms,k", [
     ("fixed", None, 3, 10), ("lognormal", None, 5, 10), ("mixed", None, 2, 1),
-    ("lognormal", 1.0, 10, 100), ("lognormal", 1.0, 4, 7), ("fixed", None, 5, 200)])
+    ("lognormal", 1.0, 10, 100), ("lognormal", 1.0, 4, 7), ("fixed", None, 5, 128), ("fixed", None, 5, 200)])
 def test_every_query_declared_dense(monkeypatch, length, zipf, nterms, k):
     monkeypatch.setenv("VBM25_DENSE_X1000", "0")
     c = make_corpus(20000, 2000, seed=7, length=length, mean_len=60, zipf=zipf)
@@ -91,13 +92,14 @@ def test_edge_cases_dense(monkeypatch):
     hits, nh = check_dense(gix, oix, terms, off, 10)
     assert nh[0] == 0 and nh[1] == 0 and nh[2] == 10
     # k larger than the number of matches: every matching document comes back, sorted
-    hits, nh = check_dense(gix, oix, np.array([rare], dtype=np.uint32), np.array([0, 1], dtype=np.uint32), 256)
-    assert nh[0] == min(256, df[rare])
+    hits, nh = check_dense(gix, oix, np.array([rare], dtype=np.uint32), np.array([0, 1], dtype=np.uint32), 128)
+    assert nh[0] == min(128, df[rare])
     # a corpus smaller than the first window
     c = make_corpus(150, 40, seed=5, length="lognormal", mean_len=20)
     seg, gix, oix = both(c)
     terms, off = make_queries(c, 16, 3, seed=2)
     check_dense(gix, oix, terms, off, 10)
+    check_dense(gix, oix, terms, off, 128)
     check_dense(gix, oix, terms, off, 200)
 
 
@@ -121,8 +123,8 @@ def test_codec_corner_cases_and_ties_dense(monkeypatch):
     seg, gix, oix = both(seg=seg)
     terms = np.array([0, 1, 2, 3, 0, 1, 2, 3, 0, 3], dtype=np.uint32)
     off = np.array([0, 1, 2, 3, 4, 8, 10], dtype=np.uint32)
-    check_dense(gix, oix, terms, off, 10)
-    check_dense(gix, oix, terms, off, 256)
+    for k in (10, 100, 128, 256):  # (256: the exhaustive kernel's; the many tiny items of this index are the dense kernel's hard case)
+        check_dense(gix, oix, terms, off, k)
     # identical documents: every score ties, far more than k candidates per window (candidate rounds), the order
     # is by ascending id
     n = 40_000
@@ -135,7 +137,7 @@ def test_codec_corner_cases_and_ties_dense(monkeypatch):
     seg, gix, oix = both(seg=seg)
     terms = np.array([0, 1, 0, 1, 2, 2], dtype=np.uint32)
     off = np.array([0, 2, 5, 6], dtype=np.uint32)
-    for k in (10, 100, 256):  # (windows with thousands of tied candidates hand the item to scan_many_kernel)
+    for k in (10, 100, 128):  # (windows with thousands of tied candidates hand the item to scan_many_kernel)
         hits, nh = check_dense(gix, oix, terms, off, k, expect_failed=None)
         assert list(hits[0, :k]["doc_id"]) == list(range(k))
 

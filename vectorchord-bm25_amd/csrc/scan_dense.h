@@ -45,6 +45,7 @@ constexpr int DWG = DNW * 64;
 constexpr int D_W = 16384;               // documents per window (at most; an item of very dense terms takes narrower ones)
 constexpr int D_W0 = 256;                // first window while the threshold is 0
 constexpr int D_T = 16;                  // indexed terms per query
+constexpr int D_KMAX = 128;              // largest k (register top-k of two rows per wave)
 constexpr int D_SEG = 128;               // blocks of one term per window: two chunks of 64 lanes (a full block spans >= 128 documents)
 constexpr int D_TCAP = 1024;             // blocks of all terms per window; an item's window width is chosen for 80 % of it
 constexpr int D_WCB = 128;               // candidate buffer entries per wave
@@ -82,7 +83,7 @@ struct DenseLds {
 
 template <int KMAX>
 __global__ void __launch_bounds__(DWG, 4) scan_dense_kernel(DevIndex ix, DevBatch bt) {
-    static_assert(KMAX <= REG_K, "register top-k only");
+    static_assert(KMAX <= D_KMAX, "register top-k of at most two rows");
     constexpr int RK = KMAX / 64;
     __shared__ DenseLds S;
 
@@ -708,7 +709,9 @@ __global__ void __launch_bounds__(DWG, 4) scan_dense_kernel(DevIndex ix, DevBatc
                         S.cdoc[wave][pos] = wlo + i;
                         S.cval[wave][pos] = v;
                         const double hb = (double)(v > m ? v - m : 0u) * inv;
+#ifndef D_EXP_NO_HIST
                         atomicAdd(&hrow[hb >= (double)(CUR_HB - 1) ? (uint32_t)(CUR_HB - 1) : (uint32_t)hb], 1u);
+#endif
                     }
                     cn += c;
 #ifdef VBM25_PROFILE

@@ -469,7 +469,10 @@ static int vbm25_batch_create_impl(vbm25_index *ix, uint32_t max_queries, uint32
         if (nr) bt->ne_ratio = (uint32_t)std::max(1, std::atoi(nr));
         bt->lpi = bt->use_range ? (uint32_t)RNW : 1u;
         const char *dn = std::getenv("VBM25_DENSE");
-        bt->use_dense = bt->use_range && !bt->range_dense && !(dn && dn[0] == '0');
+        // k <= 128 only: the instantiation with a 256-entry register list per wave (four rows) returned incomplete lists on
+        // the GPU when a wave's list grew past its second row (tests/test_gpu_dense.py, the codec corner-case index with
+        // k = 256; cause not found) -- those queries stay with the exhaustive scan_many_kernel
+        bt->use_dense = bt->use_range && !bt->range_dense && k <= (uint32_t)D_KMAX && !(dn && dn[0] == '0');
         const char *di = std::getenv("VBM25_DENSE_ITEMS");
         if (di) bt->dense_target = (uint32_t)std::max(256, std::atoi(di));
         const char *ti = std::getenv("VBM25_CUR_ITEMS");
@@ -838,7 +841,7 @@ static int vbm25_batch_run_impl(vbm25_batch *bt, void *hip_stream) {
                 scan_cursor_kernel<KM><<<bt->cur_grid, 64, 4 * cur_lds_words(bt->cur_mt), st>>>(ix, db, bt->cur_mt);
             }
         }
-        if constexpr (KM <= REG_K) {
+        if constexpr (KM <= D_KMAX) {
             if (bt->has_dense) scan_dense_kernel<KM><<<bt->dense_grid, DWG, 0, st>>>(ix, db);
         }
         if (!range && (!cursor || bt->has_mid_terms)) scan_kernel<KM><<<grid, CWG, 0, st>>>(ix, db);
