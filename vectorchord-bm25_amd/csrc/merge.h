@@ -32,9 +32,7 @@ __global__ void __launch_bounds__(64) merge_kernel(DevIndex ix, DevBatch bt) {
             if (has) {
                 sc = bt.res_score[(size_t)item * k + base + lane];
                 d = bt.res_doc[(size_t)item * k + base + lane];
-#ifndef VBM25_NO_MERGE_FILTER
                 has = (unsigned long long)__double_as_longlong(sc) >= theta;
-#endif
             }
             if constexpr (KMAX <= REG_K) rtop.offer(has, sc, d, k, lane);
             else topk_offer<(KMAX > REG_K ? KMAX : 1)>(s_top, k, has, sc, d, lane);

@@ -124,7 +124,7 @@ __global__ void __launch_bounds__(DWG, 4) scan_dense_kernel(DevIndex ix, DevBatc
         PROF_T(t_item);
 
         // ---- threshold poll (wave 0): the query's published k-th score and the histogram of the candidates' lower bounds
-        unsigned long long pg = 0, hist_published = 0;
+        unsigned long long pg = 0;
         uint32_t pc[4] = {0, 0, 0, 0};
         auto poll_request = [&]() {
             pg = __hip_atomic_load(&bt.theta[q], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -132,7 +132,8 @@ __global__ void __launch_bounds__(DWG, 4) scan_dense_kernel(DevIndex ix, DevBatc
             for (int i = 0; i < 4; ++i) pc[i] = __hip_atomic_load(&hrow[4 * lane + i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         };
         auto poll_consume = [&]() {
-            unsigned long long th = ((unsigned long long)uni((uint32_t)(pg >> 32)) << 32) | uni((uint32_t)pg);
+            const unsigned long long seen = ((unsigned long long)uni((uint32_t)(pg >> 32)) << 32) | uni((uint32_t)pg);
+            unsigned long long th = seen;
             const uint32_t own = pc[0] + pc[1] + pc[2] + pc[3];
             const uint32_t incl = wave_incl_scan_u32(own);
             const uint32_t total = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
@@ -154,10 +155,7 @@ __global__ void __launch_bounds__(DWG, 4) scan_dense_kernel(DevIndex ix, DevBatc
             }
             if (lane == 0) {
                 atomicMax(&S.theta, th);
-                if (th > hist_published) {  // for merge_kernel: entries below the threshold need no merging
-                    atomicMax(&bt.theta[q], th);
-                    hist_published = th;
-                }
+                if (th > seen) atomicMax(&bt.theta[q], th);  // (for merge_kernel too: entries below the threshold need no merging)
             }
         };
 
@@ -351,9 +349,6 @@ __global__ void __launch_bounds__(DWG, 4) scan_dense_kernel(DevIndex ix, DevBatc
 #pragma unroll
             for (int i = 0; i < D_UN; ++i) {
                 if ((uint32_t)i < nv && fast[i]) task_accumulate(c[i], s0i[i], r[i], wlo, wspan);
-#ifdef D_SCHED_BARRIER
-                __builtin_amdgcn_sched_barrier(0);  // one decode at a time
-#endif
                 if ((uint32_t)i < nv && !fast[i]) slow |= 1u << i;
             }
             while (slow) {
@@ -709,9 +704,7 @@ __global__ void __launch_bounds__(DWG, 4) scan_dense_kernel(DevIndex ix, DevBatc
                         S.cdoc[wave][pos] = wlo + i;
                         S.cval[wave][pos] = v;
                         const double hb = (double)(v > m ? v - m : 0u) * inv;
-#ifndef D_EXP_NO_HIST
                         atomicAdd(&hrow[hb >= (double)(CUR_HB - 1) ? (uint32_t)(CUR_HB - 1) : (uint32_t)hb], 1u);
-#endif
                     }
                     cn += c;
 #ifdef VBM25_PROFILE
