@@ -1,4 +1,5 @@
 #!/bin/bash
+# scan_dense_kernel on the GPU box: its parity tests, step time of the variants on a 10 M-document Zipf corpus, phase timers
 set -u
 R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/d4; rm -rf $O; mkdir -p $O
 cd $R
