@@ -45,7 +45,10 @@ constexpr int DWG = DNW * 64;
 constexpr int D_W = 16384;               // documents per window (at most; an item of very dense terms takes narrower ones)
 constexpr int D_W0 = 256;                // first window while the threshold is 0
 constexpr int D_T = 16;                  // indexed terms per query
-constexpr int D_KMAX = 128;              // largest k (register top-k of two rows per wave)
+#ifndef D_KMAX_V
+#define D_KMAX_V 128
+#endif
+constexpr int D_KMAX = D_KMAX_V;         // largest k (register top-k of two rows per wave; 256 = four rows: see search.hip)
 constexpr int D_SEG = 128;               // blocks of one term per window: two chunks of 64 lanes (a full block spans >= 128 documents)
 constexpr int D_TCAP = 1024;             // blocks of all terms per window; an item's window width is chosen for 80 % of it
 constexpr int D_WCB = 128;               // candidate buffer entries per wave

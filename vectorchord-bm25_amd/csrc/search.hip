@@ -469,9 +469,12 @@ static int vbm25_batch_create_impl(vbm25_index *ix, uint32_t max_queries, uint32
         if (nr) bt->ne_ratio = (uint32_t)std::max(1, std::atoi(nr));
         bt->lpi = bt->use_range ? (uint32_t)RNW : 1u;
         const char *dn = std::getenv("VBM25_DENSE");
-        // k <= 128 only: the instantiation with a 256-entry register list per wave (four rows) returned incomplete lists on
-        // the GPU when a wave's list grew past its second row (tests/test_gpu_dense.py, the codec corner-case index with
-        // k = 256; cause not found) -- those queries stay with the exhaustive scan_many_kernel
+        // k <= D_KMAX (128): the instantiation with a 256-entry register list per wave (four rows, 53 spilled registers)
+        // returned incomplete lists in ONE build of this file -- the one that kept two more registers live for the published
+        // histogram threshold -- on the codec corner-case index (tests/test_gpu_dense.py, tools/dense_debug.py: thousands of
+        // tiny items, nondeterministic, memory faults).  The same instantiation of the present code passes that test and
+        // the reproduction (-DD_KMAX_V=256), but the cause was not found, so it is not built: those queries stay with the
+        // exhaustive scan_many_kernel.
         bt->use_dense = bt->use_range && !bt->range_dense && k <= (uint32_t)D_KMAX && !(dn && dn[0] == '0');
         const char *di = std::getenv("VBM25_DENSE_ITEMS");
         if (di) bt->dense_target = (uint32_t)std::max(256, std::atoi(di));
