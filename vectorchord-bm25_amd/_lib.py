@@ -5,7 +5,8 @@ import subprocess
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 _CSRC = os.path.join(_HERE, "csrc")
-_SO = os.path.join(_CSRC, "libvbm25.so")
+# VBM25_LIBRARY (tools/ and tuning only): another build of the library, e.g. csrc/libvbm25_chk.so
+_SO = os.environ.get("VBM25_LIBRARY") or os.path.join(_CSRC, "libvbm25.so")
 
 
 class Vbm25Error(RuntimeError):

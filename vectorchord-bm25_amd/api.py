@@ -261,6 +261,29 @@ class Batch:
         check(f(self.h, C.byref(ni), C.byref(nf)))
         return ni.value, nf.value
 
+    def debug_theta(self, nq):
+        """test aid: the thresholds (as float64 scores) the last run ended with; None if the library lacks the entry"""
+        f = getattr(lib(), "vbm25_batch_debug_theta", None)
+        if f is None:
+            return None
+        f.restype = C.c_int
+        f.argtypes = [C.c_void_p, C.c_void_p]
+        out = np.zeros(nq, dtype=np.uint64)
+        check(f(self.h, out.ctypes.data))
+        return out.view(np.float64)
+
+    def debug_check(self):
+        """-DVBM25_CHECK builds (tools/dense_stress.py): (code, value, item, thread) of the first violated device
+        assertion since the last call; code 0 = none.  A library without the entry point reports None."""
+        f = getattr(lib(), "vbm25_batch_debug_check", None)
+        if f is None:
+            return None
+        f.restype = C.c_int
+        f.argtypes = [C.c_void_p, C.c_void_p]
+        out = (C.c_uint32 * 4)()
+        check(f(self.h, out))
+        return tuple(int(x) for x in out)
+
 
 def search_batch(index, term_ids, q_off, k):
     """vbm25_search_batch: nq queries (CSR of ascending term ids) -> (hits[nq,k], n_hits[nq])."""

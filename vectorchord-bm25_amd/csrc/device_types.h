@@ -21,6 +21,7 @@ struct DevIndex {
     const uint8_t *post_fn;      // derived: fieldnorm of every posting, 128 bytes per block
     const uint16_t *doc_payload;
     const double *s1;            // 256 entries
+    unsigned long long blob_bytes;  // bytes of blob that hold block bodies (the allocation has slack behind them)
 };
 
 struct Item {
@@ -58,7 +59,24 @@ struct DevBatch {
     uint32_t fused_g;          // scan_range_kernel alone: items per query made in the kernel, lists merged by the query's last workgroup (0: off)
     uint32_t *fused_state;     // [0] workgroups that left, [1 + q] finished items of query q; zero between launches
     uint32_t merge_marked;     // merge_kernel: only the queries whose n_hits is NONE32
+    uint32_t max_items;        // capacity of items / item_failed; res_* hold max_items * lpi lists of k entries
+    uint32_t *dbg;             // -DVBM25_CHECK builds: [0] first violated check (0: none), [1] value, [2] item, [3] thread
 };
+
+// Bounds / consistency assertions of the scan kernels, compiled in by -DVBM25_CHECK only (tools/dense_stress.py): the
+// first violation is recorded in bt.dbg and read back with vbm25_batch_debug_check.
+#ifdef VBM25_CHECK
+#define VCHK(cond, code, val)                                                     \
+    do {                                                                          \
+        if (!(cond) && atomicCAS(&bt.dbg[0], 0u, (uint32_t)(code)) == 0u) {       \
+            bt.dbg[1] = (uint32_t)(val);                                          \
+            bt.dbg[2] = S.item;                                                   \
+            bt.dbg[3] = threadIdx.x;                                              \
+        }                                                                         \
+    } while (0)
+#else
+#define VCHK(cond, code, val) do { } while (0)
+#endif
 
 constexpr int WG = 256;
 constexpr int NW = WG / 64;

@@ -291,14 +291,25 @@ __global__ void __launch_bounds__(DWG, 4) scan_dense_kernel(DevIndex ix, DevBatc
         };
         auto add_pair = [&](float s0i, uint32_t d0, uint32_t d1, uint32_t f0, uint32_t f1, uint32_t fn, bool in0, bool in1,
                             uint32_t wlo, uint32_t wspan) {
+            VCHK(wspan <= (uint32_t)D_W, 10, wspan);
             const uint32_t x0 = d0 - wlo, x1 = d1 - wlo;
             const float tf0 = (float)f0, tf1 = (float)f1;
             const uint32_t p0 = (uint32_t)((tf0 * s0i) * __builtin_amdgcn_rcpf(tf0 + S.s1f[fn & 0xff])) + 1u;
             const uint32_t p1 = (uint32_t)((tf1 * s0i) * __builtin_amdgcn_rcpf(tf1 + S.s1f[fn >> 8])) + 1u;
+            VCHK(!(in0 && x0 < wspan) || p0 < 32768u, 11, p0);
+            VCHK(!(in1 && x1 < wspan) || p1 < 32768u, 11, p1);
             // the add that comes last in an accumulator's order sees the final sum: the bucket maximum is never below it
             // (no carry between the halves of a word: every document's sum stays below 2^16)
-            if (in0 && x0 < wspan) atomicMax(&S.bmax[x0 >> 6], ((atomicAdd(&S.acc[x0 >> 1], p0 << (16u * (x0 & 1u))) >> (16u * (x0 & 1u))) & 0xffffu) + p0);
-            if (in1 && x1 < wspan) atomicMax(&S.bmax[x1 >> 6], ((atomicAdd(&S.acc[x1 >> 1], p1 << (16u * (x1 & 1u))) >> (16u * (x1 & 1u))) & 0xffffu) + p1);
+            if (in0 && x0 < wspan) {
+                const uint32_t sum = ((atomicAdd(&S.acc[x0 >> 1], p0 << (16u * (x0 & 1u))) >> (16u * (x0 & 1u))) & 0xffffu) + p0;
+                VCHK(sum < 65536u, 12, sum);
+                atomicMax(&S.bmax[x0 >> 6], sum);
+            }
+            if (in1 && x1 < wspan) {
+                const uint32_t sum = ((atomicAdd(&S.acc[x1 >> 1], p1 << (16u * (x1 & 1u))) >> (16u * (x1 & 1u))) & 0xffffu) + p1;
+                VCHK(sum < 65536u, 12, sum);
+                atomicMax(&S.bmax[x1 >> 6], sum);
+            }
         };
         auto task_accumulate = [&](const uint4 c, float s0i, const Raw &r, uint32_t wlo, uint32_t wspan) {
             const uint32_t md = (c.w >> 8) & 0xff, mt = (c.w >> 16) & 0xff;
@@ -333,8 +344,17 @@ __global__ void __launch_bounds__(DWG, 4) scan_dense_kernel(DevIndex ix, DevBatc
                 uint32_t el = e[0];
 #pragma unroll
                 for (int i = 1; i < D_UN; ++i) el = lane == (uint32_t)i && (uint32_t)i < nv ? e[i] : el;
+                VCHK(el < (uint32_t)D_TCAP, 2, el);
                 const uint4 cm = S.tmeta[el];
                 const uint32_t jb = S.tblk[el];
+                VCHK(lane >= nv || jb < ix.n_blocks, 3, jb);
+                VCHK(lane >= nv || 8ull * cm.z < ix.blob_bytes, 4, cm.z);
+#ifdef VBM25_CHECK
+                if (lane < nv && jb < ix.n_blocks) {  // the entry is the block it names (a stale or torn entry is not)
+                    const uint4 gm = ix.blk_meta[jb];
+                    VCHK(gm.x == cm.x && gm.y == cm.y && gm.z == cm.z && gm.w == cm.w, 5, el);
+                }
+#endif
                 const float sv = S.t_s0i[S.tterm[el]];
 #pragma unroll
                 for (int i = 0; i < D_UN; ++i) {
@@ -452,6 +472,7 @@ __global__ void __launch_bounds__(DWG, 4) scan_dense_kernel(DevIndex ix, DevBatc
                     const unsigned long long pmask = __ballot(pend);
                     if (!pmask) break;
                     const uint32_t blk = (uint32_t)__builtin_amdgcn_readlane((int)b, __ffsll((long long)pmask) - 1);
+                    VCHK(blk < ix.n_blocks, 8, blk);
                     const uint4 bm = uni4(ix.blk_meta[blk]);
                     const uint32_t n = bm.w & 0xff, md = (bm.w >> 8) & 0xff, mt = (bm.w >> 16) & 0xff;
                     uint32_t a0, a1;
@@ -503,6 +524,7 @@ __global__ void __launch_bounds__(DWG, 4) scan_dense_kernel(DevIndex ix, DevBatc
             __builtin_amdgcn_wave_barrier();
             PROF_T(t_fb);
             PROF_ADD(6, t_fa, t_fb);
+            VCHK(w <= (uint32_t)D_WCB && cn <= (uint32_t)D_WCB, 7, cn);
             for (uint32_t base = 0; base < w; base += 64) {
                 const bool has = base + lane < w;
                 resolve(has, has ? S.cdoc[wave][base + lane] : 0u);
@@ -634,6 +656,7 @@ __global__ void __launch_bounds__(DWG, 4) scan_dense_kernel(DevIndex ix, DevBatc
                             for (int ch = 0; ch < 2; ++ch) {
                                 const uint32_t i = 64u * ch + lane;
                                 if (i < ecnt[s]) {
+                                    VCHK(before + i < (uint32_t)D_TCAP, 1, before + i);
                                     S.tmeta[before + i] = em[s][ch];
                                     S.tblk[before + i] = ecur[s] + i;
                                     S.tub[before + i] = __double2uint_ru(eub[s][ch] * scale) + 1u;
@@ -704,6 +727,8 @@ __global__ void __launch_bounds__(DWG, 4) scan_dense_kernel(DevIndex ix, DevBatc
                     }
                     if (cand) {
                         const uint32_t pos = cn + __builtin_amdgcn_mbcnt_hi((uint32_t)(cm >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)cm, 0u));
+                        VCHK(pos < (uint32_t)D_WCB, 6, pos);
+                        VCHK(wlo + i < hi, 15, wlo + i);
                         S.cdoc[wave][pos] = wlo + i;
                         S.cval[wave][pos] = v;
                         const double hb = (double)(v > m ? v - m : 0u) * inv;
@@ -767,6 +792,8 @@ __global__ void __launch_bounds__(DWG, 4) scan_dense_kernel(DevIndex ix, DevBatc
         {
             const uint32_t n = failed ? 0u : rtop.cnt;
             const size_t list = (size_t)item * bt.lpi + wave;
+            VCHK(item < bt.max_items && bt.lpi == (uint32_t)DNW, 9, item);
+            VCHK(n <= k, 14, n);
 #pragma unroll
             for (int r = 0; r < RK; ++r)
                 if (r * 64 + lane < n) {

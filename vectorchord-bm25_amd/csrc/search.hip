@@ -208,7 +208,7 @@ struct vbm25_batch {
     int device = 0;  // the index's device ordinal: the batch can be destroyed after its index
     uint32_t max_queries = 0, max_terms = 0, k = 0, nq = 0, max_items = 0;
     DeviceBuffer term_ids, q_off, items, n_items, q_item_base, theta, res_score, res_doc, res_cnt,
-        hits, n_hits, error_flag, prof, q_dense, spill, item_failed, work_ctr, hist, fused_state;
+        hits, n_hits, error_flag, prof, q_dense, spill, item_failed, work_ctr, hist, fused_state, dbg;
     bool bigk = false;            // k > 1024: exhaustive path, one query at a time
     DeviceBuffer bk_acc, bk_keys, bk_iota, bk_docs, bk_tmp;
     size_t bk_tmp_bytes = 0;
@@ -399,6 +399,7 @@ static int vbm25_index_create_impl(const vbm25_index_desc *d, int device, vbm25_
     ix->dev.post_fn = ix->post_fn.as<uint8_t>();
     ix->dev.doc_payload = ix->doc_payload.as<uint16_t>();
     ix->dev.s1 = ix->s1.as<double>();
+    ix->dev.blob_bytes = d->blob_bytes;
     {   // for vbm25_evaluate_batch: per-term idf (host libm log, bm25.rs:285-289) and the fieldnorm table
         std::vector<double> idf(d->n_terms);
         for (uint32_t t = 0; t < d->n_terms; ++t)
@@ -528,6 +529,8 @@ static int vbm25_batch_create_impl(vbm25_index *ix, uint32_t max_queries, uint32
         bt->use_fused = bt->use_range && !(fz && fz[0] == '0');
     }
     HIP_TRY(hipMemset(bt->error_flag.p, 0, 4));
+    if (int rc2 = bt->dbg.alloc(64)) return rc2;
+    HIP_TRY(hipMemset(bt->dbg.p, 0, 64));
 #ifdef VBM25_PROFILE
     if (int rc2 = bt->prof.alloc(8ull * 33 * CUR_GRID)) return rc2;
     HIP_TRY(hipMemset(bt->prof.p, 0, 8ull * 33 * CUR_GRID));
@@ -752,6 +755,8 @@ static int vbm25_batch_run_impl(vbm25_batch *bt, void *hip_stream) {
     db.prof = bt->prof.as<unsigned long long>();
     db.hist = bt->hist.as<uint32_t>();
     db.work_ctr = bt->work_ctr.as<uint32_t>();
+    db.max_items = bt->max_items;
+    db.dbg = bt->dbg.as<uint32_t>();
     const bool cursor = bt->run_cursor;
     db.chain_min_terms = cursor ? (uint32_t)CUR_T + 1u : 0u;
     db.lpi = bt->lpi;
@@ -996,6 +1001,31 @@ int vbm25_batch_debug_counts(vbm25_batch *bt, uint32_t *n_items, uint32_t *n_fai
     if (std::getenv("VBM25_DEBUG"))
         for (int c = 0; c < 64; ++c)
             if (codes[c]) std::fprintf(stderr, "vbm25: %u items failed with code 0x%x\n", codes[c], c);
+    return VBM25_OK;
+}
+
+// -DVBM25_CHECK builds (not declared in include/vbm25.h): the first violated assertion of the scan kernels, then reset.
+// out[0] = check code (0: none), out[1] = offending value, out[2] = work item, out[3] = thread
+int vbm25_batch_debug_check(vbm25_batch *bt, uint32_t *out4) {
+    if (!bt || !out4) return set_error(VBM25_ERR_INVALID, "NULL argument");
+    if (int rc = use_device(bt->index->device)) return rc;
+    HIP_TRY(hipDeviceSynchronize());
+    if (!bt->dbg.p) {
+        out4[0] = out4[1] = out4[2] = out4[3] = 0;
+        return VBM25_OK;
+    }
+    HIP_TRY(hipMemcpy(out4, bt->dbg.p, 16, hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemset(bt->dbg.p, 0, 64));
+    return VBM25_OK;
+}
+
+// test aid (not declared in include/vbm25.h): the per-query thresholds the last run ended with (bits of a lower bound of
+// each query's k-th best score; the merge drops list entries below them)
+int vbm25_batch_debug_theta(vbm25_batch *bt, unsigned long long *out) {
+    if (!bt || !out) return set_error(VBM25_ERR_INVALID, "NULL argument");
+    if (int rc = use_device(bt->index->device)) return rc;
+    HIP_TRY(hipDeviceSynchronize());
+    if (bt->nq && bt->theta.p) HIP_TRY(hipMemcpy(out, bt->theta.p, 8ull * bt->nq, hipMemcpyDeviceToHost));
     return VBM25_OK;
 }
 
