@@ -280,7 +280,7 @@ class Batch:
             return None
         f.restype = C.c_int
         f.argtypes = [C.c_void_p, C.c_void_p]
-        out = (C.c_uint32 * 4)()
+        out = (C.c_uint32 * 16)()
         check(f(self.h, out))
         return tuple(int(x) for x in out)
 

@@ -334,7 +334,8 @@ static int vbm25_index_create_impl(const vbm25_index_desc *d, int device, vbm25_
     }
     DeviceBuffer fieldnorm, err;
     int rc = 0;
-    const size_t blob_alloc = ((size_t(d->blob_bytes) + 15) & ~size_t(15)) + 64;  // slack for word reads
+    // slack: the scan kernels read whole 256-byte LDS-DMA slots / word pairs from a block's first byte
+    const size_t blob_alloc = ((size_t(d->blob_bytes) + 15) & ~size_t(15)) + 512;
     if ((rc = ix->term_df.upload(d->term_df, 4ull * d->n_terms)) ||
         (rc = ix->term_first_block.upload(d->term_first_block, 4ull * (d->n_terms + 1))) ||
         (rc = ix->term_s0.upload(s0.data(), 8ull * d->n_terms)) ||
@@ -464,8 +465,7 @@ static int vbm25_batch_create_impl(vbm25_index *ix, uint32_t max_queries, uint32
         if (bt->use_range) bt->use_cursor = false;
         const char *ne = std::getenv("VBM25_NE");
         bt->ne_on = bt->use_range && !(ne && ne[0] == '0');
-        const char *rd = std::getenv("VBM25_RANGE_DENSE");
-        bt->range_dense = bt->ne_on && rd && rd[0] == '1';
+        bt->range_dense = false;  // (scan_range_kernel no longer takes dense items)
         const char *nr = std::getenv("VBM25_NE_RATIO");
         if (nr) bt->ne_ratio = (uint32_t)std::max(1, std::atoi(nr));
         bt->lpi = bt->use_range ? (uint32_t)RNW : 1u;
@@ -1006,15 +1006,15 @@ int vbm25_batch_debug_counts(vbm25_batch *bt, uint32_t *n_items, uint32_t *n_fai
 
 // -DVBM25_CHECK builds (not declared in include/vbm25.h): the first violated assertion of the scan kernels, then reset.
 // out[0] = check code (0: none), out[1] = offending value, out[2] = work item, out[3] = thread
-int vbm25_batch_debug_check(vbm25_batch *bt, uint32_t *out4) {
+int vbm25_batch_debug_check(vbm25_batch *bt, uint32_t *out4) {  // out4: 16 words
     if (!bt || !out4) return set_error(VBM25_ERR_INVALID, "NULL argument");
     if (int rc = use_device(bt->index->device)) return rc;
     HIP_TRY(hipDeviceSynchronize());
     if (!bt->dbg.p) {
-        out4[0] = out4[1] = out4[2] = out4[3] = 0;
+        std::memset(out4, 0, 64);
         return VBM25_OK;
     }
-    HIP_TRY(hipMemcpy(out4, bt->dbg.p, 16, hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(out4, bt->dbg.p, 64, hipMemcpyDeviceToHost));
     HIP_TRY(hipMemset(bt->dbg.p, 0, 64));
     return VBM25_OK;
 }
