@@ -68,7 +68,7 @@ constexpr int R_STAGE_SLOTS = R_NBLK;  // staging: slots of 128 x 16 bits; a wid
 
 template <int KMAX>
 struct RangePool {
-    static constexpr int N = KMAX <= 64 ? 512 : (KMAX <= 128 ? 640 : 864);
+    static constexpr int N = KMAX <= 64 ? 512 : (KMAX <= 128 ? 640 : 704);
 };
 
 template <int KMAX, int RT>
@@ -107,14 +107,19 @@ struct RangeLds {
     uint32_t sel_need, sel_b, sel_above, sel_stop;
     uint32_t nrows[2];
     uint32_t hcnt[RNW];
-    uint32_t pool_n, pool_w, nlate, cold_retry, rows_seen, pool_snap, late_snap;
+    uint32_t pool_n, pool_w, nlate, cold_retry, rows_seen, pool_snap, late_snap, theta_zero;
     uint32_t item, q, lo, hi, mq, fail;
     uint32_t scratch[64];
     // planner state (wave 0), kept here between its turns so that the workers do not carry it in registers:
-    // per lane {cur, quota, base, slot term, slot offset}, then the uniform words {ne, relax, cap, tlo}
+    // per lane {cur, quota, base, slot term, slot offset}, then the uniform words {ne, relax, cap, tlo, prefetch valid}
     uint32_t pl[5][64];
     uint32_t t_df[RT];
-    uint32_t plu[4];
+    // inputs of the next plan, requested by LDS-DMA at the end of the previous one: candidate lane -> block metadata and upper
+    // bound; term lane -> min_doc of the first block beyond its quota
+    uint4 pf_meta[64];
+    uint32_t pf_ub[2][64];
+    uint32_t pf_bnd[64];
+    uint32_t plu[5];
 };
 
 // First block of [b0, b1) whose max_doc >= d (b1 if none): guess by interpolation over the document space,
@@ -160,6 +165,18 @@ __device__ __forceinline__ void r_glds_dword(const uint8_t *gbase, uint32_t voff
     uint32_t keep;
     asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dword %1, %2\n\ts_mov_b32 m0, %0"
                  : "=&s"(keep) : "v"(voff), "s"(gbase), "s"(lds_dst) : "memory");
+}
+
+// ... per-lane source addresses (vaddr form): 16 bytes / 4 bytes per lane at lds_dst + 16 / 4 * lane
+__device__ __forceinline__ void r_glds_dwordx4_v(const void *gsrc, uint32_t lds_dst) {
+    uint32_t keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(gsrc), "s"(lds_dst) : "memory");
+}
+__device__ __forceinline__ void r_glds_dword_v(const void *gsrc, uint32_t lds_dst) {
+    uint32_t keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dword %1, off\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(gsrc), "s"(lds_dst) : "memory");
 }
 
 template <int KMAX, int RT, bool FUSED = false>
@@ -288,7 +305,7 @@ __global__ void __launch_bounds__(RWG, R_LB_V) scan_range_kernel(DevIndex ix, De
 
         // ---- tile planner (wave 0).  State in LDS between its turns.
         uint32_t p_cur = 0, p_end = 0, p_quota = 0, p_base = 0, p_st = NONE32, p_so = 0, p_df = 0, p_rank = 0, p_ne = 0, p_relax = 0;
-        uint32_t p_cap = R_STAGE_SLOTS, p_tlo = lo;
+        uint32_t p_cap = R_STAGE_SLOTS, p_tlo = lo, p_pf = 0;  // p_pf: the staged inputs belong to the cursors / quotas of now
         auto pl_load = [&]() {
             const bool act = lane < uni(S.mq);
             p_cur = S.pl[0][lane];
@@ -303,6 +320,7 @@ __global__ void __launch_bounds__(RWG, R_LB_V) scan_range_kernel(DevIndex ix, De
             p_relax = uni(S.plu[1]);
             p_cap = uni(S.plu[2]);
             p_tlo = uni(S.plu[3]);
+            p_pf = uni(S.plu[4]);
         };
         auto pl_store = [&]() {
             S.pl[0][lane] = p_cur;
@@ -315,6 +333,7 @@ __global__ void __launch_bounds__(RWG, R_LB_V) scan_range_kernel(DevIndex ix, De
                 S.plu[1] = p_relax;
                 S.plu[2] = p_cap;
                 S.plu[3] = p_tlo;
+                S.plu[4] = p_pf;
             }
         };
         // quotas of the essential terms: the 64 candidate slots (one per planner lane) shared in proportion to df,
@@ -371,27 +390,39 @@ __global__ void __launch_bounds__(RWG, R_LB_V) scan_range_kernel(DevIndex ix, De
             if (p_new > p_ne) {
                 p_ne = p_new;
                 assign_quotas();
+                p_pf = 0;  // (the staged inputs were requested for the old quotas)
             }
             const double nesum = S.t_cum[p_ne];
             const bool alive = lane < mqp && p_rank >= p_ne && p_cur < p_end;
-            uint32_t bnd = NONE32;
-            if (alive && p_cur + p_quota < p_end) bnd = ix.blk_min_doc[p_cur + p_quota];
             if (!__ballot(alive) || p_tlo >= hi) {
+                p_pf = 0;
                 plan_empty(buf);
                 return;
             }
-            uint32_t thi = min(hi, wave_min_u32(bnd));
             const uint32_t st = p_st < 64u ? p_st : 0u;
             const uint32_t cur_s = (uint32_t)__shfl((int)p_cur, (int)st), end_s = (uint32_t)__shfl((int)p_end, (int)st);
             const uint32_t quo_s = (uint32_t)__shfl((int)p_quota, (int)st);
             const uint32_t j = cur_s + p_so;
             const bool valid = p_st != NONE32 && p_so < quo_s && j < end_s;
+            const bool want_bnd = alive && p_cur + p_quota < p_end;
+            uint32_t bnd = NONE32;
             uint4 meta = make_uint4(NONE32, 0, 0, 0);
             double ub = 0.0;
-            if (valid) {
-                meta = ix.blk_meta[j];
-                ub = ix.blk_ub[j];
+            if (p_pf) {  // requested by LDS-DMA when the previous plan ended: no memory round trip here
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                if (want_bnd) bnd = S.pf_bnd[lane];
+                if (valid) {
+                    meta = S.pf_meta[lane];
+                    ub = __hiloint2double((int)S.pf_ub[1][lane], (int)S.pf_ub[0][lane]);
+                }
+            } else {
+                if (want_bnd) bnd = ix.blk_min_doc[p_cur + p_quota];
+                if (valid) {
+                    meta = ix.blk_meta[j];
+                    ub = ix.blk_ub[j];
+                }
             }
+            uint32_t thi = min(hi, wave_min_u32(bnd));
             // a block that spans 2^16 documents or more is staged with 32-bit ids: two slots
             const bool wide = valid && meta.y - meta.x >= 65536u;
             // the 64 candidates (quotas) may hold more than a tile takes: the largest thi with <= p_cap slots
@@ -439,6 +470,19 @@ __global__ void __launch_bounds__(RWG, R_LB_V) scan_range_kernel(DevIndex ix, De
             const bool any_cold_blocks = __ballot(cold) != 0ull;
             if (lane == 0) S.hdr[buf] = make_uint4(p_tlo, thi, np, p_ne | (any_cold_blocks ? 0x100u : 0u));
             p_tlo = thi;
+            {   // the next plan's inputs (same formulas on the advanced cursors), fetched by LDS-DMA while the tile is worked on
+                const uint32_t cur_n = (uint32_t)__shfl((int)p_cur, (int)st);
+                const uint32_t jn = cur_n + p_so;
+                const bool valid_n = p_st != NONE32 && p_so < quo_s && jn < end_s;
+                const bool alive_n = lane < mqp && p_rank >= p_ne && p_cur < p_end;
+                if (valid_n) {
+                    r_glds_dwordx4_v(&ix.blk_meta[jn], (uint32_t)(uintptr_t)&S.pf_meta[0]);
+                    r_glds_dword_v(&ix.blk_ub[jn], (uint32_t)(uintptr_t)&S.pf_ub[0][0]);
+                    r_glds_dword_v(reinterpret_cast<const uint32_t *>(&ix.blk_ub[jn]) + 1, (uint32_t)(uintptr_t)&S.pf_ub[1][0]);
+                }
+                if (alive_n && p_cur + p_quota < p_end) r_glds_dword_v(&ix.blk_min_doc[p_cur + p_quota], (uint32_t)(uintptr_t)&S.pf_bnd[0]);
+                p_pf = 1;
+            }
         };
 
         // ---- item setup (wave 0): terms, cursors, quotas, slot map; the first two plans
@@ -559,22 +603,24 @@ __global__ void __launch_bounds__(RWG, R_LB_V) scan_range_kernel(DevIndex ix, De
         // raw slot (a full block of width <= 15 reads at most 16 * 15 + 16 + 8 bytes; the rest of the slot is slack)
         auto dma_issue = [&](uint32_t buf) {
             const uint32_t np1 = uni(S.hdr[buf].z);
+            uint32_t off8[RB], fl[RB];
+#pragma unroll
+            for (int i = 0; i < RB; ++i) {  // (all the descriptor reads in flight together)
+                const uint32_t e = (wave - 1u) + (RNW - 1) * i;
+                off8[i] = S.pm[buf][e].z;
+                fl[i] = S.pa[buf][e].y;
+            }
 #pragma unroll
             for (int i = 0; i < RB; ++i) {
                 const uint32_t e = (wave - 1u) + (RNW - 1) * i;
-                if (e < np1) {
-                    const uint32_t off8 = uni(S.pm[buf][e].z), fl = uni(S.pa[buf][e].y);
-                    VCHK(8ull * off8 < ix.blob_bytes && ((fl >> 18) & 1u), 32, off8);
-#ifdef VBM25_CHECK
-                    if (8ull * off8 >= ix.blob_bytes) continue;
-#endif
-                    if ((fl >> 17) & 1u) {
+                if (e < np1 && ((uni(fl[i]) >> 17) & 1u)) {
+                    const uint32_t o8 = uni(off8[i]);
+                    VCHK(8ull * o8 < ix.blob_bytes, 32, o8);
 #ifdef R_NO_DMA  // (tools: plain loads + LDS stores instead of the LDS-DMA)
-                        reinterpret_cast<uint32_t *>(&S.raw[e * 16])[lane] = *reinterpret_cast<const uint32_t *>(ix.blob + 8ull * off8 + 4u * lane);
+                    reinterpret_cast<uint32_t *>(&S.raw[e * 16])[lane] = *reinterpret_cast<const uint32_t *>(ix.blob + 8ull * o8 + 4u * lane);
 #else
-                        r_glds_dword(ix.blob + 8ull * off8, 4u * lane, (uint32_t)(uintptr_t)&S.raw[e * 16]);
+                    r_glds_dword(ix.blob + 8ull * o8, 4u * lane, (uint32_t)(uintptr_t)&S.raw[e * 16]);
 #endif
-                    }
                 }
             }
         };
@@ -965,8 +1011,8 @@ __global__ void __launch_bounds__(RWG, R_LB_V) scan_range_kernel(DevIndex ix, De
                 for (int i = 0; i < RB; ++i) {
                     if ((uint32_t)i < nv) {
                         const uint32_t t0 = x0[i] >> 17, t1 = x1[i] >> 17;
-                        const uint32_t m0 = (1u << (x0[i] & 31u)) | (1u << ((x0[i] + t0 * 5u + 1u) & 31u));
-                        const uint32_t m1 = (1u << (x1[i] & 31u)) | (1u << ((x1[i] + t1 * 5u + 1u) & 31u));
+                        const uint32_t m0 = (1u << (x0[i] & 31u)) | (1u << ((x0[i] + t0 * 5u + 1u) & 31u)) | (1u << ((x0[i] + 13u) & 31u));
+                        const uint32_t m1 = (1u << (x1[i] & 31u)) | (1u << ((x1[i] + t1 * 5u + 1u) & 31u)) | (1u << ((x1[i] + 13u) & 31u));
                         const uint32_t o0 = atomicOr(&S.bm[(x0[i] >> 5) & (R_BM_WORDS - 1)], m0);
                         const uint32_t o1 = atomicOr(&S.bm[(x1[i] >> 5) & (R_BM_WORDS - 1)], m1);
                         ev |= ((o0 & m0) == m0 ? 1u : 0u) << (2 * i) | ((o1 & m1) == m1 ? 1u : 0u) << (2 * i + 1);
@@ -1063,30 +1109,35 @@ __global__ void __launch_bounds__(RWG, R_LB_V) scan_range_kernel(DevIndex ix, De
                         const uint32_t d = S.mdoc[par][r];
                         uint32_t eb = S.ptb[buf][t], len = S.ptb[buf][t + 1] - eb;
                         if (len != 0) {
-                            while (len > 1) {  // last entry of the term with min_doc <= d
-                                const uint32_t half = len >> 1;
-                                if (S.pm[buf][eb + half].x <= d) {
-                                    eb += half;
-                                    len -= half;
-                                } else {
-                                    len = half;
-                                }
+                            // last entry of the term with min_doc <= d: 4-ary (three independent reads per round trip)
+                            while (len > 1) {
+                                const uint32_t qn = (len + 3u) >> 2;
+                                const uint32_t p1 = qn, p2 = 2u * qn, p3 = 3u * qn;
+                                const uint32_t m1 = p1 < len ? S.pm[buf][eb + p1].x : NONE32;
+                                const uint32_t m2 = p2 < len ? S.pm[buf][eb + p2].x : NONE32;
+                                const uint32_t m3 = p3 < len ? S.pm[buf][eb + p3].x : NONE32;
+                                const uint32_t c = (p1 < len && m1 <= d ? 1u : 0u) + (p2 < len && m2 <= d ? 1u : 0u) + (p3 < len && m3 <= d ? 1u : 0u);
+                                eb += c * qn;
+                                len = c == 3u ? len - p3 : min(qn, len - c * qn);
                             }
                             const uint4 sj = S.pm[buf][eb];
                             if (d >= sj.x && d <= sj.y) {
                                 const uint32_t fl = S.pa[buf][eb].y, slot = (fl >> 8) & 0xffu, rel = d - sj.x;
+                                // first staged id >= rel among the block's 128 (sorted, padded above): 4-ary as well
                                 uint32_t idx = 0;
                                 if ((fl >> 16) & 1u) {
                                     const uint32_t *sb = &S.stage[slot * 64u];
-#pragma unroll
-                                    for (int st = 64; st > 0; st >>= 1)
-                                        if (sb[idx + st - 1] < rel) idx += st;
+                                    idx = 32u * ((sb[31] < rel ? 1u : 0u) + (sb[63] < rel ? 1u : 0u) + (sb[95] < rel ? 1u : 0u));
+                                    idx += 8u * ((sb[idx + 7] < rel ? 1u : 0u) + (sb[idx + 15] < rel ? 1u : 0u) + (sb[idx + 23] < rel ? 1u : 0u));
+                                    idx += 2u * ((sb[idx + 1] < rel ? 1u : 0u) + (sb[idx + 3] < rel ? 1u : 0u) + (sb[idx + 5] < rel ? 1u : 0u));
+                                    idx += sb[idx] < rel ? 1u : 0u;
                                     found = sb[idx] == rel;
                                 } else {
                                     const uint16_t *sb = reinterpret_cast<const uint16_t *>(&S.stage[slot * 64u]);
-#pragma unroll
-                                    for (int st = 64; st > 0; st >>= 1)
-                                        if ((uint32_t)sb[idx + st - 1] < rel) idx += st;
+                                    idx = 32u * (((uint32_t)sb[31] < rel ? 1u : 0u) + ((uint32_t)sb[63] < rel ? 1u : 0u) + ((uint32_t)sb[95] < rel ? 1u : 0u));
+                                    idx += 8u * (((uint32_t)sb[idx + 7] < rel ? 1u : 0u) + ((uint32_t)sb[idx + 15] < rel ? 1u : 0u) + ((uint32_t)sb[idx + 23] < rel ? 1u : 0u));
+                                    idx += 2u * (((uint32_t)sb[idx + 1] < rel ? 1u : 0u) + ((uint32_t)sb[idx + 3] < rel ? 1u : 0u) + ((uint32_t)sb[idx + 5] < rel ? 1u : 0u));
+                                    idx += (uint32_t)sb[idx] < rel ? 1u : 0u;
                                     found = (uint32_t)sb[idx] == rel;
                                 }
                                 found = found && idx < (sj.w & 0xffu);  // (not an entry past a tail block's end)
@@ -1150,6 +1201,7 @@ __global__ void __launch_bounds__(RWG, R_LB_V) scan_range_kernel(DevIndex ix, De
                     if (tile != 0) S.nrows[ppar] = 0;
                     S.pool_snap = S.pool_n;   // (nobody else pushes between the barriers A and B)
                     S.late_snap = S.nlate;
+                    S.theta_zero = S.theta == 0ull ? 1u : 0u;
                 }
             }
             PROF_T(t_e);
@@ -1162,10 +1214,147 @@ __global__ void __launch_bounds__(RWG, R_LB_V) scan_range_kernel(DevIndex ix, De
             }
 
             // ---- pool housekeeping + cold pass: blocks whose upper bound reaches the threshold (search.rs:203), per
-            // worker over its own blocks; ids from the wave's own stage rows.  A block that finds no room in the pool
-            // stays pending: the pool is shrunk (which raises the threshold) and the pass repeated.
+            // worker over its own blocks; ids from the wave's own stage rows; tf / fieldnorm bytes of up to four blocks in
+            // flight together.  A block that finds no room in the pool stays pending: the pool is shrunk (which raises the
+            // threshold) and the pass repeated.  While the item knows no threshold at all (its first tile), the pass runs
+            // twice: first the single-term scores only feed a histogram whose k-th entry starts the threshold, then the
+            // few postings at or above it are pushed.
             uint32_t pending = 0;
             if (wave != 0 && any_cold) pending = uni(S.coldw[buf][wave]) & ((1u << nv) - 1u);
+            const bool boot = any_cold && uni(S.theta_zero) != 0u;  // (snapshot taken before barrier B: uniform)
+            const double nesum = pne ? S.t_cum[pne] : 0.0;
+            uint32_t emask = 0xffffffffu;  // bit t: term t is essential
+            if (pne && any_cold) {
+                emask = 0;
+                for (uint32_t t = 0; t < mq; ++t) emask |= ((uint32_t)S.t_rank[t] >= pne ? 1u : 0u) << t;
+            }
+            // mode 0: push; mode 1: histogram of the scores only
+            auto cold_blocks = [&](uint32_t mode) {
+                uint32_t *bh = S.bm;
+                uint32_t todo = pending;
+                while (todo) {
+                    uint32_t gi[4];
+                    uint32_t n4 = 0;
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) {
+                        gi[g] = 0;
+                        if (todo) {
+                            gi[g] = (uint32_t)__ffs((int)todo) - 1u;
+                            todo &= todo - 1u;
+                            ++n4;
+                        }
+                    }
+                    uint32_t l0[4], h0[4], l1[4], h1[4], fnp[4];
+                    uint32_t skip = 0;  // bit g: block not scored in this pass (below the threshold: done; no room: next round)
+                    const double thd = __longlong_as_double((long long)theta_now());
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) {
+                        l0[g] = h0[g] = l1[g] = h1[g] = fnp[g] = 0;
+                        if ((uint32_t)g < n4) {
+                            const uint32_t e = (wave - 1u) + (RNW - 1) * gi[g];
+                            const float pubv = __uint_as_float(uni(__float_as_uint(S.pub[buf][e])));
+                            if (thd > (double)pubv * (1.0 + 1e-7) + nesum) {  // the planner decided one tile early: the threshold of now
+                                pending &= ~(1u << gi[g]);
+                                skip |= 1u << g;
+                            } else if (mode == 0 && uni(S.pool_n) >= POOL_COLD) {
+                                skip |= 1u << g;  // no room at all: next round
+                            } else {
+                                const uint4 sj = uni4(S.pm[buf][e]);
+                                const uint32_t blkj = uni(S.pa[buf][e].x);
+                                const uint32_t nj = sj.w & 0xff, mdj = (sj.w >> 8) & 0xff, mtj = (sj.w >> 16) & 0xff;
+                                VCHK(e < np && blkj < ix.n_blocks && 8ull * sj.z < ix.blob_bytes, 31, e);
+                                const uint8_t *tbody = ix.blob + 8ull * sj.z + ((payload_bytes(mdj, nj) + 7u) & ~7u);
+                                const FieldAddr f0 = field_addr(mtj, nj, 2 * lane), f1 = field_addr(mtj, nj, 2 * lane + 1);
+                                l0[g] = *reinterpret_cast<const uint32_t *>(tbody + f0.off0);
+                                h0[g] = *reinterpret_cast<const uint32_t *>(tbody + f0.off1);
+                                l1[g] = *reinterpret_cast<const uint32_t *>(tbody + f1.off0);
+                                h1[g] = *reinterpret_cast<const uint32_t *>(tbody + f1.off1);
+                                fnp[g] = reinterpret_cast<const uint16_t *>(ix.post_fn + 128ull * blkj)[lane];
+                            }
+                        }
+                    }
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) {
+                        if ((uint32_t)g < n4 && !((skip >> g) & 1u)) {
+                            const uint32_t i = gi[g];
+                            const uint32_t e = (wave - 1u) + (RNW - 1) * i;
+                            const uint4 sj = uni4(S.pm[buf][e]);
+                            const uint32_t fl = uni(S.pa[buf][e].y), t = fl & 0xffu, slot = (fl >> 8) & 0xffu;
+                            uint32_t rel0, rel1;
+                            if ((fl >> 16) & 1u) {
+                                const uint2 dd = *reinterpret_cast<const uint2 *>(&S.stage[slot * 64u + 2u * lane]);
+                                rel0 = dd.x;
+                                rel1 = dd.y;
+                            } else {
+                                const uint32_t dd = S.stage[slot * 64u + lane];
+                                rel0 = dd & 0xffffu;
+                                rel1 = dd >> 16;
+                            }
+                            const uint32_t nj = sj.w & 0xff, mtj = (sj.w >> 16) & 0xff;
+                            const uint32_t d0 = sj.x + rel0, d1 = sj.x + rel1;
+                            const uint32_t dwi = S.done[e * 4 + (lane >> 4)];
+                            bool ok0 = 2 * lane < nj && d0 - tlo < span && !((dwi >> ((2 * lane) & 31)) & 1u);
+                            bool ok1 = 2 * lane + 1 < nj && d1 - tlo < span && !((dwi >> ((2 * lane + 1) & 31)) & 1u);
+                            const FieldAddr f0 = field_addr(mtj, nj, 2 * lane), f1 = field_addr(mtj, nj, 2 * lane + 1);
+                            const double s0t = S.t_s0[t];
+                            const double tf0 = (double)field_val(l0[g], h0[g], f0), tf1 = (double)field_val(l1[g], h1[g], f1);
+                            double p0 = (tf0 * s0t) / (tf0 + S.s1[fnp[g] & 0xff]);
+                            double p1 = (tf1 * s0t) / (tf1 + S.s1[fnp[g] >> 8]);
+                            if (mode == 1) {  // (non-essential terms: the single-term score is a lower bound of the document's -- as good)
+                                if (ok0) atomicAdd(&bh[min((uint32_t)(p0 * S.hscale), (uint32_t)(CUR_HB - 1))], 1u);
+                                if (ok1) atomicAdd(&bh[min((uint32_t)(p1 * S.hscale), (uint32_t)(CUR_HB - 1))], 1u);
+                                continue;
+                            }
+                            if (pne != 0 && __ballot(ok0 || ok1)) {  // completion by lookups in the non-essential lists
+                                p0 = complete(ok0, d0, NONE32, t, p0, p0, emask, nesum);
+                                p1 = complete(ok1, d1, NONE32, t, p1, p1, emask, nesum);
+                            }
+                            const unsigned long long thb = theta_now();
+                            const bool a0 = ok0 && (unsigned long long)__double_as_longlong(p0) >= thb && p0 != 0.0;
+                            const bool a1 = ok1 && (unsigned long long)__double_as_longlong(p1) >= thb && p1 != 0.0;
+                            const unsigned long long am0 = __ballot(a0), am1 = __ballot(a1);
+                            const uint32_t c0 = (uint32_t)__popcll(am0), cnt = c0 + (uint32_t)__popcll(am1);
+                            if (cnt) {  // room for exactly the postings that pass, reserved with one atomic
+                                // (compare-and-swap, not add-then-undo: an undo that is not the last reservation leaves a hole)
+                                uint32_t base = NONE32;
+                                if (lane == 0) {
+                                    uint32_t old = S.pool_n;
+                                    while (old + cnt <= POOL_COLD) {
+                                        const uint32_t prev = atomicCAS(&S.pool_n, old, old + cnt);
+                                        if (prev == old) {
+                                            base = old;
+                                            break;
+                                        }
+                                        old = prev;
+                                    }
+                                }
+                                base = uni(base);
+                                if (base == NONE32) continue;  // next round (after the shrink)
+                                const uint32_t q0 = base + __builtin_amdgcn_mbcnt_hi((uint32_t)(am0 >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)am0, 0u));
+                                const uint32_t q1 = base + c0 + __builtin_amdgcn_mbcnt_hi((uint32_t)(am1 >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)am1, 0u));
+                                VCHK(!a0 || p0 * S.hscale < (double)CUR_HB, 22, d0);
+                                VCHK(!a1 || p1 * S.hscale < (double)CUR_HB, 22, d1);
+                                if (a0) {
+                                    S.pool_s[q0] = (unsigned long long)__double_as_longlong(p0);
+                                    S.pool_d[q0] = d0;
+                                    const double hb = p0 * S.hscale;
+                                    atomicAdd(&hrow[hb >= (double)(CUR_HB - 1) ? (uint32_t)(CUR_HB - 1) : (uint32_t)hb], 1u);
+                                }
+                                if (a1) {
+                                    S.pool_s[q1] = (unsigned long long)__double_as_longlong(p1);
+                                    S.pool_d[q1] = d1;
+                                    const double hb = p1 * S.hscale;
+                                    atomicAdd(&hrow[hb >= (double)(CUR_HB - 1) ? (uint32_t)(CUR_HB - 1) : (uint32_t)hb], 1u);
+                                }
+                            }
+                            pending &= ~(1u << i);
+#ifdef VBM25_PROFILE
+                            prof[11] += 1;
+#endif
+                        }
+                    }
+                }
+            };
             bool stop = false;
             for (uint32_t round = 0;; ++round) {
                 // (uniform decisions: the snapshots were taken before barrier B, a later round follows barrier C)
@@ -1181,110 +1370,35 @@ __global__ void __launch_bounds__(RWG, R_LB_V) scan_range_kernel(DevIndex ix, De
                     break;
                 }
                 if (!any_cold) break;
-                const double nesum = pne ? S.t_cum[pne] : 0.0;
-                uint32_t emask = 0xffffffffu;
-                if (pne) {
-                    emask = 0;
-                    for (uint32_t t = 0; t < mq; ++t) emask |= ((uint32_t)S.t_rank[t] >= pne ? 1u : 0u) << t;
-                }
-                uint32_t todo = pending;
-                while (todo) {
-                    const uint32_t i = (uint32_t)__ffs((int)todo) - 1u;
-                    todo &= todo - 1u;
-                    const uint32_t e = (wave - 1u) + (RNW - 1) * i;
-                    const double thd = __longlong_as_double((long long)theta_now());
-                    const float pubv = __uint_as_float(uni(__float_as_uint(S.pub[buf][e])));
-                    if (thd > (double)pubv * (1.0 + 1e-7) + nesum) {  // the planner decided one tile early: the threshold of now
-                        pending &= ~(1u << i);
-                        continue;
-                    }
-                    if (uni(S.pool_n) >= POOL_COLD) continue;  // no room at all: next round
-                    const uint4 sj = uni4(S.pm[buf][e]);
-                    const uint2 aux = S.pa[buf][e];
-                    const uint32_t blkj = uni(aux.x), fl = uni(aux.y), t = fl & 0xffu, slot = (fl >> 8) & 0xffu;
-                    VCHK(e < np && t < mq && blkj < ix.n_blocks && 8ull * sj.z < ix.blob_bytes && ((fl >> 18) & 1u), 31, fl);
-#ifdef VBM25_CHECK
-                    if (!(e < np && t < mq && blkj < ix.n_blocks && 8ull * sj.z < ix.blob_bytes)) {
-                        pending &= ~(1u << i);
-                        continue;
-                    }
-#endif
-                    uint32_t rel0, rel1;
-                    if ((fl >> 16) & 1u) {
-                        const uint2 dd = *reinterpret_cast<const uint2 *>(&S.stage[slot * 64u + 2u * lane]);
-                        rel0 = dd.x;
-                        rel1 = dd.y;
-                    } else {
-                        const uint32_t dd = S.stage[slot * 64u + lane];
-                        rel0 = dd & 0xffffu;
-                        rel1 = dd >> 16;
-                    }
-                    const uint32_t nj = sj.w & 0xff, mdj = (sj.w >> 8) & 0xff, mtj = (sj.w >> 16) & 0xff;
-                    const uint32_t d0 = sj.x + rel0, d1 = sj.x + rel1;
-                    const uint32_t dwi = S.done[e * 4 + (lane >> 4)];
-                    bool ok0 = 2 * lane < nj && d0 - tlo < span && !((dwi >> ((2 * lane) & 31)) & 1u);
-                    bool ok1 = 2 * lane + 1 < nj && d1 - tlo < span && !((dwi >> ((2 * lane + 1) & 31)) & 1u);
-                    if (__ballot(ok0 || ok1)) {
-                        const uint8_t *tbody = ix.blob + 8ull * sj.z + ((payload_bytes(mdj, nj) + 7u) & ~7u);
-                        const FieldAddr f0 = field_addr(mtj, nj, 2 * lane), f1 = field_addr(mtj, nj, 2 * lane + 1);
-                        const uint32_t l0 = *reinterpret_cast<const uint32_t *>(tbody + f0.off0);
-                        const uint32_t h0 = *reinterpret_cast<const uint32_t *>(tbody + f0.off1);
-                        const uint32_t l1 = *reinterpret_cast<const uint32_t *>(tbody + f1.off0);
-                        const uint32_t h1 = *reinterpret_cast<const uint32_t *>(tbody + f1.off1);
-                        const uint32_t fnp = reinterpret_cast<const uint16_t *>(ix.post_fn + 128ull * blkj)[lane];
-                        const double s0t = S.t_s0[t];
-                        const double tf0 = (double)field_val(l0, h0, f0), tf1 = (double)field_val(l1, h1, f1);
-                        double p0 = (tf0 * s0t) / (tf0 + S.s1[fnp & 0xff]);
-                        double p1 = (tf1 * s0t) / (tf1 + S.s1[fnp >> 8]);
-                        if (pne != 0) {  // completion by lookups in the non-essential lists
-                            p0 = complete(ok0, d0, NONE32, t, p0, p0, emask, nesum);
-                            p1 = complete(ok1, d1, NONE32, t, p1, p1, emask, nesum);
-                        }
-                        const unsigned long long thb = theta_now();
-                        const bool a0 = ok0 && (unsigned long long)__double_as_longlong(p0) >= thb && p0 != 0.0;
-                        const bool a1 = ok1 && (unsigned long long)__double_as_longlong(p1) >= thb && p1 != 0.0;
-                        const unsigned long long am0 = __ballot(a0), am1 = __ballot(a1);
-                        const uint32_t c0 = (uint32_t)__popcll(am0), cnt = c0 + (uint32_t)__popcll(am1);
-                        if (cnt) {  // room for exactly the postings that pass, reserved with one atomic
-                            // (compare-and-swap, not add-then-undo: an undo that is not the last reservation leaves a hole)
-                            uint32_t base = NONE32;
-                            if (lane == 0) {
-                                uint32_t old = S.pool_n;
-                                while (old + cnt <= POOL_COLD) {
-                                    const uint32_t prev = atomicCAS(&S.pool_n, old, old + cnt);
-                                    if (prev == old) {
-                                        base = old;
-                                        break;
-                                    }
-                                    old = prev;
-                                }
-                            }
-                            base = uni(base);
-                            if (base == NONE32) continue;  // next round (after the shrink)
-                            const uint32_t q0 = base + __builtin_amdgcn_mbcnt_hi((uint32_t)(am0 >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)am0, 0u));
-                            const uint32_t q1 = base + c0 + __builtin_amdgcn_mbcnt_hi((uint32_t)(am1 >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)am1, 0u));
-                            VCHK(!a0 || p0 * S.hscale < (double)CUR_HB, 22, d0);
-                            VCHK(!a1 || p1 * S.hscale < (double)CUR_HB, 22, d1);
-                            VCHK(t < mq && blkj < ix.n_blocks, 27, fl);
-                            if (a0) {
-                                S.pool_s[q0] = (unsigned long long)__double_as_longlong(p0);
-                                S.pool_d[q0] = d0;
-                                const double hb = p0 * S.hscale;
-                                atomicAdd(&hrow[hb >= (double)(CUR_HB - 1) ? (uint32_t)(CUR_HB - 1) : (uint32_t)hb], 1u);
-                            }
-                            if (a1) {
-                                S.pool_s[q1] = (unsigned long long)__double_as_longlong(p1);
-                                S.pool_d[q1] = d1;
-                                const double hb = p1 * S.hscale;
-                                atomicAdd(&hrow[hb >= (double)(CUR_HB - 1) ? (uint32_t)(CUR_HB - 1) : (uint32_t)hb], 1u);
-                            }
+                if (boot && round == 0) {
+                    // no threshold yet: the k-th best single-term score of the tile's cold postings (documents with one
+                    // posting in the tile: distinct, and the score is the document's) starts it
+                    cold_blocks(1);
+                    lds_barrier();
+                    if (wave == 0) {
+                        const uint4 c4 = *reinterpret_cast<const uint4 *>(&S.bm[4 * lane]);
+                        const uint32_t own = c4.x + c4.y + c4.z + c4.w;
+                        const uint32_t incl = wave_incl_scan_u32(own);
+                        const uint32_t total = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
+                        const uint32_t above = total - incl;
+                        const unsigned long long hit = __ballot(above + own >= k);
+                        if (hit) {
+                            const uint32_t hl = 63u - (uint32_t)__builtin_clzll(hit);
+                            uint32_t a = (uint32_t)__builtin_amdgcn_readlane((int)above, (int)hl), b = 4 * hl;
+                            const uint32_t c3 = (uint32_t)__builtin_amdgcn_readlane((int)c4.w, (int)hl);
+                            const uint32_t c2 = (uint32_t)__builtin_amdgcn_readlane((int)c4.z, (int)hl);
+                            const uint32_t c1 = (uint32_t)__builtin_amdgcn_readlane((int)c4.y, (int)hl);
+                            if (a + c3 >= k) b += 3;
+                            else if (a + c3 + c2 >= k) b += 2;
+                            else if (a + c3 + c2 + c1 >= k) b += 1;
+                            const double edge = ((double)b / S.hscale) * (1.0 - 1e-12);
+                            if (lane == 0) atomicMax(&S.theta, (unsigned long long)__double_as_longlong(edge));
                         }
                     }
-                    pending &= ~(1u << i);
-#ifdef VBM25_PROFILE
-                    prof[11] += 1;
-#endif
+                    lds_barrier();
+                    if (tid < CUR_HB) S.bm[tid] = 0;  // (the filter's words again; barrier C below orders this before the next S1)
                 }
+                cold_blocks(0);
                 if (pending && lane == 0) S.cold_retry = 1;
                 lds_barrier();  // ---- C (tiles with cold blocks only)
                 const bool again = uni(S.cold_retry) != 0;
