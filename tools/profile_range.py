@@ -41,8 +41,9 @@ items = p[:, 0, 12].sum()
 print(f"{wl}: {int(items)} items, {tiles / items:.1f} tiles per item, rows per tile {p[:, 0, 10].sum() / tiles:.1f}, hits scored per tile "
       f"{p[:, :, 13].sum() / tiles:.1f}, cold blocks per tile {p[:, :, 11].sum() / tiles:.2f}, pool shrinks per item {p[:, 0, 14].sum() / items:.2f}")
 print(f"wave lifetime cycles mean {p[:, :, 15].mean():.0f} max {p[:, :, 15].max():.0f}; tile loops {p[:, :, 9].mean():.0f}; item setup {p[:, 0, 8].sum() / items:.0f} per item")
-names = [(1, "S1 (decode, stage, mark, events)"), (6, "hit contributions"), (7, "control wave: poll + plan + hits"), (2, "wait at barrier A"),
-         (3, "S2 (wipes, rows x terms)"), (4, "S3 + wait at barrier B"), (5, "cold pass / pool housekeeping")]
+print(f"first tile's tail (bootstrap) {p[:, 1:, 8].sum() / (7 * items):.0f} cycles per item and worker; tails with barriers {p[:, 1, 10].sum() / items:.2f} per item")
+names = [(1, "S1a decode (registers)"), (4, "wait at barrier B (previous tile)"), (5, "previous tile's tail: pool, cold pass"),
+         (6, "S1b stage, mark, events"), (7, "control wave: poll + plan + hits"), (2, "wait at barrier A"), (3, "S2 rows x terms (+ S3 on the control wave)")]
 for label, sel in (("workers (mean of 7)", p[:, 1:, :]), ("control wave", p[:, 0:1, :])):
     print(f"-- {label}: cycles per tile")
     tot = 0.0

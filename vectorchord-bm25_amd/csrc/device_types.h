@@ -22,6 +22,7 @@ struct DevIndex {
     const uint16_t *doc_payload;
     const double *s1;            // 256 entries
     unsigned long long blob_bytes;  // bytes of blob that hold block bodies (the allocation has slack behind them)
+    uint32_t blk_ub_attained;    // 1: every blk_ub is the score of a posting of its block (the index came with block WAND pairs)
 };
 
 struct Item {

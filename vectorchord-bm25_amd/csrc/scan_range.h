@@ -49,7 +49,7 @@
 
 constexpr int RNW = 8;               // waves per workgroup: control wave + 7 workers
 constexpr int RWG = RNW * 64;
-constexpr int RB = 8;                // blocks per worker per tile
+constexpr int RB = 7;                // blocks per worker per tile (the 64 candidate lanes of the planner fill 49 entries almost always)
 constexpr int R_NBLK = (RNW - 1) * RB;  // entries per tile (slots = lanes 0..R_NBLK-1 of the control wave)
 static_assert(R_NBLK <= 64, "one planner lane per block of a tile");
 constexpr int R_BM_WORDS = 4096;     // 2^17 bits
@@ -65,6 +65,7 @@ constexpr int R_EVENTS = R_HITS;      // per-wave list of second arrivals (the s
 constexpr int R_XROWS = 64;           // documents beyond a tile's rows: found (done bits) but scored by lookups (late list)
 constexpr int R_LATE = 128;           // documents waiting for the lookup path
 constexpr int R_STAGE_SLOTS = R_NBLK;  // staging: slots of 128 x 16 bits; a wide block takes two
+constexpr int R_SS = 66;               // words between slots: 64 would put the same column of every row on one LDS bank (S2 probes columns)
 
 template <int KMAX>
 struct RangePool {
@@ -77,7 +78,7 @@ struct RangeLds {
     static constexpr int POOL = RangePool<KMAX>::N;
     uint32_t bm[R_BM_WORDS];
     uint4 raw[R_NBLK * 16];            // LDS-DMA target: 256 bytes of id words per entry (full blocks of width <= 15)
-    uint32_t stage[R_STAGE_SLOTS * 64];  // staged ids: slot = 64 words = 128 x u16 (wide block: two slots = 128 x u32)
+    uint32_t stage[R_STAGE_SLOTS * R_SS];  // staged ids: slot = 64 words = 128 x u16 (+ 2 words of skew); wide block: two slots = 128 x u32
     uint32_t hkeys[R_HS];
     uint32_t mdoc[2][ROWS + R_XROWS];  // row -> document, by tile parity
     double contrib[ROWS * RT];
@@ -90,7 +91,7 @@ struct RangeLds {
     uint2 pa[R_PLAN_RING][R_NBLK];     // {block index, term | stage slot << 8 | wide << 16 | fast << 17 | valid << 18}
     float pub[R_PLAN_RING][R_NBLK];    // block upper bound, rounded up
     uint32_t coldw[R_PLAN_RING][RNW];  // per worker: its entries whose upper bound reaches the threshold
-    uint4 hdr[R_PLAN_RING];            // {tlo, thi, entries, non-essential terms | any cold << 8}
+    uint4 hdr[R_PLAN_RING];            // {tlo, thi, entries, non-essential terms | any cold << 8 | cold blocks << 16}
     uint8_t ptb[R_PLAN_RING][RT + 4];  // first plan entry of each term (entries of a term are contiguous)
     double s1[256];
     double t_s0[RT];
@@ -105,9 +106,9 @@ struct RangeLds {
     unsigned long long theta;          // bits of a lower bound of the query's k-th best score
     double sel_lo, sel_mul;            // pool selection: focus of the current level
     uint32_t sel_need, sel_b, sel_above, sel_stop;
-    uint32_t nrows[2];
+    uint32_t nrows[3];                 // rows of a tile, by tile mod 3 (mdoc: by parity)
     uint32_t hcnt[RNW];
-    uint32_t pool_n, pool_w, nlate, cold_retry, rows_seen, pool_snap, late_snap, theta_zero;
+    uint32_t pool_n, pool_w, nlate, cold_retry, rows_seen, pool_snap, late_snap, theta_zero, plan_seq;
     uint32_t item, q, lo, hi, mq, fail;
     uint32_t scratch[64];
     // planner state (wave 0), kept here between its turns so that the workers do not carry it in registers:
@@ -218,10 +219,15 @@ __global__ void __launch_bounds__(RWG, R_LB_V) scan_range_kernel(DevIndex ix, De
             S.item = atomicAdd(bt.work_ctr, 1u);
             S.nrows[0] = 0;
             S.nrows[1] = 0;
+            S.nrows[2] = 0;
             S.pool_n = 0;
             S.nlate = 0;
             S.cold_retry = 0;
             S.rows_seen = 0;
+            S.plan_seq = 0;
+            S.pool_snap = 0;
+            S.late_snap = 0;
+            S.theta_zero = 1;
             S.fail = 0;
             S.theta = 0;
         }
@@ -455,10 +461,44 @@ __global__ void __launch_bounds__(RWG, R_LB_V) scan_range_kernel(DevIndex ix, De
                 S.pm[buf][lane] = make_uint4(0x7fffffffu, 0x7fffffffu, 0, 0);
                 S.pa[buf][lane] = make_uint2(0, 0);
             }
+            // No threshold yet (the query's first tile): every block's upper bound is the score of one of its postings
+            // (the block's WAND pair, flush.rs:40-158), the blocks of ONE term hold distinct documents -- so the k-th largest
+            // bound among a term's blocks of this tile is a lower bound of the query's k-th best score.
+            double thd_c = thd;
+            if (thd == 0.0 && ix.blk_ub_attained) {
+                uint32_t best_t = 0, best_n = 0;
+                for (uint32_t t = 0; t < mqp; ++t) {
+                    const uint32_t nt = (uint32_t)__popcll(__ballot(in_tile && p_st == t));
+                    if (nt > best_n) {
+                        best_n = nt;
+                        best_t = t;
+                    }
+                }
+                if (best_n >= k) {
+                    const bool member = in_tile && p_st == best_t;
+                    unsigned long long mm = __ballot(member);
+                    uint32_t rank = 0;  // members with a larger bound (ties: the lower lane first)
+                    while (mm) {
+                        const uint32_t jl = (uint32_t)__ffsll((long long)mm) - 1u;
+                        mm &= mm - 1ull;
+                        const double v = readlane_f64(ub, jl);
+                        rank += (v > ub || (v == ub && jl < lane)) ? 1u : 0u;
+                    }
+                    const unsigned long long kth = __ballot(member && rank == k - 1u);
+                    if (kth) {
+                        const double t0 = readlane_f64(ub, (uint32_t)__ffsll((long long)kth) - 1u) * (1.0 - 4e-12);  // (the bound carries a factor 1 + 1e-12)
+                        thd_c = t0;
+                        if (lane == 0) {
+                            atomicMax(&S.theta, (unsigned long long)__double_as_longlong(t0));
+                            atomicMax(&bt.theta[q], (unsigned long long)__double_as_longlong(t0));
+                        }
+                    }
+                }
+            }
             // cold blocks (search.rs:203): upper bound at or above the threshold -- the threshold only rises, so
             // deciding here, one tile early, errs on the safe side.  Bit i of word w: entry (w - 1) + (RNW - 1) i
             if (lane < (uint32_t)RNW) S.coldw[buf][lane] = 0;
-            const bool cold = in_tile && thd <= ub * (1.0 + 1e-7) + nesum;
+            const bool cold = in_tile && thd_c <= ub * (1.0 + 1e-7) + nesum;
             if (cold) atomicOr(&S.coldw[buf][1u + pos % (RNW - 1)], 1u << (pos / (RNW - 1)));
             const unsigned long long cmask = __ballot(in_tile && meta.y < thi);
             if (lane <= (uint32_t)RT) {  // lane t: entries before term t's slots = first entry of term t
@@ -467,8 +507,9 @@ __global__ void __launch_bounds__(RWG, R_LB_V) scan_range_kernel(DevIndex ix, De
                 const unsigned long long qm = p_quota >= 64u ? ~0ull : ((1ull << p_quota) - 1ull);
                 if (p_base < 64u) p_cur += (uint32_t)__popcll((cmask >> p_base) & qm);
             }
-            const bool any_cold_blocks = __ballot(cold) != 0ull;
-            if (lane == 0) S.hdr[buf] = make_uint4(p_tlo, thi, np, p_ne | (any_cold_blocks ? 0x100u : 0u));
+            const unsigned long long cold_mask = __ballot(cold);
+            const bool any_cold_blocks = cold_mask != 0ull;
+            if (lane == 0) S.hdr[buf] = make_uint4(p_tlo, thi, np, p_ne | (any_cold_blocks ? 0x100u : 0u) | (uint32_t)__popcll(cold_mask) << 16);
             p_tlo = thi;
             {   // the next plan's inputs (same formulas on the advanced cursors), fetched by LDS-DMA while the tile is worked on
                 const uint32_t cur_n = (uint32_t)__shfl((int)p_cur, (int)st);
@@ -862,8 +903,6 @@ __global__ void __launch_bounds__(RWG, R_LB_V) scan_range_kernel(DevIndex ix, De
             const uint32_t par = tile & 1u;
             const uint4 hdr = uni4(S.hdr[buf]);
             const uint32_t tlo = hdr.x, thi = hdr.y, np = hdr.z;
-            const uint32_t pne = hdr.w & 0xffu;        // non-essential terms: positions 0..pne-1 of t_ord
-            const bool any_cold = (hdr.w & 0x100u) != 0;
             if (np == 0 && np_prev == 0) break;
             const uint32_t span = thi - tlo;
             PROF_T(t_a);
@@ -906,29 +945,270 @@ __global__ void __launch_bounds__(RWG, R_LB_V) scan_range_kernel(DevIndex ix, De
                 }
             };
 
+            // ---- the previous tile's tail: barrier B, pool housekeeping, cold pass
+            if (tile != 0) {
+                lds_barrier();  // ---- B: done bits and hit records of the previous tile complete; filter and hash set clean
+                PROF_T(t_f);
+                PROF_ADD(4, t_a, t_f);
+                if (uni(S.fail)) {
+                    failed = true;
+                    break;
+                }
+                bool stop = false;
+                {
+                    // (the previous tile's plan, by the names the cold pass uses)
+                    const uint4 phdr = uni4(S.hdr[pbuf]);
+                    const uint32_t buf = pbuf, tlo = phdr.x, span = phdr.y - phdr.x, np = phdr.z, pne = phdr.w & 0xffu;
+                    const bool any_cold = (phdr.w & 0x100u) != 0;
+                    const uint32_t n_cold = (phdr.w >> 16) & 0xffu;
+                    uint32_t nv = wave != 0 ? (np + (RNW - 1) - wave) / (RNW - 1) : 0u;
+                    if (nv > (uint32_t)RB) nv = RB;
+                    (void)np;
+                    uint32_t pending = 0;
+                    if (wave != 0 && any_cold) pending = uni(S.coldw[buf][wave]) & ((1u << nv) - 1u);
+                    const bool boot = any_cold && uni(S.theta_zero) != 0u;  // (snapshot taken before barrier B: uniform)
+                    const double nesum = pne ? S.t_cum[pne] : 0.0;
+                    uint32_t emask = 0xffffffffu;  // bit t: term t is essential
+                    if (pne && any_cold) {
+                        emask = 0;
+                        for (uint32_t t = 0; t < mq; ++t) emask |= ((uint32_t)S.t_rank[t] >= pne ? 1u : 0u) << t;
+                    }
+                    // mode 0: push (a block that finds no room stays pending); mode 1: histogram of the scores only; mode 2: push,
+                    // postings that find no room go to the late list
+                    auto cold_blocks = [&](uint32_t mode) {
+                        uint32_t *bh = S.bm;
+                        // (the bootstrap histogram takes a sample: the wave's first cold block -- the k-th best of any set of
+                        // distinct documents is a lower bound of the k-th best of all)
+                        uint32_t todo = mode == 1 ? pending & (0u - pending) : pending;
+                        while (todo) {
+                            uint32_t gi[4];
+                            uint32_t n4 = 0;
+        #pragma unroll
+                            for (int g = 0; g < 4; ++g) {
+                                gi[g] = 0;
+                                if (todo) {
+                                    gi[g] = (uint32_t)__ffs((int)todo) - 1u;
+                                    todo &= todo - 1u;
+                                    ++n4;
+                                }
+                            }
+                            uint32_t l0[4], h0[4], l1[4], h1[4], fnp[4];
+                            uint32_t skip = 0;  // bit g: block not scored in this pass (below the threshold: done; no room: next round)
+                            const double thd = __longlong_as_double((long long)theta_now());
+        #pragma unroll
+                            for (int g = 0; g < 4; ++g) {
+                                l0[g] = h0[g] = l1[g] = h1[g] = fnp[g] = 0;
+                                if ((uint32_t)g < n4) {
+                                    const uint32_t e = (wave - 1u) + (RNW - 1) * gi[g];
+                                    const float pubv = __uint_as_float(uni(__float_as_uint(S.pub[buf][e])));
+                                    if (thd > (double)pubv * (1.0 + 1e-7) + nesum) {  // the planner decided one tile early: the threshold of now
+                                        pending &= ~(1u << gi[g]);
+                                        skip |= 1u << g;
+                                    } else if (mode == 0 && uni(S.pool_n) >= POOL_COLD) {
+                                        skip |= 1u << g;  // no room at all: next round
+                                    } else {
+                                        const uint4 sj = uni4(S.pm[buf][e]);
+                                        const uint32_t blkj = uni(S.pa[buf][e].x);
+                                        const uint32_t nj = sj.w & 0xff, mdj = (sj.w >> 8) & 0xff, mtj = (sj.w >> 16) & 0xff;
+                                        VCHK(e < np && blkj < ix.n_blocks && 8ull * sj.z < ix.blob_bytes, 31, e);
+                                        const uint8_t *tbody = ix.blob + 8ull * sj.z + ((payload_bytes(mdj, nj) + 7u) & ~7u);
+                                        const FieldAddr f0 = field_addr(mtj, nj, 2 * lane), f1 = field_addr(mtj, nj, 2 * lane + 1);
+                                        l0[g] = *reinterpret_cast<const uint32_t *>(tbody + f0.off0);
+                                        h0[g] = *reinterpret_cast<const uint32_t *>(tbody + f0.off1);
+                                        l1[g] = *reinterpret_cast<const uint32_t *>(tbody + f1.off0);
+                                        h1[g] = *reinterpret_cast<const uint32_t *>(tbody + f1.off1);
+                                        fnp[g] = reinterpret_cast<const uint16_t *>(ix.post_fn + 128ull * blkj)[lane];
+                                    }
+                                }
+                            }
+        #pragma unroll
+                            for (int g = 0; g < 4; ++g) {
+                                if ((uint32_t)g < n4 && !((skip >> g) & 1u)) {
+                                    const uint32_t i = gi[g];
+                                    const uint32_t e = (wave - 1u) + (RNW - 1) * i;
+                                    const uint4 sj = uni4(S.pm[buf][e]);
+                                    const uint32_t fl = uni(S.pa[buf][e].y), t = fl & 0xffu, slot = (fl >> 8) & 0xffu;
+                                    uint32_t rel0, rel1;
+                                    if ((fl >> 16) & 1u) {
+                                        const uint2 dd = *reinterpret_cast<const uint2 *>(&S.stage[slot * (uint32_t)R_SS + 2u * lane]);
+                                        rel0 = dd.x;
+                                        rel1 = dd.y;
+                                    } else {
+                                        const uint32_t dd = S.stage[slot * (uint32_t)R_SS + lane];
+                                        rel0 = dd & 0xffffu;
+                                        rel1 = dd >> 16;
+                                    }
+                                    const uint32_t nj = sj.w & 0xff, mtj = (sj.w >> 16) & 0xff;
+                                    const uint32_t d0 = sj.x + rel0, d1 = sj.x + rel1;
+                                    const uint32_t dwi = S.done[e * 4 + (lane >> 4)];
+                                    bool ok0 = 2 * lane < nj && d0 - tlo < span && !((dwi >> ((2 * lane) & 31)) & 1u);
+                                    bool ok1 = 2 * lane + 1 < nj && d1 - tlo < span && !((dwi >> ((2 * lane + 1) & 31)) & 1u);
+                                    const FieldAddr f0 = field_addr(mtj, nj, 2 * lane), f1 = field_addr(mtj, nj, 2 * lane + 1);
+                                    const double s0t = S.t_s0[t];
+                                    const double tf0 = (double)field_val(l0[g], h0[g], f0), tf1 = (double)field_val(l1[g], h1[g], f1);
+                                    double p0 = (tf0 * s0t) / (tf0 + S.s1[fnp[g] & 0xff]);
+                                    double p1 = (tf1 * s0t) / (tf1 + S.s1[fnp[g] >> 8]);
+                                    if (mode == 1) {  // (non-essential terms: the single-term score is a lower bound of the document's -- as good)
+                                        if (ok0) atomicAdd(&bh[min((uint32_t)(p0 * S.hscale), (uint32_t)(CUR_HB - 1))], 1u);
+                                        if (ok1) atomicAdd(&bh[min((uint32_t)(p1 * S.hscale), (uint32_t)(CUR_HB - 1))], 1u);
+                                        continue;
+                                    }
+                                    if (pne != 0 && __ballot(ok0 || ok1)) {  // completion by lookups in the non-essential lists
+#pragma nounroll
+                                        for (uint32_t si = 0; si < 2; ++si) {  // (one call site for the lane's two postings)
+                                            bool okx = si ? ok1 : ok0;
+                                            const double px = si ? p1 : p0;
+                                            const double cx = complete(okx, si ? d1 : d0, NONE32, t, px, px, emask, nesum);
+                                            if (si) {
+                                                ok1 = okx;
+                                                p1 = cx;
+                                            } else {
+                                                ok0 = okx;
+                                                p0 = cx;
+                                            }
+                                        }
+                                    }
+                                    const unsigned long long thb = theta_now();
+                                    const bool a0 = ok0 && (unsigned long long)__double_as_longlong(p0) >= thb && p0 != 0.0;
+                                    const bool a1 = ok1 && (unsigned long long)__double_as_longlong(p1) >= thb && p1 != 0.0;
+                                    const unsigned long long am0 = __ballot(a0), am1 = __ballot(a1);
+                                    const uint32_t c0 = (uint32_t)__popcll(am0), cnt = c0 + (uint32_t)__popcll(am1);
+                                    if (cnt) {  // room for exactly the postings that pass, reserved with one atomic
+                                        // (compare-and-swap, not add-then-undo: an undo that is not the last reservation leaves a hole)
+                                        uint32_t base = NONE32;
+                                        if (lane == 0) {
+                                            uint32_t old = S.pool_n;
+                                            while (old + cnt <= POOL_COLD) {
+                                                const uint32_t prev = atomicCAS(&S.pool_n, old, old + cnt);
+                                                if (prev == old) {
+                                                    base = old;
+                                                    break;
+                                                }
+                                                old = prev;
+                                            }
+                                        }
+                                        base = uni(base);
+                                        if (base == NONE32) {
+                                            if (mode != 2) continue;  // next round (after the shrink)
+                                            if (a0) late_push(d0);    // no rounds on this path: the lookup path scores them
+                                            if (a1) late_push(d1);
+                                            pending &= ~(1u << i);
+                                            continue;
+                                        }
+                                        const uint32_t q0 = base + __builtin_amdgcn_mbcnt_hi((uint32_t)(am0 >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)am0, 0u));
+                                        const uint32_t q1 = base + c0 + __builtin_amdgcn_mbcnt_hi((uint32_t)(am1 >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)am1, 0u));
+                                        VCHK(!a0 || p0 * S.hscale < (double)CUR_HB, 22, d0);
+                                        VCHK(!a1 || p1 * S.hscale < (double)CUR_HB, 22, d1);
+                                        if (a0) {
+                                            S.pool_s[q0] = (unsigned long long)__double_as_longlong(p0);
+                                            S.pool_d[q0] = d0;
+                                            const double hb = p0 * S.hscale;
+                                            atomicAdd(&hrow[hb >= (double)(CUR_HB - 1) ? (uint32_t)(CUR_HB - 1) : (uint32_t)hb], 1u);
+                                        }
+                                        if (a1) {
+                                            S.pool_s[q1] = (unsigned long long)__double_as_longlong(p1);
+                                            S.pool_d[q1] = d1;
+                                            const double hb = p1 * S.hscale;
+                                            atomicAdd(&hrow[hb >= (double)(CUR_HB - 1) ? (uint32_t)(CUR_HB - 1) : (uint32_t)hb], 1u);
+                                        }
+                                    }
+                                    pending &= ~(1u << i);
+        #ifdef VBM25_PROFILE
+                                    prof[11] += 1;
+        #endif
+                                }
+                            }
+                        }
+                    };
+                    // `sure`: every cold block of the tile fits the pool whatever passes -- no retry rounds, no barrier: the waves
+                    // without cold blocks go on to their next tile while the others score theirs
+                    const bool sure = !boot && uni(S.pool_snap) <= POOL_HIGH && uni(S.late_snap) <= (uint32_t)R_LATE / 2u &&
+                                      uni(S.pool_snap) + 128u * n_cold <= POOL_COLD;
+                    uint32_t mode = boot ? 1u : 0u;  // 1: no threshold yet -- histogram of the single-term scores first
+#ifdef VBM25_PROFILE
+                    if (wave != 0 && !sure) prof[10] += 1;
+#endif
+                    for (uint32_t round = 0; !sure || any_cold; ++round) {
+                        if (!sure && mode == 0) {
+                            // (uniform decisions: the snapshots were taken before barrier B, a later round follows barrier C)
+                            const bool late_full = round == 0 ? uni(S.late_snap) > (uint32_t)R_LATE / 2u : uni(S.nlate) > (uint32_t)R_LATE / 2u;
+                            const bool pool_full = round == 0 ? uni(S.pool_snap) > POOL_HIGH : true;
+                            if (pool_full || late_full) {
+                                shrink_pool();
+                                // (the late documents' scores fit the shrunk pool; the next tile's check sees them)
+                                if (late_full && !uni(S.fail)) flush_late();
+                            }
+                            if (uni(S.fail)) {
+                                stop = true;
+                                break;
+                            }
+                        }
+                        if (!any_cold) break;
+                        cold_blocks(sure ? 2u : mode);
+                        if (sure) break;
+                        if (mode == 1) {
+                            // the k-th best single-term score of the tile's cold postings (documents with one posting in the
+                            // tile: distinct, and the score is the document's) starts the threshold
+                            lds_barrier();
+                            if (wave == 0) {
+                                const uint4 c4 = *reinterpret_cast<const uint4 *>(&S.bm[4 * lane]);
+                                const uint32_t own = c4.x + c4.y + c4.z + c4.w;
+                                const uint32_t incl = wave_incl_scan_u32(own);
+                                const uint32_t total = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
+                                const uint32_t above = total - incl;
+                                const unsigned long long hit = __ballot(above + own >= k);
+                                if (hit) {
+                                    const uint32_t hl = 63u - (uint32_t)__builtin_clzll(hit);
+                                    uint32_t a = (uint32_t)__builtin_amdgcn_readlane((int)above, (int)hl), b = 4 * hl;
+                                    const uint32_t c3 = (uint32_t)__builtin_amdgcn_readlane((int)c4.w, (int)hl);
+                                    const uint32_t c2 = (uint32_t)__builtin_amdgcn_readlane((int)c4.z, (int)hl);
+                                    const uint32_t c1 = (uint32_t)__builtin_amdgcn_readlane((int)c4.y, (int)hl);
+                                    if (a + c3 >= k) b += 3;
+                                    else if (a + c3 + c2 >= k) b += 2;
+                                    else if (a + c3 + c2 + c1 >= k) b += 1;
+                                    const double edge = ((double)b / S.hscale) * (1.0 - 1e-12);
+                                    if (lane == 0) atomicMax(&S.theta, (unsigned long long)__double_as_longlong(edge));
+                                }
+                            }
+                            lds_barrier();
+                            if (tid < CUR_HB) S.bm[tid] = 0;  // (the filter's words again; barrier C of the push pass orders this before the next S1)
+                            mode = 0;
+                            --round;  // (the push pass is this round's)
+                            continue;
+                        }
+                        if (pending && lane == 0) S.cold_retry = 1;
+                        lds_barrier();  // ---- C (tiles whose cold blocks may not fit the pool at once)
+                        const bool again = uni(S.cold_retry) != 0;
+                        lds_barrier();
+                        if (!again) break;
+                        if (tid == 0) S.cold_retry = 0;
+                        if (round >= 64u) {  // (a block that never fits: masses of equal scores)
+                            if (tid == 0) S.fail = 6;
+                            lds_barrier();
+                            stop = true;
+                            break;
+                        }
+                    }
+                    // this wave's done bits of that tile
+                    if (wave != 0 && lane < 4 * RB) S.done[((wave - 1u) + (RNW - 1) * (lane >> 2)) * 4 + (lane & 3)] = 0;
+                }
+                if (stop) {
+                    failed = true;
+                    break;
+                }
+                PROF_T(t_g);
+                PROF_ADD(5, t_f, t_g);
+#ifdef VBM25_PROFILE
+                if (wave != 0 && tile == 1) prof[8] += t_g - t_f;  // (workers: the first tile's tail = the threshold bootstrap)
+#endif
+            }
+            // ---- S1a (workers): decode into registers.  The raw words of tile `tile` were requested one tile ago.
+            PROF_T(t_a0);
             uint32_t nv = 0;  // this wave's entries: (wave - 1) + 7 i < np  <=>  i < nv
-            if (wave == 0) {
-                // ---- control wave: hits, threshold poll, plan of the next tile (read by the others after barrier A)
-                hits_issue(0);
-                for (uint32_t base = 64; base < nh; base += 64) {
-                    hits_consume();
-                    hits_issue(base);
-                }
-                poll_request();
-                pl_load();
-                {   // rows run short: smaller tiles (the planner's cap follows the rows the last tiles needed)
-                    const uint32_t seen = uni(S.rows_seen);
-                    if (seen > ROWS * 3u / 4u) p_cap = max(p_cap >> 1, 2u * mq);
-                    else if (seen < ROWS / 4u) p_cap = min(p_cap + (p_cap >> 2) + 1u, (uint32_t)R_STAGE_SLOTS);
-                }
-                poll_consume();
-                plan_tile((tile + 1) % R_PLAN_RING);
-                pl_store();
-                hits_consume();
-                PROF_T(t_p);
-                PROF_ADD(7, t_a, t_p);
-            } else {
-                // ---- S1: decode, stage, mark.  The raw words of tile `tile` were requested one tile ago.
+            uint32_t r0[RB], r1[RB];     // ids relative to the block's first id, two per lane
+            uint32_t bmin[RB], bfl[RB];  // per entry (uniform values kept in VGPRs): min_doc - tlo; slot << 8 | wide << 16 | fast << 17 | width << 24
+            bool allfast = true;
+            if (wave != 0) {
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                 hits_issue(0);
                 for (uint32_t base = 64; base < nh; base += 64) {  // (every record read before S1 re-uses the list for its events)
@@ -937,8 +1217,7 @@ __global__ void __launch_bounds__(RWG, R_LB_V) scan_range_kernel(DevIndex ix, De
                 }
                 nv = (np + (RNW - 1) - wave) / (RNW - 1);
                 if (nv > (uint32_t)RB) nv = RB;
-                uint32_t bmin[RB], bfl[RB];  // per entry (uniform values kept in VGPRs): min_doc - tlo; slot << 8 | wide << 16 | fast << 17 | width << 24
-                bool allfast = true;
+                asm volatile("; MARK_S1A_BEGIN");
 #pragma unroll
                 for (int i = 0; i < RB; ++i) {
                     const uint32_t e = (wave - 1u) + (RNW - 1) * i;
@@ -949,9 +1228,7 @@ __global__ void __launch_bounds__(RWG, R_LB_V) scan_range_kernel(DevIndex ix, De
                     bfl[i] = (a.y & 0x00ffff00u) | (fast ? (c.w >> 8) & 0xffu : 0u) << 24;  // (a block off the fast path decodes as width 0 here)
                     allfast = allfast && ((uint32_t)i >= nv || fast != 0u);
                 }
-                // full bit-packed blocks (compression.rs:65-92), branch-free so that the eight decodes overlap; unused
-                // entries have width 0.  x = id - tlo, two per lane; the ids relative to the block's first id are staged.
-                uint32_t x0[RB], x1[RB];
+                // full bit-packed blocks (compression.rs:65-92), branch-free so that the decodes overlap; unused entries have width 0
 #pragma unroll
                 for (int i = 0; i < RB; ++i) {
                     const uint32_t e = (wave - 1u) + (RNW - 1) * i;
@@ -965,14 +1242,52 @@ __global__ void __launch_bounds__(RWG, R_LB_V) scan_range_kernel(DevIndex ix, De
                     const uint32_t v1 = __builtin_amdgcn_alignbit(wb.y, wa.y, bit) & mask;
                     const uint32_t own = v0 + v1;
                     const uint32_t incl = wave_incl_scan_u32(own);
-                    const uint32_t r0 = (incl - own) + v0, r1 = r0 + v1;
+                    r0[i] = (incl - own) + v0;
+                    r1[i] = r0[i] + v1;
+                }
+                asm volatile("; MARK_S1A_END");
+            }
+            PROF_T(t_a1);
+
+            bool dma_done = false;
+            if (wave == 0) {
+                // ---- control wave: plan of the next tile (read by the others after barrier A), hits, threshold poll
+                PROF_T(t_p0);
+                pl_load();
+                {   // rows run short: smaller tiles (the planner's cap follows the rows the last tiles needed)
+                    const uint32_t seen = uni(S.rows_seen);
+                    if (seen > ROWS * 3u / 4u) p_cap = max(p_cap >> 1, 2u * mq);
+                    else if (seen < ROWS / 4u) p_cap = min(p_cap + (p_cap >> 2) + 1u, (uint32_t)R_STAGE_SLOTS);
+                }
+                plan_tile((tile + 1) % R_PLAN_RING);
+                pl_store();
+                if (lane == 0) S.plan_seq = tile + 1u;  // (the workers may request the next tile's id words before barrier A)
+                PROF_T(t_p1);
+                PROF_ADD(7, t_p0, t_p1);
+                if ((tile & 3u) == 3u) poll_request();  // the query's shared threshold (other items'), every fourth tile
+                for (uint32_t base = 0; base < nh; base += 64) {
+                    hits_issue(base);
+                    hits_consume();
+                }
+                if ((tile & 3u) == 3u) poll_consume();
+                PROF_T(t_p);
+                PROF_ADD(6, t_p1, t_p);
+            } else {
+                // ---- S1b: stage, mark
+                asm volatile("; MARK_S1B_BEGIN");
+#pragma unroll
+                for (int i = 0; i < RB; ++i) {
                     if ((uint32_t)i < nv) {
                         const uint32_t slot = (bfl[i] >> 8) & 0xffu;
-                        if ((bfl[i] >> 16) & 1u) *reinterpret_cast<uint2 *>(&S.stage[slot * 64u + 2u * lane]) = make_uint2(r0, r1);
-                        else S.stage[slot * 64u + lane] = r0 | r1 << 16;
+                        if ((bfl[i] >> 16) & 1u) *reinterpret_cast<uint2 *>(&S.stage[slot * (uint32_t)R_SS + 2u * lane]) = make_uint2(r0[i], r1[i]);
+                        else S.stage[slot * (uint32_t)R_SS + lane] = r0[i] | r1[i] << 16;
                     }
-                    x0[i] = bmin[i] + r0;
-                    x1[i] = bmin[i] + r1;
+                }
+                uint32_t x0[RB], x1[RB];  // id - tlo
+#pragma unroll
+                for (int i = 0; i < RB; ++i) {
+                    x0[i] = bmin[i] + r0[i];
+                    x1[i] = bmin[i] + r1[i];
                 }
                 if (!allfast) {  // raw (width 32), wide-delta or byte-packed tail blocks: generic, synchronous decode
 #pragma nounroll
@@ -992,9 +1307,9 @@ __global__ void __launch_bounds__(RWG, R_LB_V) scan_range_kernel(DevIndex ix, De
                             // entries past the block's end: staged above every id of the block (S2 checks the index), marked
                             // far outside the tile, one distinct id each
                             if ((fl >> 16) & 1u)
-                                *reinterpret_cast<uint2 *>(&S.stage[slot * 64u + 2u * lane]) = make_uint2(in0 ? a0 - cc.x : NONE32, in1 ? a1 - cc.x : NONE32);
+                                *reinterpret_cast<uint2 *>(&S.stage[slot * (uint32_t)R_SS + 2u * lane]) = make_uint2(in0 ? a0 - cc.x : NONE32, in1 ? a1 - cc.x : NONE32);
                             else
-                                S.stage[slot * 64u + lane] = (in0 ? a0 - cc.x : 0xffffu) | (in1 ? a1 - cc.x : 0xffffu) << 16;
+                                S.stage[slot * (uint32_t)R_SS + lane] = (in0 ? a0 - cc.x : 0xffffu) | (in1 ? a1 - cc.x : 0xffffu) << 16;
                             const uint32_t y0 = in0 ? a0 - tlo : 0xffffff00u + 2 * lane, y1 = in1 ? a1 - tlo : 0xffffff01u + 2 * lane;
 #pragma unroll
                             for (int j = 0; j < RB; ++j) {
@@ -1005,19 +1320,32 @@ __global__ void __launch_bounds__(RWG, R_LB_V) scan_range_kernel(DevIndex ix, De
                     }
                 }
                 // mark.  Postings of a straddling block that belong to a neighbour tile mark a bit too (no range test
-                // here); the event / cold paths test the range.
+                // here); the event / cold paths test the range.  All the atomics of the wave's blocks are in flight together.
                 uint32_t ev = 0;  // bit 2 i + j: posting j of entry i is a second arrival
+                asm volatile("; MARK_MARKS_BEGIN");
 #pragma unroll
-                for (int i = 0; i < RB; ++i) {
-                    if ((uint32_t)i < nv) {
-                        const uint32_t t0 = x0[i] >> 17, t1 = x1[i] >> 17;
-                        const uint32_t m0 = (1u << (x0[i] & 31u)) | (1u << ((x0[i] + t0 * 5u + 1u) & 31u)) | (1u << ((x0[i] + 13u) & 31u));
-                        const uint32_t m1 = (1u << (x1[i] & 31u)) | (1u << ((x1[i] + t1 * 5u + 1u) & 31u)) | (1u << ((x1[i] + 13u) & 31u));
-                        const uint32_t o0 = atomicOr(&S.bm[(x0[i] >> 5) & (R_BM_WORDS - 1)], m0);
-                        const uint32_t o1 = atomicOr(&S.bm[(x1[i] >> 5) & (R_BM_WORDS - 1)], m1);
-                        ev |= ((o0 & m0) == m0 ? 1u : 0u) << (2 * i) | ((o1 & m1) == m1 ? 1u : 0u) << (2 * i + 1);
+                for (int h = 0; h < RB; h += 4) {  // (four blocks' atomics in flight together)
+                    uint32_t m0[4], m1[4], o0[4], o1[4];
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) {
+                        const int i = h + g;
+                        if (i < RB) {
+                            const uint32_t t0 = x0[i] >> 17, t1 = x1[i] >> 17;
+                            m0[g] = (1u << (x0[i] & 31u)) | (1u << ((x0[i] + t0 * 5u + 1u) & 31u)) | (1u << ((x0[i] + 13u) & 31u));
+                            m1[g] = (1u << (x1[i] & 31u)) | (1u << ((x1[i] + t1 * 5u + 1u) & 31u)) | (1u << ((x1[i] + 13u) & 31u));
+                            if ((uint32_t)i >= nv) m0[g] = m1[g] = 0;  // (an unused entry marks nothing; uniform)
+                            o0[g] = atomicOr(&S.bm[(x0[i] >> 5) & (R_BM_WORDS - 1)], m0[g]);
+                            o1[g] = atomicOr(&S.bm[(x1[i] >> 5) & (R_BM_WORDS - 1)], m1[g]);
+                        }
+                    }
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) {
+                        const int i = h + g;
+                        if (i < RB)
+                            ev |= ((o0[g] & m0[g]) == m0[g] && m0[g] != 0u ? 1u : 0u) << (2 * i) | ((o1[g] & m1[g]) == m1[g] && m1[g] != 0u ? 1u : 0u) << (2 * i + 1);
                     }
                 }
+                asm volatile("; MARK_MARKS_END");
                 // second arrivals -> this wave's event list -> insert passes into the hash set (one row per document)
                 if (__ballot(ev != 0)) {
                     uint32_t cnt = 0;
@@ -1029,7 +1357,7 @@ __global__ void __launch_bounds__(RWG, R_LB_V) scan_range_kernel(DevIndex ix, De
                             for (uint32_t probes = 0;; ++probes) {
                                 const uint32_t prev = atomicCAS(&S.hkeys[slot], EMPTY, d);
                                 if (prev == EMPTY) {
-                                    const uint32_t r = atomicAdd(&S.nrows[par], 1u);
+                                    const uint32_t r = atomicAdd(&S.nrows[buf], 1u);
                                     if (r < ROWS + (uint32_t)R_XROWS) S.mdoc[par][r] = d;
                                     else S.fail = 1;
                                     if (r >= ROWS) late_push(d);  // found like a row (done bits), scored by lookups
@@ -1055,8 +1383,8 @@ __global__ void __launch_bounds__(RWG, R_LB_V) scan_range_kernel(DevIndex ix, De
                         const uint32_t e = (wave - 1u) + (RNW - 1) * (b >> 1);
                         const uint32_t fl = S.pa[buf][e].y;
                         const uint32_t slot = (fl >> 8) & 0xffu, idx = 2u * lane + (b & 1u);
-                        const uint32_t rel = (fl >> 16) & 1u ? S.stage[slot * 64u + idx]
-                                                              : (uint32_t)reinterpret_cast<const uint16_t *>(&S.stage[slot * 64u])[idx];
+                        const uint32_t rel = (fl >> 16) & 1u ? S.stage[slot * (uint32_t)R_SS + idx]
+                                                              : (uint32_t)reinterpret_cast<const uint16_t *>(&S.stage[slot * (uint32_t)R_SS])[idx];
                         const uint32_t x = S.pm[buf][e].x - tlo + rel;
                         const bool ok = has && x < span;  // (postings of the neighbour tiles, entries past a tail block's end)
                         const unsigned long long om = __ballot(ok);
@@ -1066,16 +1394,19 @@ __global__ void __launch_bounds__(RWG, R_LB_V) scan_range_kernel(DevIndex ix, De
                     }
                     if (cnt) insert_events();
                 }
+                asm volatile("; MARK_EVENTS_END");
                 PROF_T(t_s);
-                PROF_ADD(1, t_a, t_s);
+                PROF_ADD(1, t_a0, t_a1);
+                PROF_ADD(6, t_a1, t_s);
                 hits_consume();
+                // the wave's raw slots are free: request the next tile's id words as soon as its plan is there
+                if (uni(S.plan_seq) == tile + 1u) {
+                    dma_issue((tile + 1) % R_PLAN_RING);
+                    dma_done = true;
+                }
 #ifdef VBM25_PROFILE
                 prof[0] += 1;
                 prof[13] += nh;
-                {
-                    const unsigned long long t_h = __builtin_readcyclecounter();
-                    prof[6] += t_h - t_s;
-                }
 #endif
             }
             if (lane == 0) S.hcnt[wave] = 0;
@@ -1087,11 +1418,10 @@ __global__ void __launch_bounds__(RWG, R_LB_V) scan_range_kernel(DevIndex ix, De
                 failed = true;
                 break;
             }
-            // the workers' raw slots are free: request the next tile's id words (in flight until the next S1)
-            if (wave != 0) dma_issue((tile + 1) % R_PLAN_RING);
+            if (wave != 0 && !dma_done) dma_issue((tile + 1) % R_PLAN_RING);
 
             // ---- S2: wipe the filter and the hash set; rows x terms: find the postings
-            const uint32_t nm = min(uni(S.nrows[par]), ROWS + (uint32_t)R_XROWS);
+            const uint32_t nm = min(uni(S.nrows[buf]), ROWS + (uint32_t)R_XROWS);
 #pragma unroll
             for (int i = 0; i < R_BM_WORDS / 4 / RWG; ++i)
                 reinterpret_cast<uint4 *>(S.bm)[tid + i * RWG] = make_uint4(0, 0, 0, 0);
@@ -1126,14 +1456,14 @@ __global__ void __launch_bounds__(RWG, R_LB_V) scan_range_kernel(DevIndex ix, De
                                 // first staged id >= rel among the block's 128 (sorted, padded above): 4-ary as well
                                 uint32_t idx = 0;
                                 if ((fl >> 16) & 1u) {
-                                    const uint32_t *sb = &S.stage[slot * 64u];
+                                    const uint32_t *sb = &S.stage[slot * (uint32_t)R_SS];
                                     idx = 32u * ((sb[31] < rel ? 1u : 0u) + (sb[63] < rel ? 1u : 0u) + (sb[95] < rel ? 1u : 0u));
                                     idx += 8u * ((sb[idx + 7] < rel ? 1u : 0u) + (sb[idx + 15] < rel ? 1u : 0u) + (sb[idx + 23] < rel ? 1u : 0u));
                                     idx += 2u * ((sb[idx + 1] < rel ? 1u : 0u) + (sb[idx + 3] < rel ? 1u : 0u) + (sb[idx + 5] < rel ? 1u : 0u));
                                     idx += sb[idx] < rel ? 1u : 0u;
                                     found = sb[idx] == rel;
                                 } else {
-                                    const uint16_t *sb = reinterpret_cast<const uint16_t *>(&S.stage[slot * 64u]);
+                                    const uint16_t *sb = reinterpret_cast<const uint16_t *>(&S.stage[slot * (uint32_t)R_SS]);
                                     idx = 32u * (((uint32_t)sb[31] < rel ? 1u : 0u) + ((uint32_t)sb[63] < rel ? 1u : 0u) + ((uint32_t)sb[95] < rel ? 1u : 0u));
                                     idx += 8u * (((uint32_t)sb[idx + 7] < rel ? 1u : 0u) + ((uint32_t)sb[idx + 15] < rel ? 1u : 0u) + ((uint32_t)sb[idx + 23] < rel ? 1u : 0u));
                                     idx += 2u * (((uint32_t)sb[idx + 1] < rel ? 1u : 0u) + ((uint32_t)sb[idx + 3] < rel ? 1u : 0u) + ((uint32_t)sb[idx + 5] < rel ? 1u : 0u));
@@ -1164,262 +1494,49 @@ __global__ void __launch_bounds__(RWG, R_LB_V) scan_range_kernel(DevIndex ix, De
             PROF_T(t_d);
             PROF_ADD(3, t_c, t_d);
 
-            // ---- S3 (control wave): rows of the previous tile -> documents -> pool.  Their contributions were written
-            // before barrier A.
-            if (wave == 0) {
-                const uint32_t ppar = par ^ 1u;
-                const uint32_t nmp = min(uni(S.nrows[ppar]), ROWS);
+            // ---- S3 (all waves, ROWS / 8 rows each): rows of the previous tile -> documents -> pool.  Their contributions were
+            // written before barrier A.
+            {
+                const uint32_t nmp = min(uni(S.nrows[pbuf]), ROWS);
                 const uint32_t ppne = uni(S.hdr[pbuf].w) & 0xffu;
-                if (tile != 0 && nmp != 0) {
+                if (tid == 0) {
+                    // what the previous tile's... this tile's tail decides by, uniformly: an upper bound of the pool after the
+                    // rows' pushes, the late list, whether a threshold exists
+                    S.pool_snap = S.pool_n + (tile != 0 ? nmp : 0u);
+                    S.late_snap = S.nlate;
+                    S.theta_zero = S.theta == 0ull ? 1u : 0u;
+                    S.rows_seen = nm;
+                    S.nrows[(tile + 1) % 3u] = 0;  // (last read by the S3 of the previous iteration)
+                }
+                constexpr uint32_t RPW = ROWS / RNW;
+                if (tile != 0 && nmp > wave * RPW) {
                     const double pnes = ppne ? S.t_cum[ppne] : 0.0;
                     uint32_t emask = 0xffffffffu;  // bit t: term t is essential
                     if (ppne) {
                         emask = 0;
                         for (uint32_t t = 0; t < mq; ++t) emask |= ((uint32_t)S.t_rank[t] >= ppne ? 1u : 0u) << t;
                     }
-                    for (uint32_t r0w = 0; r0w < nmp; r0w += 64) {
-                        const uint32_t r = r0w + lane;
-                        bool has = r < nmp;
-                        double acc = 0.0;
-                        uint32_t d = 0;
-                        if (has) {
-                            d = S.mdoc[ppar][r];
-                            for (uint32_t t = 0; t < mq; ++t) acc += S.contrib[(r << LRT) + t];  // ascending key order; absent terms add 0.0
-                        }
-                        VCHK(!has || acc * S.hscale < (double)CUR_HB, 35, r);
-                        if (ppne != 0) acc = complete(has, d, has ? r : NONE32, 0, 0.0, acc, emask, pnes);
-                        pool_push(has, acc, d);
-                        if (r < nmp)
-                            for (uint32_t t = 0; t < mq; ++t) S.contrib[(r << LRT) + t] = 0.0;
+                    const uint32_t r = wave * RPW + lane;
+                    bool has = lane < RPW && r < nmp;
+                    double acc = 0.0;
+                    uint32_t d = 0;
+                    if (has) {
+                        d = S.mdoc[par ^ 1u][r];
+                        for (uint32_t t = 0; t < mq; ++t) acc += S.contrib[(r << LRT) + t];  // ascending key order; absent terms add 0.0
                     }
+                    const bool mine = has;
+                    VCHK(!has || acc * S.hscale < (double)CUR_HB, 35, r);
+                    if (ppne != 0) acc = complete(has, d, has ? r : NONE32, 0, 0.0, acc, emask, pnes);  // (reads the row's contributions)
+                    pool_push(has, acc, d);
+                    if (mine)
+                        for (uint32_t t = 0; t < mq; ++t) S.contrib[(r << LRT) + t] = 0.0;
 #ifdef VBM25_PROFILE
-                    prof[10] += nmp;
+                    if (wave == 0) prof[10] += nmp;
 #endif
-                }
-                if (lane == 0) {
-                    S.rows_seen = nm;
-                    if (tile != 0) S.nrows[ppar] = 0;
-                    S.pool_snap = S.pool_n;   // (nobody else pushes between the barriers A and B)
-                    S.late_snap = S.nlate;
-                    S.theta_zero = S.theta == 0ull ? 1u : 0u;
                 }
             }
             PROF_T(t_e);
-            lds_barrier();  // ---- B: done bits and hit records complete; filter and hash set clean; rows of the previous tile in the pool
-            PROF_T(t_f);
-            PROF_ADD(4, t_e, t_f);
-            if (uni(S.fail)) {
-                failed = true;
-                break;
-            }
-
-            // ---- pool housekeeping + cold pass: blocks whose upper bound reaches the threshold (search.rs:203), per
-            // worker over its own blocks; ids from the wave's own stage rows; tf / fieldnorm bytes of up to four blocks in
-            // flight together.  A block that finds no room in the pool stays pending: the pool is shrunk (which raises the
-            // threshold) and the pass repeated.  While the item knows no threshold at all (its first tile), the pass runs
-            // twice: first the single-term scores only feed a histogram whose k-th entry starts the threshold, then the
-            // few postings at or above it are pushed.
-            uint32_t pending = 0;
-            if (wave != 0 && any_cold) pending = uni(S.coldw[buf][wave]) & ((1u << nv) - 1u);
-            const bool boot = any_cold && uni(S.theta_zero) != 0u;  // (snapshot taken before barrier B: uniform)
-            const double nesum = pne ? S.t_cum[pne] : 0.0;
-            uint32_t emask = 0xffffffffu;  // bit t: term t is essential
-            if (pne && any_cold) {
-                emask = 0;
-                for (uint32_t t = 0; t < mq; ++t) emask |= ((uint32_t)S.t_rank[t] >= pne ? 1u : 0u) << t;
-            }
-            // mode 0: push; mode 1: histogram of the scores only
-            auto cold_blocks = [&](uint32_t mode) {
-                uint32_t *bh = S.bm;
-                uint32_t todo = pending;
-                while (todo) {
-                    uint32_t gi[4];
-                    uint32_t n4 = 0;
-#pragma unroll
-                    for (int g = 0; g < 4; ++g) {
-                        gi[g] = 0;
-                        if (todo) {
-                            gi[g] = (uint32_t)__ffs((int)todo) - 1u;
-                            todo &= todo - 1u;
-                            ++n4;
-                        }
-                    }
-                    uint32_t l0[4], h0[4], l1[4], h1[4], fnp[4];
-                    uint32_t skip = 0;  // bit g: block not scored in this pass (below the threshold: done; no room: next round)
-                    const double thd = __longlong_as_double((long long)theta_now());
-#pragma unroll
-                    for (int g = 0; g < 4; ++g) {
-                        l0[g] = h0[g] = l1[g] = h1[g] = fnp[g] = 0;
-                        if ((uint32_t)g < n4) {
-                            const uint32_t e = (wave - 1u) + (RNW - 1) * gi[g];
-                            const float pubv = __uint_as_float(uni(__float_as_uint(S.pub[buf][e])));
-                            if (thd > (double)pubv * (1.0 + 1e-7) + nesum) {  // the planner decided one tile early: the threshold of now
-                                pending &= ~(1u << gi[g]);
-                                skip |= 1u << g;
-                            } else if (mode == 0 && uni(S.pool_n) >= POOL_COLD) {
-                                skip |= 1u << g;  // no room at all: next round
-                            } else {
-                                const uint4 sj = uni4(S.pm[buf][e]);
-                                const uint32_t blkj = uni(S.pa[buf][e].x);
-                                const uint32_t nj = sj.w & 0xff, mdj = (sj.w >> 8) & 0xff, mtj = (sj.w >> 16) & 0xff;
-                                VCHK(e < np && blkj < ix.n_blocks && 8ull * sj.z < ix.blob_bytes, 31, e);
-                                const uint8_t *tbody = ix.blob + 8ull * sj.z + ((payload_bytes(mdj, nj) + 7u) & ~7u);
-                                const FieldAddr f0 = field_addr(mtj, nj, 2 * lane), f1 = field_addr(mtj, nj, 2 * lane + 1);
-                                l0[g] = *reinterpret_cast<const uint32_t *>(tbody + f0.off0);
-                                h0[g] = *reinterpret_cast<const uint32_t *>(tbody + f0.off1);
-                                l1[g] = *reinterpret_cast<const uint32_t *>(tbody + f1.off0);
-                                h1[g] = *reinterpret_cast<const uint32_t *>(tbody + f1.off1);
-                                fnp[g] = reinterpret_cast<const uint16_t *>(ix.post_fn + 128ull * blkj)[lane];
-                            }
-                        }
-                    }
-#pragma unroll
-                    for (int g = 0; g < 4; ++g) {
-                        if ((uint32_t)g < n4 && !((skip >> g) & 1u)) {
-                            const uint32_t i = gi[g];
-                            const uint32_t e = (wave - 1u) + (RNW - 1) * i;
-                            const uint4 sj = uni4(S.pm[buf][e]);
-                            const uint32_t fl = uni(S.pa[buf][e].y), t = fl & 0xffu, slot = (fl >> 8) & 0xffu;
-                            uint32_t rel0, rel1;
-                            if ((fl >> 16) & 1u) {
-                                const uint2 dd = *reinterpret_cast<const uint2 *>(&S.stage[slot * 64u + 2u * lane]);
-                                rel0 = dd.x;
-                                rel1 = dd.y;
-                            } else {
-                                const uint32_t dd = S.stage[slot * 64u + lane];
-                                rel0 = dd & 0xffffu;
-                                rel1 = dd >> 16;
-                            }
-                            const uint32_t nj = sj.w & 0xff, mtj = (sj.w >> 16) & 0xff;
-                            const uint32_t d0 = sj.x + rel0, d1 = sj.x + rel1;
-                            const uint32_t dwi = S.done[e * 4 + (lane >> 4)];
-                            bool ok0 = 2 * lane < nj && d0 - tlo < span && !((dwi >> ((2 * lane) & 31)) & 1u);
-                            bool ok1 = 2 * lane + 1 < nj && d1 - tlo < span && !((dwi >> ((2 * lane + 1) & 31)) & 1u);
-                            const FieldAddr f0 = field_addr(mtj, nj, 2 * lane), f1 = field_addr(mtj, nj, 2 * lane + 1);
-                            const double s0t = S.t_s0[t];
-                            const double tf0 = (double)field_val(l0[g], h0[g], f0), tf1 = (double)field_val(l1[g], h1[g], f1);
-                            double p0 = (tf0 * s0t) / (tf0 + S.s1[fnp[g] & 0xff]);
-                            double p1 = (tf1 * s0t) / (tf1 + S.s1[fnp[g] >> 8]);
-                            if (mode == 1) {  // (non-essential terms: the single-term score is a lower bound of the document's -- as good)
-                                if (ok0) atomicAdd(&bh[min((uint32_t)(p0 * S.hscale), (uint32_t)(CUR_HB - 1))], 1u);
-                                if (ok1) atomicAdd(&bh[min((uint32_t)(p1 * S.hscale), (uint32_t)(CUR_HB - 1))], 1u);
-                                continue;
-                            }
-                            if (pne != 0 && __ballot(ok0 || ok1)) {  // completion by lookups in the non-essential lists
-                                p0 = complete(ok0, d0, NONE32, t, p0, p0, emask, nesum);
-                                p1 = complete(ok1, d1, NONE32, t, p1, p1, emask, nesum);
-                            }
-                            const unsigned long long thb = theta_now();
-                            const bool a0 = ok0 && (unsigned long long)__double_as_longlong(p0) >= thb && p0 != 0.0;
-                            const bool a1 = ok1 && (unsigned long long)__double_as_longlong(p1) >= thb && p1 != 0.0;
-                            const unsigned long long am0 = __ballot(a0), am1 = __ballot(a1);
-                            const uint32_t c0 = (uint32_t)__popcll(am0), cnt = c0 + (uint32_t)__popcll(am1);
-                            if (cnt) {  // room for exactly the postings that pass, reserved with one atomic
-                                // (compare-and-swap, not add-then-undo: an undo that is not the last reservation leaves a hole)
-                                uint32_t base = NONE32;
-                                if (lane == 0) {
-                                    uint32_t old = S.pool_n;
-                                    while (old + cnt <= POOL_COLD) {
-                                        const uint32_t prev = atomicCAS(&S.pool_n, old, old + cnt);
-                                        if (prev == old) {
-                                            base = old;
-                                            break;
-                                        }
-                                        old = prev;
-                                    }
-                                }
-                                base = uni(base);
-                                if (base == NONE32) continue;  // next round (after the shrink)
-                                const uint32_t q0 = base + __builtin_amdgcn_mbcnt_hi((uint32_t)(am0 >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)am0, 0u));
-                                const uint32_t q1 = base + c0 + __builtin_amdgcn_mbcnt_hi((uint32_t)(am1 >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)am1, 0u));
-                                VCHK(!a0 || p0 * S.hscale < (double)CUR_HB, 22, d0);
-                                VCHK(!a1 || p1 * S.hscale < (double)CUR_HB, 22, d1);
-                                if (a0) {
-                                    S.pool_s[q0] = (unsigned long long)__double_as_longlong(p0);
-                                    S.pool_d[q0] = d0;
-                                    const double hb = p0 * S.hscale;
-                                    atomicAdd(&hrow[hb >= (double)(CUR_HB - 1) ? (uint32_t)(CUR_HB - 1) : (uint32_t)hb], 1u);
-                                }
-                                if (a1) {
-                                    S.pool_s[q1] = (unsigned long long)__double_as_longlong(p1);
-                                    S.pool_d[q1] = d1;
-                                    const double hb = p1 * S.hscale;
-                                    atomicAdd(&hrow[hb >= (double)(CUR_HB - 1) ? (uint32_t)(CUR_HB - 1) : (uint32_t)hb], 1u);
-                                }
-                            }
-                            pending &= ~(1u << i);
-#ifdef VBM25_PROFILE
-                            prof[11] += 1;
-#endif
-                        }
-                    }
-                }
-            };
-            bool stop = false;
-            for (uint32_t round = 0;; ++round) {
-                // (uniform decisions: the snapshots were taken before barrier B, a later round follows barrier C)
-                const bool late_full = round == 0 ? uni(S.late_snap) > (uint32_t)R_LATE / 2u : uni(S.nlate) > (uint32_t)R_LATE / 2u;
-                const bool pool_full = round == 0 ? uni(S.pool_snap) > POOL_HIGH : true;
-                if (late_full) {
-                    shrink_pool();   // room for the late documents' scores first
-                    if (!uni(S.fail)) flush_late();
-                }
-                if ((pool_full || late_full) && !uni(S.fail)) shrink_pool();
-                if (uni(S.fail)) {
-                    stop = true;
-                    break;
-                }
-                if (!any_cold) break;
-                if (boot && round == 0) {
-                    // no threshold yet: the k-th best single-term score of the tile's cold postings (documents with one
-                    // posting in the tile: distinct, and the score is the document's) starts it
-                    cold_blocks(1);
-                    lds_barrier();
-                    if (wave == 0) {
-                        const uint4 c4 = *reinterpret_cast<const uint4 *>(&S.bm[4 * lane]);
-                        const uint32_t own = c4.x + c4.y + c4.z + c4.w;
-                        const uint32_t incl = wave_incl_scan_u32(own);
-                        const uint32_t total = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
-                        const uint32_t above = total - incl;
-                        const unsigned long long hit = __ballot(above + own >= k);
-                        if (hit) {
-                            const uint32_t hl = 63u - (uint32_t)__builtin_clzll(hit);
-                            uint32_t a = (uint32_t)__builtin_amdgcn_readlane((int)above, (int)hl), b = 4 * hl;
-                            const uint32_t c3 = (uint32_t)__builtin_amdgcn_readlane((int)c4.w, (int)hl);
-                            const uint32_t c2 = (uint32_t)__builtin_amdgcn_readlane((int)c4.z, (int)hl);
-                            const uint32_t c1 = (uint32_t)__builtin_amdgcn_readlane((int)c4.y, (int)hl);
-                            if (a + c3 >= k) b += 3;
-                            else if (a + c3 + c2 >= k) b += 2;
-                            else if (a + c3 + c2 + c1 >= k) b += 1;
-                            const double edge = ((double)b / S.hscale) * (1.0 - 1e-12);
-                            if (lane == 0) atomicMax(&S.theta, (unsigned long long)__double_as_longlong(edge));
-                        }
-                    }
-                    lds_barrier();
-                    if (tid < CUR_HB) S.bm[tid] = 0;  // (the filter's words again; barrier C below orders this before the next S1)
-                }
-                cold_blocks(0);
-                if (pending && lane == 0) S.cold_retry = 1;
-                lds_barrier();  // ---- C (tiles with cold blocks only)
-                const bool again = uni(S.cold_retry) != 0;
-                lds_barrier();
-                if (!again) break;
-                if (tid == 0) S.cold_retry = 0;
-                if (round >= 64u) {  // (a block that never fits: masses of equal scores)
-                    if (tid == 0) S.fail = 6;
-                    lds_barrier();
-                    stop = true;
-                    break;
-                }
-            }
-            if (stop) {
-                failed = true;
-                break;
-            }
-            // this wave's done bits of the tile
-            if (wave != 0 && lane < 4 * RB) S.done[((wave - 1u) + (RNW - 1) * (lane >> 2)) * 4 + (lane & 3)] = 0;
-            PROF_T(t_g);
-            PROF_ADD(5, t_f, t_g);
+            PROF_ADD(3, t_c, t_e);
             np_prev = np;
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // (an LDS-DMA in flight must not land in the next item's LDS)

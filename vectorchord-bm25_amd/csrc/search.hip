@@ -401,6 +401,7 @@ static int vbm25_index_create_impl(const vbm25_index_desc *d, int device, vbm25_
     ix->dev.doc_payload = ix->doc_payload.as<uint16_t>();
     ix->dev.s1 = ix->s1.as<double>();
     ix->dev.blob_bytes = d->blob_bytes;
+    ix->dev.blk_ub_attained = d->blk_wand_fn && d->blk_wand_tf ? 1u : 0u;
     {   // for vbm25_evaluate_batch: per-term idf (host libm log, bm25.rs:285-289) and the fieldnorm table
         std::vector<double> idf(d->n_terms);
         for (uint32_t t = 0; t < d->n_terms; ++t)
