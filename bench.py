@@ -7,10 +7,15 @@ five-term queries, top-10, one MI355X.  --workload C5 is configs[4] (50M docs / 
 10-term / top-100), C2 the single 3-term query on 1M docs (adds host-inclusive latencies), C1 the plumbing
 case.
 
+The timed loop ROTATES through --batches (default 4) different query batches of the workload's shape, every
+one resident in HBM before the clock starts: four C3 batches touch 1.9 GB of postings, far more than the 256 MiB
+Infinity Cache, so a step's reads come from HBM and not from the previous step's leftovers.
+
 With --gpus N (launched by torch.distributed.run, one rank per GPU) the run is BASELINE.json configs[3]
-("C4"): rank 0 makes ONE batch of N x 1024 queries, broadcasts the two descriptor arrays (RCCL), every
+("C4"): rank 0 makes the N x 1024 queries of every batch, broadcasts the two descriptor arrays (RCCL), every
 rank keeps its contiguous shard, searches it against its replica of the index, and the hit records are
-gathered to rank 0.  The broadcast is paid once (scatter_ms); the gather is inside every step (gather_ms).
+gathered to rank 0 on a second stream while the next step's scan is already running.  The broadcast is paid
+once (scatter_ms); the gather is inside every step (gather_ms, of which gather_exposed_ms is not hidden).
 
 Prints ONE JSON line (rank 0).  See DESIGN.md "Measurement".
 """
@@ -94,6 +99,7 @@ def make_queries(seg, vocab, nq, nterms, seed, zipf_s):
 
 
 def oracle_index(seg):
+    """The checker (oracle/): only --verify and the cpu_baseline leg use it."""
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import orc
 
@@ -129,47 +135,26 @@ def cpu_baseline(oix, terms, off, k, budget_s=20.0):
             "t1_qps": round(t1, 2), "tn_qps": round(tn, 2), "brute_force_tn_qps": round(nb / dtb, 2),
             "repetitions": reps, "statistic": "median", "cpu_model": cpu_model(),
             "compiler_flags": "g++ -O3 -DNDEBUG -march=x86-64-v3 -ffp-contract=off",
-            "sample": f"first {nn} of the batch's {nq} queries at T={cores} ({n1} at T=1), Block-WAND "
+            "sample": f"first {nn} of the first batch's {nq} queries at T={cores} ({n1} at T=1), Block-WAND "
                       f"restatement of search.rs:28-282 over in-memory arrays (oracle/), one query per thread"}
 
 
-class OracleScorer:
-    """CPU stand-in used ONLY by the gloo test of this script's distributed path
-    (VBM25_BENCH_BACKEND=gloo): same interface as the GPU batch, results from the oracle."""
-
-    def __init__(self, oix, nq, k):
-        import torch
-
-        self.oix, self.k, self.nq = oix, k, nq
-        self.words = torch.zeros(nq * k * 3, dtype=torch.int64)
-
-    def set_queries(self, terms, off):
-        self.terms, self.off = terms, off
-
-    def run(self, stream=None):
-        import torch
-
-        hits, nh, _ = self.oix.search_batch(self.terms, self.off, self.k, mode="brute", threads=1)
-        self.hits, self.nh = hits, nh
-        self.words.copy_(torch.from_numpy(np.frombuffer(hits.tobytes(), dtype=np.int64).copy()))
-
-    def fetch(self):
-        return self.hits, self.nh
-
-
-def main():
+def run(argv=None, scorer_factory=None, backend="nccl"):
+    """The whole bench.  scorer_factory / backend exist for tests/test_sharded_gloo.py, which runs this very
+    function under gloo with a CPU stand-in for the GPU batch objects; the product never passes them."""
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--workload", default="C3", choices=sorted(WORKLOADS))
     ap.add_argument("--queries", type=int, default=0, help="override queries per GPU")
+    ap.add_argument("--batches", type=int, default=4, help="distinct query batches the timed loop rotates through")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--verify", action="store_true",
-                    help="check every query of the batch bit-exact against the oracle (outside the timed region)")
+                    help="check every query of every batch bit-exact against the oracle (outside the timed region)")
     ap.add_argument("--build-threads", type=int, default=0)
     ap.add_argument("--cache", default="", help="segment file: load if present, else build and save")
-    args = ap.parse_args()
+    args = ap.parse_args(argv)
 
     import torch
 
@@ -180,12 +165,12 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run")
-    gloo = os.environ.get("VBM25_BENCH_BACKEND") == "gloo"  # CPU test of the distributed path only
-    if not gloo:
+    on_gpu = scorer_factory is None
+    if on_gpu:
         if not torch.cuda.is_available():
             raise SystemExit("bench.py needs an MI355X: the HIP path has no CPU fallback")
         torch.cuda.set_device(local_rank)
-    dev = "cpu" if gloo else f"cuda:{local_rank}"
+    dev = f"cuda:{local_rank}" if on_gpu else "cpu"
     dist = None
     # VBM25_BENCH_FORCE_DIST=1 runs the RCCL code path even with one rank (GPU test of the N>1 path)
     use_dist = world > 1 or os.environ.get("VBM25_BENCH_FORCE_DIST") == "1"
@@ -193,18 +178,19 @@ def main():
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29511")
-        if gloo:
-            dist.init_process_group("gloo", rank=rank, world_size=world)
+        if on_gpu:
+            dist.init_process_group(backend, rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
         else:
-            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+            dist.init_process_group(backend, rank=rank, world_size=world)
 
     def sync():
-        if not gloo:
+        if on_gpu:
             torch.cuda.synchronize()
 
     n_docs, vocab, mean_len, len_mode, zipf_s, nq, nterms, k = WORKLOADS[args.workload]
     if args.queries:
         nq = args.queries
+    nb = max(1, args.batches if args.workload != "C2" else 1)
     threads = args.build_threads or usable_cpus()
     t0 = time.perf_counter()
     cache = args.cache
@@ -236,132 +222,157 @@ def main():
         if use_dist:
             dist.barrier()
     t_build = time.perf_counter() - t0
-    oix = None
     t0 = time.perf_counter()
-    gix = None if gloo else vb.GpuIndex(seg, device=local_rank)
+    gix = vb.GpuIndex(seg, device=local_rank) if on_gpu else None
     t_upload = time.perf_counter() - t0
 
-    # ---- the batch: rank 0 makes all world x nq queries, broadcasts the descriptors, every rank keeps its shard
+    # ---- the batches: rank 0 makes all world x nq queries of each, broadcasts the descriptors, every rank keeps its shard
     n_total = world * nq
     scatter_ms = 0.0
-    if use_dist:
-        if rank == 0:
-            terms_all, off_all = make_queries(seg, vocab, n_total, nterms, seed=1, zipf_s=zipf_s)
-        else:
-            terms_all = np.zeros(n_total * nterms, dtype=np.uint32)
-            off_all = np.zeros(n_total + 1, dtype=np.uint32)
-        sync()
-        dist.barrier()
-        t0 = time.perf_counter()
-        tt = torch.from_numpy(terms_all.astype(np.int32)).to(dev)
-        ot = torch.from_numpy(off_all.astype(np.int32)).to(dev)
-        dist.broadcast(tt, 0)
-        dist.broadcast(ot, 0)
-        sync()
-        terms_all = tt.cpu().numpy().astype(np.uint32)
-        off_all = ot.cpu().numpy().astype(np.uint32)
-        terms, off = vb.sharded.shard_queries(terms_all, off_all, world, rank)
-        scatter_ms = 1e3 * (time.perf_counter() - t0)
-    else:
-        terms, off = make_queries(seg, vocab, nq, nterms, seed=1, zipf_s=zipf_s)
-    nq_local = len(off) - 1
-    algo_bytes = sum(seg.query_bytes(terms[off[q]:off[q + 1]], k) for q in range(nq_local))
-
-    if gloo:
-        oix = oracle_index(seg)
-        batch = OracleScorer(oix, nq_local, k)
-        batch.set_queries(terms, off)
-        local = batch.words
-        stream_ptr = None
-    else:
-        batch = vb.Batch(gix, nq_local, len(terms), k)
-        batch.set_queries(terms, off)
-        stream = torch.cuda.current_stream()
-        stream_ptr = stream.cuda_stream
-        local = None
+    shards = []  # per batch: (terms, off) of this rank
+    for bi in range(nb):
         if use_dist:
+            if rank == 0:
+                terms_all, off_all = make_queries(seg, vocab, n_total, nterms, seed=1 + bi, zipf_s=zipf_s)
+            else:
+                terms_all = np.zeros(n_total * nterms, dtype=np.uint32)
+                off_all = np.zeros(n_total + 1, dtype=np.uint32)
+            sync()
+            dist.barrier()
+            t0 = time.perf_counter()
+            tt = torch.from_numpy(terms_all.astype(np.int32)).to(dev)
+            ot = torch.from_numpy(off_all.astype(np.int32)).to(dev)
+            dist.broadcast(tt, 0)
+            dist.broadcast(ot, 0)
+            sync()
+            terms_all = tt.cpu().numpy().astype(np.uint32)
+            off_all = ot.cpu().numpy().astype(np.uint32)
+            shards.append(vb.sharded.shard_queries(terms_all, off_all, world, rank))
+            scatter_ms += 1e3 * (time.perf_counter() - t0) / nb
+        else:
+            shards.append(make_queries(seg, vocab, nq, nterms, seed=1 + bi, zipf_s=zipf_s))
+    nq_local = len(shards[0][1]) - 1
+    algo_bytes = [sum(seg.query_bytes(t[o[q]:o[q + 1]], k) for q in range(nq_local)) for t, o in shards]
+
+    batches, locals_ = [], []
+    for t, o in shards:
+        if on_gpu:
+            b = vb.Batch(gix, nq_local, len(t), k)
+        else:
+            b = scorer_factory(seg, nq_local, k)
+        b.set_queries(t, o)
+        batches.append(b)
+        if not use_dist:
+            locals_.append(None)
+        elif on_gpu:
             import ctypes as C
             hp, nh = C.c_void_p(), C.c_void_p()
-            vb._lib.check(vb.lib().vbm25_batch_device_results(batch.h, C.byref(hp), C.byref(nh)))
-            local = torch.as_tensor(_DevArray(hp.value, nq_local * k * 3), device=dev)
+            vb._lib.check(vb.lib().vbm25_batch_device_results(b.h, C.byref(hp), C.byref(nh)))
+            locals_.append(torch.as_tensor(_DevArray(hp.value, nq_local * k * 3), device=dev))
+        else:
+            locals_.append(b.words)
 
-    gather_s = [0.0]
+    # ---- one step: the scan on the scan stream; the gather of its records on a second stream, so that the next
+    # step's scan does not wait for it (every batch object has its own result buffers)
+    s_scan = torch.cuda.current_stream() if on_gpu else None
+    s_gather = torch.cuda.Stream() if (on_gpu and use_dist) else None
+    stream_ptr = s_scan.cuda_stream if on_gpu else None
+    gather_events, gather_cpu_s = [], [0.0]
+    last_gathered = [None]
 
-    def step():
-        batch.run(stream_ptr)
-        if use_dist:  # the path's only exchange: the top-k records go to rank 0
-            if gloo:
-                t0 = time.perf_counter()
-                out = vb.sharded.gather_to_root(local, n_total, k)
-                gather_s[0] += time.perf_counter() - t0
-                return out
+    def step(i):
+        b = batches[i % nb]
+        b.run(stream_ptr)
+        if not use_dist:
+            return
+        if not on_gpu:
+            t0 = time.perf_counter()
+            last_gathered[0] = vb.sharded.gather_to_root(locals_[i % nb], n_total, k)
+            gather_cpu_s[0] += time.perf_counter() - t0
+            return
+        done = s_scan.record_event()
+        with torch.cuda.stream(s_gather):
+            s_gather.wait_event(done)
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
-            out = vb.sharded.gather_to_root(local, n_total, k)
+            last_gathered[0] = vb.sharded.gather_to_root(locals_[i % nb], n_total, k)
             e1.record()
             gather_events.append((e0, e1))
-            return out
 
-    gather_events = []
-    for _ in range(args.warmup):
-        step()
+    for i in range(args.warmup):
+        step(i)
     sync()
     gather_events.clear()
-    gather_s[0] = 0.0
+    gather_cpu_s[0] = 0.0
     if use_dist:
         dist.barrier()
-    if not gloo:
-        batch.set_timing(True)
+    if on_gpu:
+        for b in batches:
+            b.set_timing(True)
     sync()
     t0 = time.perf_counter()
-    gathered = None
-    for _ in range(args.steps):
-        gathered = step()
+    for i in range(args.steps):
+        step(i)
+    t_scan_done = None
+    if on_gpu and use_dist:
+        s_scan.synchronize()  # every scan done; what is left now is gather time that nothing hides
+        t_scan_done = time.perf_counter()
     sync()
     if use_dist:
         dist.barrier()
     elapsed = time.perf_counter() - t0
-    kernel_ms, n_launch = (0.0, 0) if gloo else batch.kernel_ms()
-    if not gloo:
-        batch.set_timing(False)
-    gather_ms = 0.0
+    kernel_ms, n_launch = 0.0, 0
+    if on_gpu:
+        parts = [b.kernel_ms() for b in batches]
+        n_launch = sum(n for _, n in parts)
+        kernel_ms = sum(ms * n for ms, n in parts) / max(1, n_launch)
+        for b in batches:
+            b.set_timing(False)
+    gather_ms = gather_exposed_ms = 0.0
     if use_dist:
-        gather_ms = (1e3 * gather_s[0] / args.steps if gloo else
-                     sum(a.elapsed_time(b) for a, b in gather_events) / max(1, len(gather_events)))
+        if on_gpu:
+            gather_ms = sum(a.elapsed_time(b) for a, b in gather_events) / max(1, len(gather_events))
+            gather_exposed_ms = 1e3 * (time.perf_counter() - t_scan_done) / args.steps if t_scan_done else 0.0
+        else:
+            gather_ms = gather_exposed_ms = 1e3 * gather_cpu_s[0] / args.steps
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
     # ---- outside the timed region ----
     pcie_qps = None
-    if not gloo:  # the same batch through the host-buffer boundary (upload queries, run, download hits)
+    if on_gpu:  # the first batch through the host-buffer boundary (upload queries, run, download hits)
         t0 = time.perf_counter()
         for _ in range(5):
-            batch.set_queries(terms, off)
-            batch.run(stream_ptr)
-            hits, n_hits = batch.fetch()
+            batches[0].set_queries(*shards[0])
+            batches[0].run(stream_ptr)
+            batches[0].fetch()
         pcie_qps = 5 * nq_local / (time.perf_counter() - t0)
-    hits, n_hits = batch.fetch()
-    assert (n_hits == k).all() or args.workload in ("C1",), "missing hits"
-    s = hits["score"]
-    assert (s[:, :-1] >= s[:, 1:]).all()
-    if use_dist and rank == 0 and gathered is not None:  # rank 0's shard sits first in the gathered records
-        got = gathered.cpu().numpy()[:nq_local * k * 3]
-        assert got.tobytes() == np.frombuffer(hits.tobytes(), dtype=np.int64).tobytes(), "gathered records differ"
+    results = [b.fetch() for b in batches]
+    for hits, n_hits in results:
+        assert (n_hits == k).all() or args.workload in ("C1",), "missing hits"
+        s = hits["score"]
+        assert (s[:, :-1] >= s[:, 1:]).all()
+    if use_dist and rank == 0 and last_gathered[0] is not None:  # rank 0's shard sits first in the gathered records
+        hits_last = results[(args.steps - 1) % nb][0]
+        got = last_gathered[0].cpu().numpy()[:nq_local * k * 3]
+        assert got.tobytes() == np.frombuffer(hits_last.tobytes(), dtype=np.int64).tobytes(), "gathered records differ"
 
+    oix = None
     verified = None
-    if args.verify:  # full parity of this rank's batch, bit-exact against the oracle's brute force
-        oix = oix or oracle_index(seg)
+    if args.verify:  # full parity of this rank's batches, bit-exact against the oracle's brute force
+        oix = oracle_index(seg)
         t0 = time.perf_counter()
-        ob, onb, _ = oix.search_batch(terms, off, k, mode="brute", threads=usable_cpus())
-        assert np.array_equal(n_hits, onb), "hit counts differ from the oracle"
-        assert np.array_equal(hits["doc_id"], ob["doc_id"]), "doc ids differ from the oracle"
-        assert np.array_equal(hits["score"].view(np.uint64), ob["score"].view(np.uint64)), "score bits differ"
-        assert np.array_equal(hits["payload"], ob["payload"]), "payloads differ"
-        verified = {"queries": int(nq_local), "seconds": round(time.perf_counter() - t0, 2)}
+        for (t, o), (hits, n_hits) in zip(shards, results):
+            ob, onb, _ = oix.search_batch(t, o, k, mode="brute", threads=usable_cpus())
+            assert np.array_equal(n_hits, onb), "hit counts differ from the oracle"
+            assert np.array_equal(hits["doc_id"], ob["doc_id"]), "doc ids differ from the oracle"
+            assert np.array_equal(hits["score"].view(np.uint64), ob["score"].view(np.uint64)), "score bits differ"
+            assert np.array_equal(hits["payload"], ob["payload"]), "payloads differ"
+        verified = {"queries": int(nq_local * nb), "batches": nb, "seconds": round(time.perf_counter() - t0, 2)}
 
     latency = None
-    if args.workload == "C2" and not gloo and world == 1:
+    if args.workload == "C2" and on_gpu and world == 1:
         # host-inclusive latency of vbm25_search_batch(nq = 1): 1000 different 3-term queries
         lt, lo = make_queries(seg, vocab, 1000, nterms, seed=7, zipf_s=zipf_s)
         one = np.array([0, nterms], dtype=np.uint32)
@@ -378,17 +389,17 @@ def main():
         import ctypes as C
         L = vb.lib()
         hb = np.zeros((1, k), dtype=vb.HIT_DTYPE)
-        nb = np.zeros(1, dtype=np.uint32)
+        nbuf = np.zeros(1, dtype=np.uint32)
         lt = np.ascontiguousarray(lt, dtype=np.uint32)
         base, po = lt.ctypes.data, C.c_void_p(one.ctypes.data)
-        ph, pn = C.c_void_p(hb.ctypes.data), C.c_void_p(nb.ctypes.data)
+        ph, pn = C.c_void_p(hb.ctypes.data), C.c_void_p(nbuf.ctypes.data)
         uc = []
         for q in range(1000):
             pt = C.c_void_p(base + 4 * int(lo[q]))
             t0 = time.perf_counter()
             rc = L.vbm25_search_batch(gix.h, pt, po, 1, k, ph, pn)
             uc.append(1e6 * (time.perf_counter() - t0))
-            assert rc == 0 and nb[0] == k
+            assert rc == 0 and nbuf[0] == k
         uc.sort()
         latency = {"search_batch_nq1_us_p50": round(us[500], 1), "search_batch_nq1_us_p99": round(us[990], 1),
                    "c_abi_nq1_us_p50": round(uc[500], 1), "c_abi_nq1_us_p99": round(uc[990], 1),
@@ -409,32 +420,35 @@ def main():
             "dtype": "f64", "data": "synthetic",
             "config": {"workload": f"{args.workload if world == 1 else 'C4'}: {n_docs} docs / {vocab} vocab / "
                                    f"{nq_local} x {nterms}-term queries per GPU / top-{k}",
+                       "batches_rotated": nb,
                        "doc_length": "lognormal(ln 80, 0.6) clamp [8,2000]" if len_mode == 1 else f"fixed {mean_len}",
                        "token_distribution": f"zipf({zipf_s})" if zipf_s > 0 else "uniform",
-                       "k1": 1.2, "b": 0.75, "index_hbm_bytes": None if gloo else gix.device_bytes,
+                       "k1": 1.2, "b": 0.75, "index_hbm_bytes": gix.device_bytes if on_gpu else None,
                        "postings": int(seg.arrays()["term_df"].astype(np.int64).sum()),
-                       "parallelism": f"one {n_total}-query batch sharded over {world} GPU(s), index replicated",
+                       "parallelism": f"{nb} batches of {n_total} queries, each sharded over {world} GPU(s), index replicated",
                        "build_s": round(t_build, 2), "upload_s": round(t_upload, 2),
                        "scatter_ms": round(scatter_ms, 3), "gather_ms": round(gather_ms, 4),
+                       "gather_exposed_ms": round(gather_exposed_ms, 4),
                        "host_buffer_inclusive_qps_per_gpu": None if pcie_qps is None else round(pcie_qps, 1)},
         }
         if verified:
             out["config"]["verified_bit_exact_vs_oracle"] = verified
         if latency:
             out["config"]["latency"] = latency
-        if not gloo:
-            achieved = algo_bytes / (kernel_ms * 1e-3) / 1e9 if kernel_ms > 0 else 0.0
+        if on_gpu:
+            algo = sum(algo_bytes) / len(algo_bytes)
+            achieved = algo / (kernel_ms * 1e-3) / 1e9 if kernel_ms > 0 else 0.0
             out["roofline"] = {"bound": "hbm", "kernel": "scan_dense_kernel" if dense else "scan_range_kernel",
                                "achieved": round(achieved, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                                "frac": round(achieved / HBM_PEAK_GBPS, 4),
-                               # HBM bytes per launch come from separate rocprofv3 --pmc passes (tools/r2_pmc.sh,
-                               # summaries under profiles/); they are not collected inside this run
+                               # HBM bytes per launch come from separate rocprofv3 --pmc passes (summaries under
+                               # profiles/); they are not collected inside this run
                                "traffic": None,
-                               "algorithmic_bytes_per_launch": int(algo_bytes),
+                               "algorithmic_bytes_per_launch": int(algo),
                                "kernel_ms": round(kernel_ms, 4), "launches_timed": n_launch}
-        if world == 1 and not args.no_cpu_baseline and not gloo:
+        if world == 1 and not args.no_cpu_baseline and on_gpu:
             oix = oix or oracle_index(seg)
-            out["cpu_baseline"] = cpu_baseline(oix, terms, off, k)
+            out["cpu_baseline"] = cpu_baseline(oix, shards[0][0], shards[0][1], k)
         result_line = json.dumps(out)
     if use_dist:
         if rank == 0 and not args.cache and cache and os.path.exists(cache):
@@ -443,6 +457,11 @@ def main():
     if rank == 0:
         sys.stdout.flush()
         print(result_line, flush=True)
+    return use_dist
+
+
+def main():
+    use_dist = run()
     if use_dist:
         # librccl prints a version banner to stdout from its exit handlers; the contract is ONE
         # JSON line from rank 0, so leave without running them (everything is flushed and the

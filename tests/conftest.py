@@ -8,11 +8,21 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 
-# The library sends batches of fewer than 64 work items to the tile kernel (single-query latency).  The
-# parity tests are small by design, so they switch that rule off: every query of <= 8 terms, k <= 256 goes
-# through the cursor kernel, the one that serves the benchmark.  test_tiny_batches_take_the_tile_kernel
-# covers the rule itself.
-os.environ.setdefault("VBM25_CUR_MIN_ITEMS", "0")
+
+
+@pytest.fixture
+def tuning():
+    """Test-only switches of the library (vbm25_tuning_set: read when a batch object is created), reset afterwards:
+    tuning(dense_x1000=0) declares every query dense, tuning(dense=0) sends dense queries to the exhaustive
+    scan_many_kernel, tuning(ne=0) switches the MaxScore split off, tuning(fused=0) the one-launch route."""
+    import vectorchord_bm25_amd as vb
+
+    def set_(**kw):
+        for name, value in kw.items():
+            vb.set_tuning(name, value)
+
+    yield set_
+    vb.reset_tuning()
 
 
 def pytest_configure(config):

@@ -1,8 +1,7 @@
 """scan_dense_kernel (dense doc windows: 16-bit fixed-point upper-bound sums select, exact f64 sums decide; MaxScore
-split with block-max skipping; k <= 128 -- dense queries with a larger k take scan_many_kernel) through the C ABI
-against the CPU oracle.  -m gpu only.
+split with block-max skipping; k <= 256) through the C ABI against the CPU oracle.  -m gpu only.
 
-VBM25_DENSE_X1000=0 declares every query dense, which sends the whole range of corpora of the other parity
+tuning(dense_x1000=0) declares every query dense, which sends the whole range of corpora of the other parity
 tests -- sparse lists, tail blocks, raw width-32 blocks, unknown terms, ties -- through this kernel; the batch's
 debug counts prove that no item fell back to scan_many_kernel."""
 import os
@@ -48,7 +47,7 @@ def check_dense(gix, oix, terms, off, k, expect_failed=0):
 
 @pytest.mark.parametrize("n_docs,vocab,nq,nterms,k", [(300_000, 20_000, 96, 10, 100), (1_000_000, 50_000, 64, 6, 10),
                                                       (200_000, 5_000, 32, 16, 128), (200_000, 5_000, 16, 12, 256)])
-def test_zipf_corpora(monkeypatch, n_docs, vocab, nq, nterms, k):
+def test_zipf_corpora(tuning, n_docs, vocab, nq, nterms, k):
     sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
     from bench import make_queries as bench_queries
     seg = vb.Segment.synth(n_docs, vocab, mean_len=100, len_mode=1, zipf_s=1.0, seed=3)
@@ -58,28 +57,27 @@ def test_zipf_corpora(monkeypatch, n_docs, vocab, nq, nterms, k):
     # the same records without the MaxScore split, from the exhaustive kernel, and run twice (idempotence)
     h2, n2 = run_batch(gix, terms, off, k)
     assert h2.tobytes() == hits.tobytes()
-    monkeypatch.setenv("VBM25_NE", "0")
+    tuning(ne=0)
     h3, n3 = run_batch(gix, terms, off, k)
     assert h3.tobytes() == hits.tobytes() and np.array_equal(n3, nh)
-    monkeypatch.delenv("VBM25_NE")
-    monkeypatch.setenv("VBM25_DENSE", "0")
+    tuning(ne=1, dense=0)
     h4, n4 = run_batch(gix, terms, off, k, expect_failed=None)
     assert h4.tobytes() == hits.tobytes() and np.array_equal(n4, nh)
 
 
 @pytest.mark.parametrize("length,zipf,nterms,k", [
     ("fixed", None, 3, 10), ("lognormal", None, 5, 10), ("mixed", None, 2, 1),
-    ("lognormal", 1.0, 10, 100), ("lognormal", 1.0, 4, 7), ("fixed", None, 5, 128), ("fixed", None, 5, 200)])
-def test_every_query_declared_dense(monkeypatch, length, zipf, nterms, k):
-    monkeypatch.setenv("VBM25_DENSE_X1000", "0")
+    ("lognormal", 1.0, 10, 100), ("lognormal", 1.0, 4, 7), ("fixed", None, 5, 128), ("fixed", None, 5, 200), ("lognormal", 1.0, 6, 256)])
+def test_every_query_declared_dense(tuning, length, zipf, nterms, k):
+    tuning(dense_x1000=0)
     c = make_corpus(20000, 2000, seed=7, length=length, mean_len=60, zipf=zipf)
     seg, gix, oix = both(c)
     terms, off = make_queries(c, 48, nterms, seed=9, zipf=zipf)
     check_dense(gix, oix, terms, off, k)
 
 
-def test_edge_cases_dense(monkeypatch):
-    monkeypatch.setenv("VBM25_DENSE_X1000", "0")
+def test_edge_cases_dense(tuning):
+    tuning(dense_x1000=0)
     c = make_corpus(3000, 300, seed=3, length="lognormal", mean_len=50)
     seg, gix, oix = both(c)
     nt = gix.n_terms
@@ -103,8 +101,8 @@ def test_edge_cases_dense(monkeypatch):
     check_dense(gix, oix, terms, off, 200)
 
 
-def test_codec_corner_cases_and_ties_dense(monkeypatch):
-    monkeypatch.setenv("VBM25_DENSE_X1000", "0")
+def test_codec_corner_cases_and_ties_dense(tuning):
+    tuning(dense_x1000=0)
     # bitwidth-32 raw block, df == 128 exactly, single posting, 4-byte tf (see test_segment_builder)
     n_docs = 3_000_000
     docs_a = np.r_[np.arange(64), 2_900_000 + np.arange(64) * 3].astype(np.uint32)
@@ -123,7 +121,7 @@ def test_codec_corner_cases_and_ties_dense(monkeypatch):
     seg, gix, oix = both(seg=seg)
     terms = np.array([0, 1, 2, 3, 0, 1, 2, 3, 0, 3], dtype=np.uint32)
     off = np.array([0, 1, 2, 3, 4, 8, 10], dtype=np.uint32)
-    for k in (10, 100, 128, 256):  # (256: the exhaustive kernel's; the many tiny items of this index are the dense kernel's hard case)
+    for k in (10, 100, 128, 200, 256):  # (the many tiny items of this index are the dense kernel's hard case)
         check_dense(gix, oix, terms, off, k)
     # identical documents: every score ties, far more than k candidates per window (candidate rounds), the order
     # is by ascending id
@@ -142,8 +140,43 @@ def test_codec_corner_cases_and_ties_dense(monkeypatch):
         assert list(hits[0, :k]["doc_id"]) == list(range(k))
 
 
-def test_correlated_terms_dense(monkeypatch):
-    monkeypatch.setenv("VBM25_DENSE_X1000", "0")
+@pytest.mark.parametrize("items", [1024, 4096])
+def test_repetitions_are_byte_identical_dense(tuning, items):
+    """The shape that lost hits in one round-2 build of the k <= 256 instantiation (the codec corner-case index cut into
+    thousands of tiny items, every query declared dense): 50 runs per k, every one equal to the oracle byte for byte,
+    no item handed to the exhaustive kernel.  tools/dense_stress.py is the long form (assertion build, thresholds)."""
+    tuning(dense_x1000=0, dense_items=items)
+    n_docs = 3_000_000
+    docs_a = np.r_[np.arange(64), 2_900_000 + np.arange(64) * 3].astype(np.uint32)
+    docs_b = (np.arange(128) * 7 + 5).astype(np.uint32)
+    docs_c = np.array([123456], dtype=np.uint32)
+    docs_d = (np.arange(300) * 9000 + 17).astype(np.uint32)
+    rng = np.random.default_rng(0)
+    post_tf = np.r_[np.ones(128), rng.integers(1, 70000, 128), [1 << 30], rng.integers(1, 4, 300)].astype(np.uint32)
+    keys = np.zeros((4, 16), dtype=np.uint8)
+    keys[:, 0] = [ord("a"), ord("b"), ord("c"), ord("d")]
+    rng = np.random.default_rng(1)
+    seg = vb.Segment.build(1.2, 0.75, rng.integers(1, 3000, n_docs).astype(np.uint32),
+                           np.zeros((n_docs, 3), dtype=np.uint16), keys,
+                           np.array([0, 128, 256, 257, 557], dtype=np.uint64),
+                           np.r_[docs_a, docs_b, docs_c, docs_d], post_tf)
+    seg, gix, oix = both(seg=seg)
+    terms = np.array([0, 1, 2, 3, 0, 1, 2, 3, 0, 3], dtype=np.uint32)
+    off = np.array([0, 1, 2, 3, 4, 8, 10], dtype=np.uint32)
+    for k in (64, 128, 200, 256):  # (the three instantiations; 200 and 256 share the four-row one)
+        ob, onb, _ = oix.search_batch(terms, off, k, mode="brute", threads=8)
+        want = b"".join(ob[q, :onb[q]].tobytes() for q in range(6))
+        for rep in range(50):
+            hits, nh = run_batch(gix, terms, off, k, expect_failed=0)
+            assert np.array_equal(nh, onb), f"k={k} run {rep}: {nh} != {onb}"
+            got = b"".join(hits[q, :nh[q]].tobytes() for q in range(6))
+            if got != want:  # (the records' padding bytes may differ between the two sources: compare the fields)
+                for q in range(6):
+                    assert_bit_exact(ob[q, :onb[q]], hits[q, :nh[q]], what=f"k={k} run {rep} q{q}")
+
+
+def test_correlated_terms_dense(tuning):
+    tuning(dense_x1000=0)
     n_docs = 600_000
     rng = np.random.default_rng(42)
     base = np.sort(rng.choice(n_docs, 9000, replace=False)).astype(np.uint32)

@@ -58,23 +58,42 @@ def test_random_corpora(length, zipf, nterms, k):
     check_batch(gix, oix, terms, off, k)
 
 
-@pytest.mark.parametrize("nterms,k", [(1, 10), (8, 256), (9, 10), (12, 64)])
+@pytest.mark.parametrize("nterms,k", [(1, 10), (8, 256), (9, 10), (12, 64), (16, 10), (17, 10), (40, 100), (5, 300), (5, 1000)])
 def test_kernel_routing_by_term_count(nterms, k):
-    """Queries of 1..8 indexed terms (k <= 256) take the cursor kernel, 9..12 the tile kernel; a
-    single-term query is all single-posting documents (the cold pass)."""
+    """Sparse queries of 1..8 / 9..16 indexed terms (k <= 256) take scan_range_kernel<., 8> / <., 16>; more terms, or
+    256 < k <= 1024, scan_many_kernel.  A single-term query is all single-posting documents (the cold pass)."""
     c = make_corpus(150_000, 3000, seed=11, length="lognormal", mean_len=60)
     seg, gix, oix = both(c)
     terms, off = make_queries(c, 24, nterms, seed=5)
-    check_batch(gix, oix, terms, off, k)
+    check_batch(gix, oix, terms, off, k, wand=k <= 256)
 
 
-def test_tiny_batches_take_the_tile_kernel(monkeypatch):
-    """Default routing: a batch of fewer than 64 work items (a single query) runs on the tile kernel,
-    larger ones on the cursor kernel; same results either way."""
+def test_queries_of_hundreds_of_terms():
+    """search.rs:53-79 pushes one Token per found key, without a limit (a tsvector of a whole document): 400 and 1000
+    indexed terms through scan_many_kernel (term loops of four per thread); 1025 is the documented limit."""
+    c = make_corpus(60_000, 3000, seed=4, length="lognormal", mean_len=80)
+    seg, gix, oix = both(c)
+    rng = np.random.default_rng(8)
+    n_terms = seg.meta()["n_terms"]
+    qs = [np.sort(rng.choice(n_terms, n, replace=False)).astype(np.uint32) for n in (400, 1000, 17, 257)]
+    terms = np.concatenate(qs)
+    off = np.r_[0, np.cumsum([len(q) for q in qs])].astype(np.uint32)
+    for k in (10, 300):
+        hits, nh = vb.search_batch(gix, terms, off, k)
+        for q in range(len(qs)):
+            assert_bit_exact(oix.search_brute(qs[q], k), hits[q, :nh[q]], what=f"k={k} q{q} ({len(qs[q])} terms)")
+    big = np.sort(rng.choice(n_terms, 1025, replace=False)).astype(np.uint32)
+    with pytest.raises(vb.Vbm25Error) as e:
+        vb.search_batch(gix, big, np.array([0, 1025], dtype=np.uint32), 10)
+    assert e.value.code == -4  # VBM25_ERR_UNSUPPORTED
+
+
+def test_tiny_and_large_batches_through_batch_run():
+    """vbm25_batch_run: a handful of work items takes the one-launch instantiation of scan_range_kernel (device buffers),
+    a batch that fills the GPU plan_kernel + scan_range_kernel + merge_kernel; same results either way."""
     c = make_corpus(150_000, 3000, seed=11, length="lognormal", mean_len=60)
     seg, gix, oix = both(c)
     terms, off = make_queries(c, 200, 4, seed=6)
-    monkeypatch.setenv("VBM25_CUR_MIN_ITEMS", "64")  # read when a batch object is created
     for nq in (1, 3, 200):
         b = vb.Batch(gix, nq, int(off[nq]), 10)
         b.set_queries(terms[:off[nq]], off[:nq + 1])
@@ -86,8 +105,8 @@ def test_tiny_batches_take_the_tile_kernel(monkeypatch):
 
 
 def test_mixed_batch_all_kernels():
-    """One batch whose queries are spread over the cursor, tile and many-term kernels, with unknown
-    tokens and an empty query in between."""
+    """One batch whose queries are spread over scan_range_kernel (row strides 8 and 16) and scan_many_kernel, with
+    unknown tokens and an empty query in between."""
     c = make_corpus(150_000, 3000, seed=12, length="lognormal", mean_len=60)
     seg, gix, oix = both(c)
     rng = np.random.default_rng(3)
@@ -116,13 +135,12 @@ def test_fuzz_shape_100_term_queries_top100():
     seg, gix, oix = both(c)
     terms, off = make_queries(c, 16, 100, seed=5)
     check_batch(gix, oix, terms, off, 100)
-    # 250-term queries (the GPU path's limit is 256 indexed terms), and the error beyond it
+    # 250- and 300-term queries (the GPU path's limit is 1024 indexed terms; the error beyond it is covered by
+    # test_queries_of_hundreds_of_terms)
     terms, off = make_queries(c, 4, 250, seed=6)
     check_batch(gix, oix, terms, off, 20, wand=False)
-    with pytest.raises(vb.Vbm25Error) as e:
-        t = np.arange(300, dtype=np.uint32)
-        vb.search_batch(gix, t, np.array([0, 300], dtype=np.uint32), 5)
-    assert e.value.code == -4  # VBM25_ERR_UNSUPPORTED
+    t = np.arange(300, dtype=np.uint32)
+    check_batch(gix, oix, t, np.array([0, 300], dtype=np.uint32), 5, wand=False)
 
 
 def test_edge_cases():
@@ -380,7 +398,7 @@ def test_bench_distributed_code_path_single_rank():
 def test_c3_full_size_full_batch_parity():
     """BASELINE config C3 at full size (10M docs / 30k vocab, 5-term queries, top-10): ALL 1024 of the
     bench's own queries bit-exact against the oracle's brute force, a sample against the faithful
-    Block-WAND restatement, plus batch invariance."""
+    Block-WAND restatement, plus batch invariance; no work item of the batch is served by the fallback kernel."""
     import sys
     import time
     sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -388,8 +406,15 @@ def test_c3_full_size_full_batch_parity():
     seg = vb.Segment.synth(10_000_000, 30000, mean_len=100, len_mode=1, seed=20260925, threads=usable_cpus())
     gix = vb.GpuIndex(seg)
     terms, off = bench_queries(seg, 30000, 1024, 5, seed=1, zipf_s=0.0)
-    hits, nh = vb.search_batch(gix, terms, off, 10)
+    b = vb.Batch(gix, 1024, len(terms), 10)  # (the bench's own object and call sequence)
+    b.set_queries(terms, off)
+    b.run()
+    hits, nh = b.fetch()
+    items, failed = b.debug_counts()
+    assert failed == 0, f"{failed} of {items} work items fell back to scan_many_kernel: the bench line would not be scan_range_kernel's"
     assert (nh == 10).all()
+    h1, n1 = vb.search_batch(gix, terms, off, 10)
+    assert h1.tobytes() == hits.tobytes() and np.array_equal(n1, nh)
     oix = orc.OracleIndex.from_arrays(seg.meta(), seg.arrays())
     t0 = time.perf_counter()
     ob, onb, _ = oix.search_batch(terms, off, 10, mode="brute", threads=usable_cpus())
@@ -411,10 +436,10 @@ def test_c3_full_size_full_batch_parity():
 
 
 @pytest.mark.parametrize("n_docs,vocab,nq,nterms,k", [(300_000, 20_000, 96, 10, 100), (1_000_000, 50_000, 64, 6, 10)])
-def test_maxscore_split_zipf(monkeypatch, n_docs, vocab, nq, nterms, k):
-    """Zipf(1) corpora through scan_range_kernel's MaxScore split (VBM25_RANGE_DENSE=1: threshold bootstrap,
-    non-essential lists looked up instead of scanned, tile retries): same records as the default route for dense
-    queries (scan_dense_kernel) and as the oracle."""
+def test_maxscore_split_zipf(tuning, n_docs, vocab, nq, nterms, k):
+    """Zipf(1) queries through scan_range_kernel's MaxScore split (tuning(dense_x1000=...) declares nothing dense:
+    non-essential lists looked up instead of scanned, tile retries; the items it gives up go to scan_many_kernel): same
+    records as the default route (scan_dense_kernel), as without the split, and as the oracle."""
     import sys
     sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
     from bench import make_queries as bench_queries
@@ -423,22 +448,25 @@ def test_maxscore_split_zipf(monkeypatch, n_docs, vocab, nq, nterms, k):
     oix = orc.OracleIndex.from_arrays(seg.meta(), seg.arrays())
     terms, off = bench_queries(seg, vocab, nq, nterms, seed=5, zipf_s=1.0)
     h_ex, n_ex = vb.search_batch(gix, terms, off, k)
-    monkeypatch.setenv("VBM25_RANGE_DENSE", "1")  # read when a batch object is created
-    b = vb.Batch(gix, nq, len(terms), k)
-    b.set_queries(terms, off)
-    b.run()
-    h_ne, n_ne = b.fetch()
-    assert h_ne.tobytes() == h_ex.tobytes() and np.array_equal(n_ne, n_ex)
+    for ne in (1, 0):
+        tuning(dense_x1000=10 ** 9, ne=ne)  # read when a batch object is created
+        b = vb.Batch(gix, nq, len(terms), k)
+        b.set_queries(terms, off)
+        b.run()
+        h_ne, n_ne = b.fetch()
+        assert np.array_equal(n_ne, n_ex)
+        for q in range(nq):
+            assert h_ne[q, :n_ne[q]].tobytes() == h_ex[q, :n_ex[q]].tobytes(), (ne, q)
     ob, onb, _ = oix.search_batch(terms, off, k, mode="brute", threads=8)
     for q in range(nq):
         assert_bit_exact(ob[q, :onb[q]], h_ne[q, :n_ne[q]], what=f"q{q} vs brute")
 
 
-def test_c5_full_size_sample_parity(monkeypatch):
+def test_c5_full_size_sample_parity(tuning):
     """BASELINE config C5 at full size (50M docs / 100k vocab Zipf(1), 10-term queries, top-100): the bench's
     batch of 1024 runs on scan_dense_kernel (the default route); 32 of its queries bit-exact against the oracle's
-    brute force and ranking-equal to the faithful Block-WAND restatement; scan_range_kernel's MaxScore split gives
-    the same records on 64 of them, the exhaustive scan_many_kernel on 16."""
+    brute force and ranking-equal to the faithful Block-WAND restatement; the exhaustive scan_many_kernel gives the
+    same records on 16 of them."""
     import sys
     sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
     from bench import make_queries as bench_queries, usable_cpus
@@ -458,14 +486,7 @@ def test_c5_full_size_sample_parity(monkeypatch):
         assert_bit_exact(ob[q, :onb[q]], hits[q, :nh[q]], what=f"q{q} vs brute")
         assert_same_ranking(ow[q, :onw[q]], hits[q, :nh[q]], ref_ext=oix.search_brute(terms[off[q]:off[q + 1]], 400),
                             what=f"q{q} vs wand")
-    monkeypatch.setenv("VBM25_RANGE_DENSE", "1")
-    b = vb.Batch(gix, 64, int(off[64]), 100)
-    b.set_queries(terms[:off[64]], off[:65])
-    b.run()
-    h2, n2 = b.fetch()
-    assert h2.tobytes() == hits[:64].tobytes() and np.array_equal(n2, nh[:64])
-    monkeypatch.delenv("VBM25_RANGE_DENSE")
-    monkeypatch.setenv("VBM25_DENSE", "0")  # the exhaustive dense-window kernel of round 1
+    tuning(dense=0)  # the exhaustive kernel
     b = vb.Batch(gix, 16, int(off[16]), 100)
     b.set_queries(terms[:off[16]], off[:17])
     b.run()
@@ -483,7 +504,12 @@ def test_evaluate_batch_on_the_device_matches_the_oracle_bitwise():
     rng = np.random.default_rng(4)
     for trial in range(4):
         q_rank = np.sort(rng.choice(n_terms, int(rng.integers(1, 9)), replace=False)).astype(np.uint32)
-        q_ids = q_rank if trial % 2 == 0 else np.sort(np.r_[q_rank, np.uint32(0xFFFFFFFF)])  # an unknown query token
+        q_ids = q_rank
+        if trial == 1:
+            q_ids = np.r_[q_rank, np.uint32(0xFFFFFFFF)]  # an unknown query token, last in key order
+        if trial == 3:  # ... and in the middle and in front (ids follow key order, unknown ones stay where they sorted)
+            mid = len(q_rank) // 2
+            q_ids = np.r_[np.uint32(0xFFFFFFFF), q_rank[:mid], np.uint32(0xFFFFFFFF), q_rank[mid:]].astype(np.uint32)
         docs_t, docs_f, start = [], [], [0]
         for i in range(500):
             d_rank = np.sort(rng.choice(n_terms, int(rng.integers(0, 40)), replace=False)).astype(np.uint32)
@@ -498,6 +524,10 @@ def test_evaluate_batch_on_the_device_matches_the_oracle_bitwise():
             want = orc.lib().orc_score_to_f64(oix.evaluate(docs_t[i], docs_f[i], q_rank))
             assert got[i] == want, (trial, i)
         assert (got > 0).sum() > 100
+    one_doc = (np.array([0, 1], dtype=np.uint64), np.array([5], dtype=np.uint32), np.array([1], dtype=np.uint32))
+    assert vb.evaluate_batch(gix, np.array([5, 0xFFFFFFFF, 7], dtype=np.uint32), *one_doc)[0] > 0
+    with pytest.raises(vb.Vbm25Error):  # known ids out of order around an unknown one are still rejected
+        vb.evaluate_batch(gix, np.array([7, 0xFFFFFFFF, 5], dtype=np.uint32), *one_doc)
     # an element whose key is not in the index still counts for the document's length (vector.rs:77-83)
     k3 = np.array([3], dtype=np.uint32)
     s_known = vb.evaluate_batch(gix, k3, np.array([0, 1], dtype=np.uint64), k3, np.array([2], dtype=np.uint32))[0]
@@ -547,18 +577,18 @@ def test_k_up_to_bm25_limit_maximum(k):
     assert nh[:-1].min() > 1024
 
 
-def test_one_launch_route_of_search_batch(monkeypatch):
+def test_one_launch_route_of_search_batch(tuning):
     """vbm25_search_batch with at most 8 sparse queries: ONE launch (scan_range_kernel makes the items, the query's last
-    workgroup merges, queries / hits in pinned host memory).  Same records as the general route (VBM25_FUSED=0) and the
+    workgroup merges, queries / hits in pinned host memory).  Same records as the general route (tuning(fused=0)) and the
     oracle; repeated calls and general-route calls in between find the per-launch state clean; 9 queries take the
     general route; an item the kernel gives up sends the batch to the general route (correlated lists)."""
     c = make_corpus(400_000, 4000, seed=21, length="lognormal", mean_len=70)
     seg, gix, oix = both(c)
     terms, off = make_queries(c, 64, 4, seed=8)
-    monkeypatch.setenv("VBM25_FUSED", "0")
-    gix0 = vb.GpuIndex(seg)  # its scratch batch is created under VBM25_FUSED=0
+    tuning(fused=0)
+    gix0 = vb.GpuIndex(seg)  # its scratch batch is created with the one-launch route off
     ref = {nq: vb.search_batch(gix0, terms[:off[nq]], off[:nq + 1], 10) for nq in (1, 3, 8, 9)}
-    monkeypatch.delenv("VBM25_FUSED")
+    tuning(fused=1)
     for rep in range(3):
         for nq in (1, 3, 8, 9, 1):
             hits, nh = vb.search_batch(gix, terms[:off[nq]], off[:nq + 1], 10)

@@ -67,22 +67,110 @@ def test_two_rank_gather_equals_single_process(nq):
         assert max(h - l for l, h in b) - min(h - l for l, h in b) <= 1
 
 
+BENCH_WORKER = r"""
+# bench.run() under gloo: the test supplies the CPU stand-in for the GPU batch object (bench.py itself knows
+# nothing about the oracle outside its --verify / cpu_baseline legs)
+import os, sys
+import numpy as np
+import torch
+sys.path.insert(0, sys.argv[1]); sys.path.insert(0, os.path.join(sys.argv[1], "tests"))
+import bench
+import orc
+import vectorchord_bm25_amd as vb
+
+
+class OracleScorer:
+    def __init__(self, seg, nq, k):
+        self.oix = orc.OracleIndex.from_arrays(seg.meta(), seg.arrays())
+        self.k = k
+        self.words = torch.zeros(nq * k * 3, dtype=torch.int64)
+
+    def set_queries(self, terms, off):
+        self.terms, self.off = terms, off
+
+    def run(self, stream=None):
+        self.hits, self.n_hits, _ = self.oix.search_batch(self.terms, self.off, self.k, mode="brute", threads=1)
+        self.words.copy_(torch.from_numpy(np.frombuffer(self.hits.tobytes(), dtype=np.int64).copy()))
+
+    def fetch(self):
+        return self.hits, self.n_hits
+
+
+bench.run(sys.argv[2:], scorer_factory=OracleScorer, backend="gloo")
+"""
+
+
 def test_bench_step_two_ranks_gloo():
-    """bench.py's own distributed step (rank 0 makes the batch, broadcast, shard, search, gather to rank 0)
-    under gloo with the oracle standing in for the GPU (VBM25_BENCH_BACKEND=gloo is a test-only switch)."""
+    """bench.py's own distributed step (rank 0 makes the batches, broadcast, shard, search, gather to rank 0) under
+    gloo, with an oracle-backed scorer injected from here in place of the GPU batch objects."""
     import json
 
-    env = dict(os.environ, VBM25_BENCH_BACKEND="gloo")
-    port = 29500 + (os.getpid() + 77) % 1000
-    out = subprocess.run(
-        [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
-         "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.join(ROOT, "bench.py"),
-         "--gpus", "2", "--workload", "C1", "--steps", "3", "--warmup", "1", "--verify"],
-        env=env, timeout=600, capture_output=True, text=True)
+    with tempfile.TemporaryDirectory() as d:
+        script = os.path.join(d, "bench_worker.py")
+        open(script, "w").write(BENCH_WORKER)
+        port = 29500 + (os.getpid() + 77) % 1000
+        out = subprocess.run(
+            [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+             "--master-addr", "127.0.0.1", "--master-port", str(port), script, ROOT,
+             "--gpus", "2", "--workload", "C1", "--steps", "3", "--warmup", "1", "--batches", "2", "--verify"],
+            timeout=600, capture_output=True, text=True)
     assert out.returncode == 0, out.stderr[-2000:]
     line = [l for l in out.stdout.splitlines() if l.startswith("{")][-1]
     d = json.loads(line)
     assert d["n_gpus"] == 2 and d["steps"] == 3 and d["value"] > 0
     assert d["config"]["scatter_ms"] > 0 and d["config"]["gather_ms"] > 0
-    assert d["config"]["verified_bit_exact_vs_oracle"]["queries"] == 64
+    assert d["config"]["verified_bit_exact_vs_oracle"]["queries"] == 128
+    assert d["config"]["batches_rotated"] == 2
     assert d["config"]["workload"].startswith("C4")
+    assert "roofline" not in d and "cpu_baseline" not in d  # nothing measured on a GPU here
+
+
+def test_bench_has_no_cpu_scorer():
+    """The bench's product path may not reach the oracle: only --verify and cpu_baseline import it."""
+    src = open(os.path.join(ROOT, "bench.py")).read()
+    assert "OracleScorer" not in src and "VBM25_BENCH_BACKEND" not in src
+    assert src.count("import orc") == 1  # inside oracle_index(), used by --verify and cpu_baseline only
+
+
+SUBGROUP_WORKER = r"""
+import os, sys
+import numpy as np
+import torch
+import torch.distributed as dist
+sys.path.insert(0, sys.argv[1])
+import vectorchord_bm25_amd as vb
+
+rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+dist.init_process_group("gloo", rank=rank, world_size=world)
+group = dist.new_group([1, 2])      # shard ranks 0, 1 of this group are global ranks 1, 2
+nq, k = 5, 2
+if rank in (1, 2):
+    g = dist.get_rank(group)
+    lo, hi = vb.sharded.shard_bounds(nq, 2, g)
+    local = torch.arange(lo * k * 3, hi * k * 3, dtype=torch.int64)
+    for dst in (0, 1):
+        got = vb.sharded.gather_to_root(local, nq, k, dst=dst, group=group)
+        if g == dst:
+            assert torch.equal(got, torch.arange(nq * k * 3, dtype=torch.int64)), got
+        else:
+            assert got is None
+    if rank == 1:
+        open(sys.argv[2], "w").write("ok")
+dist.barrier()
+dist.destroy_process_group()
+"""
+
+
+def test_gather_to_root_in_a_subgroup():
+    """dst of gather_to_root is a rank of the group; a group that does not start at global rank 0 must work."""
+    with tempfile.TemporaryDirectory() as d:
+        script = os.path.join(d, "worker.py")
+        open(script, "w").write(SUBGROUP_WORKER)
+        out = os.path.join(d, "ok")
+        port = 29500 + (os.getpid() + 191) % 1000
+        r = subprocess.run(
+            [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "3",
+             "--master-addr", "127.0.0.1", "--master-port", str(port), script, ROOT, out],
+            timeout=300, capture_output=True, text=True)
+        assert r.returncode == 0, r.stderr[-2000:]
+        assert open(out).read() == "ok"

@@ -285,6 +285,23 @@ class Batch:
         return tuple(int(x) for x in out)
 
 
+def set_tuning(name, value):
+    """test / tuning aid (vbm25_tuning_set, not in include/vbm25.h): process-wide switch read when a Batch / GpuIndex
+    scratch batch is created.  Names: dense_x1000, dense, ne, fused, ne_ratio, dense_items, range_items,
+    range_min_chunk, range_grid, dense_grid."""
+    f = lib().vbm25_tuning_set
+    f.restype = C.c_int
+    f.argtypes = [C.c_char_p, C.c_longlong]
+    check(f(name.encode(), int(value)))
+
+
+def reset_tuning():
+    f = lib().vbm25_tuning_reset
+    f.restype = None
+    f.argtypes = []
+    f()
+
+
 def search_batch(index, term_ids, q_off, k):
     """vbm25_search_batch: nq queries (CSR of ascending term ids) -> (hits[nq,k], n_hits[nq])."""
     term_ids = np.ascontiguousarray(term_ids, dtype=np.uint32)

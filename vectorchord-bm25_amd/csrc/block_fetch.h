@@ -1,7 +1,5 @@
-// block_fetch.h -- split decode: raw words fetched early, fields extracted later; DPP row helpers.
-// Part of libvbm25's single device translation unit: included by search.hip inside namespace vbm25, in
-// this order: device_types, decode, plan, topk_lds, scan_many, block_fetch, topk_reg, scan_tile,
-// scan_cursor, merge.
+// block_fetch.h -- split decode: raw words fetched early, fields extracted later; DPP wave helpers.
+// Part of libvbm25's single device translation unit: included by search.hip inside namespace vbm25.
 
 // ---------------------------------------------------------------------------
 // Split decode used by scan_kernel: the two dwords that hold a field are fetched early
@@ -128,4 +126,25 @@ __device__ __forceinline__ double wave_shr1_f64(double v) {
     const uint32_t lo = wave_shr1_u32((uint32_t)__double2loint(v));
     const uint32_t hi = wave_shr1_u32((uint32_t)__double2hiint(v));
     return __hiloint2double((int)hi, (int)lo);
+}
+
+// Inclusive prefix sum / minimum over the wave: DPP row shifts inside 16-lane rows, then row broadcasts across rows.
+// All 64 lanes must be active.
+__device__ __forceinline__ uint32_t wave_incl_scan_u32(uint32_t x) {
+    x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x111, 0xf, 0xf, false);  // row_shr:1
+    x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x112, 0xf, 0xf, false);  // row_shr:2
+    x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x114, 0xf, 0xf, false);  // row_shr:4
+    x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x118, 0xf, 0xf, false);  // row_shr:8
+    x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x142, 0xa, 0xf, false);  // row_bcast:15
+    x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x143, 0xc, 0xf, false);  // row_bcast:31
+    return x;
+}
+__device__ __forceinline__ uint32_t wave_min_u32(uint32_t x) {  // uniform result
+    x = min(x, (uint32_t)__builtin_amdgcn_update_dpp(-1, (int)x, 0x111, 0xf, 0xf, false));
+    x = min(x, (uint32_t)__builtin_amdgcn_update_dpp(-1, (int)x, 0x112, 0xf, 0xf, false));
+    x = min(x, (uint32_t)__builtin_amdgcn_update_dpp(-1, (int)x, 0x114, 0xf, 0xf, false));
+    x = min(x, (uint32_t)__builtin_amdgcn_update_dpp(-1, (int)x, 0x118, 0xf, 0xf, false));
+    x = min(x, (uint32_t)__builtin_amdgcn_update_dpp(-1, (int)x, 0x142, 0xa, 0xf, false));
+    x = min(x, (uint32_t)__builtin_amdgcn_update_dpp(-1, (int)x, 0x143, 0xc, 0xf, false));
+    return (uint32_t)__builtin_amdgcn_readlane((int)x, 63);
 }

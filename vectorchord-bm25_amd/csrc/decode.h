@@ -1,7 +1,6 @@
 // decode.h -- block decode (compression.rs:65-136 formats): one wave, two postings per lane.
 // Part of libvbm25's single device translation unit: included by search.hip inside namespace vbm25, in
-// this order: device_types, decode, plan, topk_lds, scan_many, block_fetch, topk_reg, scan_tile,
-// scan_cursor, merge.
+// this order: device_types, decode, plan, topk_lds, block_fetch, topk_reg, scan_range, scan_dense, scan_many, merge.
 
 // ---------------------------------------------------------------------------
 // Block decode: one wave, two postings per lane (value indices 2*lane, 2*lane+1)

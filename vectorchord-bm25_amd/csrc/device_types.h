@@ -1,7 +1,6 @@
 // device_types.h -- device-side views of the index and of one batch; constants of the kernels.
 // Part of libvbm25's single device translation unit: included by search.hip inside namespace vbm25, in
-// this order: device_types, decode, plan, topk_lds, scan_many, block_fetch, topk_reg, scan_tile,
-// scan_cursor, merge.
+// this order: device_types, decode, plan, topk_lds, block_fetch, topk_reg, scan_range, scan_dense, scan_many, merge.
 
 // ---------------------------------------------------------------------------
 // Device-side view of the index and of one batch
@@ -45,15 +44,12 @@ struct DevBatch {
     uint32_t *n_hits;
     uint32_t *error_flag;
     const uint8_t *q_dense;    // per query: 1 = dense (many postings per document), host decided
-    unsigned long long *spill; // per scan workgroup: candidates that did not fit the LDS buffer
-    uint32_t *item_failed;     // per item: 1 = the chain kernel gave up (dense tile), redo it
-    unsigned long long *prof;  // VBM25_PROFILE builds: 33 counters per workgroup
-    uint32_t *work_ctr;        // [0] next item of the cursor / range kernel, [1] of the dense kernel (reset by plan_kernel)
+    uint32_t *item_failed;     // per item: != 0 = the first-choice kernel gave the item up, scan_many_kernel redoes it
+    unsigned long long *prof;  // VBM25_PROFILE builds: 16 counters per wave
+    uint32_t *work_ctr;        // [0] next item of the range kernel, [1] of the dense kernel (reset by plan_kernel)
     uint32_t *hist;            // per query: CUR_HB score buckets, documents accepted by any item
-    uint32_t chain_min_terms;  // scan_kernel leaves queries with fewer terms to scan_cursor_kernel
     uint32_t lpi;              // result lists per item (scan_range_kernel: one per wave; the others use list 0)
     uint32_t range_max_terms;  // scan_range_kernel takes the queries with at most this many terms (0: off)
-    uint32_t range_dense;      // ... the dense ones too; 0: dense queries go to scan_many_kernel
     uint32_t ne_on;            // MaxScore split in scan_range_kernel (non-essential lists looked up, not scanned)
     uint32_t ne_ratio;         // a non-essential list must be this many times longer than the essential lists together
     uint32_t dense_on;         // dense queries of <= D_T terms take scan_dense_kernel (its items come from work_ctr[1])
@@ -79,27 +75,16 @@ struct DevBatch {
 #define VCHK(cond, code, val) do { } while (0)
 #endif
 
-constexpr int WG = 256;
+constexpr int WG = 256;                // scan_many_kernel's workgroup
 constexpr int NW = WG / 64;
 constexpr int SLOTS_LOG2 = 12;
-constexpr int SLOTS = 1 << SLOTS_LOG2;  // hash table slots per workgroup
+constexpr int SLOTS = 1 << SLOTS_LOG2;  // hash table slots / window documents per scan_many_kernel workgroup
 constexpr int CAP_BLOCKS = SLOTS / 2 / 128;  // blocks admitted per tile in hash mode
-constexpr int MAX_TERMS = 256;         // terms per query handled on the GPU (scan_many_kernel: one thread per term, WG = 256)
+constexpr int MAX_TERMS = 1024;        // indexed terms per query handled on the GPU (scan_many_kernel's LDS arrays)
 constexpr uint32_t EMPTY = 0xffffffffu;
-constexpr uint32_t TARGET_ITEMS = 1536;  // 2 x (256 CUs x 3 resident workgroups): measured best of 768..3072
+constexpr uint32_t TARGET_ITEMS = 1536;  // work items of a batch on the scan_many_kernel route
 constexpr uint32_t MIN_CHUNK_POSTINGS = 8192;
 constexpr int PLAN_WG = 1024;
-// chain kernel (scan_kernel) geometry
-constexpr int CNW = 6;                   // worker waves per workgroup
-constexpr int CWG = (CNW + 2) * 64;      // + one planner / merger wave + one joiner wave
-constexpr int C_BLOCKS = 2 * CNW;        // block slots of staging per workgroup (2 per worker)
-constexpr int C_POSTINGS = C_BLOCKS * 128;
-constexpr int CHAIN_MAX_TERMS = C_BLOCKS;  // queries with more indexed terms use scan_many_kernel
-constexpr int SLOW_CAP = 64;              // colliding postings per tile kept in LDS (rest: global spill)
-constexpr int SLOW_ABORT = 512;           // beyond this the tile is dense: give the item to scan_many_kernel
-constexpr int JC_CAP = 64;                // joined documents per tile kept in LDS (rest: global spill)
-constexpr int CAND_CAP = 96;              // fast-path documents per tile kept in LDS (rest: global spill)
-constexpr int BM_BITS_LOG2 = 14;          // hashed document bitmaps: 16384 bits each
-constexpr int BM_WORDS = (1 << BM_BITS_LOG2) / 32;
+constexpr int CUR_HB = 256;            // score buckets of the per-query histogram of accepted documents
 constexpr int REG_K = 256;                // largest k whose running top-k lives in registers
 constexpr uint32_t NONE32 = 0xffffffffu;

@@ -1,7 +1,6 @@
 // merge.h -- merge_kernel: per-chunk lists -> hits.
 // Part of libvbm25's single device translation unit: included by search.hip inside namespace vbm25, in
-// this order: device_types, decode, plan, topk_lds, scan_many, block_fetch, topk_reg, scan_tile,
-// scan_cursor, merge.
+// this order: device_types, decode, plan, topk_lds, block_fetch, topk_reg, scan_range, scan_dense, scan_many, merge.
 
 // ---------------------------------------------------------------------------
 // Merge of per-chunk lists -> hits

@@ -1,7 +1,6 @@
 // plan.h -- post_fn_kernel (index preparation + validation) and plan_kernel (work items).
 // Part of libvbm25's single device translation unit: included by search.hip inside namespace vbm25, in
-// this order: device_types, decode, plan, topk_lds, scan_many, block_fetch, topk_reg, scan_tile,
-// scan_cursor, merge.
+// this order: device_types, decode, plan, topk_lds, block_fetch, topk_reg, scan_range, scan_dense, scan_many, merge.
 
 // ---------------------------------------------------------------------------
 // Index preparation: fieldnorm of every posting + structural validation

@@ -45,10 +45,7 @@ constexpr int DWG = DNW * 64;
 constexpr int D_W = 16384;               // documents per window (at most; an item of very dense terms takes narrower ones)
 constexpr int D_W0 = 256;                // first window while the threshold is 0
 constexpr int D_T = 16;                  // indexed terms per query
-#ifndef D_KMAX_V
-#define D_KMAX_V 128
-#endif
-constexpr int D_KMAX = D_KMAX_V;         // largest k (register top-k of two rows per wave; 256 = four rows: see search.hip)
+constexpr int D_KMAX = 256;              // largest k (register top-k of up to four rows per wave)
 constexpr int D_SEG = 128;               // blocks of one term per window: two chunks of 64 lanes (a full block spans >= 128 documents)
 constexpr int D_TCAP = 1024;             // blocks of all terms per window; an item's window width is chosen for 80 % of it
 constexpr int D_WCB = 128;               // candidate buffer entries per wave
@@ -84,9 +81,16 @@ struct DenseLds {
     uint32_t scratch[64];
 };
 
+// Register budget: at 128 registers (two workgroups per CU) the four-row instantiation spills 53 registers, and a build of
+// this kernel under that pressure returned incomplete lists / faulted on the codec corner-case index (round 2).  The same
+// source compiled for 256 registers is correct in every run, so is the present source at 128 (tools/dense_stress.py, 360
+// runs), and no assertion of the -DVBM25_CHECK build ever fires: the defect follows the compiler's spill code, not an
+// index or a race of this file.  k > 128 is therefore compiled without register pressure (one workgroup per
+// CU: still an order of magnitude faster than the exhaustive kernel); k <= 128 keeps two workgroups per CU and is covered
+// by the repetition test of tests/test_gpu_dense.py.
 template <int KMAX>
-__global__ void __launch_bounds__(DWG, 4) scan_dense_kernel(DevIndex ix, DevBatch bt) {
-    static_assert(KMAX <= D_KMAX, "register top-k of at most two rows");
+__global__ void __launch_bounds__(DWG, KMAX > 128 ? 2 : 4) scan_dense_kernel(DevIndex ix, DevBatch bt) {
+    static_assert(KMAX <= D_KMAX, "register top-k of at most four rows");
     constexpr int RK = KMAX / 64;
     __shared__ DenseLds S;
 

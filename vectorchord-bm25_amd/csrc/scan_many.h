@@ -1,7 +1,8 @@
-// scan_many.h -- scan_many_kernel: many terms / dense queries / failed items.
+// scan_many.h -- scan_many_kernel: more than 16 terms (up to MAX_TERMS), every query of 256 < k <= 1024, dense queries when
+// scan_dense_kernel is off, and the items the first-choice kernels gave up.  Exhaustive: term-phased exact f64 accumulation
+// in dense doc windows or an LDS hash, LDS top-k, the query's shared threshold.
 // Part of libvbm25's single device translation unit: included by search.hip inside namespace vbm25, in
-// this order: device_types, decode, plan, topk_lds, scan_many, block_fetch, topk_reg, scan_tile,
-// scan_cursor, merge.
+// this order: device_types, decode, plan, topk_lds, block_fetch, topk_reg, scan_range, scan_dense, scan_many, merge.
 
 // ---------------------------------------------------------------------------
 // Posting scan
@@ -25,8 +26,8 @@ __global__ void __launch_bounds__(WG) scan_many_kernel(DevIndex ix, DevBatch bt)
     const uint32_t n_items = *bt.n_items;
     for (uint32_t item = blockIdx.x; item < n_items; item += gridDim.x) {
         const Item it = bt.items[item];
-        const uint32_t others_max = max((uint32_t)CHAIN_MAX_TERMS, bt.range_max_terms);  // taken by the other kernels
-        const uint32_t mt_item = (bt.range_dense || bt.dense_on) ? (it.m & ~ITEM_DENSE) : it.m;  // dense items: scan_dense_kernel's / scan_range_kernel's
+        const uint32_t others_max = bt.range_max_terms;  // up to that many terms: the other kernels' (0: everything is this kernel's)
+        const uint32_t mt_item = bt.dense_on ? (it.m & ~ITEM_DENSE) : it.m;  // dense items: scan_dense_kernel's
         const bool failed = mt_item <= others_max && bt.item_failed[item] != 0;
         if (mt_item <= others_max && !failed) continue;
         const bool force_dense = failed || (it.m & ITEM_DENSE) != 0;
@@ -53,8 +54,8 @@ __global__ void __launch_bounds__(WG) scan_many_kernel(DevIndex ix, DevBatch bt)
         __syncthreads();
         const uint32_t m = s_m;
         const bool dense = s_dense != 0;
-        if (tid < m) {
-            const uint32_t term = t_cur[tid];
+        for (uint32_t tt = tid; tt < m; tt += WG) {  // (up to MAX_TERMS terms: four per thread)
+            const uint32_t term = t_cur[tt];
             const uint32_t b0 = ix.term_first_block[term], b1 = ix.term_first_block[term + 1];
             // first block whose max_doc >= clo
             uint32_t lo = b0, hi = b1;
@@ -62,12 +63,12 @@ __global__ void __launch_bounds__(WG) scan_many_kernel(DevIndex ix, DevBatch bt)
                 const uint32_t mid = (lo + hi) >> 1;
                 if (ix.blk_max_doc[mid] < clo) lo = mid + 1; else hi = mid;
             }
-            t_end[tid] = b1;
-            t_s0[tid] = ix.term_s0[term];
+            t_end[tt] = b1;
+            t_s0[tt] = ix.term_s0[term];
             const unsigned long long df = ix.term_df[term];
             const uint32_t share = (uint32_t)(((unsigned long long)(CAP_BLOCKS - (dense ? 0 : (int)m)) * df) / s_sumdf);
-            t_quota[tid] = share > 1 ? share : 1;
-            t_cur[tid] = lo;
+            t_quota[tt] = share > 1 ? share : 1;
+            t_cur[tt] = lo;
         }
         __syncthreads();
 
@@ -83,10 +84,11 @@ __global__ void __launch_bounds__(WG) scan_many_kernel(DevIndex ix, DevBatch bt)
             }
             for (int i = tid; i < SLOTS; i += WG) s_key[i] = EMPTY;
             __syncthreads();
-            if (!dense && tid < m) {
-                const uint32_t j = t_cur[tid] + t_quota[tid];
-                if (j < t_end[tid]) atomicMin(&s_hi, ix.blk_min_doc[j]);
-            }
+            if (!dense)
+                for (uint32_t tt = tid; tt < m; tt += WG) {
+                    const uint32_t j = t_cur[tt] + t_quota[tt];
+                    if (j < t_end[tt]) atomicMin(&s_hi, ix.blk_min_doc[j]);
+                }
             __syncthreads();
             const uint32_t hi = s_hi;
 
@@ -195,9 +197,9 @@ __global__ void __launch_bounds__(WG) scan_many_kernel(DevIndex ix, DevBatch bt)
                 }
             }
             // ---- advance cursors; next tile starts at the first remaining posting
-            if (tid < m) {
-                uint32_t j = t_cur[tid];
-                const uint32_t e = t_end[tid];
+            for (uint32_t tt = tid; tt < m; tt += WG) {
+                uint32_t j = t_cur[tt];
+                const uint32_t e = t_end[tt];
                 // first block whose max_doc >= hi: gallop, then bisect (a dense term has tens of blocks per
                 // window; walking them one dependent load at a time was a fifth of the window's time)
                 if (j < e && ix.blk_max_doc[j] < hi) {
@@ -216,7 +218,7 @@ __global__ void __launch_bounds__(WG) scan_many_kernel(DevIndex ix, DevBatch bt)
                     }
                     j = lo_b;
                 }
-                t_cur[tid] = j;
+                t_cur[tt] = j;
                 if (j < e) atomicMin(&s_next_lo, max(hi, ix.blk_min_doc[j]));
             }
             __syncthreads();

@@ -3,12 +3,9 @@
 // (bm25::search) for the sealed segment.  One translation unit; the kernels live in headers:
 //   plan.h         post_fn_kernel (index preparation: per-posting fieldnorm stream + validation of block
 //                  structure and WAND bounds) and plan_kernel (queries -> doc-range work items)
-//   scan_cursor.h  scan_cursor_kernel: queries of <= 8 terms, k <= 256 -- one wave per item, cursors
-//                  processed in min_doc order (the dominant kernel)
-//   scan_tile.h    scan_kernel: 9..12 terms or k > 256 -- workgroup per item, doc-range tiles
-//   scan_range.h   scan_range_kernel: sparse queries of <= 16 terms, k <= 256 (the dominant kernel)
-//   scan_dense.h   scan_dense_kernel: queries with many postings per document (Zipf head terms), <= 16 terms, k <= 256
-//   scan_many.h    scan_many_kernel: many terms, k > 256 dense queries, items the others gave up
+//   scan_range.h   scan_range_kernel: sparse queries of <= 16 terms, k <= 256 (the dominant kernel: C3, C2)
+//   scan_dense.h   scan_dense_kernel: queries with many postings per document (Zipf head terms; C5), <= 16 terms, k <= 256
+//   scan_many.h    scan_many_kernel: up to 1024 terms, 256 < k <= 1024, items the others gave up (exhaustive)
 //   merge.h        merge_kernel: per-item top-k lists -> hits with payloads
 //   decode.h / block_fetch.h / topk_lds.h / topk_reg.h / device_types.h   shared pieces
 // This file: error text, host objects (index, batch) and the C ABI of include/vbm25.h.  DESIGN.md has
@@ -28,6 +25,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <memory>
+#include <string>
 #include <vector>
 
 #include "vbm25_internal.h"
@@ -58,8 +56,6 @@ int set_error(int code, const char *fmt, ...) {
 #include "topk_lds.h"
 #include "block_fetch.h"
 #include "topk_reg.h"
-#include "scan_tile.h"
-#include "scan_cursor.h"
 #include "scan_range.h"
 #include "scan_dense.h"
 #include "scan_many.h"
@@ -203,43 +199,48 @@ struct vbm25_index {
     uint64_t device_bytes = 0;
 };
 
+// Tuning / test switches (not part of the ABI of include/vbm25.h; set through vbm25_tuning_set by tools and tests, read when a
+// batch object is created).  No entry point of the library reads the environment.
+struct Tuning {
+    long long dense_x1000 = 100;   // a query with this many postings per 1000 documents is dense (0: every query)
+    int dense = 1;                 // dense queries take scan_dense_kernel (0: the exhaustive scan_many_kernel)
+    int ne = 1;                    // MaxScore split (non-essential lists looked up, not scanned)
+    int fused = 1;                 // one-launch route for a handful of sparse queries
+    uint32_t ne_ratio = 2;
+    uint32_t dense_items = D_TARGET_ITEMS;
+    uint32_t range_items = R_TARGET_ITEMS, range_min_chunk = R_MIN_CHUNK_POSTINGS;
+    uint32_t range_grid = R_GRID, dense_grid = D_GRID;
+};
+static Tuning g_tune;
+
 struct vbm25_batch {
     vbm25_index *index = nullptr;
     int device = 0;  // the index's device ordinal: the batch can be destroyed after its index
     uint32_t max_queries = 0, max_terms = 0, k = 0, nq = 0, max_items = 0;
     DeviceBuffer term_ids, q_off, items, n_items, q_item_base, theta, res_score, res_doc, res_cnt,
-        hits, n_hits, error_flag, prof, q_dense, spill, item_failed, work_ctr, hist, fused_state, dbg;
+        hits, n_hits, error_flag, prof, q_dense, item_failed, work_ctr, hist, fused_state, dbg;
     bool bigk = false;            // k > 1024: exhaustive path, one query at a time
     DeviceBuffer bk_acc, bk_keys, bk_iota, bk_docs, bk_tmp;
     size_t bk_tmp_bytes = 0;
     std::vector<uint32_t> h_terms, h_off;  // host copy of the queries (bigk launches per term)
+    std::vector<uint8_t> h_dense;          // per query: dense (scratch of set_queries, sized once)
+    std::vector<unsigned long long> h_postings;
+    Tuning tune;                  // the switches of the moment the batch was created
     bool timing = false;
-    bool has_many_terms = false;  // some query has more than CHAIN_MAX_TERMS indexed terms
-    bool use_cursor = false;      // k <= REG_K: queries with at most CUR_T terms take scan_cursor_kernel
-    bool run_cursor = false;      // ... for the current queries (tiny batches stay with the tile kernel)
-    uint32_t cur_min_items = 64;
-    bool has_mid_terms = false;   // some sparse query has CUR_T < terms <= CHAIN_MAX_TERMS
-    bool use_range = false;       // k <= REG_K: sparse queries of <= 16 terms take scan_range_kernel (VBM25_RANGE=0: off)
+    bool use_range = false;       // k <= REG_K: sparse queries of <= 16 terms take scan_range_kernel, dense ones scan_dense_kernel
     uint32_t range_rt = 0;        // ... with this row stride (8 or 16) for the current queries; 0 = not used
     uint32_t lpi = 1;             // result lists per work item
     uint32_t range_grid = R_GRID;
-    bool ne_on = true;            // MaxScore split in scan_range_kernel (VBM25_NE=0: off)
-    bool range_dense = false;     // dense queries take scan_range_kernel too (VBM25_RANGE_DENSE=1); default: scan_many_kernel
-    uint32_t ne_ratio = 2;        // VBM25_NE_RATIO
-    bool use_dense = false;       // k <= REG_K: dense queries of <= D_T terms take scan_dense_kernel (VBM25_DENSE=0: scan_many_kernel)
+    bool use_dense = false;       // dense queries of <= D_T terms take scan_dense_kernel
     bool has_dense = false;       // ... and the current queries have such a query
-    uint32_t dense_target = D_TARGET_ITEMS;  // work items of a batch with dense queries (VBM25_DENSE_ITEMS)
     uint32_t dense_grid = D_GRID;
     uint32_t dense_c = 0;         // items per dense query of the current queries (0: chunks by postings, as the other queries)
     // vbm25_search_batch with a handful of sparse queries: ONE launch (scan_range_kernel plans, scans and merges)
     uint32_t fused_g = 0;         // items per query of the current queries on that route (0: general route)
     bool fused_pinned = false;    // ... with queries and hits in pinned host memory (vbm25_search_batch, <= 8 queries); else device buffers
-    bool use_fused = true;        // VBM25_FUSED=0: off
     bool state_clean = false;     // threshold / histogram / counters are zero (the fused route leaves them so; the general one does not)
-    uint32_t cur_mt = 1;          // most indexed terms among the cursor kernel's queries
     uint32_t target_items = TARGET_ITEMS;
     uint32_t min_chunk = MIN_CHUNK_POSTINGS;
-    uint32_t cur_grid = CUR_GRID;  // persistent workgroups of the cursor kernel for the current queries
     std::vector<std::pair<hipEvent_t, hipEvent_t>> events;
     size_t events_used = 0;
     // vbm25_search_batch's low-latency route: pinned staging buffers and a private stream -- queries go up and
@@ -458,44 +459,21 @@ static int vbm25_batch_create_impl(vbm25_index *ix, uint32_t max_queries, uint32
     bt->max_queries = max_queries;
     bt->max_terms = max_total_terms;
     bt->k = k;
-    {
-        const char *env = std::getenv("VBM25_NO_CURSOR");
-        bt->use_cursor = k <= (uint32_t)REG_K && !(env && env[0] == '1');
-        const char *rg = std::getenv("VBM25_RANGE");
-        bt->use_range = k <= (uint32_t)REG_K && !(rg && rg[0] == '0');
-        if (bt->use_range) bt->use_cursor = false;
-        const char *ne = std::getenv("VBM25_NE");
-        bt->ne_on = bt->use_range && !(ne && ne[0] == '0');
-        bt->range_dense = false;  // (scan_range_kernel no longer takes dense items)
-        const char *nr = std::getenv("VBM25_NE_RATIO");
-        if (nr) bt->ne_ratio = (uint32_t)std::max(1, std::atoi(nr));
-        bt->lpi = bt->use_range ? (uint32_t)RNW : 1u;
-        const char *dn = std::getenv("VBM25_DENSE");
-        // k <= D_KMAX (128): the instantiation with a 256-entry register list per wave (four rows, 53 spilled registers)
-        // returned incomplete lists in ONE build of this file -- the one that kept two more registers live for the published
-        // histogram threshold -- on the codec corner-case index (tests/test_gpu_dense.py, tools/dense_debug.py: thousands of
-        // tiny items, nondeterministic, memory faults).  The same instantiation of the present code passes that test and
-        // the reproduction (-DD_KMAX_V=256), but the cause was not found, so it is not built: those queries stay with the
-        // exhaustive scan_many_kernel.
-        bt->use_dense = bt->use_range && !bt->range_dense && k <= (uint32_t)D_KMAX && !(dn && dn[0] == '0');
-        const char *di = std::getenv("VBM25_DENSE_ITEMS");
-        if (di) bt->dense_target = (uint32_t)std::max(256, std::atoi(di));
-        const char *ti = std::getenv("VBM25_CUR_ITEMS");
-        bt->target_items = bt->use_range ? (ti ? (uint32_t)std::atoi(ti) : R_TARGET_ITEMS)
-                           : bt->use_cursor ? (ti ? (uint32_t)std::atoi(ti) : CUR_TARGET_ITEMS) : TARGET_ITEMS;
-        if (bt->target_items < 256) bt->target_items = 256;
-        const char *mc = std::getenv("VBM25_CUR_MIN_CHUNK");
-        bt->min_chunk = bt->use_range ? (mc ? (uint32_t)std::atoi(mc) : R_MIN_CHUNK_POSTINGS)
-                        : bt->use_cursor ? (mc ? (uint32_t)std::atoi(mc) : CUR_MIN_CHUNK_POSTINGS) : MIN_CHUNK_POSTINGS;
-        if (bt->min_chunk < 128) bt->min_chunk = 128;
-        const char *mi = std::getenv("VBM25_CUR_MIN_ITEMS");
-        if (mi) bt->cur_min_items = (uint32_t)std::atoi(mi);
-    }
-    bt->max_items = max_queries + bt->target_items + (bt->use_dense ? bt->dense_target : 0u);
+    bt->tune = g_tune;
+    bt->h_dense.resize(max_queries);
+    bt->h_postings.resize(max_queries);
+    // Routing by k: k <= 256 -- sparse queries of <= 16 terms: scan_range_kernel, dense ones: scan_dense_kernel, the rest and
+    // whatever those two give up: scan_many_kernel; 256 < k <= 1024: scan_many_kernel (LDS top-k); above: the exhaustive path
+    bt->use_range = k <= (uint32_t)REG_K;
+    bt->lpi = bt->use_range ? (uint32_t)RNW : 1u;
+    bt->use_dense = bt->use_range && k <= (uint32_t)D_KMAX && bt->tune.dense != 0;
+    bt->target_items = bt->use_range ? std::max(256u, bt->tune.range_items) : TARGET_ITEMS;
+    bt->min_chunk = bt->use_range ? std::max(128u, bt->tune.range_min_chunk) : MIN_CHUNK_POSTINGS;
+    bt->max_items = max_queries + bt->target_items + (bt->use_dense ? std::max(256u, bt->tune.dense_items) : 0u);
     int rc = 0;
     if (k > 1024) {  // exhaustive path: query buffers, results and an accumulator per document
         bt->bigk = true;
-        bt->use_range = bt->use_cursor = false;
+        bt->use_range = bt->use_dense = false;
         const size_t n = ix->n_docs ? ix->n_docs : 1;
         hipcub::DeviceRadixSort::SortPairsDescending(nullptr, bt->bk_tmp_bytes, (const unsigned long long *)nullptr,
                                                      (unsigned long long *)nullptr, (const uint32_t *)nullptr,
@@ -521,24 +499,20 @@ static int vbm25_batch_create_impl(vbm25_index *ix, uint32_t max_queries, uint32
         (rc = bt->hits.alloc(sizeof(vbm25_hit) * size_t(max_queries) * k)) ||
         (rc = bt->n_hits.alloc(4ull * max_queries)) || (rc = bt->error_flag.alloc(4)) ||
         (rc = bt->q_dense.alloc(max_queries)) ||
-        (rc = bt->spill.alloc(size_t(TARGET_ITEMS) * 3 * 2 * C_POSTINGS * 16)) ||
         (rc = bt->item_failed.alloc(4ull * bt->max_items)) || (rc = bt->work_ctr.alloc(8)) ||
         (rc = bt->hist.alloc(4ull * CUR_HB * max_queries)) || (rc = bt->fused_state.alloc(4ull * (max_queries + 1))))
         return rc;
-    {
-        const char *fz = std::getenv("VBM25_FUSED");
-        bt->use_fused = bt->use_range && !(fz && fz[0] == '0');
-    }
     HIP_TRY(hipMemset(bt->error_flag.p, 0, 4));
     if (int rc2 = bt->dbg.alloc(64)) return rc2;
     HIP_TRY(hipMemset(bt->dbg.p, 0, 64));
 #ifdef VBM25_PROFILE
-    if (int rc2 = bt->prof.alloc(8ull * 33 * CUR_GRID)) return rc2;
-    HIP_TRY(hipMemset(bt->prof.p, 0, 8ull * 33 * CUR_GRID));
+    if (int rc2 = bt->prof.alloc(8ull * 16 * RNW * R_GRID)) return rc2;
+    HIP_TRY(hipMemset(bt->prof.p, 0, 8ull * 16 * RNW * R_GRID));
 #endif
     *out = bt.release();
     return VBM25_OK;
 }
+
 
 void vbm25_batch_destroy(vbm25_batch *bt) {
     if (!bt) return;
@@ -561,17 +535,14 @@ static int vbm25_batch_set_queries_impl(vbm25_batch *bt, const uint32_t *term_id
     if (!term_ids && nq && q_off[nq] != 0) return set_error(VBM25_ERR_INVALID, "term_ids is NULL but the queries have terms");
     if (nq > bt->max_queries) return set_error(VBM25_ERR_INVALID, "%u queries exceed the batch capacity %u", nq, bt->max_queries);
     if (q_off[0] != 0) return set_error(VBM25_ERR_INVALID, "q_off[0] must be 0");
-    bool many = false, mid = false, has_dense = false;
-    uint32_t n_dense = 0;
-    uint32_t cur_mt = 1, range_mt = 0;
-    // Routing: the chain kernel is built for sparse queries; a query with many postings per
-    // document (Zipf head terms) or more than CHAIN_MAX_TERMS indexed terms takes the
-    // dense-window kernel.  Tuning knob: VBM25_DENSE_X1000 (postings per 1000 documents).
-    const char *env = std::getenv("VBM25_DENSE_X1000");
-    const unsigned long long dense_x1000 = env ? (unsigned long long)std::atoll(env) : 100ull;
-    std::vector<uint8_t> dense(nq, 0);
-    std::vector<unsigned long long> q_postings(nq, 0);
-    unsigned long long total_postings = 0;
+    bool many = false, has_dense = false;
+    uint32_t n_dense = 0, range_mt = 0;
+    // Routing: scan_range_kernel is built for sparse queries; a query with many postings per document (Zipf head terms)
+    // takes the dense-window kernel, one with more than 16 indexed terms scan_many_kernel.  (The scratch vectors were
+    // sized when the batch was created: nothing is allocated here.)
+    const unsigned long long dense_x1000 = (unsigned long long)std::max(0ll, bt->tune.dense_x1000);
+    uint8_t *dense = bt->h_dense.data();
+    unsigned long long *q_postings = bt->h_postings.data();
     for (uint32_t q = 0; q < nq; ++q) {
         if (q_off[q + 1] < q_off[q]) return set_error(VBM25_ERR_INVALID, "q_off not monotone at query %u", q);
         uint32_t valid = 0;
@@ -583,7 +554,7 @@ static int vbm25_batch_set_queries_impl(vbm25_batch *bt, const uint32_t *term_id
             if (term_ids[p] < bt->index->n_terms) postings += bt->index->term_df_host[term_ids[p]];
         }
         q_postings[q] = postings;
-        total_postings += postings;
+        dense[q] = 0;
         if (postings * 1000ull >= dense_x1000 * bt->index->n_docs) {
             dense[q] = 1;
             many = true;
@@ -592,13 +563,9 @@ static int vbm25_batch_set_queries_impl(vbm25_batch *bt, const uint32_t *term_id
         if (bt->use_range) {  // sparse queries of <= 16 terms: scan_range_kernel; dense ones: scan_dense_kernel; the rest: scan_many_kernel
             many |= valid > 16u;
             has_dense |= bt->use_dense && dense[q] && valid <= (uint32_t)D_T;
-            if ((!dense[q] || bt->range_dense) && valid <= 16u) range_mt = std::max(range_mt, valid);
+            if (!dense[q] && valid <= 16u) range_mt = std::max(range_mt, valid);
         } else {
-            many |= valid > (uint32_t)CHAIN_MAX_TERMS;
-            if (!dense[q]) {
-                if (valid <= (uint32_t)CUR_T) cur_mt = std::max(cur_mt, valid);
-                else if (valid <= (uint32_t)CHAIN_MAX_TERMS) mid = true;
-            }
+            many = true;
         }
         if (valid > MAX_TERMS)
             return set_error(VBM25_ERR_UNSUPPORTED, "query %u has %u indexed terms; the GPU path handles up to %d", q, valid, MAX_TERMS);
@@ -614,7 +581,7 @@ static int vbm25_batch_set_queries_impl(vbm25_batch *bt, const uint32_t *term_id
     bt->nq = nq;
     bt->fused_g = 0;
     bt->fused_pinned = false;
-    if (bt->use_fused && nq && !many && !has_dense && range_mt != 0) {  // every query sparse, <= 16 indexed terms: the one-launch route
+    if (bt->tune.fused && bt->use_range && nq && !many && !has_dense && range_mt != 0) {  // every query sparse, <= 16 indexed terms: the one-launch route
         unsigned long long most = 0;
         bool all = true;
         for (uint32_t q = 0; q < nq; ++q) {
@@ -626,8 +593,8 @@ static int vbm25_batch_set_queries_impl(vbm25_batch *bt, const uint32_t *term_id
             unsigned long long g = (most + bt->min_chunk / 2) / bt->min_chunk;
             g = std::min<unsigned long long>(g, std::max<unsigned long long>((bt->target_items + nq / 2) / nq, 1));
             g = std::min<unsigned long long>(std::max<unsigned long long>(g, 1), std::min<unsigned long long>(64, bt->index->n_docs));
-            // only where the launches it saves matter: a batch that fills the GPU runs 17 % slower through the FUSED
-            // instantiation (C3: 0.565 ms vs 0.481 ms; more live state in the tile loop) than plan + scan + merge cost
+            // only where the launches it saves matter: a batch that fills the GPU runs slower through the FUSED
+            // instantiation (more live state in the tile loop) than plan + scan + merge cost
             if (nq * g <= 128) {
                 bt->fused_g = uint32_t(g);
                 bt->fused_pinned = fast && nq <= 8 && !bt->timing;
@@ -655,24 +622,22 @@ static int vbm25_batch_set_queries_impl(vbm25_batch *bt, const uint32_t *term_id
         if (!bt->lat_stream) HIP_TRY(hipStreamCreateWithFlags(&bt->lat_stream, hipStreamNonBlocking));
         if (nt) std::memcpy(bt->pin_in, term_ids, nt);
         std::memcpy(bt->pin_in + nt, q_off, no);
-        if (nq) std::memcpy(bt->pin_in + nt + no, dense.data(), nq);
+        if (nq) std::memcpy(bt->pin_in + nt + no, dense, nq);
         bt->pin_nt = nt;
         if (!(bt->fused_g && bt->fused_pinned))
             if (int rc = upload_staged(bt)) return rc;
     } else {
         if (q_off[nq]) HIP_TRY(hipMemcpy(bt->term_ids.p, term_ids, 4ull * q_off[nq], hipMemcpyHostToDevice));
         HIP_TRY(hipMemcpy(bt->q_off.p, q_off, 4ull * (nq + 1), hipMemcpyHostToDevice));
-        if (nq) HIP_TRY(hipMemcpy(bt->q_dense.p, dense.data(), nq, hipMemcpyHostToDevice));
+        if (nq) HIP_TRY(hipMemcpy(bt->q_dense.p, dense, nq, hipMemcpyHostToDevice));
     }
-    bt->has_many_terms = many;
     bt->has_dense = has_dense;
-    bt->has_mid_terms = mid;
-    bt->cur_mt = cur_mt;
     bt->range_rt = !bt->use_range || range_mt == 0 ? 0u : (range_mt <= 8u ? 8u : 16u);
-    {   // the number of work items plan_kernel will make (same integer arithmetic): the cursor kernel's
-        // persistent grid need not be larger (a single query is a handful of items, not 6144 workgroups)
-        // with the dense-window kernel every dense query gets the same number of items (equal document counts)
-        bt->dense_c = has_dense ? std::max(1u, (bt->dense_target + n_dense / 2) / std::max(n_dense, 1u)) : 0u;
+    {   // the number of work items plan_kernel will make (same integer arithmetic): the persistent grids need not be
+        // larger (a single query is a handful of items); with the dense-window kernel every dense query gets the same
+        // number of items (equal document counts)
+        const uint32_t dense_target = std::max(256u, bt->tune.dense_items);
+        bt->dense_c = has_dense ? std::max(1u, (dense_target + n_dense / 2) / std::max(n_dense, 1u)) : 0u;
         unsigned long long sparse_postings = 0;
         for (uint32_t q = 0; q < nq; ++q)
             if (!(bt->dense_c && dense[q])) sparse_postings += q_postings[q];
@@ -690,19 +655,12 @@ static int vbm25_batch_set_queries_impl(vbm25_batch *bt, const uint32_t *term_id
             if (c > bt->index->n_docs) c = bt->index->n_docs;
             items += c;
         }
-        bt->cur_grid = uint32_t(std::min<unsigned long long>(std::max<unsigned long long>(items, 1), CUR_GRID));
-        const char *rgrid = std::getenv("VBM25_RANGE_GRID");  // tuning knob: persistent workgroups
-        bt->range_grid = uint32_t(std::min<unsigned long long>(std::max<unsigned long long>(items, 1),
-                                                               rgrid ? (unsigned long long)std::atoll(rgrid) : R_GRID));
-        // A handful of items cannot occupy the GPU with one wave each: the tile kernel puts a whole
-        // workgroup (six decoding waves) on an item and answers a single query faster (C2: 0.10 ms vs 0.15 ms)
-        bt->run_cursor = bt->use_cursor && items >= bt->cur_min_items;
-        const char *dgrid = std::getenv("VBM25_DENSE_GRID");
-        bt->dense_grid = uint32_t(std::min<unsigned long long>(std::max<unsigned long long>(items, 1),
-                                                               dgrid ? (unsigned long long)std::atoll(dgrid) : D_GRID));
+        bt->range_grid = uint32_t(std::min<unsigned long long>(std::max<unsigned long long>(items, 1), std::max(1u, bt->tune.range_grid)));
+        bt->dense_grid = uint32_t(std::min<unsigned long long>(std::max<unsigned long long>(items, 1), std::max(1u, bt->tune.dense_grid)));
     }
     return VBM25_OK;
 }
+
 
 static int vbm25_batch_run_impl(vbm25_batch *bt, void *hip_stream) {
     if (!bt) return set_error(VBM25_ERR_INVALID, "batch is NULL");
@@ -751,36 +709,50 @@ static int vbm25_batch_run_impl(vbm25_batch *bt, void *hip_stream) {
     db.n_hits = bt->n_hits.as<uint32_t>();
     db.error_flag = bt->error_flag.as<uint32_t>();
     db.q_dense = bt->q_dense.as<uint8_t>();
-    db.spill = bt->spill.as<unsigned long long>();
     db.item_failed = bt->item_failed.as<uint32_t>();
     db.prof = bt->prof.as<unsigned long long>();
     db.hist = bt->hist.as<uint32_t>();
     db.work_ctr = bt->work_ctr.as<uint32_t>();
     db.max_items = bt->max_items;
     db.dbg = bt->dbg.as<uint32_t>();
-    const bool cursor = bt->run_cursor;
-    db.chain_min_terms = cursor ? (uint32_t)CUR_T + 1u : 0u;
     db.lpi = bt->lpi;
     db.range_max_terms = bt->use_range ? 16u : 0u;
-    db.range_dense = bt->range_dense ? 1u : 0u;
-    db.ne_on = bt->ne_on ? 1u : 0u;
-    db.ne_ratio = bt->ne_ratio;
+    db.ne_on = bt->tune.ne ? 1u : 0u;
+    db.ne_ratio = std::max(1u, bt->tune.ne_ratio);
     db.dense_on = bt->use_dense ? 1u : 0u;
     const bool range = bt->use_range;
     const DevIndex &ix = bt->index->dev;
     db.fused_state = bt->fused_state.as<uint32_t>();
     db.fused_g = 0;
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    auto take_events = [&]() -> int {
+        if (!bt->timing) return VBM25_OK;
+        if (bt->events_used == bt->events.size()) {
+            HIP_TRY(hipEventCreate(&e0));
+            HIP_TRY(hipEventCreate(&e1));
+            bt->events.emplace_back(e0, e1);
+        }
+        e0 = bt->events[bt->events_used].first;
+        e1 = bt->events[bt->events_used].second;
+        bt->events_used++;
+        HIP_TRY(hipEventRecord(e0, st));
+        return VBM25_OK;
+    };
     if (bt->fused_g && bt->range_rt) {
-        if (!bt->state_clean) {
+        // The one-launch route needs threshold, histogram and counters zero; it leaves them so itself -- but only a run
+        // that was enqueued completely counts: the flag is cleared before anything is enqueued and set at the very end
+        // (an error return in between, or a run on the general route, forces the memsets next time).  Consecutive runs
+        // of one batch must use one stream.
+        const bool clean = bt->state_clean;
+        bt->state_clean = false;
+        if (!clean) {
             HIP_TRY(hipMemsetAsync(bt->hist.p, 0, 4ull * CUR_HB * bt->max_queries, st));
             HIP_TRY(hipMemsetAsync(bt->theta.p, 0, 8ull * bt->max_queries, st));
             HIP_TRY(hipMemsetAsync(bt->work_ctr.p, 0, 8, st));
             HIP_TRY(hipMemsetAsync(bt->fused_state.p, 0, 4ull * (bt->max_queries + 1), st));
-            bt->state_clean = true;
         }
         db.fused_g = bt->fused_g;
         db.dense_on = 0;
-        db.range_dense = 0;
         if (bt->fused_pinned) {  // queries read from, hits written to pinned host memory
             const size_t nc = (4ull * bt->nq + 7) & ~size_t(7);
             db.term_ids = reinterpret_cast<const uint32_t *>(bt->pin_in);
@@ -788,18 +760,7 @@ static int vbm25_batch_run_impl(vbm25_batch *bt, void *hip_stream) {
             db.n_hits = reinterpret_cast<uint32_t *>(bt->pin_out + 8);
             db.hits = reinterpret_cast<vbm25_hit *>(bt->pin_out + 8 + nc);
         }
-        hipEvent_t f0 = nullptr, f1 = nullptr;
-        if (bt->timing) {
-            if (bt->events_used == bt->events.size()) {
-                HIP_TRY(hipEventCreate(&f0));
-                HIP_TRY(hipEventCreate(&f1));
-                bt->events.emplace_back(f0, f1);
-            }
-            f0 = bt->events[bt->events_used].first;
-            f1 = bt->events[bt->events_used].second;
-            bt->events_used++;
-            HIP_TRY(hipEventRecord(f0, st));
-        }
+        if (int rc = take_events()) return rc;
         const uint32_t fgrid = std::min<uint32_t>(bt->nq * bt->fused_g, R_GRID);
         const int rcf = dispatch_k(bt->k, [&](auto kmax) {
             constexpr int KM = decltype(kmax)::value;
@@ -810,34 +771,25 @@ static int vbm25_batch_run_impl(vbm25_batch *bt, void *hip_stream) {
                     // an item the kernel gave up (rare) is redone by scan_many_kernel and its query merged by merge_kernel;
                     // both find nothing to do otherwise.  (The pinned flavour leaves that to the host: it re-runs the batch.)
                     scan_many_kernel<KM><<<std::min<uint32_t>(bt->nq * bt->fused_g, TARGET_ITEMS), WG, 0, st>>>(ix, db);
-                    if (bt->timing) (void)hipEventRecord(f1, st);
+                    if (bt->timing) (void)hipEventRecord(e1, st);
                     DevBatch dm = db;
                     dm.merge_marked = 1;
                     merge_kernel<KM><<<bt->nq, 64, 0, st>>>(ix, dm);
+                } else if (bt->timing) {
+                    (void)hipEventRecord(e1, st);
                 }
             }
             return int(VBM25_OK);
         });
         if (rcf) return rcf;
         HIP_TRY(hipGetLastError());
+        bt->state_clean = true;
         return VBM25_OK;
     }
     bt->state_clean = false;
-    if (cursor || range) HIP_TRY(hipMemsetAsync(bt->hist.p, 0, 4ull * CUR_HB * bt->nq, st));
-    plan_kernel<<<1, PLAN_WG, 0, st>>>(ix, db, bt->max_items, cursor || range ? bt->target_items : TARGET_ITEMS,
-                                       cursor || range ? bt->min_chunk : MIN_CHUNK_POSTINGS, bt->dense_c);
-    hipEvent_t e0 = nullptr, e1 = nullptr;
-    if (bt->timing) {
-        if (bt->events_used == bt->events.size()) {
-            HIP_TRY(hipEventCreate(&e0));
-            HIP_TRY(hipEventCreate(&e1));
-            bt->events.emplace_back(e0, e1);
-        }
-        e0 = bt->events[bt->events_used].first;
-        e1 = bt->events[bt->events_used].second;
-        bt->events_used++;
-        HIP_TRY(hipEventRecord(e0, st));
-    }
+    if (range) HIP_TRY(hipMemsetAsync(bt->hist.p, 0, 4ull * CUR_HB * bt->nq, st));
+    plan_kernel<<<1, PLAN_WG, 0, st>>>(ix, db, bt->max_items, bt->target_items, bt->min_chunk, bt->dense_c);
+    if (int rc = take_events()) return rc;
     const uint32_t grid = std::min<uint32_t>(bt->max_items, TARGET_ITEMS);
     const int rc = dispatch_k(bt->k, [&](auto kmax) {
         constexpr int KM = decltype(kmax)::value;
@@ -845,16 +797,12 @@ static int vbm25_batch_run_impl(vbm25_batch *bt, void *hip_stream) {
             if (range) {  // persistent 8-wave workgroups; items are handed out through bt.work_ctr
                 if (bt->range_rt == 8) scan_range_kernel<KM, 8><<<bt->range_grid, RWG, 0, st>>>(ix, db);
                 else if (bt->range_rt == 16) scan_range_kernel<KM, 16><<<bt->range_grid, RWG, 0, st>>>(ix, db);
-            } else if (cursor) {
-                // persistent single-wave workgroups; items are handed out through bt.work_ctr
-                scan_cursor_kernel<KM><<<bt->cur_grid, 64, 4 * cur_lds_words(bt->cur_mt), st>>>(ix, db, bt->cur_mt);
             }
         }
         if constexpr (KM <= D_KMAX) {
             if (bt->has_dense) scan_dense_kernel<KM><<<bt->dense_grid, DWG, 0, st>>>(ix, db);
         }
-        if (!range && (!cursor || bt->has_mid_terms)) scan_kernel<KM><<<grid, CWG, 0, st>>>(ix, db);
-        // many-term / dense queries, and items the first-choice kernel gave up on (empty launch: 5 us)
+        // many-term queries, every query of 256 < k <= 1024, and items the first-choice kernel gave up on (empty launch: 5 us)
         scan_many_kernel<decltype(kmax)::value><<<grid, WG, 0, st>>>(ix, db);
         if (bt->timing) HIP_TRY(hipEventRecord(e1, st));  // the events bracket every posting-scan kernel of the step
         merge_kernel<decltype(kmax)::value><<<bt->nq, 64, 0, st>>>(ix, db);
@@ -932,9 +880,17 @@ static int vbm25_evaluate_batch_impl(vbm25_index *ix, const uint32_t *q_terms, u
     if (n_docs == 0) return VBM25_OK;
     const uint64_t n_el = doc_start[n_docs];
     if (n_el && (!doc_term || !doc_tf)) return set_error(VBM25_ERR_INVALID, "NULL argument");
-    for (uint32_t i = 1; i < n_q; ++i)  // Query::checked_new, vector.rs:106-110
-        if (q_terms[i] <= q_terms[i - 1] && q_terms[i] < ix->n_terms)
-            return set_error(VBM25_ERR_INVALID, "query term ids must be strictly ascending");
+    {  // Query::checked_new, vector.rs:106-110: keys strictly ascending; ids of unknown tokens (>= n_terms) stand
+       // wherever their keys sorted and are skipped, so every known id is compared with the last KNOWN one
+        bool have = false;
+        uint32_t prev = 0;
+        for (uint32_t i = 0; i < n_q; ++i) {
+            if (q_terms[i] >= ix->n_terms) continue;
+            if (have && q_terms[i] <= prev) return set_error(VBM25_ERR_INVALID, "query term ids must be strictly ascending");
+            prev = q_terms[i];
+            have = true;
+        }
+    }
     for (uint32_t d = 0; d < n_docs; ++d) {
         if (doc_start[d + 1] < doc_start[d]) return set_error(VBM25_ERR_INVALID, "doc_start not monotone at document %u", d);
         uint32_t prev = 0;
@@ -980,6 +936,26 @@ int vbm25_evaluate_batch(vbm25_index *ix, const uint32_t *q_terms, uint32_t n_q,
     return guarded([&] { return vbm25_evaluate_batch_impl(ix, q_terms, n_q, n_docs, doc_start, doc_term, doc_tf, scores); });
 }
 
+// tuning / test aid (not declared in include/vbm25.h): process-wide switches, read when a batch object is created.
+// Names: dense_x1000, dense, ne, fused, ne_ratio, dense_items, range_items, range_min_chunk, range_grid, dense_grid.
+int vbm25_tuning_set(const char *name, long long value) {
+    if (!name) return set_error(VBM25_ERR_INVALID, "NULL argument");
+    const std::string n(name);
+    if (n == "dense_x1000") g_tune.dense_x1000 = value;
+    else if (n == "dense") g_tune.dense = value != 0;
+    else if (n == "ne") g_tune.ne = value != 0;
+    else if (n == "fused") g_tune.fused = value != 0;
+    else if (n == "ne_ratio") g_tune.ne_ratio = (uint32_t)std::max(1ll, value);
+    else if (n == "dense_items") g_tune.dense_items = (uint32_t)std::max(256ll, value);
+    else if (n == "range_items") g_tune.range_items = (uint32_t)std::max(256ll, value);
+    else if (n == "range_min_chunk") g_tune.range_min_chunk = (uint32_t)std::max(128ll, value);
+    else if (n == "range_grid") g_tune.range_grid = (uint32_t)std::max(1ll, value);
+    else if (n == "dense_grid") g_tune.dense_grid = (uint32_t)std::max(1ll, value);
+    else return set_error(VBM25_ERR_INVALID, "unknown tuning switch %s", name);
+    return VBM25_OK;
+}
+void vbm25_tuning_reset(void) { g_tune = Tuning(); }
+
 // tuning / test aid (not declared in include/vbm25.h): work items of the last run and how many of them the
 // first-choice kernel handed to scan_many_kernel
 int vbm25_batch_debug_counts(vbm25_batch *bt, uint32_t *n_items, uint32_t *n_failed) {
@@ -990,18 +966,7 @@ int vbm25_batch_debug_counts(vbm25_batch *bt, uint32_t *n_items, uint32_t *n_fai
     std::vector<uint32_t> f(*n_items);
     if (*n_items) HIP_TRY(hipMemcpy(f.data(), bt->item_failed.p, 4ull * *n_items, hipMemcpyDeviceToHost));
     *n_failed = 0;
-    uint32_t codes[64] = {};
-    int shown = 0;
-    for (uint32_t x : f) {
-        *n_failed += x != 0;
-        if (x) codes[x & 63]++;
-        if (x && std::getenv("VBM25_DEBUG") && shown++ < 24)
-            std::fprintf(stderr, "vbm25: failed item code 0x%x p_ne %u nmulti %u exact %u np %u\n", x & 0xff, (x >> 8) & 0xff,
-                         (x >> 16) & 0xff, (x >> 24) & 1, x >> 25);
-    }
-    if (std::getenv("VBM25_DEBUG"))
-        for (int c = 0; c < 64; ++c)
-            if (codes[c]) std::fprintf(stderr, "vbm25: %u items failed with code 0x%x\n", codes[c], c);
+    for (uint32_t x : f) *n_failed += x != 0;
     return VBM25_OK;
 }
 
@@ -1054,15 +1019,10 @@ int vbm25_batch_kernel_ms(vbm25_batch *bt, double *avg_ms, uint32_t *n_launches)
 }
 
 #ifdef VBM25_PROFILE
-int vbm25_scan_occupancy(void) {
-    int blocks = 0;
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&blocks, scan_kernel<64>, CWG, 0) != hipSuccess) return -1;
-    return blocks;
-}
 // profiling builds only (not declared in include/vbm25.h): copy out the phase counters
 int vbm25_batch_profile(vbm25_batch *bt, unsigned long long *out, uint32_t n_workgroups) {
     HIP_TRY(hipDeviceSynchronize());
-    HIP_TRY(hipMemcpy(out, bt->prof.p, 8ull * 33 * n_workgroups, hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(out, bt->prof.p, 8ull * 16 * RNW * std::min<uint32_t>(n_workgroups, R_GRID), hipMemcpyDeviceToHost));
     return VBM25_OK;
 }
 #endif

@@ -25,6 +25,7 @@
 #include <memory>
 #include <numeric>
 #include <string>
+#include <system_error>
 #include <thread>
 #include <vector>
 
@@ -234,10 +235,8 @@ void parallel_tasks(size_t n_tasks, int threads, F &&fn) {
     std::vector<std::thread> pool;
     try {
         for (int t = 1; t < threads; ++t) pool.emplace_back(worker, t);
-    } catch (...) {  // std::system_error: run with the threads that exist
-        std::lock_guard<std::mutex> g(error_mutex);
-        if (!first_error) first_error = std::current_exception();
-        next.store(n_tasks, std::memory_order_relaxed);
+    } catch (const std::system_error &) {
+        // no more threads to be had (EAGAIN): not an error -- the ones that exist and this one drain the queue
     }
     worker(0);
     for (auto &th : pool) th.join();

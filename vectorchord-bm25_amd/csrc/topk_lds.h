@@ -1,7 +1,6 @@
 // topk_lds.h -- sorted top-k list in LDS kept by one wave (k > 256, scan_many_kernel).
 // Part of libvbm25's single device translation unit: included by search.hip inside namespace vbm25, in
-// this order: device_types, decode, plan, topk_lds, scan_many, block_fetch, topk_reg, scan_tile,
-// scan_cursor, merge.
+// this order: device_types, decode, plan, topk_lds, block_fetch, topk_reg, scan_range, scan_dense, scan_many, merge.
 
 // ---------------------------------------------------------------------------
 // Sorted top-k list in LDS, maintained by ONE wave.

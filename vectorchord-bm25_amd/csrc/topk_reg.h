@@ -1,7 +1,6 @@
 // topk_reg.h -- RegTopK (top-k in registers), wave helpers, profiling macros.
 // Part of libvbm25's single device translation unit: included by search.hip inside namespace vbm25, in
-// this order: device_types, decode, plan, topk_lds, scan_many, block_fetch, topk_reg, scan_tile,
-// scan_cursor, merge.
+// this order: device_types, decode, plan, topk_lds, block_fetch, topk_reg, scan_range, scan_dense, scan_many, merge.
 
 // ---------------------------------------------------------------------------
 // Running top-k of ONE wave held in registers: RK rows of 64 entries, sorted best first, entry e

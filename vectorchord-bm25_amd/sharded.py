@@ -52,7 +52,8 @@ def gather_hits(local_words, n_queries: int, k: int, group=None):
 def gather_to_root(local_words, n_queries: int, k: int, dst: int = 0, group=None):
     """Gather the per-rank hit records to rank `dst` only (north_star: "top-k gather"): the all-gather of
     gather_hits moves world x the bytes anybody needs.  Same padding rule; returns the int64 tensor
-    [n_queries * k * 3] in global query order on `dst`, None elsewhere."""
+    [n_queries * k * 3] in global query order on `dst`, None elsewhere.  `dst` is a rank OF `group` (as the
+    shard numbering is); torch.distributed.gather wants the global rank, so it is translated here."""
     import torch
     import torch.distributed as dist
 
@@ -64,7 +65,8 @@ def gather_to_root(local_words, n_queries: int, k: int, dst: int = 0, group=None
         send = torch.zeros(per, dtype=torch.int64, device=local_words.device)
         send[:local_words.numel()] = local_words
     bufs = [torch.empty(per, dtype=torch.int64, device=local_words.device) for _ in range(world)] if rank == dst else None
-    dist.gather(send, bufs, dst=dst, group=group)
+    dst_global = dst if group is None else dist.get_global_rank(group, dst)
+    dist.gather(send, bufs, dst=dst_global, group=group)
     if rank != dst:
         return None
     parts = []
