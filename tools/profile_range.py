@@ -11,7 +11,7 @@ sys.path.insert(0, ROOT)
 import vectorchord_bm25_amd as vb
 from vectorchord_bm25_amd import _lib
 
-_lib._SO = os.path.join(ROOT, "vectorchord-bm25_amd", "csrc", "libvbm25_prof.so")
+_lib._SO = os.environ.get("VBM25_LIBRARY") or os.path.join(ROOT, "vectorchord-bm25_amd", "csrc", "libvbm25_prof.so")
 _lib._lib = None
 from bench import WORKLOADS, make_queries
 
@@ -40,8 +40,7 @@ tiles = p[:, 1:, 0]
 print(f"tiles per wave mean {tiles.mean():.1f}; items per WG {p[:, 0, 12].mean():.2f}; rows/tile {p[:, 1, 10].sum() / max(1, tiles[:, 0].sum()):.1f}; "
       f"cold blocks/tile {p[:, :, 11].sum() / max(1, tiles[:, 0].sum()):.2f}")
 print(f"wave lifetime cycles mean {p[:, :, 15].mean():.0f} max {p[:, :, 15].max():.0f}; in tile loops {p[:, :, 9].mean():.0f}; setup/item {p[:, :, 8].sum() / max(1, p[:, :, 12].sum()):.0f}")
-names = {1: "S1 plan reads + issue loads", 2: "S1 wait loads", 14: "S1 until marks returned", 3: "S1 total (.. dups inserted)", 4: "barrier A", 5: "S2 (wipe, rows x terms, plan)",
-         6: "barrier B", 7: "S3 rows", 13: "S3 cold"}
+names = {1: "S1 (workers) / plan (wave 0)", 2: "barrier A", 5: "S2 (wipe, rows x terms)", 6: "barrier B", 7: "S3 rows", 13: "S3 cold"}
 for w in ("workers", 0, 1):
     sel = p[:, 1:, :] if w == "workers" else p[:, w:w + 1, :]
     t = p[:, 1:2, 0].sum() * sel.shape[1]

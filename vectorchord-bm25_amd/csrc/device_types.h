@@ -18,11 +18,19 @@ struct DevIndex {
     const double *blk_ub;        // Cache::evaluate(block WAND pair) x (1 + 1e-12): no posting of the block scores higher
     const uint8_t *blob;
     const uint8_t *post_fn;      // derived: fieldnorm of every posting, 128 bytes per block
+    const uint32_t *post_rel16;  // derived: 64 words per block -- word l = (id[2l + 1] - min_doc) << 16 | (id[2l] - min_doc) of a
+                                 // full bit-packed block that spans < 2^16 documents (rel16_block), undefined for the others
     const uint16_t *doc_payload;
     const double *s1;            // 256 entries
     unsigned long long blob_bytes;  // bytes of blob that hold block bodies (the allocation has slack behind them)
     uint32_t blk_ub_attained;    // 1: every blk_ub is the score of a posting of its block (the index came with block WAND pairs)
 };
+
+// Blocks whose ids scan_range_kernel reads from post_rel16 (one coalesced word per lane, two adds) instead of unpacking the
+// delta stream: full blocks (128 postings, bit-packed, not raw) that span at most 65535 documents.
+__device__ __forceinline__ bool rel16_block(uint32_t min_doc, uint32_t max_doc, uint32_t w) {
+    return ((w >> 8) & 0xffu) < 32u && (w & 0xffu) == 128u && max_doc - min_doc <= 0xffffu;
+}
 
 struct Item {
     uint32_t q, doc_lo, doc_hi, m;  // m = number of indexed terms of query q | ITEM_DENSE

@@ -10,6 +10,7 @@ struct PostFnArgs {
     const uint4 *blk_meta;
     const uint8_t *blob, *doc_fieldnorm;
     uint8_t *post_fn;
+    uint32_t *post_rel16;
     uint32_t *error_flag;
     // upper bounds to verify: the scan kernels prune with them
     const uint32_t *term_first_block, *term_wand_tf;
@@ -44,6 +45,7 @@ __global__ void __launch_bounds__(256) post_fn_kernel(PostFnArgs a) {
     if (i1 == n - 1) bad |= d1 != m.y;
     if (bad) atomicOr(a.error_flag, 1u);
     reinterpret_cast<uchar2 *>(a.post_fn + 128ull * j)[lane] = make_uchar2(f0, f1);
+    a.post_rel16[64ull * j + lane] = rel16_block(m.x, m.y, m.w) ? (d1 - m.x) << 16 | (d0 - m.x) : 0u;
 
     // The WAND pairs must bound every posting: Cache::evaluate of each posting against the block's
     // bound (blk_ub, margin included) and the token's (search.rs:363,377-380).

@@ -579,6 +579,21 @@ __global__ void __launch_bounds__(RWG, 4) scan_range_kernel(DevIndex ix, DevBatc
             }
         };
 
+        // the lane's post_rel16 words of its wave's blocks of a planned tile, loaded one tile ahead (right after the barrier
+        // that publishes the plan) so that S1 does not start with a round trip to HBM
+        uint32_t reln[RB];
+        auto fetch_rel = [&](uint32_t b) {
+            // branch-free (a branch per load made the compiler wait for every load at the join): entries beyond the plan
+            // read the plan's last block, a plan of no blocks reads block 0; S1 masks those entries
+            const uint32_t npn = uni(S.hdr[b].z), last = npn ? npn - 1u : 0u, bmax = ix.n_blocks - 1u;
+            uint32_t blk[RB];
+#pragma unroll
+            for (int i = 0; i < RB; ++i) blk[i] = S.pa[b][min((wave - 1u) + (RNW - 1) * i, last)].x;
+#pragma unroll
+            for (int i = 0; i < RB; ++i) reln[i] = ix.post_rel16[64ull * min(uni(blk[i]), bmax) + lane];
+        };
+        fetch_rel(0);
+
         for (uint32_t tile = 0;; ++tile) {
             const uint32_t buf = tile % R_PLAN_RING;
             par = tile & 1u;
@@ -607,41 +622,26 @@ __global__ void __launch_bounds__(RWG, 4) scan_range_kernel(DevIndex ix, DevBatc
                 bool allfast = true;
 #pragma unroll
                 for (int i = 0; i < RB; ++i) c[i] = S.pm[buf][(wave - 1u) + (RNW - 1) * i];
-                uint32_t flo0[RB], fhi0[RB], flo1[RB], fhi1[RB];
 #pragma unroll
                 for (int i = 0; i < RB; ++i) {
                     c[i] = uni4(c[i]);
-                    flo0[i] = fhi0[i] = flo1[i] = fhi1[i] = 0;
-                    const uint32_t md = (c[i].w >> 8) & 0xff;
-                    allfast = allfast && ((uint32_t)i >= nv || md < 32u);
-                    if ((uint32_t)i < nv && md < 32u) pair_fetch(ix.blob + 8ull * c[i].z, md, lane, flo0[i], fhi0[i], flo1[i], fhi1[i]);
+                    allfast = allfast && ((uint32_t)i >= nv || rel16_block(c[i].x, c[i].y, c[i].w));
                 }
-#ifdef VBM25_PROFILE
-                {
-                    const unsigned long long t_a1 = __builtin_readcyclecounter();
-                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                    const unsigned long long t_a2 = __builtin_readcyclecounter();
-                }
-#endif
                 asm volatile("; MARK_S1_DECODE");
-                // full bit-packed blocks (compression.rs:65-92), branch-free so that the eight decodes overlap;
-                // entries beyond nv decode zeros and are masked below
+                // ids of the rel16 blocks: min_doc + the two halves of the lane's word (fetched one tile ahead); entries
+                // beyond nv are masked below
                 uint32_t d0[RB], d1[RB];
 #pragma unroll
                 for (int i = 0; i < RB; ++i) {
-                    uint32_t v0, v1;
-                    pair_extract((c[i].w >> 8) & 31u, lane, flo0[i], fhi0[i], flo1[i], fhi1[i], v0, v1);
-                    const uint32_t own = v0 + v1;
-                    const uint32_t incl = wave_incl_scan_u32(own);
-                    d0[i] = c[i].x + (incl - own) + v0;
-                    d1[i] = d0[i] + v1;
+                    d0[i] = c[i].x + (reln[i] & 0xffffu);
+                    d1[i] = c[i].x + (reln[i] >> 16);
                 }
-                if (!allfast) {  // raw (width 32) or byte-packed tail blocks: generic, synchronous decode
+                if (!allfast) {  // wide, raw (width 32) or byte-packed tail blocks: generic, synchronous decode from the blob
 #pragma nounroll
                     for (uint32_t i = 0; i < nv; ++i) {
                         const uint4 cc = uni4(S.pm[buf][(wave - 1u) + (RNW - 1) * i]);
                         const uint32_t md = (cc.w >> 8) & 0xff;
-                        if (md >= 32u) {
+                        if (!rel16_block(cc.x, cc.y, cc.w)) {
                             const uint32_t n = cc.w & 0xff;
                             uint32_t a0, a1;
                             decode_doc_ids(ix.blob + 8ull * cc.z, md, n, cc.x, lane, a0, a1);
@@ -678,11 +678,6 @@ __global__ void __launch_bounds__(RWG, 4) scan_range_kernel(DevIndex ix, DevBatc
                     o1[i] = atomicOr(&S.bm[(x1 >> 5) & (R_BM_WORDS - 1)], m1[i]);
                 }
                 asm volatile("; MARK_S1_DUPS");
-#ifdef VBM25_PROFILE
-                {
-                    const unsigned long long t_m = __builtin_readcyclecounter();
-                }
-#endif
                 uint32_t dupmask = 0;
 #pragma unroll
                 for (int i = 0; i < RB; ++i)
@@ -711,8 +706,10 @@ __global__ void __launch_bounds__(RWG, 4) scan_range_kernel(DevIndex ix, DevBatc
             }
             asm volatile("; MARK_S1_END");
             PROF_T(t_b);
+            PROF_ADD(1, t_a, t_b);
             lds_barrier();  // ---- A: every mark, staged id and row of the tile is in LDS; the next plan too
             PROF_T(t_c);
+            PROF_ADD(2, t_b, t_c);
 
             if (uni(S.fail)) {
                 // The tile overflowed its rows (or a wave its list of second arrivals): lists that intersect that
@@ -751,8 +748,12 @@ __global__ void __launch_bounds__(RWG, 4) scan_range_kernel(DevIndex ix, DevBatc
                     failed = true;
                     break;
                 }
+                fetch_rel((tile + 1) % R_PLAN_RING);
                 continue;  // the next iteration runs the re-planned tile (a backward goto into this loop cost 20 %)
             }
+            asm volatile("; MARK_PREFETCH");
+            fetch_rel((tile + 1) % R_PLAN_RING);
+            asm volatile("; MARK_S2_BEGIN");
             const uint32_t nm = min(uni(S.nmulti[par]), (uint32_t)(R_ROWS * 8 / RT));
 
             // ---- S2: wipe the filter; rows x terms: find the postings, score them
@@ -797,6 +798,7 @@ __global__ void __launch_bounds__(RWG, 4) scan_range_kernel(DevIndex ix, DevBatc
                     S.contrib[(r << LRT) + t] = (tf * S.t_s0[t]) / (tf + S.s1[fn]);  // Cache::evaluate, bm25.rs:355-358
                 }
             }
+            asm volatile("; MARK_S2_END");
             PROF_T(t_d);
             PROF_ADD(5, t_c, t_d);
             lds_barrier();  // ---- B: contributions and done bits complete; filter clean
@@ -821,10 +823,6 @@ __global__ void __launch_bounds__(RWG, 4) scan_range_kernel(DevIndex ix, DevBatc
                 const double thd = __longlong_as_double((long long)theta_now());
                 cand = cand && partial + nes >= thd;
                 if (!__ballot(cand)) return;
-#ifdef VBM25_PROFILE
-                prof[1] += (unsigned long long)__popcll(__ballot(cand));
-                const unsigned long long t_c0 = __builtin_readcyclecounter();
-#endif
                 // pass 1: block upper bounds (search.rs:177-203) instead of the token bounds
                 double bound = partial;
                 for (uint32_t t = 0; t < mq; ++t) {
@@ -837,10 +835,6 @@ __global__ void __launch_bounds__(RWG, 4) scan_range_kernel(DevIndex ix, DevBatc
                 }
                 cand = cand && bound * (1.0 + 1e-12) >= thd;
                 if (!__ballot(cand)) return;
-#ifdef VBM25_PROFILE
-                prof[2] += (unsigned long long)__popcll(__ballot(cand));
-                const unsigned long long t_c1 = __builtin_readcyclecounter();
-#endif
                 // pass 2: the exact score, terms in ascending key order (evaluate.rs:43-72)
                 uint32_t *scr = S.list[wave];  // 128 ids of the block being looked into
                 double acc = 0.0;
@@ -861,9 +855,6 @@ __global__ void __launch_bounds__(RWG, 4) scan_range_kernel(DevIndex ix, DevBatc
                             if (!pmask) break;
                             const uint32_t blk = (uint32_t)__builtin_amdgcn_readlane((int)b, __ffsll((long long)pmask) - 1);
                             const uint4 bm = uni4(ix.blk_meta[blk]);
-#ifdef VBM25_PROFILE
-                            prof[14] += 1;
-#endif
                             const uint32_t n = bm.w & 0xff, md = (bm.w >> 8) & 0xff, mt = (bm.w >> 16) & 0xff;
                             uint32_t a0, a1;
                             decode_doc_ids(ix.blob + 8ull * bm.z, md, n, bm.x, lane, a0, a1);
@@ -890,13 +881,6 @@ __global__ void __launch_bounds__(RWG, 4) scan_range_kernel(DevIndex ix, DevBatc
                     }
                     acc += c;
                 }
-#ifdef VBM25_PROFILE
-                {
-                    const unsigned long long t_c2 = __builtin_readcyclecounter();
-                    prof[3] += t_c1 - t_c0;
-                    prof[4] += t_c2 - t_c1;
-                }
-#endif
                 offer(cand, acc, d);
             };
 
