@@ -52,6 +52,7 @@ struct DevBatch {
     uint32_t *n_hits;
     uint32_t *error_flag;
     const uint8_t *q_dense;    // per query: 1 = dense (many postings per document), host decided
+    uint32_t *item_order;      // plan_kernel: the items longest first -- the order the persistent workgroups draw them in
     uint32_t *item_failed;     // per item: != 0 = the first-choice kernel gave the item up, scan_many_kernel redoes it
     unsigned long long *prof;  // VBM25_PROFILE builds: 16 counters per wave
     uint32_t *work_ctr;        // [0] next item of the range kernel, [1] of the dense kernel (reset by plan_kernel)
@@ -93,6 +94,7 @@ constexpr uint32_t EMPTY = 0xffffffffu;
 constexpr uint32_t TARGET_ITEMS = 1536;  // work items of a batch on the scan_many_kernel route
 constexpr uint32_t MIN_CHUNK_POSTINGS = 8192;
 constexpr int PLAN_WG = 1024;
+constexpr int PLAN_BUCKETS = 512;      // of plan_kernel's sort of the items by length (<= PLAN_WG)
 constexpr int CUR_HB = 256;            // score buckets of the per-query histogram of accepted documents
 constexpr int REG_K = 256;                // largest k whose running top-k lives in registers
 constexpr uint32_t NONE32 = 0xffffffffu;

@@ -102,7 +102,9 @@ __device__ __forceinline__ unsigned long long plan_incl_scan(unsigned long long 
 __global__ void __launch_bounds__(PLAN_WG) plan_kernel(DevIndex ix, DevBatch bt, uint32_t max_items,
                                                        uint32_t target_items, uint32_t min_chunk, uint32_t dense_c) {
     __shared__ unsigned long long s_wave[PLAN_WG / 64];
+    __shared__ uint32_t s_bucket[PLAN_BUCKETS];
     const uint32_t tid = threadIdx.x;
+    for (uint32_t i = tid; i < (uint32_t)PLAN_BUCKETS; i += PLAN_WG) s_bucket[i] = 0;
     const uint32_t per = (bt.nq + PLAN_WG - 1) / PLAN_WG;
     const uint32_t q0 = min(bt.nq, tid * per), q1 = min(bt.nq, q0 + per);
     // per-launch state of the scan kernels (saves two memset launches per step)
@@ -157,12 +159,34 @@ __global__ void __launch_bounds__(PLAN_WG) plan_kernel(DevIndex ix, DevBatch bt,
         bt.q_item_base[bt.nq] = (uint32_t)min(run, (unsigned long long)max_items);
     }
     uint32_t base = (uint32_t)(incl - cnt);
+    // The persistent scan kernels draw items through item_order: longest first (the last items drawn decide when the
+    // launch ends).  A counting sort over buckets of the items' postings: exponent and three mantissa bits.
+    auto bucket_of = [&](unsigned long long postings, uint32_t c) -> uint32_t {
+        const unsigned long long w = postings / (c ? c : 1u) + 1ull;
+        const uint32_t e = 63u - (uint32_t)__builtin_clzll(w);
+        const uint32_t sub = e >= 3u ? (uint32_t)(w >> (e - 3u)) & 7u : 0u;
+        return min(8u * e + sub, (uint32_t)PLAN_BUCKETS - 1u);
+    };
+    for (uint32_t q = q0; q < q1; ++q) {
+        const uint32_t c = chunks_of(q);
+        if (c) atomicAdd(&s_bucket[bucket_of(one ? own_postings : postings_of(q), c)], c);
+    }
+    __syncthreads();
+    {   // first position of every bucket, from the largest bucket down (PLAN_BUCKETS <= PLAN_WG: one bucket per thread)
+        const uint32_t bkt = (uint32_t)PLAN_BUCKETS - 1u - tid;
+        const unsigned long long v = tid < (uint32_t)PLAN_BUCKETS ? s_bucket[bkt] : 0u;
+        unsigned long long all = 0;
+        const unsigned long long in = plan_incl_scan(v, s_wave, all);
+        if (tid < (uint32_t)PLAN_BUCKETS) s_bucket[bkt] = (uint32_t)(in - v);
+    }
+    __syncthreads();
     for (uint32_t q = q0; q < q1; ++q) {
         const uint32_t c = chunks_of(q);
         uint32_t nterms = 0;
         for (uint32_t p = bt.q_off[q]; p < bt.q_off[q + 1]; ++p) nterms += bt.term_ids[p] < ix.n_terms;
         if (bt.q_dense[q]) nterms |= ITEM_DENSE;
         bt.q_item_base[q] = min(base, max_items);
+        const uint32_t pos = c ? atomicAdd(&s_bucket[bucket_of(one ? own_postings : postings_of(q), c)], c) : 0u;
         for (uint32_t i = 0; i < c && base + i < max_items; ++i) {
             Item it;
             it.q = q;
@@ -170,6 +194,7 @@ __global__ void __launch_bounds__(PLAN_WG) plan_kernel(DevIndex ix, DevBatch bt,
             it.doc_hi = (uint32_t)((unsigned long long)ix.n_docs * (i + 1) / c);
             it.m = nterms;
             bt.items[base + i] = it;
+            if (pos + i < max_items) bt.item_order[pos + i] = base + i;
         }
         base += c;
     }

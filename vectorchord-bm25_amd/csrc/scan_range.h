@@ -151,7 +151,10 @@ __global__ void __launch_bounds__(RWG, 4) scan_range_kernel(DevIndex ix, DevBatc
 
     for (;;) {
         __syncthreads();  // previous item fully done with LDS
-        if (tid == 0) S.item = atomicAdd(bt.work_ctr, 1u);
+        if (tid == 0) {
+            const uint32_t drawn = atomicAdd(bt.work_ctr, 1u);
+            S.item = !fused_g && drawn < n_items ? bt.item_order[drawn] : drawn;  // plan_kernel's order: longest first
+        }
         for (uint32_t i = tid; i < R_HS; i += RWG) S.hkeys[i] = EMPTY;
         for (uint32_t i = tid; i < R_BM_WORDS + 4; i += RWG) S.bm[i] = 0;
         for (uint32_t i = tid; i < R_ROWS * 8; i += RWG) S.contrib[i] = 0.0;
@@ -321,7 +324,6 @@ __global__ void __launch_bounds__(RWG, 4) scan_range_kernel(DevIndex ix, DevBatc
                 if (lane == 0) S.hdr[buf] = make_uint4(p_tlo, p_tlo, 0, 0);
                 return;
             }
-            uint32_t thi = min(hi, wave_min_u32(bnd));
             const uint32_t st = p_st < 64u ? p_st : 0u;
             const uint32_t cur_s = (uint32_t)__shfl((int)p_cur, (int)st), end_s = (uint32_t)__shfl((int)p_end, (int)st);
             const uint32_t quo_s = (uint32_t)__shfl((int)p_quota, (int)st);
@@ -329,10 +331,11 @@ __global__ void __launch_bounds__(RWG, 4) scan_range_kernel(DevIndex ix, DevBatc
             const bool valid = p_st != NONE32 && p_so < quo_s && j < end_s;
             uint4 meta = make_uint4(NONE32, 0, 0, 0);
             double ub = 0.0;
-            if (valid) {
+            if (valid) {  // (issued before the boundary above is waited for: one round trip to memory per plan, not two)
                 meta = ix.blk_meta[j];
                 ub = ix.blk_ub[j];
             }
+            uint32_t thi = min(hi, wave_min_u32(bnd));
             // the 64 candidates (quotas) may hold more than a tile takes: the largest thi with <= R_NBLK blocks
             if ((uint32_t)__popcll(__ballot(valid && meta.x < thi)) > p_cap) {
                 uint32_t lo_v = p_tlo + 1, hi_v = thi;  // count(lo_v) <= terms <= p_cap < count(hi_v)

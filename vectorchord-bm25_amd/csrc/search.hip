@@ -218,7 +218,7 @@ struct vbm25_batch {
     int device = 0;  // the index's device ordinal: the batch can be destroyed after its index
     uint32_t max_queries = 0, max_terms = 0, k = 0, nq = 0, max_items = 0;
     DeviceBuffer term_ids, q_off, items, n_items, q_item_base, theta, res_score, res_doc, res_cnt,
-        hits, n_hits, error_flag, prof, q_dense, item_failed, work_ctr, hist, fused_state, dbg;
+        hits, n_hits, error_flag, prof, q_dense, item_failed, item_order, work_ctr, hist, fused_state, dbg;
     bool bigk = false;            // k > 1024: exhaustive path, one query at a time
     DeviceBuffer bk_acc, bk_keys, bk_iota, bk_docs, bk_tmp;
     size_t bk_tmp_bytes = 0;
@@ -502,7 +502,7 @@ static int vbm25_batch_create_impl(vbm25_index *ix, uint32_t max_queries, uint32
         (rc = bt->hits.alloc(sizeof(vbm25_hit) * size_t(max_queries) * k)) ||
         (rc = bt->n_hits.alloc(4ull * max_queries)) || (rc = bt->error_flag.alloc(4)) ||
         (rc = bt->q_dense.alloc(max_queries)) ||
-        (rc = bt->item_failed.alloc(4ull * bt->max_items)) || (rc = bt->work_ctr.alloc(8)) ||
+        (rc = bt->item_failed.alloc(4ull * bt->max_items)) || (rc = bt->item_order.alloc(4ull * bt->max_items)) || (rc = bt->work_ctr.alloc(8)) ||
         (rc = bt->hist.alloc(4ull * CUR_HB * max_queries)) || (rc = bt->fused_state.alloc(4ull * (max_queries + 1))))
         return rc;
     HIP_TRY(hipMemset(bt->error_flag.p, 0, 4));
@@ -713,6 +713,7 @@ static int vbm25_batch_run_impl(vbm25_batch *bt, void *hip_stream) {
     db.error_flag = bt->error_flag.as<uint32_t>();
     db.q_dense = bt->q_dense.as<uint8_t>();
     db.item_failed = bt->item_failed.as<uint32_t>();
+    db.item_order = bt->item_order.as<uint32_t>();
     db.prof = bt->prof.as<unsigned long long>();
     db.hist = bt->hist.as<uint32_t>();
     db.work_ctr = bt->work_ctr.as<uint32_t>();
