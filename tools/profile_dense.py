@@ -12,7 +12,7 @@ sys.path.insert(0, ROOT)
 import vectorchord_bm25_amd as vb
 from vectorchord_bm25_amd import _lib
 
-_lib._SO = os.path.join(ROOT, "vectorchord-bm25_amd", "csrc", os.environ.get("VBM25_SO", "libvbm25_prof.so"))
+_lib._SO = os.environ.get("VBM25_LIBRARY") or os.path.join(ROOT, "vectorchord-bm25_amd", "csrc", "libvbm25_prof.so")
 _lib._lib = None
 from bench import make_queries, usable_cpus
 

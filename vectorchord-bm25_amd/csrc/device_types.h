@@ -20,6 +20,9 @@ struct DevIndex {
     const uint8_t *post_fn;      // derived: fieldnorm of every posting, 128 bytes per block
     const uint32_t *post_rel16;  // derived: 64 words per block -- word l = (id[2l + 1] - min_doc) << 16 | (id[2l] - min_doc) of a
                                  // full bit-packed block that spans < 2^16 documents (rel16_block), undefined for the others
+    const uint32_t *post_tfn;    // derived: 64 words per block -- word l = tf[2l] | tf[2l + 1] << 8 | fieldnorm[2l] << 16 |
+                                 // fieldnorm[2l + 1] << 24 of a full block whose term frequencies are bit-packed in <= 7 bits
+                                 // (tfn_block), undefined for the others
     const uint16_t *doc_payload;
     const double *s1;            // 256 entries
     unsigned long long blob_bytes;  // bytes of blob that hold block bodies (the allocation has slack behind them)
@@ -31,6 +34,10 @@ struct DevIndex {
 __device__ __forceinline__ bool rel16_block(uint32_t min_doc, uint32_t max_doc, uint32_t w) {
     return ((w >> 8) & 0xffu) < 32u && (w & 0xffu) == 128u && max_doc - min_doc <= 0xffffu;
 }
+
+// Blocks whose term frequencies and fieldnorm bytes scan_dense_kernel reads from post_tfn: full blocks, tf fields of at most
+// 7 bits.
+__device__ __forceinline__ bool tfn_block(uint32_t w) { return (w & 0xffu) == 128u && ((w >> 16) & 0xffu) <= 7u; }
 
 struct Item {
     uint32_t q, doc_lo, doc_hi, m;  // m = number of indexed terms of query q | ITEM_DENSE

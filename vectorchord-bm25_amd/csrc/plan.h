@@ -10,7 +10,7 @@ struct PostFnArgs {
     const uint4 *blk_meta;
     const uint8_t *blob, *doc_fieldnorm;
     uint8_t *post_fn;
-    uint32_t *post_rel16;
+    uint32_t *post_rel16, *post_tfn;
     uint32_t *error_flag;
     // upper bounds to verify: the scan kernels prune with them
     const uint32_t *term_first_block, *term_wand_tf;
@@ -60,6 +60,7 @@ __global__ void __launch_bounds__(256) post_fn_kernel(PostFnArgs a) {
     const double bub = a.blk_ub[j];
     uint32_t t0, t1;
     decode_fields(body + ((payload_bytes(md, n) + 7u) & ~7u), mt, n, lane, t0, t1);
+    a.post_tfn[64ull * j + lane] = tfn_block(m.w) ? t0 | t1 << 8 | (uint32_t)f0 << 16 | (uint32_t)f1 << 24 : 0u;
     bool loose = false;
     if (i0 < n) {
         const double tf = (double)t0, p = (tf * s0) / (tf + a.s1[f0]);

@@ -282,17 +282,17 @@ __global__ void __launch_bounds__(DWG, KMAX > 128 ? 2 : 4) scan_dense_kernel(Dev
 
         // ---- one task: decode the block, add the postings' upper bounds to their documents' accumulators
         struct Raw {
-            uint32_t a0, a1, a2, a3, b0, b1, b2, b3;
-            uint32_t fn;
+            uint32_t rel, tfn;  // the lane's words of post_rel16 and post_tfn: two postings
         };
-        auto task_fetch = [&](const uint4 c, uint32_t j, Raw &r) {
-            const uint32_t md = (c.w >> 8) & 0xff, mt = (c.w >> 16) & 0xff;
-            const uint8_t *body = ix.blob + 8ull * c.z;
-            const uint8_t *tbody = body + 16u * md;  // bit-packed: 16 bytes per bit of width (a multiple of 8)
-            pair_fetch(body, md, lane, r.a0, r.a1, r.a2, r.a3);
-            pair_fetch(tbody, mt, lane, r.b0, r.b1, r.b2, r.b3);
-            r.fn = reinterpret_cast<const uint16_t *>(ix.post_fn + 128ull * j)[lane];
+        auto task_fetch = [&](uint32_t j, Raw &r) {
+            r.rel = ix.post_rel16[64ull * j + lane];
+            r.tfn = ix.post_tfn[64ull * j + lane];
         };
+        // bucket maxima are read by the skip test of P2 (largest accumulator of a span + the bounds the head terms can still add
+        // >= threshold) and by P3 (>= threshold): a sum below bmax_floor = threshold - (all the head terms' bounds) can make neither
+        // true, so only the sums at or above it are recorded -- with a warm threshold almost none, and the same-address LDS
+        // atomics of 64 postings that share a few buckets go away
+        uint32_t bmax_floor = 0;
         auto add_pair = [&](float s0i, uint32_t d0, uint32_t d1, uint32_t f0, uint32_t f1, uint32_t fn, bool in0, bool in1,
                             uint32_t wlo, uint32_t wspan) {
             VCHK(wspan <= (uint32_t)D_W, 10, wspan);
@@ -307,25 +307,19 @@ __global__ void __launch_bounds__(DWG, KMAX > 128 ? 2 : 4) scan_dense_kernel(Dev
             if (in0 && x0 < wspan) {
                 const uint32_t sum = ((atomicAdd(&S.acc[x0 >> 1], p0 << (16u * (x0 & 1u))) >> (16u * (x0 & 1u))) & 0xffffu) + p0;
                 VCHK(sum < 65536u, 12, sum);
-                atomicMax(&S.bmax[x0 >> 6], sum);
+                if (sum >= bmax_floor) atomicMax(&S.bmax[x0 >> 6], sum);
             }
             if (in1 && x1 < wspan) {
                 const uint32_t sum = ((atomicAdd(&S.acc[x1 >> 1], p1 << (16u * (x1 & 1u))) >> (16u * (x1 & 1u))) & 0xffffu) + p1;
                 VCHK(sum < 65536u, 12, sum);
-                atomicMax(&S.bmax[x1 >> 6], sum);
+                if (sum >= bmax_floor) atomicMax(&S.bmax[x1 >> 6], sum);
             }
         };
         auto task_accumulate = [&](const uint4 c, float s0i, const Raw &r, uint32_t wlo, uint32_t wspan) {
-            const uint32_t md = (c.w >> 8) & 0xff, mt = (c.w >> 16) & 0xff;
-            uint32_t v0, v1, f0, f1;
-            pair_extract(md, lane, r.a0, r.a1, r.a2, r.a3, v0, v1);
-            pair_extract(mt, lane, r.b0, r.b1, r.b2, r.b3, f0, f1);
-            const uint32_t own = v0 + v1;
-            const uint32_t incl = wave_incl_scan_u32(own);
-            const uint32_t d0 = c.x + (incl - own) + v0;
-            add_pair(s0i, d0, d0 + v1, f0, f1, r.fn, true, true, wlo, wspan);
+            add_pair(s0i, c.x + (r.rel & 0xffffu), c.x + (r.rel >> 16), r.tfn & 0xffu, (r.tfn >> 8) & 0xffu, r.tfn >> 16, true, true, wlo, wspan);
         };
-        // byte-packed tail or raw block: generic, synchronous decode (rare: one call site)
+        // byte-packed tail, raw or wide block, term frequencies of 8 bits and more: generic, synchronous decode from the blob
+        // (rare: one call site)
         auto task_slow = [&](uint32_t e, uint32_t wlo, uint32_t wspan) {
             const uint4 c = uni4(S.tmeta[e]);
             const uint32_t j = uni(S.tblk[e]), t = uni((uint32_t)S.tterm[e]);
@@ -366,12 +360,12 @@ __global__ void __launch_bounds__(DWG, KMAX > 128 ? 2 : 4) scan_dense_kernel(Dev
                                       (uint32_t)__builtin_amdgcn_readlane((int)cm.z, i), (uint32_t)__builtin_amdgcn_readlane((int)cm.w, i));
                     j[i] = (uint32_t)__builtin_amdgcn_readlane((int)jb, i);
                     s0i[i] = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(sv), i));
-                    fast[i] = ((c[i].w >> 8) & 0xff) < 32u && ((c[i].w >> 16) & 0xff) < 32u;
+                    fast[i] = rel16_block(c[i].x, c[i].y, c[i].w) && tfn_block(c[i].w);
                 }
             }
 #pragma unroll
             for (int i = 0; i < D_UN; ++i)
-                if ((uint32_t)i < nv && fast[i]) task_fetch(c[i], j[i], r[i]);
+                if ((uint32_t)i < nv && fast[i]) task_fetch(j[i], r[i]);
             uint32_t slow = 0;
 #pragma unroll
             for (int i = 0; i < D_UN; ++i) {
@@ -680,6 +674,10 @@ __global__ void __launch_bounds__(DWG, KMAX > 128 ? 2 : 4) scan_dense_kernel(Dev
             if (tid == 0) S.ntask = 0;  // (read by nobody until the next window's counts)
             if (p_ne >= m) break;  // no document can reach the threshold any more (search.rs:153-169 with every term)
             const uint32_t theta_i = theta_fix(theta_now());
+            {   // rem + tub of any head block <= scale x (sum of the head terms' bounds) + a few units of rounding (t_rem, tub above)
+                const uint32_t heads = __double2uint_ru(S.t_cum[h_ne] * scale) + 8u;
+                bmax_floor = theta_i > heads ? theta_i - heads : 0u;
+            }
             PROF_T(t_b);
             PROF_ADD(1, t_a, t_b);
 

@@ -194,7 +194,7 @@ struct vbm25_index {
     std::vector<uint32_t> term_df_host;  // host copy for query routing
     vbm25_batch *scratch = nullptr;      // batch object re-used by vbm25_search_batch
     DeviceBuffer term_wand_tf, term_wand_fn, term_df, term_first_block, term_s0, blk_min_doc, blk_max_doc, blk_meta, blk_ub, blob,
-        post_fn, post_rel16, doc_payload, s1, term_idf, fn_len;
+        post_fn, post_rel16, post_tfn, doc_payload, s1, term_idf, fn_len;
     double k1 = 1.2;
     uint64_t device_bytes = 0;
 };
@@ -349,6 +349,7 @@ static int vbm25_index_create_impl(const vbm25_index_desc *d, int device, vbm25_
         (rc = ix->blob.alloc(blob_alloc)) ||
         (rc = ix->post_fn.alloc(128ull * d->n_blocks)) ||
         (rc = ix->post_rel16.alloc(256ull * d->n_blocks)) ||
+        (rc = ix->post_tfn.alloc(256ull * d->n_blocks)) ||
         (rc = ix->doc_payload.upload(d->doc_payload, 6ull * d->n_docs)) ||
         (rc = ix->s1.upload(s1, sizeof s1)) ||
         (rc = fieldnorm.upload(d->doc_fieldnorm, d->n_docs)) || (rc = err.alloc(4)))
@@ -367,6 +368,7 @@ static int vbm25_index_create_impl(const vbm25_index_desc *d, int device, vbm25_
         pa.doc_fieldnorm = fieldnorm.as<uint8_t>();
         pa.post_fn = ix->post_fn.as<uint8_t>();
         pa.post_rel16 = ix->post_rel16.as<uint32_t>();
+        pa.post_tfn = ix->post_tfn.as<uint32_t>();
         pa.error_flag = err.as<uint32_t>();
         pa.term_first_block = ix->term_first_block.as<uint32_t>();
         pa.term_wand_tf = ix->term_wand_tf.as<uint32_t>();
@@ -402,6 +404,7 @@ static int vbm25_index_create_impl(const vbm25_index_desc *d, int device, vbm25_
     ix->dev.blob = ix->blob.as<uint8_t>();
     ix->dev.post_fn = ix->post_fn.as<uint8_t>();
     ix->dev.post_rel16 = ix->post_rel16.as<uint32_t>();
+    ix->dev.post_tfn = ix->post_tfn.as<uint32_t>();
     ix->dev.doc_payload = ix->doc_payload.as<uint16_t>();
     ix->dev.s1 = ix->s1.as<double>();
     ix->dev.blob_bytes = d->blob_bytes;
@@ -417,7 +420,7 @@ static int vbm25_index_create_impl(const vbm25_index_desc *d, int device, vbm25_
     }
     for (const DeviceBuffer *b : {&ix->term_df, &ix->term_first_block, &ix->term_s0, &ix->blk_min_doc,
                                   &ix->blk_max_doc, &ix->blk_meta, &ix->blk_ub, &ix->blob, &ix->post_fn,
-                                  &ix->post_rel16, &ix->doc_payload, &ix->s1})
+                                  &ix->post_rel16, &ix->post_tfn, &ix->doc_payload, &ix->s1})
         ix->device_bytes += b->bytes;
     *out = ix.release();
     return VBM25_OK;
