@@ -46,6 +46,8 @@ print(f"workgroups with work {int((w0[:, 12] > 0).sum())}; items {int(w0[:, 12].
       f"candidates buffered {int(p[:, :, 10].sum())} ({p[:, :, 10].sum() / max(1, win):.2f} per window), re-scored exactly {int(p[:, :, 11].sum())}")
 print(f"tasks fetched {int(p[:, :, 13].sum())} skipped {int(p[:, :, 14].sum())}; per window {p[:, :, 13].sum() / max(1, win):.1f} + {p[:, :, 14].sum() / max(1, win):.1f}")
 print(f"wave lifetime cycles mean {p[:, :, 15].mean():.0f} max {p[:, :, 15].max():.0f} min {p[:, :, 15].min():.0f}; in window loops mean {p[:, :, 9].mean():.0f}; item setup {p[:, :, 8].sum() / max(1, p[:, :, 12].sum()):.0f} per item")
+if os.environ.get("PD_SUB"):
+    print(f"run_group per window per wave: entry read {p[:, :, 10].sum() / win / 8:.0f}  fetch wait {p[:, :, 11].sum() / win / 8:.0f}  accumulate {p[:, :, 14].sum() / win / 8:.0f}")
 names = {1: "P0 enumerate (2 barriers)", 2: "P1 essential tasks", 3: "P2 non-essential phases", 4: "barrier before P3", 5: "P3 scan + barrier",
          6: "flush: filter", 7: "flush: exact re-scoring"}
 for w in ("all", 0, 7):

@@ -284,10 +284,6 @@ __global__ void __launch_bounds__(DWG, KMAX > 128 ? 2 : 4) scan_dense_kernel(Dev
         struct Raw {
             uint32_t rel, tfn;  // the lane's words of post_rel16 and post_tfn: two postings
         };
-        auto task_fetch = [&](uint32_t j, Raw &r) {
-            r.rel = ix.post_rel16[64ull * j + lane];
-            r.tfn = ix.post_tfn[64ull * j + lane];
-        };
         // bucket maxima are read by the skip test of P2 (largest accumulator of a span + the bounds the head terms can still add
         // >= threshold) and by P3 (>= threshold): a sum below bmax_floor = threshold - (all the head terms' bounds) can make neither
         // true, so only the sums at or above it are recorded -- with a warm threshold almost none, and the same-address LDS
@@ -315,9 +311,6 @@ __global__ void __launch_bounds__(DWG, KMAX > 128 ? 2 : 4) scan_dense_kernel(Dev
                 if (sum >= bmax_floor) atomicMax(&S.bmax[x1 >> 6], sum);
             }
         };
-        auto task_accumulate = [&](const uint4 c, float s0i, const Raw &r, uint32_t wlo, uint32_t wspan) {
-            add_pair(s0i, c.x + (r.rel & 0xffffu), c.x + (r.rel >> 16), r.tfn & 0xffu, (r.tfn >> 8) & 0xffu, r.tfn >> 16, true, true, wlo, wspan);
-        };
         // byte-packed tail, raw or wide block, term frequencies of 8 bits and more: generic, synchronous decode from the blob
         // (rare: one call site)
         auto task_slow = [&](uint32_t e, uint32_t wlo, uint32_t wspan) {
@@ -331,77 +324,108 @@ __global__ void __launch_bounds__(DWG, KMAX > 128 ? 2 : 4) scan_dense_kernel(Dev
             const uint32_t fn = reinterpret_cast<const uint16_t *>(ix.post_fn + 128ull * j)[lane];
             add_pair(S.t_s0i[t], d0, d1, f0, f1, fn, 2 * lane < n, 2 * lane + 1 < n, wlo, wspan);
         };
-        // up to D_UN tasks of this wave (entries e[0 .. nv) of the task list), all of them in flight together
-        auto run_group = [&](const uint32_t (&e)[D_UN], uint32_t nv, uint32_t wlo, uint32_t wspan) {
-            uint4 c[D_UN];
-            uint32_t j[D_UN];
+        // A GROUP: up to D_UN tasks of this wave (entries e[0 .. nv) of the task list), all of them in flight together.
+        // grp_issue reads the entries and starts the loads, grp_finish adds the postings up; P1 issues group n + 1
+        // before it finishes group n, so that the round trip to memory and the entry reads hide behind the adds.
+        static_assert(D_TCAP <= 1024 && D_UN <= 6, "ten bits per task entry in Grp::epk");
+        struct Grp {
+            unsigned long long epk;  // the entries of the tasks, ten bits each (an array here would be indexed by the slow-task loop
+                                     // and drag the whole group into scratch memory)
+            uint32_t mind[D_UN], nv, fastm, slowm;
             float s0i[D_UN];
-            bool fast[D_UN];
             Raw r[D_UN];
-            {   // lane i reads the entry of task i: one LDS round trip for the whole group instead of one per field and task
-                uint32_t el = e[0];
-#pragma unroll
-                for (int i = 1; i < D_UN; ++i) el = lane == (uint32_t)i && (uint32_t)i < nv ? e[i] : el;
-                VCHK(el < (uint32_t)D_TCAP, 2, el);
-                const uint4 cm = S.tmeta[el];
-                const uint32_t jb = S.tblk[el];
-                VCHK(lane >= nv || jb < ix.n_blocks, 3, jb);
-                VCHK(lane >= nv || 8ull * cm.z < ix.blob_bytes, 4, cm.z);
+        };
+        auto grp_issue = [&](Grp &g) __attribute__((always_inline)) {
+            // lane i reads the entry of task i: one LDS round trip for the whole group instead of one per field and task
+            const uint32_t el = (uint32_t)(g.epk >> (10u * (lane < g.nv ? lane : 0u))) & 1023u;
+            const uint4 cm = S.tmeta[el];
+            const uint32_t jb = S.tblk[el];
+            VCHK(lane >= g.nv || jb < ix.n_blocks, 3, jb);
+            VCHK(lane >= g.nv || 8ull * cm.z < ix.blob_bytes, 4, cm.z);
 #ifdef VBM25_CHECK
-                if (lane < nv && jb < ix.n_blocks) {  // the entry is the block it names (a stale or torn entry is not)
-                    const uint4 gm = ix.blk_meta[jb];
-                    VCHK(gm.x == cm.x && gm.y == cm.y && gm.z == cm.z && gm.w == cm.w, 5, el);
-                }
-#endif
-                const float sv = S.t_s0i[S.tterm[el]];
-#pragma unroll
-                for (int i = 0; i < D_UN; ++i) {
-                    c[i] = make_uint4((uint32_t)__builtin_amdgcn_readlane((int)cm.x, i), (uint32_t)__builtin_amdgcn_readlane((int)cm.y, i),
-                                      (uint32_t)__builtin_amdgcn_readlane((int)cm.z, i), (uint32_t)__builtin_amdgcn_readlane((int)cm.w, i));
-                    j[i] = (uint32_t)__builtin_amdgcn_readlane((int)jb, i);
-                    s0i[i] = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(sv), i));
-                    fast[i] = rel16_block(c[i].x, c[i].y, c[i].w) && tfn_block(c[i].w);
-                }
+            if (lane < g.nv && jb < ix.n_blocks) {  // the entry is the block it names (a stale or torn entry is not)
+                const uint4 gm = ix.blk_meta[jb];
+                VCHK(gm.x == cm.x && gm.y == cm.y && gm.z == cm.z && gm.w == cm.w, 5, el);
             }
-#pragma unroll
-            for (int i = 0; i < D_UN; ++i)
-                if ((uint32_t)i < nv && fast[i]) task_fetch(j[i], r[i]);
-            uint32_t slow = 0;
+#endif
+            const float sv = S.t_s0i[S.tterm[el]];
+            g.fastm = 0;
+            g.slowm = 0;
 #pragma unroll
             for (int i = 0; i < D_UN; ++i) {
-                if ((uint32_t)i < nv && fast[i]) task_accumulate(c[i], s0i[i], r[i], wlo, wspan);
-                if ((uint32_t)i < nv && !fast[i]) slow |= 1u << i;
+                const uint32_t cx = (uint32_t)__builtin_amdgcn_readlane((int)cm.x, i), cy = (uint32_t)__builtin_amdgcn_readlane((int)cm.y, i);
+                const uint32_t cw = (uint32_t)__builtin_amdgcn_readlane((int)cm.w, i);
+                const uint32_t jj = min((uint32_t)__builtin_amdgcn_readlane((int)jb, i), ix.n_blocks - 1u);
+                g.mind[i] = cx;
+                g.s0i[i] = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(sv), i));
+                const bool fast = rel16_block(cx, cy, cw) && tfn_block(cw);
+                g.fastm |= ((uint32_t)i < g.nv && fast ? 1u : 0u) << i;
+                g.slowm |= ((uint32_t)i < g.nv && !fast ? 1u : 0u) << i;
+                // unconditional (lanes beyond nv hold the first task's entry, the planes of other blocks hold zeros): a branch per
+                // load makes the compiler wait for each one at the join
+                g.r[i].rel = ix.post_rel16[64ull * jj + lane];
+                g.r[i].tfn = ix.post_tfn[64ull * jj + lane];
             }
+        };
+        auto grp_finish = [&](const Grp &g, uint32_t wlo, uint32_t wspan) __attribute__((always_inline)) {
+#pragma unroll
+            for (int i = 0; i < D_UN; ++i)
+                if ((g.fastm >> i) & 1u)
+                    add_pair(g.s0i[i], g.mind[i] + (g.r[i].rel & 0xffffu), g.mind[i] + (g.r[i].rel >> 16), g.r[i].tfn & 0xffu,
+                             (g.r[i].tfn >> 8) & 0xffu, g.r[i].tfn >> 16, true, true, wlo, wspan);
+            uint32_t slow = g.slowm;
             while (slow) {
                 const uint32_t i = (uint32_t)__ffs((int)slow) - 1u;
                 slow &= slow - 1u;
-                uint32_t ee = e[0];
-#pragma unroll
-                for (int x = 1; x < D_UN; ++x) ee = i == (uint32_t)x ? e[x] : ee;
-                task_slow(ee, wlo, wspan);
+                task_slow((uint32_t)(g.epk >> (10u * i)) & 1023u, wlo, wspan);
             }
 #ifdef VBM25_PROFILE
-            prof[13] += nv;
+            prof[13] += g.nv;
 #endif
         };
         // essential tasks [0, cnt): strided over the waves, every one of them fetched
-        auto run_all = [&](uint32_t cnt, uint32_t wlo, uint32_t wspan) {
-            for (uint32_t base = wave; base < cnt; base += DNW * D_UN) {
-                uint32_t e[D_UN];
-                uint32_t nv = 0;
+        auto run_all = [&](uint32_t cnt, uint32_t wlo, uint32_t wspan) __attribute__((always_inline)) {
+            Grp g0, g1;
+            auto entries = [&](Grp &g, uint32_t base) __attribute__((always_inline)) {
+                g.nv = 0;
+                g.epk = 0;
 #pragma unroll
                 for (int i = 0; i < D_UN; ++i) {
-                    e[i] = base + DNW * i;
-                    nv += e[i] < cnt ? 1u : 0u;  // a prefix
+                    const uint32_t e = base + DNW * i;
+                    if (e < cnt) {  // a prefix
+                        g.epk |= (unsigned long long)e << (10 * i);
+                        ++g.nv;
+                    }
                 }
-                run_group(e, nv, wlo, wspan);
+            };
+            uint32_t base = wave;
+            if (base >= cnt) return;
+            entries(g0, base);
+            grp_issue(g0);
+            for (;;) {
+                base += DNW * D_UN;
+                const bool more1 = base < cnt;
+                if (more1) {
+                    entries(g1, base);
+                    grp_issue(g1);
+                }
+                grp_finish(g0, wlo, wspan);
+                if (!more1) break;
+                base += DNW * D_UN;
+                const bool more0 = base < cnt;
+                if (more0) {
+                    entries(g0, base);
+                    grp_issue(g0);
+                }
+                grp_finish(g1, wlo, wspan);
+                if (!more0) break;
             }
         };
         // non-essential tasks [first, first + cnt) of one term, a contiguous share per wave: one lane per task tests
         // whether any document of the block's span can still reach the threshold (largest accumulator of the
         // 64-document buckets the span touches + rem_i, the scaled bounds of the terms not yet complete, + the
         // block's own bound); the blocks that pass are fetched, the others never touched.
-        auto run_tested = [&](uint32_t first, uint32_t cnt, uint32_t theta_i, uint32_t wlo, uint32_t wspan) {
+        auto run_tested = [&](uint32_t first, uint32_t cnt, uint32_t theta_i, uint32_t wlo, uint32_t wspan) __attribute__((always_inline)) {
             const uint32_t share = (cnt + DNW - 1) / DNW;
           for (uint32_t o0 = 0; o0 < share; o0 += 64) {  // (a share above 64: phases of many terms)
             const uint32_t o = wave * share + o0 + lane;
@@ -421,18 +445,18 @@ __global__ void __launch_bounds__(DWG, KMAX > 128 ? 2 : 4) scan_dense_kernel(Dev
             prof[14] += (uint32_t)__popcll(__ballot(o0 + lane < share && o < cnt)) - (uint32_t)__popcll(mask);
 #endif
             while (mask) {
-                uint32_t e[D_UN];
-                uint32_t nv = 0;
+                Grp g;
+                g.nv = 0;
+                g.epk = 0;
 #pragma unroll
-                for (int i = 0; i < D_UN; ++i) {
-                    e[i] = first;
+                for (int i = 0; i < D_UN; ++i)
                     if (mask) {
-                        e[i] = first + wave * share + o0 + (uint32_t)__ffsll((long long)mask) - 1u;
+                        g.epk |= (unsigned long long)(first + wave * share + o0 + (uint32_t)__ffsll((long long)mask) - 1u) << (10 * i);
                         mask &= mask - 1ull;
-                        ++nv;
+                        ++g.nv;
                     }
-                }
-                run_group(e, nv, wlo, wspan);
+                grp_issue(g);
+                grp_finish(g, wlo, wspan);
             }
           }
         };
