@@ -96,6 +96,15 @@ int vbm25_segment_build_device(int device, double k1, double b, uint32_t n_docs,
                                const uint64_t *term_start, const uint32_t *post_doc,
                                const uint32_t *post_tf, vbm25_segment **out);
 
+/* The same from mappings in ANY order -- (token rank, document, term frequency) triples as the tokenizer emits them:
+ * the device radix-sorts them into the (token, document) order of segment.rs:41-45 (the reference merges sorted
+ * runs, io.rs:244-282) and encodes.  Byte-identical to vbm25_segment_build on the sorted CSR form.  Errors: a token
+ * rank >= n_terms, a token without mappings, a repeated (token, document) pair, tf = 0 (VBM25_ERR_INVALID). */
+int vbm25_segment_build_device_unsorted(int device, double k1, double b, uint32_t n_docs, const uint32_t *doc_len,
+                                        const uint16_t *doc_payload, uint32_t n_terms, const uint8_t *term_key,
+                                        uint64_t n_mappings, const uint32_t *map_term, const uint32_t *map_doc,
+                                        const uint32_t *map_tf, vbm25_segment **out);
+
 /* Synthetic corpus of SURVEY section 8(d), generated per token so that 10M-50M
  * documents stream: every document is `len` i.i.d. token draws (uniform, or
  * Zipf(s) over token rank when zipf_s > 0); token t's key is its ASCII decimal,

@@ -73,3 +73,45 @@ def test_device_flush_rejects_bad_mappings():
     with pytest.raises(vb.Vbm25Error) as e:
         vb.Segment.build_device(1.2, 0.75, c["doc_len"], c["doc_payload"], c["term_key"], c["term_start"], bad, c["post_tf"])
     assert e.value.code == -1
+
+
+def _triples(c):
+    """The CSR mappings of a corpus as (token rank, document, tf) triples."""
+    ts = c["term_start"].astype(np.int64)
+    term = np.repeat(np.arange(len(ts) - 1, dtype=np.uint32), np.diff(ts))
+    return term, c["post_doc"].astype(np.uint32), c["post_tf"].astype(np.uint32)
+
+
+@pytest.mark.parametrize("n_docs,vocab,length,zipf", [
+    (1000, 1000, "fixed", None), (5000, 50, "mixed", 1.0), (700, 3, "fixed", None), (200_000, 5000, "lognormal", 1.0)])
+def test_device_build_from_unsorted_mappings_is_byte_identical(n_docs, vocab, length, zipf):
+    """vbm25_segment_build_device_unsorted: the triples shuffled (the order a tokenizer or several writers would hand them
+    over in) -> radix sort on the device into segment.rs:41-45's (token, document) order -> the device encode; every array
+    byte for byte what the host builder makes of the sorted CSR form."""
+    c = make_corpus(n_docs, vocab, seed=n_docs + 1, length=length, mean_len=40, zipf=zipf)
+    host = vb.Segment.build(1.2, 0.75, c["doc_len"], c["doc_payload"], c["term_key"], c["term_start"], c["post_doc"], c["post_tf"])
+    term, doc, tf = _triples(c)
+    perm = np.random.default_rng(5).permutation(len(term))
+    t0 = time.perf_counter()
+    dev = vb.Segment.build_device_unsorted(1.2, 0.75, c["doc_len"], c["doc_payload"], c["term_key"], term[perm], doc[perm], tf[perm])
+    print(f"{len(term)} mappings sorted and encoded on the device in {time.perf_counter() - t0:.3f} s (incl. PCIe both ways)")
+    assert_same_segment(dev, host)
+    # already sorted input and reversed input give the same bytes
+    assert_same_segment(vb.Segment.build_device_unsorted(1.2, 0.75, c["doc_len"], c["doc_payload"], c["term_key"], term[::-1], doc[::-1], tf[::-1]), host)
+
+
+def test_device_build_from_unsorted_mappings_rejects_bad_input():
+    c = make_corpus(500, 50, seed=2, length="fixed", mean_len=20)
+    term, doc, tf = _triples(c)
+    args = (1.2, 0.75, c["doc_len"], c["doc_payload"], c["term_key"])
+    with pytest.raises(vb.Vbm25Error):  # a token rank beyond the keys
+        vb.Segment.build_device_unsorted(*args, np.r_[term, np.uint32(len(c["term_key"]))], np.r_[doc, np.uint32(0)], np.r_[tf, np.uint32(1)])
+    with pytest.raises(vb.Vbm25Error):  # the same (token, document) twice
+        vb.Segment.build_device_unsorted(*args, np.r_[term, term[:1]], np.r_[doc, doc[:1]], np.r_[tf, tf[:1]])
+    with pytest.raises(vb.Vbm25Error):  # a token without mappings
+        keep = term != 7
+        vb.Segment.build_device_unsorted(*args, term[keep], doc[keep], tf[keep])
+    with pytest.raises(vb.Vbm25Error):  # tf = 0
+        z = tf.copy()
+        z[3] = 0
+        vb.Segment.build_device_unsorted(*args, term, doc, z)

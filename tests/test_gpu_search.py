@@ -393,6 +393,8 @@ def test_bench_distributed_code_path_single_rank():
                                   env=env, text=True, timeout=600)
     line = json.loads([l for l in out.splitlines() if l.startswith("{")][-1])
     assert line["n_gpus"] == 1 and line["value"] > 0 and line["roofline"]["frac"] > 0
+    cfg = line["config"]  # the gather runs on its own stream: what of it is left after the last scan is reported apart
+    assert cfg["gather_ms"] > 0 and 0 <= cfg["gather_exposed_ms"] <= line["ms_per_step"]
 
 
 def test_c3_full_size_full_batch_parity():

@@ -27,3 +27,20 @@ for name, fn in (("host builder (all cores)", lambda: vb.Segment.build(1.2, 0.75
         seg = fn()
         ts.append(time.perf_counter() - t0)
     print(f"{name}: {min(ts):.3f} s  ({len(c['post_doc']) / min(ts) / 1e6:.0f} M postings/s)", flush=True)
+
+# the same from SHUFFLED (token, document, tf) triples: numpy's sort in front of the host builder vs the device's radix sort
+ts_ = c["term_start"].astype(np.int64)
+term = np.repeat(np.arange(len(ts_) - 1, dtype=np.uint32), np.diff(ts_))
+perm = np.random.default_rng(3).permutation(len(term))
+term, doc, tf = term[perm], c["post_doc"][perm], c["post_tf"][perm]
+t0 = time.perf_counter()
+order = np.argsort(term.astype(np.uint64) << np.uint64(32) | doc.astype(np.uint64), kind="stable")
+sdoc, stf = doc[order], tf[order]
+t_sort = time.perf_counter() - t0
+print(f"unsorted triples: numpy sort of the 64-bit keys {t_sort:.3f} s (then the host or device builder above)", flush=True)
+ts = []
+for _ in range(3):
+    t0 = time.perf_counter()
+    seg = vb.Segment.build_device_unsorted(1.2, 0.75, c["doc_len"], c["doc_payload"], c["term_key"], term, doc, tf)
+    ts.append(time.perf_counter() - t0)
+print(f"unsorted triples: device radix sort + encode (incl. PCIe both ways): {min(ts):.3f} s  ({len(term) / min(ts) / 1e6:.0f} M mappings/s)", flush=True)

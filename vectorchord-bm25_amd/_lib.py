@@ -44,6 +44,7 @@ ABI = {
     "vbm25_version": (C.c_char_p, []),
     "vbm25_segment_build": (i32, [C.c_double, C.c_double, u32, vp, vp, u32, vp, vp, vp, vp, i32, vp]),
     "vbm25_segment_build_device": (i32, [i32, C.c_double, C.c_double, u32, vp, vp, u32, vp, vp, vp, vp, vp]),
+    "vbm25_segment_build_device_unsorted": (i32, [i32, C.c_double, C.c_double, u32, vp, vp, u32, vp, C.c_uint64, vp, vp, vp, vp]),
     "vbm25_segment_synth": (i32, [vp, vp]),
     "vbm25_segment_synth_token_terms": (i32, [vp, vp, u32, vp]),
     "vbm25_segment_desc": (i32, [vp, vp]),

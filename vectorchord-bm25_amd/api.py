@@ -95,6 +95,21 @@ class Segment:
         return cls(out)
 
     @classmethod
+    def build_device_unsorted(cls, k1, b, doc_len, doc_payload, term_key, map_term, map_doc, map_tf, device=0):
+        """vbm25_segment_build_device_unsorted: (token rank, document, tf) triples in any order; the device sorts and encodes."""
+        doc_len = np.ascontiguousarray(doc_len, dtype=np.uint32)
+        doc_payload = np.ascontiguousarray(doc_payload, dtype=np.uint16)
+        term_key = np.ascontiguousarray(term_key, dtype=np.uint8)
+        map_term = np.ascontiguousarray(map_term, dtype=np.uint32)
+        map_doc = np.ascontiguousarray(map_doc, dtype=np.uint32)
+        map_tf = np.ascontiguousarray(map_tf, dtype=np.uint32)
+        out = C.c_void_p()
+        check(lib().vbm25_segment_build_device_unsorted(device, k1, b, len(doc_len), _p(doc_len), _p(doc_payload),
+                                                        len(term_key), _p(term_key), len(map_term), _p(map_term),
+                                                        _p(map_doc), _p(map_tf), C.byref(out)))
+        return cls(out)
+
+    @classmethod
     def synth(cls, n_docs, vocab, mean_len=100, len_mode=1, zipf_s=0.0, k1=1.2, b=0.75,
               seed=20260925, threads=0):
         p = SynthParams(n_docs, vocab, mean_len, len_mode, zipf_s, k1, b, seed, threads, 0)

@@ -286,12 +286,14 @@ __global__ void __launch_bounds__(256) doc_kernel(uint32_t n_docs, const uint32_
     if ((threadIdx.x & 63) == 0) atomicAdd(sum_len, local);
 }
 
+// dev_doc / dev_tf != nullptr: the mappings are already on the device, sorted (vbm25_segment_build_device_unsorted);
+// post_doc / post_tf are not read then.
 int build_device_impl(int device, double k1, double b, uint32_t n_docs, const uint32_t *doc_len, const uint16_t *doc_payload,
                       uint32_t n_terms, const uint8_t *term_key, const uint64_t *term_start, const uint32_t *post_doc,
-                      const uint32_t *post_tf, vbm25_segment **out) {
+                      const uint32_t *post_tf, vbm25_segment **out, const uint32_t *dev_doc = nullptr, const uint32_t *dev_tf = nullptr) {
     if (!out) return set_error(VBM25_ERR_INVALID, "out is NULL");
     *out = nullptr;
-    if (!doc_len || !doc_payload || !term_start || (n_terms && (!term_key || !post_doc || !post_tf)))
+    if (!doc_len || !doc_payload || !term_start || (n_terms && (!term_key || ((!post_doc || !post_tf) && (!dev_doc || !dev_tf)))))
         return set_error(VBM25_ERR_INVALID, "NULL argument");
     if (!n_docs) return set_error(VBM25_ERR_INVALID, "segment without documents");
     if (!(k1 >= 1.2 && k1 <= 2.0) || !(b >= 0.0 && b <= 1.0))  // types.rs:18-45
@@ -347,12 +349,14 @@ int build_device_impl(int device, double k1, double b, uint32_t n_docs, const ui
 
     FL_TRY(d_ts.alloc(8ull * (n_terms + 1)));
     FL_TRY(d_tfb.alloc(4ull * (n_terms + 1)));
-    FL_TRY(d_pd.alloc(4ull * n_post));
-    FL_TRY(d_pt.alloc(4ull * n_post));
+    if (!dev_doc) {
+        FL_TRY(d_pd.alloc(4ull * n_post));
+        FL_TRY(d_pt.alloc(4ull * n_post));
+    }
     FL_TRY(d_denom.alloc(8 * 256));
     FL_TRY(hipMemcpy(d_ts.p, term_start, 8ull * (n_terms + 1), hipMemcpyHostToDevice));
     FL_TRY(hipMemcpy(d_tfb.p, seg->term_first_block.data(), 4ull * (n_terms + 1), hipMemcpyHostToDevice));
-    if (n_post) {
+    if (n_post && !dev_doc) {
         FL_TRY(hipMemcpy(d_pd.p, post_doc, 4ull * n_post, hipMemcpyHostToDevice));
         FL_TRY(hipMemcpy(d_pt.p, post_tf, 4ull * n_post, hipMemcpyHostToDevice));
     }
@@ -376,8 +380,8 @@ int build_device_impl(int device, double k1, double b, uint32_t n_docs, const ui
     a.n_blocks = n_blocks;
     a.term_start = d_ts.as<uint64_t>();
     a.term_first_block = d_tfb.as<uint32_t>();
-    a.post_doc = d_pd.as<uint32_t>();
-    a.post_tf = d_pt.as<uint32_t>();
+    a.post_doc = dev_doc ? dev_doc : d_pd.as<uint32_t>();
+    a.post_tf = dev_tf ? dev_tf : d_pt.as<uint32_t>();
     a.fieldnorm = d_fn.as<uint8_t>();
     a.denom = d_denom.as<double>();
     a.kp1 = k1 + 1.0;
@@ -439,7 +443,96 @@ int build_device_impl(int device, double k1, double b, uint32_t n_docs, const ui
     return VBM25_OK;
 }
 
+// ---------------------------------------------------------------------------
+// Mappings in any order (segment.rs:41-45: the sealed segment wants them by (token, document); the reference gets there
+// with a k-way merge of sorted runs, io.rs:244-282): one radix sort of the 64-bit keys token << 32 | document on the
+// device, the term frequencies riding along, then the same encode.
+// ---------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) mapping_keys_kernel(uint64_t n, uint32_t n_terms, const uint32_t *term, const uint32_t *doc,
+                                                           unsigned long long *key, uint32_t *error_flag) {
+    for (uint64_t i = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x) {
+        const uint32_t t = term[i];
+        if (t >= n_terms) atomicOr(error_flag, 1u);
+        key[i] = (unsigned long long)t << 32 | doc[i];
+    }
+}
+// sorted keys -> document column + the first mapping of every token (CSR starts)
+__global__ void __launch_bounds__(256) mapping_split_kernel(uint64_t n, const unsigned long long *key, uint32_t *doc,
+                                                            unsigned long long *term_start) {
+    for (uint64_t i = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x) {
+        const unsigned long long k = key[i];
+        doc[i] = (uint32_t)k;
+        const uint32_t t = (uint32_t)(k >> 32);
+        if (i == 0 || (uint32_t)(key[i - 1] >> 32) != t) term_start[t] = i;
+    }
+}
+
+int build_device_unsorted_impl(int device, double k1, double b, uint32_t n_docs, const uint32_t *doc_len, const uint16_t *doc_payload,
+                               uint32_t n_terms, const uint8_t *term_key, uint64_t n_map, const uint32_t *map_term,
+                               const uint32_t *map_doc, const uint32_t *map_tf, vbm25_segment **out) {
+    if (!out) return set_error(VBM25_ERR_INVALID, "out is NULL");
+    *out = nullptr;
+    if (n_map && (!map_term || !map_doc || !map_tf)) return set_error(VBM25_ERR_INVALID, "NULL argument");
+    if (n_map > 0x7fffffffull) return set_error(VBM25_ERR_UNSUPPORTED, "more than 2^31 mappings in one sort");
+    int n_dev = 0;
+    if (hipGetDeviceCount(&n_dev) != hipSuccess || n_dev == 0)
+        return set_error(VBM25_ERR_DEVICE, "no HIP device: the device builder has no CPU fallback (vbm25_segment_build is the host builder)");
+    if (device < 0 || device >= n_dev) return set_error(VBM25_ERR_INVALID, "device %d out of range (%d devices)", device, n_dev);
+    FL_TRY(hipSetDevice(device));
+    DBuf d_term, d_doc, d_tf, d_tf2, d_key, d_key2, d_tmp, d_ts, d_err;
+    FL_TRY(d_term.alloc(4ull * n_map));
+    FL_TRY(d_doc.alloc(4ull * n_map));
+    FL_TRY(d_tf.alloc(4ull * n_map));
+    FL_TRY(d_tf2.alloc(4ull * n_map));
+    FL_TRY(d_key.alloc(8ull * n_map));
+    FL_TRY(d_key2.alloc(8ull * n_map));
+    FL_TRY(d_ts.alloc(8ull * (n_terms + 1ull)));
+    FL_TRY(d_err.alloc(4));
+    FL_TRY(hipMemset(d_err.p, 0, 4));
+    FL_TRY(hipMemset(d_ts.p, 0xff, 8ull * (n_terms + 1ull)));
+    std::vector<uint64_t> term_start(size_t(n_terms) + 1, n_map);
+    if (n_map) {
+        FL_TRY(hipMemcpy(d_term.p, map_term, 4ull * n_map, hipMemcpyHostToDevice));
+        FL_TRY(hipMemcpy(d_doc.p, map_doc, 4ull * n_map, hipMemcpyHostToDevice));
+        FL_TRY(hipMemcpy(d_tf.p, map_tf, 4ull * n_map, hipMemcpyHostToDevice));
+        mapping_keys_kernel<<<2048, 256>>>(n_map, n_terms, d_term.as<uint32_t>(), d_doc.as<uint32_t>(), d_key.as<unsigned long long>(),
+                                           d_err.as<uint32_t>());
+        FL_TRY(hipGetLastError());
+        int end_bit = 32;  // the bits of the key that can differ: the document and as much of the token as n_terms needs
+        while (end_bit < 64 && (uint64_t(n_terms) >> (end_bit - 32)) != 0) ++end_bit;
+        hipcub::DoubleBuffer<unsigned long long> keys(d_key.as<unsigned long long>(), d_key2.as<unsigned long long>());
+        hipcub::DoubleBuffer<uint32_t> vals(d_tf.as<uint32_t>(), d_tf2.as<uint32_t>());
+        size_t tmp_bytes = 0;
+        FL_TRY(hipcub::DeviceRadixSort::SortPairs(nullptr, tmp_bytes, keys, vals, (int)n_map, 0, end_bit));
+        FL_TRY(d_tmp.alloc(tmp_bytes));
+        FL_TRY(hipcub::DeviceRadixSort::SortPairs(d_tmp.p, tmp_bytes, keys, vals, (int)n_map, 0, end_bit));
+        mapping_split_kernel<<<2048, 256>>>(n_map, keys.Current(), d_doc.as<uint32_t>(), d_ts.as<unsigned long long>());
+        FL_TRY(hipGetLastError());
+        uint32_t flag = 0;
+        FL_TRY(hipMemcpy(&flag, d_err.p, 4, hipMemcpyDeviceToHost));
+        if (flag) return set_error(VBM25_ERR_INVALID, "a mapping names a token >= n_terms");
+        FL_TRY(hipMemcpy(term_start.data(), d_ts.p, 8ull * n_terms, hipMemcpyDeviceToHost));
+        term_start[n_terms] = n_map;
+        for (uint32_t t = 0; t < n_terms; ++t)
+            if (term_start[t] == ~0ull) return set_error(VBM25_ERR_INVALID, "term %u has no postings", t);
+        // (a repeated (token, document) pair is found by the encode's validation: ids strictly ascending inside a token)
+        return build_device_impl(device, k1, b, n_docs, doc_len, doc_payload, n_terms, term_key, term_start.data(), nullptr, nullptr, out,
+                                 d_doc.as<uint32_t>(), vals.Current());
+    }
+    return build_device_impl(device, k1, b, n_docs, doc_len, doc_payload, n_terms, term_key, term_start.data(), map_doc, map_tf, out);
+}
+
 }  // namespace
+
+extern "C" int vbm25_segment_build_device_unsorted(int device, double k1, double b, uint32_t n_docs, const uint32_t *doc_len,
+                                                   const uint16_t *doc_payload, uint32_t n_terms, const uint8_t *term_key,
+                                                   uint64_t n_mappings, const uint32_t *map_term, const uint32_t *map_doc,
+                                                   const uint32_t *map_tf, vbm25_segment **out) {
+    return vbm25::guarded([&] {
+        return build_device_unsorted_impl(device, k1, b, n_docs, doc_len, doc_payload, n_terms, term_key, n_mappings, map_term, map_doc,
+                                          map_tf, out);
+    });
+}
 
 extern "C" int vbm25_segment_build_device(int device, double k1, double b, uint32_t n_docs, const uint32_t *doc_len,
                                           const uint16_t *doc_payload, uint32_t n_terms, const uint8_t *term_key,
