@@ -604,3 +604,51 @@ def test_one_launch_route_of_search_batch(tuning):
         t = terms[off[q]:off[q + 1]]
         hits, nh = vb.search_batch(gix, t, np.array([0, len(t)], dtype=np.uint32), k)
         assert_bit_exact(oix.search_brute(t, k), hits[0, :nh[0]], what=f"k={k}")
+
+
+def test_plane_block_boundaries(tuning):
+    """The derived planes (post_rel16: ids relative to min_doc in 16 bits; post_tfn: term frequencies in a byte) serve
+    only the blocks that fit them -- full blocks spanning <= 65535 documents / tf fields of <= 7 bits; every other block is
+    decoded from the blob.  Blocks exactly on either side of both limits, mixed in one query, through scan_range_kernel
+    and (every query declared dense) scan_dense_kernel, against the oracle bit for bit."""
+    n_docs = 70_000
+    docs_a = np.r_[np.arange(127), 65535].astype(np.uint32)            # span 65535: plane
+    docs_b = np.r_[np.arange(1, 128), 65537].astype(np.uint32)          # span 65536: no plane
+    docs_c = (3 * np.arange(128)).astype(np.uint32)                     # plane ids, a tf of 128 -> 8-bit tf fields: no tf plane
+    docs_d = (2 * np.arange(256)).astype(np.uint32)                     # two full plane blocks, tf up to 127
+    docs_e = np.r_[5 * np.arange(128), 60_000 + 7 * np.arange(40)].astype(np.uint32)  # a full block and a byte-packed tail
+    rng = np.random.default_rng(9)
+    tf_a = rng.integers(1, 4, 128)
+    tf_a[[0, 127]] = 127
+    tf_c = rng.integers(1, 4, 128)
+    tf_c[17] = 128
+    tf_d = rng.integers(1, 128, 256)
+    tf_d[[3, 200]] = 127
+    post_doc = np.r_[docs_a, docs_b, docs_c, docs_d, docs_e]
+    post_tf = np.r_[tf_a, rng.integers(1, 4, 128), tf_c, tf_d, rng.integers(1, 300, 168)].astype(np.uint32)
+    term_start = np.cumsum([0, 128, 128, 128, 256, 168]).astype(np.uint64)
+    keys = np.zeros((5, 16), dtype=np.uint8)
+    keys[:, 0] = [ord(x) for x in "abcde"]
+    seg = vb.Segment.build(1.2, 0.75, rng.integers(1, 3000, n_docs).astype(np.uint32), np.zeros((n_docs, 3), dtype=np.uint16),
+                           keys, term_start, post_doc, post_tf)
+    a = seg.arrays()
+    assert a["blk_max_doc"][0] - a["blk_min_doc"][0] == 65535 and a["blk_max_doc"][1] - a["blk_min_doc"][1] == 65536
+    assert a["blk_meta_tf"][0] == 7 and a["blk_meta_tf"][2] == 8 and a["blk_n"].tolist() == [128, 128, 128, 128, 128, 128, 40]
+    gix = vb.GpuIndex(seg)
+    oix = orc.OracleIndex.from_arrays(seg.meta(), a)
+    terms = np.array([0, 1, 0, 2, 3, 1, 2, 3, 0, 1, 2, 3, 4, 4, 2, 4, 1], dtype=np.uint32)
+    off = np.array([0, 2, 5, 7, 8, 13, 14, 16, 17], dtype=np.uint32)
+    for dense in (False, True):
+        if dense:
+            tuning(dense_x1000=0)
+        for k in (5, 100, 256):
+            check_batch(gix, oix, terms, off, k, wand=False)
+        b = vb.Batch(gix, len(off) - 1, len(terms), 10)  # the general route (vbm25_search_batch of eight queries is the one-launch route)
+        b.set_queries(terms, off)
+        b.run()
+        hits, nh = b.fetch()
+        ob, onb, _ = oix.search_batch(terms, off, 10, mode="brute", threads=4)
+        assert np.array_equal(nh, onb)
+        for q in range(len(off) - 1):
+            assert_bit_exact(ob[q, :onb[q]], hits[q, :nh[q]], what=f"dense={dense} q{q}")
+        assert b.debug_counts()[1] == 0

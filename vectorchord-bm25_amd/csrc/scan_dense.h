@@ -10,9 +10,11 @@
 //   P0  enumerate: the blocks of every term that start below the window's end (one lane per block: 16-byte
 //       metadata + block upper bound), laid out as TASKS in descending order of the terms' token upper bounds.
 //   P1  ESSENTIAL terms (search.rs:153-169: the MaxScore split on token upper bounds against the threshold):
-//       every task decoded -- ids, term frequencies, fieldnorm bytes -- and an UPPER BOUND of each posting's
+//       every task fetched -- the lane's words of post_rel16 and post_tfn: two ids, two term frequencies, two
+//       fieldnorms (blocks without plane words: generic decode of the blob) -- and an UPPER BOUND of each posting's
 //       score (f32 rounded up, scaled to an integer, + 1) added to its document's accumulator, in any order:
-//       no barrier between terms, all eight waves busy, four blocks per wave in flight.
+//       no barrier between terms, all eight waves busy, groups of four blocks per wave, the next group issued
+//       before the current one is added up.
 //   P2  NON-ESSENTIAL terms, one phase per term in descending order of upper bound.  A block is fetched only
 //       if some document of its span can still reach the threshold: max accumulator over the span + the bounds
 //       of the terms not yet complete, with the block's own upper bound for its term (search.rs:177-203: the

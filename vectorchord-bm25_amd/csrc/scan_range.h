@@ -7,9 +7,11 @@
 // the PLANNER (tile n + 1 while the others work on tile n; it also polls the query's shared threshold),
 // waves 1..7 are WORKERS with RB blocks each.  A tile is three phases separated by two LDS-only barriers:
 //
-//   S1  workers decode their blocks (two ids per lane per block), stage the ids in LDS (one 128-id row per
-//       block) and mark every in-range id in the tile's SEEN filter with ONE 32-bit LDS atomic: word
-//       (x >> 5) mod 4096, bit x mod 32, x = id - tlo -- exact when the tile is <= 2^17 documents wide; wider
+//   S1  workers get the two ids of every lane and block from ONE word of post_rel16 (ids relative to the block's
+//       first document, a plane derived at index creation; fetched one tile ahead, right after the barrier that
+//       publishes the plan; blocks without a plane word -- tails, raw, wide -- are decoded from the blob), stage the
+//       ids in LDS (one 128-id row per block) and mark every in-range id in the tile's SEEN filter with ONE 32-bit LDS
+//       atomic: word (x >> 5) mod 4096, bit x mod 32, x = id - tlo -- exact when the tile is <= 2^17 documents wide; wider
 //       tiles add a second, hashed bit in the same word (a blocked Bloom filter: both bits travel in one
 //       atomic, so two postings of a document that race still see each other).  A mark that was already there
 //       = a SECOND ARRIVAL: the document may sit in two lists.  The wave collects those and inserts them in
@@ -22,9 +24,9 @@
 //       (search.rs:377-380, evaluated once per index) reaches the threshold has every posting without a done
 //       bit scored on its own; all other blocks never have their tf / fieldnorm bytes read.
 //
-// The kernel is bound by instruction issue (PMC: the SIMDs issue > 90 % of the time), so the hot path
-// (S1) is written for instruction count: branch-free over the wave's eight blocks, 32-bit filter words,
-// uniform values in SGPRs.
+// The vector pipes are busy about half of the launch (PMC + measured issue rates): S1 is
+// bound by instruction issue and written for instruction count -- branch-free over the wave's eight blocks,
+// 32-bit filter words, uniform values in SGPRs --, S2 / S3 and the two barriers are bound by latency.
 //
 // Every wave keeps its own top-k in registers (RegTopK); the k-th scores are shared through LDS, the query's
 // 64-bit atomicMax word and the 256-bucket histogram.  Lists go to res_* at
