@@ -210,6 +210,7 @@ struct Tuning {
     uint32_t dense_items = D_TARGET_ITEMS;
     uint32_t range_items = R_TARGET_ITEMS, range_min_chunk = R_MIN_CHUNK_POSTINGS;
     uint32_t range_grid = R_GRID, dense_grid = D_GRID;
+    uint32_t generation = 0;       // bumped by every vbm25_tuning_set / reset: vbm25_search_batch's batch object is rebuilt when it is stale
 };
 static Tuning g_tune;
 
@@ -959,9 +960,14 @@ int vbm25_tuning_set(const char *name, long long value) {
     else if (n == "range_grid") g_tune.range_grid = (uint32_t)std::max(1ll, value);
     else if (n == "dense_grid") g_tune.dense_grid = (uint32_t)std::max(1ll, value);
     else return set_error(VBM25_ERR_INVALID, "unknown tuning switch %s", name);
+    ++g_tune.generation;
     return VBM25_OK;
 }
-void vbm25_tuning_reset(void) { g_tune = Tuning(); }
+void vbm25_tuning_reset(void) {
+    const uint32_t gen = g_tune.generation + 1u;
+    g_tune = Tuning();
+    g_tune.generation = gen;
+}
 
 // tuning / test aid (not declared in include/vbm25.h): work items of the last run and how many of them the
 // first-choice kernel handed to scan_many_kernel
@@ -1042,7 +1048,7 @@ static int vbm25_search_batch_impl(vbm25_index *ix, const uint32_t *term_ids, co
     // the shape fits (device buffers of a batch are far more expensive to create than a search)
     vbm25_batch *bt = ix->scratch;
     const uint32_t n_terms = q_off[nq] ? q_off[nq] : 1;
-    if (!bt || bt->k != k || bt->max_queries < nq || bt->max_terms < n_terms) {
+    if (!bt || bt->k != k || bt->max_queries < nq || bt->max_terms < n_terms || bt->tune.generation != g_tune.generation) {
         if (bt) vbm25_batch_destroy(bt);
         ix->scratch = nullptr;
         if (int rc = vbm25_batch_create(ix, std::max(nq, 16u), std::max(n_terms, 256u), k, &bt)) return rc;
