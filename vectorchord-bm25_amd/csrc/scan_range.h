@@ -368,7 +368,10 @@ __global__ void __launch_bounds__(RWG, 4) scan_range_kernel(DevIndex ix, DevBatc
                 const unsigned long long qm = p_quota >= 64u ? ~0ull : ((1ull << p_quota) - 1ull);
                 if (p_base < 64u) p_cur += (uint32_t)__popcll((cmask >> p_base) & qm);
             }
-            if (lane == 0) S.hdr[buf] = make_uint4(p_tlo, thi, (uint32_t)__popcll(mask), p_ne);
+            // bit 8 of the last word: every block of the tile has its post_rel16 word (the workers then skip the per-block tests:
+            // S1 is bound by its scalar instructions -- one issue slot per SIMD every fourth cycle -- before its vector ones)
+            const bool all_rel16 = !__ballot(in_tile && !rel16_block(meta.x, meta.y, meta.w));
+            if (lane == 0) S.hdr[buf] = make_uint4(p_tlo, thi, (uint32_t)__popcll(mask), p_ne | (all_rel16 ? 0x100u : 0u));
             p_tlo = thi;
         };
         // ---- item setup (wave 0): terms, cursors, quotas, slot map; the first two plans
@@ -624,14 +627,11 @@ __global__ void __launch_bounds__(RWG, 4) scan_range_kernel(DevIndex ix, DevBatc
                 nv = (np + (RNW - 1) - wave) / (RNW - 1);
                 if (nv > (uint32_t)RB) nv = RB;
                 uint4 c[RB];
-                bool allfast = true;
+                const bool allfast = (hdr.w & 0x100u) != 0;  // (the planner's test of every block of the tile)
 #pragma unroll
                 for (int i = 0; i < RB; ++i) c[i] = S.pm[buf][(wave - 1u) + (RNW - 1) * i];
 #pragma unroll
-                for (int i = 0; i < RB; ++i) {
-                    c[i] = uni4(c[i]);
-                    allfast = allfast && ((uint32_t)i >= nv || rel16_block(c[i].x, c[i].y, c[i].w));
-                }
+                for (int i = 0; i < RB; ++i) c[i].x = uni(c[i].x);  // the first document is all the plane blocks need here
                 asm volatile("; MARK_S1_DECODE");
                 // ids of the rel16 blocks: min_doc + the two halves of the lane's word (fetched one tile ahead); entries
                 // beyond nv are masked below
