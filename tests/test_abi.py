@@ -50,6 +50,16 @@ def test_no_cpu_fallback_without_device():
     with pytest.raises(vb.Vbm25Error) as e:
         vb.GpuIndex(seg)
     assert e.value.code == -3  # VBM25_ERR_DEVICE: fails loudly, no CPU path
+    # the device builders likewise (the host builder is a different entry point, not a fallback)
+    a = seg.arrays()
+    keys, doc_len = a["term_key"], np.ones(1000, dtype=np.uint32)
+    payload = np.zeros((1000, 3), dtype=np.uint16)
+    one = np.zeros(1, dtype=np.uint32)
+    for build in (lambda: vb.Segment.build_device(1.2, 0.75, doc_len, payload, keys[:1], np.array([0, 1], dtype=np.uint64), one, one + 1),
+                  lambda: vb.Segment.build_device_unsorted(1.2, 0.75, doc_len, payload, keys[:1], one, one, one + 1)):
+        with pytest.raises(vb.Vbm25Error) as e:
+            build()
+        assert e.value.code == -3
 
 
 def test_intern_and_query():
