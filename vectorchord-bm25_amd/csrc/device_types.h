@@ -16,10 +16,14 @@ struct DevIndex {
     const uint32_t *blk_max_doc;
     const uint4 *blk_meta;       // {min_doc, max_doc, off8, n | meta_doc<<8 | meta_tf<<16 | wand_fn<<24}
     const double *blk_ub;        // Cache::evaluate(block WAND pair) x (1 + 1e-12): no posting of the block scores higher
+    const double *term_kth_ub;   // derived: 9 per term -- the 2^i-th largest block maximum of the term (the scores themselves, no margin;
+                                 // 0 when the term has fewer blocks), NULL when the block maxima are not attained
     const uint8_t *blob;
     const uint8_t *post_fn;      // derived: fieldnorm of every posting, 128 bytes per block
     const uint32_t *post_rel16;  // derived: 64 words per block -- word l = (id[2l + 1] - min_doc) << 16 | (id[2l] - min_doc) of a
                                  // full bit-packed block that spans < 2^16 documents (rel16_block), undefined for the others
+    const uint4 *blk_piv;        // derived: per block with a post_rel16 word its ids 15, 31, ..., 127 (relative, 16 bits each): the first
+                                 // level of scan_team_kernel's search for one document of the block
     const uint32_t *post_tfn;    // derived: 64 words per block -- word l = tf[2l] | tf[2l + 1] << 8 | fieldnorm[2l] << 16 |
                                  // fieldnorm[2l + 1] << 24 of a full block whose term frequencies are bit-packed in <= 7 bits
                                  // (tfn_block), undefined for the others
@@ -73,6 +77,7 @@ struct DevBatch {
     uint32_t *fused_state;     // [0] workgroups that left, [1 + q] finished items of query q; zero between launches
     uint32_t merge_marked;     // merge_kernel: only the queries whose n_hits is NONE32
     uint32_t max_items;        // capacity of items / item_failed; res_* hold max_items * lpi lists of k entries
+    uint32_t team_dbg;         // development switch of scan_team_kernel (timing only, wrong results): 1 = candidates are not completed
     uint32_t *dbg;             // -DVBM25_CHECK builds: [0] first violated check (0: none), [1] value, [2] item, [3] thread
 };
 

@@ -33,7 +33,7 @@ __global__ void __launch_bounds__(64) merge_kernel(DevIndex ix, DevBatch bt) {
                 d = bt.res_doc[(size_t)item * k + base + lane];
                 has = (unsigned long long)__double_as_longlong(sc) >= theta;
             }
-            if constexpr (KMAX <= REG_K) rtop.offer(has, sc, d, k, lane);
+            if constexpr (KMAX <= REG_K) rtop.template offer<true>(has, sc, d, k, lane);  // (scan_team_kernel: a document may be in two waves' lists)
             else topk_offer<(KMAX > REG_K ? KMAX : 1)>(s_top, k, has, sc, d, lane);
         }
     }

@@ -11,6 +11,7 @@ struct PostFnArgs {
     const uint8_t *blob, *doc_fieldnorm;
     uint8_t *post_fn;
     uint32_t *post_rel16, *post_tfn;
+    uint4 *blk_piv;
     uint32_t *error_flag;
     // upper bounds to verify: the scan kernels prune with them
     const uint32_t *term_first_block, *term_wand_tf;
@@ -46,6 +47,13 @@ __global__ void __launch_bounds__(256) post_fn_kernel(PostFnArgs a) {
     if (bad) atomicOr(a.error_flag, 1u);
     reinterpret_cast<uchar2 *>(a.post_fn + 128ull * j)[lane] = make_uchar2(f0, f1);
     a.post_rel16[64ull * j + lane] = rel16_block(m.x, m.y, m.w) ? (d1 - m.x) << 16 | (d0 - m.x) : 0u;
+    {   // every 16th id of the block (ids 15, 31, ..., 127 sit in lanes 7, 15, ..., 63)
+        const uint32_t pr = rel16_block(m.x, m.y, m.w) ? d1 - m.x : 0u;
+        uint32_t pv[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) pv[u] = (uint32_t)__shfl((int)pr, 8 * u + 7);
+        if (lane == 0) a.blk_piv[j] = make_uint4(pv[0] | pv[1] << 16, pv[2] | pv[3] << 16, pv[4] | pv[5] << 16, pv[6] | pv[7] << 16);
+    }
 
     // The WAND pairs must bound every posting: Cache::evaluate of each posting against the block's
     // bound (blk_ub, margin included) and the token's (search.rs:363,377-380).
@@ -61,16 +69,20 @@ __global__ void __launch_bounds__(256) post_fn_kernel(PostFnArgs a) {
     uint32_t t0, t1;
     decode_fields(body + ((payload_bytes(md, n) + 7u) & ~7u), mt, n, lane, t0, t1);
     a.post_tfn[64ull * j + lane] = tfn_block(m.w) ? t0 | t1 << 8 | (uint32_t)f0 << 16 | (uint32_t)f1 << 24 : 0u;
-    bool loose = false;
+    bool loose = false, attained = false;  // attained: the block's bound is the score of one of its postings (flag 4 if not: no error,
+                                           // but the k-th largest block maxima are then no lower bound of anything)
     if (i0 < n) {
         const double tf = (double)t0, p = (tf * s0) / (tf + a.s1[f0]);
         loose |= p > bub || p > tub;
+        attained |= p * (1.0 + 1e-12) == bub;
     }
     if (i1 < n) {
         const double tf = (double)t1, p = (tf * s0) / (tf + a.s1[f1]);
         loose |= p > bub || p > tub;
+        attained |= p * (1.0 + 1e-12) == bub;
     }
     if (loose) atomicOr(a.error_flag, 2u);
+    if (!__ballot(attained) && lane == 0) atomicOr(a.error_flag, 4u);
 }
 
 // ---------------------------------------------------------------------------

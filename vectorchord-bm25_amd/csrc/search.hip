@@ -3,7 +3,8 @@
 // (bm25::search) for the sealed segment.  One translation unit; the kernels live in headers:
 //   plan.h         post_fn_kernel (index preparation: per-posting fieldnorm stream + validation of block
 //                  structure and WAND bounds) and plan_kernel (queries -> doc-range work items)
-//   scan_range.h   scan_range_kernel: sparse queries of <= 16 terms, k <= 256 (the dominant kernel: C3, C2)
+//   scan_team.h    scan_team_kernel: sparse queries of <= 16 terms, k <= 256 (the dominant kernel: C3)
+//   scan_range.h   scan_range_kernel: the same queries on the one-launch route of vbm25_search_batch (C2) and behind the `team` switch
 //   scan_dense.h   scan_dense_kernel: queries with many postings per document (Zipf head terms; C5), <= 16 terms, k <= 256
 //   scan_many.h    scan_many_kernel: up to 1024 terms, 256 < k <= 1024, items the others gave up (exhaustive)
 //   merge.h        merge_kernel: per-item top-k lists -> hits with payloads
@@ -57,6 +58,7 @@ int set_error(int code, const char *fmt, ...) {
 #include "block_fetch.h"
 #include "topk_reg.h"
 #include "scan_range.h"
+#include "scan_team.h"
 #include "scan_dense.h"
 #include "scan_many.h"
 #include "merge.h"
@@ -194,7 +196,7 @@ struct vbm25_index {
     std::vector<uint32_t> term_df_host;  // host copy for query routing
     vbm25_batch *scratch = nullptr;      // batch object re-used by vbm25_search_batch
     DeviceBuffer term_wand_tf, term_wand_fn, term_df, term_first_block, term_s0, blk_min_doc, blk_max_doc, blk_meta, blk_ub, blob,
-        post_fn, post_rel16, post_tfn, doc_payload, s1, term_idf, fn_len;
+        post_fn, post_rel16, post_tfn, doc_payload, s1, term_idf, fn_len, term_kth_ub, blk_piv;
     double k1 = 1.2;
     uint64_t device_bytes = 0;
 };
@@ -210,6 +212,10 @@ struct Tuning {
     uint32_t dense_items = D_TARGET_ITEMS;
     uint32_t range_items = R_TARGET_ITEMS, range_min_chunk = R_MIN_CHUNK_POSTINGS;
     uint32_t range_grid = R_GRID, dense_grid = D_GRID;
+    int team = 1;                  // sparse queries on the general route take scan_team_kernel (0: scan_range_kernel)
+    uint32_t team_size = 4;        // waves per team: 4 (four workgroups per CU) or 8 (two)
+    uint32_t team_items = 4096;    // work items of a batch on that route
+    uint32_t team_dbg = 0;         // timing experiments only
     uint32_t generation = 0;       // bumped by every vbm25_tuning_set / reset: vbm25_search_batch's batch object is rebuilt when it is stale
 };
 static Tuning g_tune;
@@ -334,6 +340,25 @@ static int vbm25_index_create_impl(const vbm25_index_desc *d, int device, vbm25_
             blk_ub[j] = ub * (1.0 + 1e-12);  // margin: another posting's evaluate may round one ulp higher
         }
     }
+    // per term the 2^i-th largest block maximum, i = 0..8 (scan_team_kernel's first threshold: with block WAND pairs every
+    // block maximum is the score of a posting of its block -- post_fn_kernel verifies that -- so k distinct documents of
+    // the term score at least the k-th largest of them)
+    std::vector<double> kth;
+    if (d->blk_wand_fn && d->blk_wand_tf) {
+        kth.assign(size_t(TM_KTH) * d->n_terms, 0.0);
+        std::vector<double> tmp;
+        for (uint32_t t = 0; t < d->n_terms; ++t) {
+            tmp.clear();
+            for (uint32_t j = d->term_first_block[t]; j < d->term_first_block[t + 1]; ++j) {
+                const double tf = double(d->blk_wand_tf[j]);
+                tmp.push_back((tf * s0[t]) / (tf + s1[d->blk_wand_fn[j]]));
+            }
+            const size_t top = std::min<size_t>(tmp.size(), 256);
+            std::partial_sort(tmp.begin(), tmp.begin() + top, tmp.end(), std::greater<double>());
+            for (int i = 0; i < TM_KTH; ++i)
+                if ((size_t(1) << i) <= top) kth[size_t(TM_KTH) * t + i] = tmp[(size_t(1) << i) - 1];
+        }
+    }
     DeviceBuffer fieldnorm, err;
     int rc = 0;
     // slack: the scan kernels read whole 256-byte LDS-DMA slots / word pairs from a block's first byte
@@ -347,10 +372,12 @@ static int vbm25_index_create_impl(const vbm25_index_desc *d, int device, vbm25_
         (rc = ix->blk_max_doc.upload(d->blk_max_doc, 4ull * d->n_blocks)) ||
         (rc = ix->blk_meta.upload(meta.data(), 16ull * d->n_blocks)) ||
         (rc = ix->blk_ub.upload(blk_ub.data(), 8ull * d->n_blocks)) ||
+        (!kth.empty() && (rc = ix->term_kth_ub.upload(kth.data(), 8ull * kth.size()))) ||
         (rc = ix->blob.alloc(blob_alloc)) ||
         (rc = ix->post_fn.alloc(128ull * d->n_blocks)) ||
         (rc = ix->post_rel16.alloc(256ull * d->n_blocks)) ||
         (rc = ix->post_tfn.alloc(256ull * d->n_blocks)) ||
+        (rc = ix->blk_piv.alloc(16ull * d->n_blocks)) ||
         (rc = ix->doc_payload.upload(d->doc_payload, 6ull * d->n_docs)) ||
         (rc = ix->s1.upload(s1, sizeof s1)) ||
         (rc = fieldnorm.upload(d->doc_fieldnorm, d->n_docs)) || (rc = err.alloc(4)))
@@ -370,6 +397,7 @@ static int vbm25_index_create_impl(const vbm25_index_desc *d, int device, vbm25_
         pa.post_fn = ix->post_fn.as<uint8_t>();
         pa.post_rel16 = ix->post_rel16.as<uint32_t>();
         pa.post_tfn = ix->post_tfn.as<uint32_t>();
+        pa.blk_piv = ix->blk_piv.as<uint4>();
         pa.error_flag = err.as<uint32_t>();
         pa.term_first_block = ix->term_first_block.as<uint32_t>();
         pa.term_wand_tf = ix->term_wand_tf.as<uint32_t>();
@@ -406,10 +434,12 @@ static int vbm25_index_create_impl(const vbm25_index_desc *d, int device, vbm25_
     ix->dev.post_fn = ix->post_fn.as<uint8_t>();
     ix->dev.post_rel16 = ix->post_rel16.as<uint32_t>();
     ix->dev.post_tfn = ix->post_tfn.as<uint32_t>();
+    ix->dev.blk_piv = ix->blk_piv.as<uint4>();
     ix->dev.doc_payload = ix->doc_payload.as<uint16_t>();
     ix->dev.s1 = ix->s1.as<double>();
     ix->dev.blob_bytes = d->blob_bytes;
-    ix->dev.blk_ub_attained = d->blk_wand_fn && d->blk_wand_tf ? 1u : 0u;
+    ix->dev.blk_ub_attained = d->blk_wand_fn && d->blk_wand_tf && !(flag & 4u) ? 1u : 0u;
+    ix->dev.term_kth_ub = ix->dev.blk_ub_attained && !kth.empty() ? ix->term_kth_ub.as<double>() : nullptr;
     {   // for vbm25_evaluate_batch: per-term idf (host libm log, bm25.rs:285-289) and the fieldnorm table
         std::vector<double> idf(d->n_terms);
         for (uint32_t t = 0; t < d->n_terms; ++t)
@@ -421,7 +451,7 @@ static int vbm25_index_create_impl(const vbm25_index_desc *d, int device, vbm25_
     }
     for (const DeviceBuffer *b : {&ix->term_df, &ix->term_first_block, &ix->term_s0, &ix->blk_min_doc,
                                   &ix->blk_max_doc, &ix->blk_meta, &ix->blk_ub, &ix->blob, &ix->post_fn,
-                                  &ix->post_rel16, &ix->post_tfn, &ix->doc_payload, &ix->s1})
+                                  &ix->post_rel16, &ix->post_tfn, &ix->blk_piv, &ix->term_kth_ub, &ix->doc_payload, &ix->s1})
         ix->device_bytes += b->bytes;
     *out = ix.release();
     return VBM25_OK;
@@ -474,7 +504,7 @@ static int vbm25_batch_create_impl(vbm25_index *ix, uint32_t max_queries, uint32
     bt->use_range = k <= (uint32_t)REG_K;
     bt->lpi = bt->use_range ? (uint32_t)RNW : 1u;
     bt->use_dense = bt->use_range && k <= (uint32_t)D_KMAX && bt->tune.dense != 0;
-    bt->target_items = bt->use_range ? std::max(256u, bt->tune.range_items) : TARGET_ITEMS;
+    bt->target_items = bt->use_range ? std::max(256u, bt->tune.team ? bt->tune.team_items : bt->tune.range_items) : TARGET_ITEMS;
     bt->min_chunk = bt->use_range ? std::max(128u, bt->tune.range_min_chunk) : MIN_CHUNK_POSTINGS;
     bt->max_items = max_queries + bt->target_items + (bt->use_dense ? std::max(256u, bt->tune.dense_items) : 0u);
     int rc = 0;
@@ -662,7 +692,7 @@ static int vbm25_batch_set_queries_impl(vbm25_batch *bt, const uint32_t *term_id
             if (c > bt->index->n_docs) c = bt->index->n_docs;
             items += c;
         }
-        bt->range_grid = uint32_t(std::min<unsigned long long>(std::max<unsigned long long>(items, 1), std::max(1u, bt->tune.range_grid)));
+        bt->range_grid = uint32_t(std::min<unsigned long long>(std::max<unsigned long long>(items, 1), bt->tune.team ? 1024u : std::max(1u, bt->tune.range_grid)));
         bt->dense_grid = uint32_t(std::min<unsigned long long>(std::max<unsigned long long>(items, 1), std::max(1u, bt->tune.dense_grid)));
     }
     return VBM25_OK;
@@ -728,6 +758,7 @@ static int vbm25_batch_run_impl(vbm25_batch *bt, void *hip_stream) {
     db.ne_on = bt->tune.ne ? 1u : 0u;
     db.ne_ratio = std::max(1u, bt->tune.ne_ratio);
     db.dense_on = bt->use_dense ? 1u : 0u;
+    db.team_dbg = bt->tune.team_dbg;
     const bool range = bt->use_range;
     const DevIndex &ix = bt->index->dev;
     db.fused_state = bt->fused_state.as<uint32_t>();
@@ -802,7 +833,10 @@ static int vbm25_batch_run_impl(vbm25_batch *bt, void *hip_stream) {
     const int rc = dispatch_k(bt->k, [&](auto kmax) {
         constexpr int KM = decltype(kmax)::value;
         if constexpr (KM <= REG_K) {
-            if (range) {  // persistent 8-wave workgroups; items are handed out through bt.work_ctr
+            if (range && bt->range_rt && bt->tune.team) {  // persistent teams of waves; items are handed out through bt.work_ctr
+                if (bt->tune.team_size == 8) scan_team_kernel<KM, 8><<<std::min(bt->range_grid, 512u), 512, 0, st>>>(ix, db);
+                else scan_team_kernel<KM, 4><<<std::min(bt->range_grid, 1024u), 256, 0, st>>>(ix, db);
+            } else if (range) {  // persistent 8-wave workgroups
                 if (bt->range_rt == 8) scan_range_kernel<KM, 8><<<bt->range_grid, RWG, 0, st>>>(ix, db);
                 else if (bt->range_rt == 16) scan_range_kernel<KM, 16><<<bt->range_grid, RWG, 0, st>>>(ix, db);
             }
@@ -945,7 +979,8 @@ int vbm25_evaluate_batch(vbm25_index *ix, const uint32_t *q_terms, uint32_t n_q,
 }
 
 // tuning / test aid (not declared in include/vbm25.h): process-wide switches, read when a batch object is created.
-// Names: dense_x1000, dense, ne, fused, ne_ratio, dense_items, range_items, range_min_chunk, range_grid, dense_grid.
+// Names: dense_x1000, dense, ne, fused, ne_ratio, dense_items, range_items, range_min_chunk, range_grid, dense_grid, team,
+// team_size, team_items.
 int vbm25_tuning_set(const char *name, long long value) {
     if (!name) return set_error(VBM25_ERR_INVALID, "NULL argument");
     const std::string n(name);
@@ -959,6 +994,10 @@ int vbm25_tuning_set(const char *name, long long value) {
     else if (n == "range_min_chunk") g_tune.range_min_chunk = (uint32_t)std::max(128ll, value);
     else if (n == "range_grid") g_tune.range_grid = (uint32_t)std::max(1ll, value);
     else if (n == "dense_grid") g_tune.dense_grid = (uint32_t)std::max(1ll, value);
+    else if (n == "team") g_tune.team = value != 0;
+    else if (n == "team_size") g_tune.team_size = value == 8 ? 8u : 4u;
+    else if (n == "team_items") g_tune.team_items = (uint32_t)std::max(256ll, value);
+    else if (n == "team_dbg") g_tune.team_dbg = (uint32_t)value;
     else return set_error(VBM25_ERR_INVALID, "unknown tuning switch %s", name);
     ++g_tune.generation;
     return VBM25_OK;

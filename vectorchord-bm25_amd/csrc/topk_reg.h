@@ -24,7 +24,9 @@ struct RegTopK {
         kth_s = 0.0;
         kth_d = 0;
     }
-    // offer one candidate per lane (`has` marks validity); all 64 lanes call
+    // offer one candidate per lane (`has` marks validity); all 64 lanes call.  DEDUP: a candidate that is already in the
+    // list -- same document, same score bits (scan_team_kernel may score a document twice) -- is dropped.
+    template <bool DEDUP = false>
     __device__ __forceinline__ void offer(bool has, double sc, uint32_t d, uint32_t k, uint32_t lane) {
         for (;;) {
             const bool alive = has && (cnt < k || better(sc, d, kth_s, kth_d));
@@ -34,6 +36,12 @@ struct RegTopK {
             const double cs = readlane_f64(sc, leader);
             const uint32_t cd = (uint32_t)__builtin_amdgcn_readlane((int)d, (int)leader);
             if (lane == leader) has = false;
+            if (DEDUP) {
+                unsigned long long same = 0;
+#pragma unroll
+                for (int r = 0; r < RK; ++r) same |= __ballot(r * 64 + lane < cnt && doc[r] == cd && score[r] == cs);
+                if (same) continue;
+            }
             uint32_t pos = 0;  // entries better than the candidate: a prefix of the list
 #pragma unroll
             for (int r = 0; r < RK; ++r)
