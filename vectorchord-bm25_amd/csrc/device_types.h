@@ -22,6 +22,9 @@ struct DevIndex {
     const uint8_t *post_fn;      // derived: fieldnorm of every posting, 128 bytes per block
     const uint32_t *post_rel16;  // derived: 64 words per block -- word l = (id[2l + 1] - min_doc) << 16 | (id[2l] - min_doc) of a
                                  // full bit-packed block that spans < 2^16 documents (rel16_block), undefined for the others
+    const uint2 *term_loc;       // derived: per term {first entry in blk_loc, log2 of the bucket width}
+    const uint32_t *blk_loc;     // derived: bucket locator -- entry b of a term = its first block whose last document is >= b << shift
+                                 // (term_first_block[t + 1] if none); (n_docs >> shift) + 2 entries per term, buckets of about one block span
     const uint4 *blk_piv;        // derived: per block with a post_rel16 word its ids 15, 31, ..., 127 (relative, 16 bits each): the first
                                  // level of scan_team_kernel's search for one document of the block
     const uint32_t *post_tfn;    // derived: 64 words per block -- word l = tf[2l] | tf[2l + 1] << 8 | fieldnorm[2l] << 16 |
@@ -76,7 +79,14 @@ struct DevBatch {
     uint32_t fused_g;          // scan_range_kernel alone: items per query made in the kernel, lists merged by the query's last workgroup (0: off)
     uint32_t *fused_state;     // [0] workgroups that left, [1 + q] finished items of query q; zero between launches
     uint32_t merge_marked;     // merge_kernel: only the queries whose n_hits is NONE32
+    uint32_t merge_clean;      // merge_kernel leaves the per-launch state (thresholds, histogram, list counts, failure flags, item counters)
+                               // zero for the next launch: the route without plan_kernel (fused_g != 0 in the general instantiations)
+    uint32_t many_expected;    // scan_many_kernel: 0 = the host knows of no item for it; it looks at fail_any and leaves
+    uint32_t *fail_any;        // != 0: a first-choice kernel gave an item up in this launch
+    uint32_t *q_failed;        // per query: items the first-choice kernels gave up in the last launch (merge_kernel, merge_clean)
+    unsigned long long *theta_last;  // per query: the threshold the last launch ended with (merge_kernel, merge_clean)
     uint32_t max_items;        // capacity of items / item_failed; res_* hold max_items * lpi lists of k entries
+    uint32_t *team_cand;       // scan_team_kernel: TM_CAND candidate documents per wave of its grid
     uint32_t team_dbg;         // development switch of scan_team_kernel (timing only, wrong results): 1 = candidates are not completed
     uint32_t *dbg;             // -DVBM25_CHECK builds: [0] first violated check (0: none), [1] value, [2] item, [3] thread
 };

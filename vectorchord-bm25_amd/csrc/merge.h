@@ -8,6 +8,7 @@
 template <int KMAX>
 __global__ void __launch_bounds__(64) merge_kernel(DevIndex ix, DevBatch bt) {
     __shared__ TopK<(KMAX > REG_K ? KMAX : 1)> s_top;
+    __shared__ uint32_t s_map[KMAX <= REG_K ? 16 * KMAX : 1];  // (list, entry) of the entries of 16 lists
     constexpr int RK = KMAX <= REG_K ? KMAX / 64 : 1;
     RegTopK<RK> rtop;
     rtop.init();
@@ -17,24 +18,51 @@ __global__ void __launch_bounds__(64) merge_kernel(DevIndex ix, DevBatch bt) {
     if (bt.merge_marked && bt.n_hits[q] != NONE32) return;
     if (lane == 0) s_top.count = 0;
     __builtin_amdgcn_wave_barrier();
-    const uint32_t i0 = bt.q_item_base[q] * bt.lpi, i1 = bt.q_item_base[q + 1] * bt.lpi;
+    const uint32_t it0 = bt.fused_g ? q * bt.fused_g : bt.q_item_base[q], it1 = bt.fused_g ? it0 + bt.fused_g : bt.q_item_base[q + 1];
+    const uint32_t L0 = it0 * bt.lpi, NL = (it1 - it0) * bt.lpi;
     // the query's threshold is a lower bound of its k-th best score: entries below it cannot be among the hits (a
     // dense query's 32 lists of 100 entries mostly are)
     const unsigned long long theta = bt.theta[q];
-    for (uint32_t item = i0; item < i1; ++item) {  // every list of every item of the query
-        const uint32_t cnt = uni(bt.res_cnt[item]);
-        if (cnt == 0) continue;
-        for (uint32_t base = 0; base < cnt; base += 64) {
-            bool has = base + lane < cnt;
-            double sc = 0;
-            uint32_t d = 0;
-            if (has) {
-                sc = bt.res_score[(size_t)item * k + base + lane];
-                d = bt.res_doc[(size_t)item * k + base + lane];
-                has = (unsigned long long)__double_as_longlong(sc) >= theta;
+    if constexpr (KMAX <= REG_K) {
+        // all entries of 16 lists at a time: one round trip for the counts, one for the entries (a list after the other was
+        // two dependent round trips per list -- most of this kernel's time)
+        for (uint32_t lb = 0; lb < NL; lb += 16) {
+            uint32_t cnt = 0;
+            if (lane < 16u && lb + lane < NL) cnt = min(bt.res_cnt[L0 + lb + lane], k);
+            const uint32_t incl = wave_incl_scan_u32(cnt), excl = incl - cnt;
+            const uint32_t total = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
+            for (uint32_t j = 0; j < cnt; ++j) s_map[excl + j] = lane << 16 | j;
+            __builtin_amdgcn_wave_barrier();
+            for (uint32_t e0 = 0; e0 < total; e0 += 64) {
+                bool has = e0 + lane < total;
+                double sc = 0;
+                uint32_t d = 0;
+                if (has) {
+                    const uint32_t ds = s_map[e0 + lane];
+                    const size_t at = (size_t)(L0 + lb + (ds >> 16)) * k + (ds & 0xffffu);
+                    sc = bt.res_score[at];
+                    d = bt.res_doc[at];
+                    has = (unsigned long long)__double_as_longlong(sc) >= theta;
+                }
+                rtop.template offer<true>(has, sc, d, k, lane);  // (scan_team_kernel: a document may be in two waves' lists)
             }
-            if constexpr (KMAX <= REG_K) rtop.template offer<true>(has, sc, d, k, lane);  // (scan_team_kernel: a document may be in two waves' lists)
-            else topk_offer<(KMAX > REG_K ? KMAX : 1)>(s_top, k, has, sc, d, lane);
+            __builtin_amdgcn_wave_barrier();
+        }
+    } else {
+        for (uint32_t item = L0; item < L0 + NL; ++item) {  // every list of every item of the query
+            const uint32_t cnt = uni(bt.res_cnt[item]);
+            if (cnt == 0) continue;
+            for (uint32_t base = 0; base < cnt; base += 64) {
+                bool has = base + lane < cnt;
+                double sc = 0;
+                uint32_t d = 0;
+                if (has) {
+                    sc = bt.res_score[(size_t)item * k + base + lane];
+                    d = bt.res_doc[(size_t)item * k + base + lane];
+                    has = (unsigned long long)__double_as_longlong(sc) >= theta;
+                }
+                topk_offer<(KMAX > REG_K ? KMAX : 1)>(s_top, k, has, sc, d, lane);
+            }
         }
     }
     __builtin_amdgcn_wave_barrier();
@@ -59,5 +87,30 @@ __global__ void __launch_bounds__(64) merge_kernel(DevIndex ix, DevBatch bt) {
     if (lane == 0) {
         bt.n_hits[q] = n;
         if (bt.merge_marked) bt.theta[q] = 0;  // the one-launch route keeps the per-launch state clean
+    }
+    if (bt.merge_clean) {
+        // the route without plan_kernel: this query's share of the per-launch state back to zero (the next launch starts on
+        // it); what the test aids want to see afterwards is kept aside
+        uint32_t nf = 0;
+        for (uint32_t i = it0 + lane; i < it1; i += 64) {
+            nf += bt.item_failed[i] != 0u ? 1u : 0u;
+            bt.item_failed[i] = 0;
+        }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) nf += __shfl_xor(nf, o);
+        for (uint32_t i = lane; i < NL; i += 64) bt.res_cnt[L0 + i] = 0;
+        if (bt.hist)
+#pragma unroll
+            for (int i = 0; i < CUR_HB / 64; ++i) bt.hist[(size_t)q * CUR_HB + 64 * i + lane] = 0;
+        if (lane == 0) {
+            bt.q_failed[q] = nf;
+            bt.theta_last[q] = theta;
+            bt.theta[q] = 0;
+            if (q == 0) {
+                bt.work_ctr[0] = 0;
+                bt.work_ctr[1] = 0;
+                *bt.fail_any = 0;
+            }
+        }
     }
 }

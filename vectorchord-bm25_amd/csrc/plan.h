@@ -128,6 +128,7 @@ __global__ void __launch_bounds__(PLAN_WG) plan_kernel(DevIndex ix, DevBatch bt,
     if (tid == 0) {
         bt.work_ctr[0] = 0;
         bt.work_ctr[1] = 0;
+        *bt.fail_any = 0;
     }
 
     auto postings_of = [&](uint32_t q) {

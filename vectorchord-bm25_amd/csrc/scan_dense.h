@@ -830,7 +830,10 @@ __global__ void __launch_bounds__(DWG, KMAX > 128 ? 2 : 4) scan_dense_kernel(Dev
                 }
             if (lane == 0) {
                 bt.res_cnt[list] = n;
-                if (wave == 0) bt.item_failed[item] = failed ? 0x140u : 0u;
+                if (wave == 0) {
+                    bt.item_failed[item] = failed ? 0x140u : 0u;
+                    if (failed) *bt.fail_any = 1u;
+                }
             }
         }
     }

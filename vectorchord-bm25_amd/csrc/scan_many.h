@@ -23,6 +23,7 @@ __global__ void __launch_bounds__(WG) scan_many_kernel(DevIndex ix, DevBatch bt)
     const uint32_t k = bt.k;
     for (int i = tid; i < 256; i += WG) s_s1[i] = ix.s1[i];
 
+    if (!bt.many_expected && __hip_atomic_load(bt.fail_any, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0u) return;  // (a small grid then)
     const uint32_t n_items = *bt.n_items;
     for (uint32_t item = blockIdx.x; item < n_items; item += gridDim.x) {
         const Item it = bt.items[item];

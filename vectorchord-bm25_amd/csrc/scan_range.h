@@ -137,7 +137,9 @@ __global__ void __launch_bounds__(RWG, 4) scan_range_kernel(DevIndex ix, DevBatc
     // bt.fused_g != 0 (a handful of queries through vbm25_search_batch): no plan_kernel and no merge_kernel -- every query is
     // cut into fused_g equal document ranges right here, the last workgroup to finish a query merges its lists into the
     // hits and leaves the per-launch state (threshold, histogram, counters) clean for the next launch.
-    const uint32_t fused_g = FUSED ? bt.fused_g : 0u;
+    // The general instantiation with bt.fused_g != 0 (every query of the batch sparse: vbm25_batch_run without plan_kernel):
+    // the same items, made right here; merge_kernel merges and cleans.
+    const uint32_t fused_g = bt.fused_g;
     const uint32_t n_items = fused_g ? bt.nq * fused_g : *bt.n_items;
     for (uint32_t i = tid; i < 256; i += RWG) S.s1[i] = ix.s1[i];
 
@@ -166,7 +168,7 @@ __global__ void __launch_bounds__(RWG, 4) scan_range_kernel(DevIndex ix, DevBatc
         const uint32_t item = uni(S.item);
         if (item >= n_items) break;
         Item it;
-        if (FUSED) {
+        if (fused_g) {
             it.q = item / fused_g;
             const uint32_t part = item - it.q * fused_g;
             it.doc_lo = (uint32_t)((unsigned long long)ix.n_docs * part / fused_g);
@@ -400,9 +402,14 @@ __global__ void __launch_bounds__(RWG, 4) scan_range_kernel(DevIndex ix, DevBatc
             }
             m = uni(m);
             const bool act = lane < m;
-            double s0 = 0.0, tub = 0.0;
+            double s0 = 0.0, tub = 0.0, kth = 0.0;
             uint32_t df = 0, b0 = 0, b1 = 0;
             p_cur = p_end = 0;
+            if (act && ix.term_kth_ub) {  // (the smallest 2^i >= k: at least k documents of the term score that much)
+                uint32_t kidx = 0;
+                while ((1u << kidx) < k) ++kidx;
+                kth = ix.term_kth_ub[(size_t)term * 9 + kidx];
+            }
             if (act) {
                 b0 = ix.term_first_block[term];
                 b1 = ix.term_first_block[term + 1];
@@ -449,6 +456,11 @@ __global__ void __launch_bounds__(RWG, 4) scan_range_kernel(DevIndex ix, DevBatc
                 S.t_b1[lane] = b1;
             }
             // terms in ascending order of their token upper bound; prefix sums; admissible prefixes
+            // theta0: the largest, over the terms, of the term's k-th largest block maximum -- a lower bound of the final k-th
+            // score before the first posting is read (scores are >= 0: fmax over the lanes)
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) kth = fmax(kth, __shfl_xor(kth, o));
+            const unsigned long long theta0 = (unsigned long long)__double_as_longlong(kth);
             p_df = df;
             p_rank = 0;
             double sums0 = 0.0;
@@ -492,7 +504,7 @@ __global__ void __launch_bounds__(RWG, 4) scan_range_kernel(DevIndex ix, DevBatc
             assign_quotas();
             const double hscale = (double)CUR_HB / sums0;  // score -> histogram bucket: linear in [0, sum of s0)
             if (lane == 0) {
-                if constexpr (FUSED) {
+                if (fused_g) {
                     // the records plan_kernel would have made: scan_many_kernel (items this kernel gives up) and merge_kernel
                     // (queries with such an item) of the general route read them
                     Item rec;
@@ -511,7 +523,8 @@ __global__ void __launch_bounds__(RWG, 4) scan_range_kernel(DevIndex ix, DevBatc
                 S.mq = m;
                 S.fail = 0;
                 S.hscale = hscale;
-                S.theta = 0;
+                S.theta = theta0;
+                if (theta0) atomicMax(&bt.theta[q], theta0);
                 S.nmulti[0] = 0;
                 S.nmulti[1] = 0;
             }
@@ -978,7 +991,10 @@ __global__ void __launch_bounds__(RWG, 4) scan_range_kernel(DevIndex ix, DevBatc
             }
         if (lane == 0) {
             bt.res_cnt[list] = n;
-            if (wave == 0) bt.item_failed[item] = failed ? (S.fail | 0x100u) : 0u;
+            if (wave == 0) {
+                bt.item_failed[item] = failed ? (S.fail | 0x100u) : 0u;
+                if (failed) *bt.fail_any = 1u;
+            }
         }
         if constexpr (FUSED) {
             // ---- the last workgroup of the query merges its lists (merge.h's job) and leaves the per-launch state clean.

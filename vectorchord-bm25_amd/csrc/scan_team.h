@@ -22,25 +22,25 @@
 //               take the general path, one block at a time.
 //   candidates  second arrivals and -- from the blocks whose upper bound (search.rs:377-380, once per index) reaches the
 //               threshold (search.rs:203) -- every posting that could reach it alone go to the wave's candidate list.
-//   completion  a candidate document is scored from scratch, whoever found it: lanes = (candidate, term).  The term's
-//               block that holds the document comes from the window's DIRECTORY in LDS (every wave enters the first
-//               documents of the blocks it plans: [window mod 3][term][block mod 16]; Cursor::seek_block, search.rs:412-431,
-//               without a single global load), the posting from a two-level search of the block's 16-bit ids (blk_piv:
-//               every 16th id of the block, then 32 bytes of the plane), its tf / fieldnorm from post_tfn, then
-//               Cache::evaluate (bm25.rs:355-358) and the sum in ascending key order (evaluate.rs:43-72) -> the wave's
-//               register top-k.  These are four dependent round trips to memory; done on the spot they doubled the kernel's
-//               time (every wave of a team waits for the slowest).  So completion is a PIPELINE: a batch advances ONE stage
-//               after every group of marks -- its loads were issued a group earlier and return in order before the
-//               group's own plane words, which the marks wait for anyway.  Candidates of window n are completed during
-//               windows n + 1 and n + 2 (the directory keeps three windows).  A document found twice (three lists; a cold
+//   completion  a candidate document is scored from scratch, whoever found it, ONCE PER ITEM and in bulk: lanes = (candidate,
+//               term), four batches of 64 lanes interleaved in straight-line code.  The term's block that may hold the
+//               document comes from the term's bucket locator (blk_loc: first block whose last document reaches the bucket,
+//               buckets of about one block span; Cursor::seek_block, search.rs:412-431, in two round trips instead of a
+//               bisection), the posting from a two-level search of the block's 16-bit ids (blk_piv: every 16th id, then 32
+//               bytes of the plane), its tf / fieldnorm from post_tfn, then Cache::evaluate (bm25.rs:355-358) and the sum in
+//               ascending key order (evaluate.rs:43-72) -> the wave's register top-k.  Six dependent round trips to memory:
+//               done per window on the spot they doubled the kernel's time (every wave of a team waits for the slowest), as
+//               a pipeline advanced between the groups of marks they cost the compiler its count of the loads in flight
+//               (every wait became a wait for everything).  In bulk, four batches at a time, the chain costs 1.5 round
+//               trips per batch and nobody waits for it but the wave itself.  A document found twice (three lists; a cold
 //               posting that is also a second arrival; two waves) is scored twice to the same bits: RegTopK and
-//               merge_kernel drop the repetition.  Lookups the directory cannot serve (more than 16 blocks of a term in a
-//               window, a wave whose ring is full of the current window's candidates) search blk_max_doc in global memory.
+//               merge_kernel drop the repetition.  Lookups the fast path cannot serve (more than four blocks in a bucket,
+//               blocks without a plane or tf word) are redone one by one, from the generic decode.
 //   life cycle  of the bitmap, the only thing the team synchronises for: every mark of window n before it is wiped, the
 //               wipe before the marks of n + 1.  Two LDS counters, arrive early / wait late, no s_barrier inside an item.
 //
-// There is no overflow mode: a full candidate ring is drained on the spot, a round takes what its lanes hold and the
-// next round takes the rest; nothing is handed to scan_many_kernel.
+// A wave's candidates go to its list in global memory (bt.team_cand); an item whose lists intersect so densely that a
+// list overflows is handed to scan_many_kernel (item_failed), as the round-3 kernel did.
 //
 // Threshold: theta0 = the largest, over the query's terms, of the k-th largest block maximum of the term
 // (term_kth_ub, derived at index creation; every block maximum is the score of a posting of its block, documents of one
@@ -50,19 +50,15 @@
 
 constexpr int TM_TQ = 4;         // candidate blocks per term and round (16 terms x 4 = the 64 lanes)
 constexpr int TM_G = 4;          // blocks per group of the branch-free path
-constexpr int TM_LIST = 64;      // ring of candidate documents per wave (a power of two)
 constexpr int TM_KTH = 9;        // term_kth_ub entries per term: the 2^i-th largest block maximum, i = 0..8
-constexpr int TM_DIR = 16;       // directory slots per term and window
+constexpr int TM_IL = 4;         // batches of the bulk completion in flight together
+constexpr uint32_t TM_CAND = 2048;  // candidate documents per wave and item (bt.team_cand)
 
 template <int TEAM>
 struct TeamLds {
     uint32_t bm[TEAM * 2048];
-    uint32_t dir_min[3][16][TM_DIR];  // [window mod 3][term][block mod 16]: first document of the block
-    uint32_t dir_flag[3][16];         // per term, two bits per slot: 1 = the block has a post_rel16 word, 2 = a post_tfn word
-    uint32_t dir_lo[3][16], dir_hi[3][16];  // smallest / largest block of the term inside the window (lo > hi: none)
-    uint32_t cand[TEAM][TM_LIST];     // per wave: ring of candidate documents
-    uint32_t scr[TEAM][128];          // per wave: ids of a block decoded for a lookup / the contributions of a batch
-    unsigned long long theta;         // bits of a lower bound of the query's k-th best score
+    uint32_t scr[TEAM][128];       // per wave: ids of a block decoded for a lookup / the contributions of a batch
+    unsigned long long theta;      // bits of a lower bound of the query's k-th best score
     uint32_t sync[2];
     uint32_t item, fail;
 };
@@ -102,7 +98,7 @@ __device__ __forceinline__ uint32_t tm_first_block_ge(const uint32_t *blk_max_do
     return lo_b;
 }
 
-// (macros, not lambdas: with this many by-reference closures in one function the optimiser leaves every captured local --
+// (macros, not lambdas: with many by-reference closures in one large function the optimiser leaves every captured local --
 // and a copy of both argument structs -- in scratch memory)
 #define TM_THETA_NOW()                                                                                          \
     ({                                                                                                          \
@@ -124,7 +120,6 @@ __device__ __forceinline__ uint32_t tm_first_block_ge(const uint32_t *blk_max_do
             w[i_] = ix.post_rel16[64ull * blk_ + lane];                                                         \
         }                                                                                                       \
     } while (false)
-#define TM_AFTER_GROUPS() (m_slow ? (uint32_t)PH_SLOW : again ? (uint32_t)PH_ROUND : (uint32_t)PH_WIN_A)
 
 // The kernel's arguments as they lie in the kernarg segment.  The pointers that only the item setup, the item's end and the
 // rare paths need are read from there where they are used (cold_args): kept in SGPRs for the whole kernel they push the loop's
@@ -151,8 +146,8 @@ __global__ void __launch_bounds__(TEAM * 64, 4) scan_team_kernel(DevIndex ix, De
     const uint32_t tid = threadIdx.x, lane = tid & 63, wave = uni(tid >> 6);
     const uint32_t k = bt.k;
     const uint32_t n_items = *cold_args()->bt.n_items;
-    uint32_t *const cand = S.cand[wave];
     uint32_t *const scr = S.scr[wave];
+    uint32_t *const gl = bt.team_cand + (size_t)(blockIdx.x * TEAM + wave) * TM_CAND;  // this wave's candidate list
     const uint32_t slot_t = lane / TM_TQ, off = lane % TM_TQ;
     const float inv_docs = 1.0f / (float)ix.n_docs;
     uint32_t kidx = 0;  // term_kth_ub entry: the smallest 2^i >= k
@@ -161,29 +156,15 @@ __global__ void __launch_bounds__(TEAM * 64, 4) scan_team_kernel(DevIndex ix, De
     for (uint32_t i = tid; i < WORDS; i += TEAM * 64) S.bm[i] = 0;
     if (tid < 2) S.sync[tid] = 0;
     uint32_t epoch = 0;  // windows this workgroup has finished: the counters take TEAM arrivals per window
-    auto arrive = [&](int which) {
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        if (lane == 0) atomicAdd(&S.sync[which], 1u);
-    };
-    auto wait = [&](int which) {
-        const uint32_t target = (epoch + 1u) * TEAM;
-        while (__hip_atomic_load(&S.sync[which], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < target) __builtin_amdgcn_s_sleep(1);
-        asm volatile("" ::: "memory");
-    };
 
     for (;;) {
-        __syncthreads();  // previous item: every wave is past its last wait and has drained its candidates
+        __syncthreads();  // previous item: every wave is past its last wait
         if (tid == 0) {
             const TeamArgsP ca = cold_args();
             const uint32_t drawn = atomicAdd(&ca->bt.work_ctr[0], 1u);
             S.item = drawn < n_items ? ca->bt.item_order[drawn] : NONE32;  // plan_kernel's order: longest first
             S.theta = 0;
             S.fail = 0;
-        }
-        if (tid < 48) {  // the three directories: no block yet
-            (&S.dir_lo[0][0])[tid] = NONE32;
-            (&S.dir_hi[0][0])[tid] = 0;
-            (&S.dir_flag[0][0])[tid] = 0;
         }
         __syncthreads();
         const uint32_t item = uni(S.item);
@@ -217,13 +198,16 @@ __global__ void __launch_bounds__(TEAM * 64, 4) scan_team_kernel(DevIndex ix, De
         }
         m = uni(m);
         const bool act = lane < m;
-        uint32_t r_b0 = 0, r_b1 = 0, r_df = 0;
+        uint32_t r_b0 = 0, r_b1 = 0, r_df = 0, r_loc = 0, r_sh = 0;
         double r_s0 = 0.0, kth = 0.0;
         if (act) {
             r_b0 = ca->ix.term_first_block[term];
             r_b1 = ca->ix.term_first_block[term + 1];
             r_s0 = ca->ix.term_s0[term];
             r_df = ca->ix.term_df[term];
+            const uint2 tl = ca->ix.term_loc[term];
+            r_loc = tl.x;
+            r_sh = tl.y;
             const double *kub = ca->ix.term_kth_ub;
             if (kub) kth = kub[(size_t)term * TM_KTH + kidx];
         }
@@ -259,46 +243,9 @@ __global__ void __launch_bounds__(TEAM * 64, 4) scan_team_kernel(DevIndex ix, De
             }
         }
 
-        RegTopK<RK> rtop;
-        rtop.init();
-        unsigned long long published = 0;
-        // ================================================================================================================
-        // Completion pipeline.  The ring holds the candidates of up to three windows, oldest first: q0 of window w - 2, q1
-        // of w - 1, q2 of the current window w (directories (w + 1) % 3, (w + 2) % 3, w % 3).  A batch = up to 64 / m
-        // candidates of ONE window x the m terms; q2 is not touched while its window is open (the other waves are still
-        // entering their blocks) unless the ring is full of it -- then the lookups go to global memory.
-        // ================================================================================================================
-        uint32_t q_head = 0, q0 = 0, q1 = 0, q2 = 0, wpar = 0;
-        const uint32_t inv_m = (65536u + m - 1u) / m;  // p / m == (p * inv_m) >> 16 for p < 4096
-        const uint32_t per_batch = 64u / m;
-        uint32_t cs_stage = 0, cs_n = 0, cs_from = 0;  // uniform: stage, candidates of the batch, the run it was taken from (0 / 1 / 2)
-        // per lane (= one (candidate, term) of the batch), slots reused from stage to stage:
-        //   cs_d   the document            cs_j   the term's block that may hold it
-        //   cs_x   the block's first document (stages 0-2), then the posting's index in the block
-        //   cs_fl  1 plane word, 2 tfn word, 4 there is such a block, 8 look it up in global memory; bits 8.. = 16 x the id segment
-        //   cs_v   the pivots (4 words), the 16 ids (8), the tf word, tf / fieldnorm, s1 (2)
-        uint32_t cs_d = 0, cs_j = 0, cs_x = 0, cs_fl = 0;
-        uint32_t cs_v[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-        // ================================================================================================================
-        // The wave's control flow is a state machine: every iteration does ONE unit of marking work (a round's plan, a group
-        // of blocks, one general block, a step of the window's end) and then ONE stage of the completion pipeline -- so
-        // the pipeline's code exists once, and "wait until the ring has room / the old window's candidates are done" is the
-        // same iteration with no marking work in it.
-        // ================================================================================================================
-        enum : uint32_t { PH_OPEN, PH_ROUND, PH_GROUP, PH_SLOW, PH_STORE, PH_WIN_A, PH_WIN_B, PH_WIN_C, PH_END };
-        uint32_t phase = lo < hi ? (uint32_t)PH_OPEN : (uint32_t)PH_END;
-        uint32_t tlo = lo, thi = lo, span = 0;
-        unsigned long long poll = 0;  // the query's threshold as the other workgroups see it: asked for when a window opens, used at its end
-        unsigned long long m_fast = 0, m_slow = 0, m_cold = 0;
-        uint32_t ngroups = 0, g = 0;
-        bool again = false, failed = false;
-        uint32_t v_delta = 0, v_blk = 0;
-        uint32_t w[TM_G], dl[TM_G];
-#pragma unroll
-        for (int i = 0; i < TM_G; ++i) w[i] = dl[i] = 0;
-        uint32_t st_d0 = 0, st_d1 = 0, st_stored = 0;  // a general block's candidates on their way into the ring
-        unsigned long long st_e0 = 0, st_e1 = 0;
-        // the first round's candidates
+        uint32_t cnt = 0;     // candidates in gl
+        bool failed = false;  // ... more than it holds
+        // ---- the first round's candidates
         uint32_t j = cur + (uint32_t)TEAM * off;
         bool valid = slot_act && j < end;
         uint4 meta = make_uint4(NONE32, 0, 0, 0);
@@ -307,37 +254,23 @@ __global__ void __launch_bounds__(TEAM * 64, 4) scan_team_kernel(DevIndex ix, De
             meta = ix.blk_meta[j];
             ub = ix.blk_ub[j];
         }
-        for (;;) {
-            bool allow_q2 = false;
-            const uint32_t room = (uint32_t)TM_LIST - (q0 + q1 + q2);
-            if (phase == PH_OPEN) {
-                thi = hi - tlo > W ? tlo + W : hi;
-                span = thi - tlo;
-                if (wave == 0) poll = __hip_atomic_load(&bt.theta[q], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                phase = PH_ROUND;
-            } else if (phase == PH_ROUND) {
-                // ---- a round: up to TM_TQ blocks per term
+
+        for (uint32_t tlo = lo; tlo < hi;) {
+            const uint32_t thi = hi - tlo > W ? tlo + W : hi, span = thi - tlo;
+            unsigned long long poll = 0;  // the query's threshold as the other workgroups see it: asked for now, used at the window's end
+            if (wave == 0) poll = __hip_atomic_load(&bt.theta[q], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            for (;;) {  // rounds: up to TM_TQ blocks per term each
                 const double thd = __longlong_as_double((long long)TM_THETA_NOW());
                 const bool in_win = valid && meta.x < thi;
-                const bool has_plane = rel16_block(meta.x, meta.y, meta.w);
-                const bool plane = shift == 0u && has_plane;
+                const bool plane = shift == 0u && rel16_block(meta.x, meta.y, meta.w);
                 const bool cold = ub >= thd;  // search.rs:203 per block (blk_ub carries its margin)
-                m_fast = __ballot(in_win && plane && !cold);
-                m_cold = __ballot(in_win && cold);
-                m_slow = __ballot(in_win && !(plane && !cold));
+                unsigned long long m_fast = __ballot(in_win && plane && !cold);
+                const unsigned long long m_cold = __ballot(in_win && cold);
+                unsigned long long m_slow = __ballot(in_win && !(plane && !cold));
                 const unsigned long long done = __ballot(in_win && meta.y < thi);
                 const uint32_t ndone = (uint32_t)__popcll((done >> (slot_t * TM_TQ)) & ((1ull << TM_TQ) - 1ull));
-                again = __ballot(slot_act && ndone == (uint32_t)TM_TQ) != 0ull;
-                if (in_win) {  // the window's directory: who holds which document range of the term
-                    const uint32_t sl = j & (TM_DIR - 1);
-                    S.dir_min[wpar][slot_t][sl] = meta.x;
-                    const uint32_t fl = (has_plane ? 1u : 0u) | (tfn_block(meta.w) ? 2u : 0u);
-                    if (fl) atomicOr(&S.dir_flag[wpar][slot_t], fl << (2u * sl));
-                    atomicMin(&S.dir_lo[wpar][slot_t], j);
-                    atomicMax(&S.dir_hi[wpar][slot_t], j);
-                }
-                v_delta = meta.x - tlo;
-                v_blk = in_win ? j : 0u;  // (a padded group entry reads lane 0's block: a valid one)
+                const bool again = __ballot(slot_act && ndone == (uint32_t)TM_TQ) != 0ull;
+                const uint32_t v_delta = meta.x - tlo, v_blk = in_win ? j : 0u;  // (a padded group entry reads lane 0's block: a valid one)
                 // the next round's candidates (their loads fly while this round is marked)
                 cur += (uint32_t)TEAM * ndone;
                 j = cur + (uint32_t)TEAM * off;
@@ -348,384 +281,348 @@ __global__ void __launch_bounds__(TEAM * 64, 4) scan_team_kernel(DevIndex ix, De
                     meta = ix.blk_meta[j];
                     ub = ix.blk_ub[j];
                 }
-                ngroups = ((uint32_t)__popcll(m_fast) + TM_G - 1) / TM_G;
-                g = 0;
+
+                // ---- groups of TM_G blocks with a plane word: branch-free, the next group's words in flight
+                const uint32_t ngroups = ((uint32_t)__popcll(m_fast) + TM_G - 1) / TM_G;
                 if (ngroups) {
+                    uint32_t w[TM_G], dl[TM_G];
                     TM_ISSUE();
-                    phase = PH_GROUP;
-                } else {
-                    phase = TM_AFTER_GROUPS();
-                }
-            } else if (phase == PH_GROUP) {
-                // ---- a group of TM_G blocks with a plane word: branch-free, the next group's words in flight
-                if (room < 16u) {
-                    allow_q2 = q0 == 0u && q1 == 0u;  // the ring first (its current-window candidates through global lookups)
-                } else {
-                    uint32_t x[2 * TM_G], mk[2 * TM_G], o[2 * TM_G];
+                    for (uint32_t g = 0; g < ngroups; ++g) {
+                        uint32_t x[2 * TM_G], mk[2 * TM_G], o[2 * TM_G];
 #pragma unroll
-                    for (int i = 0; i < TM_G; ++i) {
-                        x[2 * i] = dl[i] + (w[i] & 0xffffu);
-                        x[2 * i + 1] = dl[i] + (w[i] >> 16);
-                    }
-                    if (g + 1 < ngroups) TM_ISSUE();
-#pragma unroll
-                    for (int p = 0; p < 2 * TM_G; ++p) {
-                        mk[p] = 1u << (x[p] & 31);
-                        if (x[p] >= span) mk[p] = 0;  // another window's document: the atomic changes nothing
-                        o[p] = atomicOr(&S.bm[(x[p] >> 5) & (WORDS - 1)], mk[p]);
-                    }
-                    unsigned long long dm[2 * TM_G], any = 0;
-#pragma unroll
-                    for (int p = 0; p < 2 * TM_G; ++p) {
-                        dm[p] = __ballot((o[p] & mk[p]) != 0);
-                        any |= dm[p];
-                    }
-                    if (any) {  // second arrivals -> the candidate ring
-                        uint32_t c = 0;
+                        for (int i = 0; i < TM_G; ++i) {
+                            x[2 * i] = dl[i] + (w[i] & 0xffffu);
+                            x[2 * i + 1] = dl[i] + (w[i] >> 16);
+                        }
+                        if (g + 1 < ngroups) TM_ISSUE();
 #pragma unroll
                         for (int p = 0; p < 2 * TM_G; ++p) {
-                            if (dm[p]) {
-                                if ((o[p] & mk[p]) != 0) {
-                                    const uint32_t at = c + __builtin_amdgcn_mbcnt_hi((uint32_t)(dm[p] >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)dm[p], 0u));
-                                    if (at < room) cand[(q_head + q0 + q1 + q2 + at) & (TM_LIST - 1)] = tlo + x[p];
-                                }
-                                c += (uint32_t)__popcll(dm[p]);
-                            }
+                            mk[p] = 1u << (x[p] & 31);
+                            if (x[p] >= span) mk[p] = 0;  // another window's document: the atomic changes nothing
+                            o[p] = atomicOr(&S.bm[(x[p] >> 5) & (WORDS - 1)], mk[p]);
                         }
-                        if (c > room) failed = true;  // lists that intersect this densely: the item is scan_many_kernel's
-                        q2 += min(c, room);
-                    }
-                    if (++g == ngroups) phase = TM_AFTER_GROUPS();
-                }
-            } else if (phase == PH_SLOW) {
-                // ---- general path, one block: blocks without a plane word, windows of 2^shift documents per bit, blocks
-                // whose upper bound reaches the threshold (every posting that could reach it alone is a candidate)
-                const int sl = __ffsll((long long)m_slow) - 1;
-                m_slow &= m_slow - 1;
-                const uint32_t blk = (uint32_t)__builtin_amdgcn_readlane((int)v_blk, sl);
-                const uint4 um = uni4(ix.blk_meta[blk]);
-                const TeamArgsP cg = cold_args();
-                const bool is_cold = (m_cold >> sl) & 1ull;
-                const uint32_t un = um.w & 0xff, umd = (um.w >> 8) & 0xff, umt = (um.w >> 16) & 0xff;
-                uint32_t d0, d1;
-                if (rel16_block(um.x, um.y, um.w)) {
-                    const uint32_t ww = ix.post_rel16[64ull * blk + lane];
-                    d0 = um.x + (ww & 0xffffu);
-                    d1 = um.x + (ww >> 16);
-                } else {
-                    decode_doc_ids(cg->ix.blob + 8ull * um.z, umd, un, um.x, lane, d0, d1);
-                    if (2 * lane >= un) d0 = NONE32;
-                    if (2 * lane + 1 >= un) d1 = NONE32;
-                }
-                const uint32_t x0 = d0 - tlo, x1 = d1 - tlo;
-                const uint32_t g0 = x0 >> shift, g1 = x1 >> shift;
-                const uint32_t k0 = x0 < span ? 1u << (g0 & 31) : 0u, k1 = x1 < span ? 1u << (g1 & 31) : 0u;
-                const uint32_t o0 = atomicOr(&S.bm[(g0 >> 5) & (WORDS - 1)], k0);
-                const uint32_t o1 = atomicOr(&S.bm[(g1 >> 5) & (WORDS - 1)], k1);
-                bool f0 = (o0 & k0) != 0, f1 = (o1 & k1) != 0;
-                if (is_cold) {
-                    uint32_t t0, t1, n0, n1;
-                    if (tfn_block(um.w)) {
-                        const uint32_t ww = ix.post_tfn[64ull * blk + lane];
-                        t0 = ww & 0xffu;
-                        t1 = (ww >> 8) & 0xffu;
-                        n0 = (ww >> 16) & 0xffu;
-                        n1 = ww >> 24;
-                    } else {
-                        decode_fields(cg->ix.blob + 8ull * um.z + ((payload_bytes(umd, un) + 7u) & ~7u), umt, un, lane, t0, t1);
-                        const uchar2 fn = reinterpret_cast<const uchar2 *>(cg->ix.post_fn + 128ull * blk)[lane];
-                        n0 = fn.x;
-                        n1 = fn.y;
-                    }
-                    // could the posting reach the threshold alone?  (tf s0) / (tf + s1) >= theta, without the division and
-                    // with a margin: a candidate is scored exactly by its completion
-                    const double s0t = readlane_f64(r_s0, (uint32_t)sl / TM_TQ);
-                    const double thm = __longlong_as_double((long long)TM_THETA_NOW());
-                    const double a0 = (double)t0, a1 = (double)t1;
-                    f0 = f0 || (x0 < span && a0 * s0t * (1.0 + 1e-9) >= thm * (a0 + ix.s1[n0]));
-                    f1 = f1 || (x1 < span && a1 * s0t * (1.0 + 1e-9) >= thm * (a1 + ix.s1[n1]));
-                }
-                st_e0 = __ballot(f0);
-                st_e1 = __ballot(f1);
-                if (st_e0 | st_e1) {
-                    st_d0 = d0;
-                    st_d1 = d1;
-                    st_stored = 0;
-                    phase = PH_STORE;
-                } else {
-                    phase = TM_AFTER_GROUPS();
-                }
-            } else if (phase == PH_STORE) {
-                // ---- the block's candidates into the ring, as many as it has room for
-                const uint32_t c0 = (uint32_t)__popcll(st_e0), c = c0 + (uint32_t)__popcll(st_e1);
-                const bool f0 = (st_e0 >> lane) & 1ull, f1 = (st_e1 >> lane) & 1ull;
-                if (f0) {
-                    const uint32_t at = __builtin_amdgcn_mbcnt_hi((uint32_t)(st_e0 >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)st_e0, 0u));
-                    if (at >= st_stored && at - st_stored < room) cand[(q_head + q0 + q1 + q2 + at - st_stored) & (TM_LIST - 1)] = st_d0;
-                }
-                if (f1) {
-                    const uint32_t at = c0 + __builtin_amdgcn_mbcnt_hi((uint32_t)(st_e1 >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)st_e1, 0u));
-                    if (at >= st_stored && at - st_stored < room) cand[(q_head + q0 + q1 + q2 + at - st_stored) & (TM_LIST - 1)] = st_d1;
-                }
-                const uint32_t add = min(c - st_stored, room);
-                q2 += add;
-                st_stored += add;
-                if (st_stored == c) phase = TM_AFTER_GROUPS();
-                else allow_q2 = q0 == 0u && q1 == 0u;
-            } else if (phase == PH_WIN_A) {
-                // ---- the window's marks of this wave are in.  Before the arrival: the candidates of window w - 2 must be done
-                // (their directory is the one that is reset below)
-                if (!(q0 || (cs_stage && cs_from == 0u))) {
-                    arrive(0);
-                    if (wave == 0 && poll > TM_THETA_NOW() && lane == 0) atomicMax(&S.theta, poll);
-                    phase = PH_WIN_B;
-                }
-            } else if (phase == PH_WIN_B) {
-                wait(0);
-                for (uint32_t i = tid; i < WORDS / 4; i += TEAM * 64) reinterpret_cast<uint4 *>(S.bm)[i] = make_uint4(0, 0, 0, 0);
-                {
-                    const uint32_t np = wpar == 2u ? 0u : wpar + 1u;  // the next window's directory
-                    if (tid < 16) {
-                        S.dir_lo[np][tid] = NONE32;
-                        S.dir_hi[np][tid] = 0;
-                        S.dir_flag[np][tid] = 0;
-                    }
-                }
-                arrive(1);
-                phase = PH_WIN_C;
-            } else if (phase == PH_WIN_C) {
-                wait(1);
-                ++epoch;
-                tlo = thi;
-                wpar = wpar == 2u ? 0u : wpar + 1u;
-                q0 = q1;  // (q0 was done before the arrival)
-                q1 = q2;
-                q2 = 0;
-                if (cs_stage) cs_from = cs_from ? cs_from - 1u : 0u;
-                phase = tlo < hi ? (uint32_t)PH_OPEN : (uint32_t)PH_END;
-            } else {
-                // ---- the item's last candidates: every directory is complete now
-                if (!(cs_stage || q0 || q1 || q2)) break;
-                allow_q2 = true;
-            }
-            // ---- one stage of the completion pipeline
-            do {
-            if (bt.team_dbg & 1u) {
-                q_head += q0 + q1 + (allow_q2 ? q2 : 0u);
-                q0 = q1 = 0;
-                if (allow_q2) q2 = 0;
-                break;
-            }
-            const uint32_t cs_ci = (lane * inv_m) >> 16, cs_t = lane - cs_ci * m;
-            if (cs_stage == 0) {
-                // ---- stage 0: a batch of the oldest window; the block of every (candidate, term) from the directory
-                uint32_t n, par;
-                bool glob = false;
-                if (q0) {
-                    n = min(q0, per_batch);
-                    par = wpar + 1u;
-                    cs_from = 0;
-                } else if (q1) {
-                    n = min(q1, per_batch);
-                    par = wpar + 2u;
-                    cs_from = 1;
-                } else if (q2 && allow_q2) {
-                    n = min(q2, per_batch);
-                    par = wpar;
-                    cs_from = 2;
-                    glob = true;
-                } else {
-                    break;
-                }
-                if (par >= 3u) par -= 3u;
-                cs_n = n;
-                const bool task = cs_ci < n;
-                cs_d = task ? cand[(q_head + cs_ci) & (TM_LIST - 1)] : 0u;
-                cs_j = NONE32;
-                cs_fl = 0;
-                if (task && !glob) {
-                    const uint32_t jl = S.dir_lo[par][cs_t], jh = S.dir_hi[par][cs_t];
-                    if (jl <= jh) {
-                        if (jh - jl >= (uint32_t)TM_DIR) {
-                            cs_fl = 8;  // more blocks of the term in the window than the directory holds
-                        } else {
-                            const uint32_t *row = S.dir_min[par][cs_t];
-                            const uint32_t cntj = jh - jl + 1u;
-                            uint32_t pos = 0;  // the last block whose first document is <= d
+                        unsigned long long dm[2 * TM_G], any = 0;
 #pragma unroll
-                            for (uint32_t step = TM_DIR / 2; step > 0; step >>= 1)
-                                if (pos + step < cntj && row[(jl + pos + step) & (TM_DIR - 1)] <= cs_d) pos += step;
-                            const uint32_t mn = row[(jl + pos) & (TM_DIR - 1)];
-                            if (mn <= cs_d) {
-                                cs_j = jl + pos;
-                                cs_x = mn;
-                                cs_fl = 4u | ((S.dir_flag[par][cs_t] >> (2u * ((jl + pos) & (TM_DIR - 1)))) & 3u);
+                        for (int p = 0; p < 2 * TM_G; ++p) {
+                            dm[p] = __ballot((o[p] & mk[p]) != 0);
+                            any |= dm[p];
+                        }
+                        if (any) {  // second arrivals -> the candidate list
+#pragma unroll
+                            for (int p = 0; p < 2 * TM_G; ++p) {
+                                if (dm[p]) {
+                                    if ((o[p] & mk[p]) != 0) {
+                                        const uint32_t at = cnt + __builtin_amdgcn_mbcnt_hi((uint32_t)(dm[p] >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)dm[p], 0u));
+                                        if (at < TM_CAND) gl[at] = tlo + x[p];
+                                    }
+                                    cnt += (uint32_t)__popcll(dm[p]);
+                                }
                             }
                         }
                     }
-                } else if (task) {
-                    cs_fl = 8;
                 }
-                if (__ballot((cs_fl & 8u) != 0)) {  // Cursor::seek_block in global memory (rare)
-                    const uint32_t tb0 = (uint32_t)__shfl((int)r_b0, (int)cs_t), tb1 = (uint32_t)__shfl((int)r_b1, (int)cs_t);
-                    if (cs_fl & 8u) {
-                        cs_fl = 0;
-                        const uint32_t jj = tm_first_block_ge(cold_args()->ix.blk_max_doc, tb0, tb1, cs_d, inv_docs);
+
+                // ---- general path, one block at a time: blocks without a plane word, windows of 2^shift documents per bit,
+                // blocks whose upper bound reaches the threshold (every posting that could reach it alone is a candidate)
+                while (m_slow) {
+                    const int sl = __ffsll((long long)m_slow) - 1;
+                    m_slow &= m_slow - 1;
+                    const uint32_t blk = (uint32_t)__builtin_amdgcn_readlane((int)v_blk, sl);
+                    const uint4 um = uni4(ix.blk_meta[blk]);
+                    const TeamArgsP cg = cold_args();
+                    const bool is_cold = (m_cold >> sl) & 1ull;
+                    const uint32_t un = um.w & 0xff, umd = (um.w >> 8) & 0xff, umt = (um.w >> 16) & 0xff;
+                    uint32_t d0, d1;
+                    if (rel16_block(um.x, um.y, um.w)) {
+                        const uint32_t ww = ix.post_rel16[64ull * blk + lane];
+                        d0 = um.x + (ww & 0xffffu);
+                        d1 = um.x + (ww >> 16);
+                    } else {
+                        decode_doc_ids(cg->ix.blob + 8ull * um.z, umd, un, um.x, lane, d0, d1);
+                        if (2 * lane >= un) d0 = NONE32;
+                        if (2 * lane + 1 >= un) d1 = NONE32;
+                    }
+                    const uint32_t x0 = d0 - tlo, x1 = d1 - tlo;
+                    const uint32_t g0 = x0 >> shift, g1 = x1 >> shift;
+                    const uint32_t k0 = x0 < span ? 1u << (g0 & 31) : 0u, k1 = x1 < span ? 1u << (g1 & 31) : 0u;
+                    const uint32_t o0 = atomicOr(&S.bm[(g0 >> 5) & (WORDS - 1)], k0);
+                    const uint32_t o1 = atomicOr(&S.bm[(g1 >> 5) & (WORDS - 1)], k1);
+                    bool f0 = (o0 & k0) != 0, f1 = (o1 & k1) != 0;
+                    if (is_cold) {
+                        uint32_t t0, t1, n0, n1;
+                        if (tfn_block(um.w)) {
+                            const uint32_t ww = ix.post_tfn[64ull * blk + lane];
+                            t0 = ww & 0xffu;
+                            t1 = (ww >> 8) & 0xffu;
+                            n0 = (ww >> 16) & 0xffu;
+                            n1 = ww >> 24;
+                        } else {
+                            decode_fields(cg->ix.blob + 8ull * um.z + ((payload_bytes(umd, un) + 7u) & ~7u), umt, un, lane, t0, t1);
+                            const uchar2 fn = reinterpret_cast<const uchar2 *>(cg->ix.post_fn + 128ull * blk)[lane];
+                            n0 = fn.x;
+                            n1 = fn.y;
+                        }
+                        // could the posting reach the threshold alone?  (tf s0) / (tf + s1) >= theta, without the division and
+                        // with a margin: a candidate is scored exactly by its completion
+                        const double s0t = readlane_f64(r_s0, (uint32_t)sl / TM_TQ);
+                        const double thm = __longlong_as_double((long long)TM_THETA_NOW());
+                        const double a0 = (double)t0, a1 = (double)t1;
+                        f0 = f0 || (x0 < span && a0 * s0t * (1.0 + 1e-9) >= thm * (a0 + ix.s1[n0]));
+                        f1 = f1 || (x1 < span && a1 * s0t * (1.0 + 1e-9) >= thm * (a1 + ix.s1[n1]));
+                    }
+                    const unsigned long long e0 = __ballot(f0), e1 = __ballot(f1);
+                    if (f0) {
+                        const uint32_t at = cnt + __builtin_amdgcn_mbcnt_hi((uint32_t)(e0 >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)e0, 0u));
+                        if (at < TM_CAND) gl[at] = d0;
+                    }
+                    cnt += (uint32_t)__popcll(e0);
+                    if (f1) {
+                        const uint32_t at = cnt + __builtin_amdgcn_mbcnt_hi((uint32_t)(e1 >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)e1, 0u));
+                        if (at < TM_CAND) gl[at] = d1;
+                    }
+                    cnt += (uint32_t)__popcll(e1);
+                }
+                if (!again) break;
+            }
+
+            // ---- the window's marks of this wave are in: the bitmap's life cycle
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            if (lane == 0) atomicAdd(&S.sync[0], 1u);
+            if (wave == 0 && poll > TM_THETA_NOW() && lane == 0) atomicMax(&S.theta, poll);
+            {
+                const uint32_t target = (epoch + 1u) * TEAM;
+                while (__hip_atomic_load(&S.sync[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < target) __builtin_amdgcn_s_sleep(1);
+                asm volatile("" ::: "memory");
+                for (uint32_t i = tid; i < WORDS / 4; i += TEAM * 64) reinterpret_cast<uint4 *>(S.bm)[i] = make_uint4(0, 0, 0, 0);
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                if (lane == 0) atomicAdd(&S.sync[1], 1u);
+                while (__hip_atomic_load(&S.sync[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < target) __builtin_amdgcn_s_sleep(1);
+                asm volatile("" ::: "memory");
+            }
+            ++epoch;
+            tlo = thi;
+        }
+        if (cnt > TM_CAND) {
+            failed = true;  // lists that intersect this densely: the item is scan_many_kernel's
+            cnt = 0;
+        }
+
+        // ================================================================================================================
+        // Bulk completion of the wave's candidates: TM_IL batches of 64 / m candidates x m terms at a time, every stage for
+        // all of them before the next stage (straight-line code: the loads of the four batches are in flight together).
+        // ================================================================================================================
+        RegTopK<RK> rtop;
+        rtop.init();
+        unsigned long long published = 0;
+        if (cnt && !(bt.team_dbg & 1u)) {
+            const uint32_t inv_m = (65536u + m - 1u) / m;  // p / m == (p * inv_m) >> 16 for p < 4096
+            const uint32_t per_batch = 64u / m;
+            const uint32_t ci = (lane * inv_m) >> 16, t = lane - ci * m;
+            const uint32_t tb1 = (uint32_t)__shfl((int)r_b1, (int)t), tb0 = (uint32_t)__shfl((int)r_b0, (int)t);
+            const uint32_t tloc = (uint32_t)__shfl((int)r_loc, (int)t), tsh = (uint32_t)__shfl((int)r_sh, (int)t);
+            const double ts0 = __shfl(r_s0, (int)t);
+            const uint32_t *blk_loc = ca->ix.blk_loc, *blk_max_doc = ca->ix.blk_max_doc;
+            for (uint32_t c0 = 0; c0 < cnt; c0 += TM_IL * per_batch) {
+                uint32_t d[TM_IL], jb[TM_IL], fl[TM_IL], xx[TM_IL];  // fl: 1 plane, 2 tfn, 4 block found, 8 redo from the generic decode
+                uint32_t v[TM_IL][8];
+                bool task[TM_IL];
+                // ---- A: the candidates; the locator's bucket
+#pragma unroll
+                for (int u = 0; u < TM_IL; ++u) {
+                    task[u] = ci < per_batch && c0 + u * per_batch + ci < cnt;
+                    d[u] = task[u] ? gl[c0 + u * per_batch + ci] : 0u;
+                    fl[u] = 0;
+                    jb[u] = tb1;
+                    if (task[u]) {
+                        const uint32_t b = tloc + (d[u] >> tsh);
+                        v[u][0] = blk_loc[b];
+                        v[u][1] = blk_loc[b + 1];
+                    }
+                }
+                // ---- B: the last documents of the bucket's first four blocks
+#pragma unroll
+                for (int u = 0; u < TM_IL; ++u) {
+                    if (task[u]) {
+                        const uint32_t ja = v[u][0], last = tb1 - 1u;
+                        xx[u] = v[u][1];  // the bucket's last candidate block (tb1: none)
+                        jb[u] = ja;
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) v[u][4 + i] = blk_max_doc[min(ja + (uint32_t)i, last)];
+                    }
+                }
+                // ---- C: the block; its first document, flags and pivots
+#pragma unroll
+                for (int u = 0; u < TM_IL; ++u) {
+                    if (task[u]) {
+                        const uint32_t ja = jb[u], je = xx[u];
+                        uint32_t jj = tb1;
+#pragma unroll
+                        for (int i = 3; i >= 0; --i)
+                            if (ja + (uint32_t)i < tb1 && v[u][4 + i] >= d[u]) jj = ja + (uint32_t)i;
+                        if (jj == tb1 && ja + 4u <= je && ja + 4u < tb1) fl[u] = 8;  // more than four blocks in the bucket: redone below
+                        jb[u] = jj;
                         if (jj < tb1) {
                             const uint4 mm = ix.blk_meta[jj];
-                            if (mm.x <= cs_d) {
-                                cs_j = jj;
-                                cs_x = mm.x;
-                                cs_fl = 4u | (rel16_block(mm.x, mm.y, mm.w) ? 1u : 0u) | (tfn_block(mm.w) ? 2u : 0u);
+                            const uint4 pv = ix.blk_piv[jj];
+                            v[u][0] = mm.x;
+                            v[u][1] = mm.y;
+                            v[u][2] = mm.w;
+                            v[u][4] = pv.x;
+                            v[u][5] = pv.y;
+                            v[u][6] = pv.z;
+                            v[u][7] = pv.w;
+                            fl[u] = 4;
+                        }
+                    }
+                }
+                // ---- D: the 16 ids that can hold the document
+#pragma unroll
+                for (int u = 0; u < TM_IL; ++u) {
+                    if (fl[u] & 4u) {
+                        const uint32_t mn = v[u][0];
+                        if (mn > d[u]) {
+                            fl[u] = 0;  // the document lies between two blocks
+                        } else if (!rel16_block(mn, v[u][1], v[u][2])) {
+                            fl[u] = 8;
+                        } else {
+                            const uint32_t r = d[u] - mn;
+                            uint32_t seg = 0;
+#pragma unroll
+                            for (int i = 4; i < 8; ++i) seg += ((v[u][i] & 0xffffu) < r ? 1u : 0u) + ((v[u][i] >> 16) < r ? 1u : 0u);
+                            if (seg > 7u) {
+                                fl[u] = 0;
+                            } else if (!tfn_block(v[u][2])) {
+                                fl[u] = 8;
+                            } else {
+                                xx[u] = r | (16u * seg) << 16;
+                                const uint4 *pp = reinterpret_cast<const uint4 *>(reinterpret_cast<const uint16_t *>(ix.post_rel16) + 128ull * jb[u] + 16u * seg);
+                                const uint4 a = pp[0], b = pp[1];
+                                v[u][0] = a.x;
+                                v[u][1] = a.y;
+                                v[u][2] = a.z;
+                                v[u][3] = a.w;
+                                v[u][4] = b.x;
+                                v[u][5] = b.y;
+                                v[u][6] = b.z;
+                                v[u][7] = b.w;
                             }
                         }
                     }
                 }
-                if ((cs_fl & 5u) == 5u) {
-                    const uint4 pv = ix.blk_piv[cs_j];
-                    cs_v[0] = pv.x;
-                    cs_v[1] = pv.y;
-                    cs_v[2] = pv.z;
-                    cs_v[3] = pv.w;
-                }
-                cs_stage = 1;
-            } else if (cs_stage == 1) {
-                // ---- stage 1: the 16 ids that can hold the document
-                if ((cs_fl & 5u) == 5u) {
-                    const uint32_t r = cs_d - cs_x;
-                    uint32_t seg = 0;
+                // ---- E: the posting's index; its tf / fieldnorm word
 #pragma unroll
-                    for (int u = 0; u < 4; ++u) seg += ((cs_v[u] & 0xffffu) < r ? 1u : 0u) + ((cs_v[u] >> 16) < r ? 1u : 0u);
-                    if (r > 0xffffu || seg > 7u) {
-                        cs_fl = 0;  // the document lies behind the block's last id
-                    } else {
-                        cs_fl |= (16u * seg) << 8;
-                        const uint4 *pp = reinterpret_cast<const uint4 *>(reinterpret_cast<const uint16_t *>(ix.post_rel16) + 128ull * cs_j + 16u * seg);
-                        const uint4 a = pp[0], b = pp[1];
-                        cs_v[0] = a.x;
-                        cs_v[1] = a.y;
-                        cs_v[2] = a.z;
-                        cs_v[3] = a.w;
-                        cs_v[4] = b.x;
-                        cs_v[5] = b.y;
-                        cs_v[6] = b.z;
-                        cs_v[7] = b.w;
-                    }
-                }
-                // blocks without a plane word (tails, raw, wide): the wave decodes each of them once
-                bool pend = (cs_fl & 5u) == 4u;
-                if (__ballot(pend)) {
-                    const uint8_t *blob = cold_args()->ix.blob;
-                    for (;;) {
-                        const unsigned long long pmask = __ballot(pend);
-                        if (!pmask) break;
-                        const uint32_t blk = (uint32_t)__builtin_amdgcn_readlane((int)cs_j, __ffsll((long long)pmask) - 1);
-                        const uint4 um = uni4(ix.blk_meta[blk]);
-                        const uint32_t un = um.w & 0xff, umd = (um.w >> 8) & 0xff;
-                        uint32_t a0, a1;
-                        decode_doc_ids(blob + 8ull * um.z, umd, un, um.x, lane, a0, a1);
-                        __builtin_amdgcn_wave_barrier();
-                        *reinterpret_cast<uint2 *>(&scr[2 * lane]) = make_uint2(2 * lane < un ? a0 : NONE32, 2 * lane + 1 < un ? a1 : NONE32);
-                        __builtin_amdgcn_wave_barrier();
-                        if (pend && cs_j == blk) {
-                            uint32_t p = 0;
+                for (int u = 0; u < TM_IL; ++u) {
+                    if (fl[u] & 4u) {
+                        const uint32_t r = xx[u] & 0xffffu, base = xx[u] >> 16;
+                        uint32_t idx = NONE32;
 #pragma unroll
-                            for (int sft = 64; sft > 0; sft >>= 1)
-                                if (scr[p + sft - 1] < cs_d) p += sft;
-                            if (scr[p] == cs_d) cs_x = p;  // (the index: stage 2 leaves it alone)
-                            else cs_fl = 0;
-                            pend = false;
+                        for (int i = 0; i < 8; ++i) {
+                            if ((v[u][i] & 0xffffu) == r) idx = base + 2 * i;
+                            if ((v[u][i] >> 16) == r) idx = base + 2 * i + 1;
                         }
-                        __builtin_amdgcn_wave_barrier();
+                        if (idx == NONE32) {
+                            fl[u] = 0;
+                        } else {
+                            xx[u] = idx;
+                            v[u][0] = ix.post_tfn[64ull * jb[u] + (idx >> 1)];
+                        }
                     }
                 }
-                cs_stage = 2;
-            } else if (cs_stage == 2) {
-                // ---- stage 2: the posting's index; its tf / fieldnorm word
-                if ((cs_fl & 5u) == 5u) {
-                    const uint32_t r = cs_d - cs_x, base = cs_fl >> 8;
-                    uint32_t idx = NONE32;
+                // ---- F: s1 of the posting's fieldnorm
 #pragma unroll
-                    for (int u = 0; u < 8; ++u) {
-                        if ((cs_v[u] & 0xffffu) == r) idx = base + 2 * u;
-                        if ((cs_v[u] >> 16) == r) idx = base + 2 * u + 1;
+                for (int u = 0; u < TM_IL; ++u) {
+                    if (fl[u] & 4u) {
+                        const uint32_t sh = (xx[u] & 1u) * 8u;
+                        const uint32_t fn = (v[u][0] >> (16u + sh)) & 0xffu;
+                        v[u][0] = (v[u][0] >> sh) & 0xffu;
+                        const double s1v = ix.s1[fn];
+                        v[u][2] = (uint32_t)__double2loint(s1v);
+                        v[u][3] = (uint32_t)__double2hiint(s1v);
                     }
-                    cs_x = idx;
-                    if (idx == NONE32) cs_fl = 0;
                 }
-                cs_fl &= 0xffu;
-                if (cs_fl & 4u) {
-                    if (cs_fl & 2u) {
-                        cs_v[0] = ix.post_tfn[64ull * cs_j + (cs_x >> 1)];
-                    } else {  // tf fields wider than 7 bits / tails: the generic decode of the one field (rare)
+                // ---- G: Cache::evaluate (bm25.rs:355-358); the lookups the fast path could not serve; the document's terms summed
+                // in ascending key order (absent terms add 0.0, exact); the offer
+#pragma unroll
+                for (int u = 0; u < TM_IL; ++u) {
+                    if (c0 + u * per_batch >= cnt) break;
+                    double c = 0.0;
+                    if (fl[u] & 4u) {
+                        const double tfd = (double)v[u][0];
+                        c = (tfd * ts0) / (tfd + __hiloint2double((int)v[u][3], (int)v[u][2]));
+                    }
+                    if (__ballot((fl[u] & 8u) != 0)) {  // from the generic decode, one block at a time (rare)
                         const TeamArgsP cg = cold_args();
-                        const uint4 mm = ix.blk_meta[cs_j];
-                        const uint32_t nj = mm.w & 0xff, mdj = (mm.w >> 8) & 0xff, mtj = (mm.w >> 16) & 0xff;
-                        const uint8_t *tbody = cg->ix.blob + 8ull * mm.z + ((payload_bytes(mdj, nj) + 7u) & ~7u);
-                        const FieldAddr fa = field_addr(mtj, nj, cs_x);
-                        const uint32_t flo = *reinterpret_cast<const uint32_t *>(tbody + fa.off0);
-                        const uint32_t fhi = *reinterpret_cast<const uint32_t *>(tbody + fa.off1);
-                        cs_v[0] = field_val(flo, fhi, fa);
-                        cs_v[1] = cg->ix.post_fn[128ull * cs_j + cs_x];
+                        uint32_t jj = tb1;
+                        uint4 mm = make_uint4(0, 0, 0, 0);
+                        bool pend = false;
+                        if (fl[u] & 8u) {
+                            jj = tm_first_block_ge(blk_max_doc, tb0, tb1, d[u], inv_docs);
+                            if (jj < tb1) {
+                                mm = ix.blk_meta[jj];
+                                pend = mm.x <= d[u];
+                            }
+                        }
+                        uint32_t idx = NONE32;
+                        for (;;) {
+                            const unsigned long long pmask = __ballot(pend);
+                            if (!pmask) break;
+                            const uint32_t blk = (uint32_t)__builtin_amdgcn_readlane((int)jj, __ffsll((long long)pmask) - 1);
+                            const uint4 um = uni4(ix.blk_meta[blk]);
+                            const uint32_t un = um.w & 0xff, umd = (um.w >> 8) & 0xff;
+                            uint32_t a0, a1;
+                            decode_doc_ids(cg->ix.blob + 8ull * um.z, umd, un, um.x, lane, a0, a1);
+                            __builtin_amdgcn_wave_barrier();
+                            *reinterpret_cast<uint2 *>(&scr[2 * lane]) = make_uint2(2 * lane < un ? a0 : NONE32, 2 * lane + 1 < un ? a1 : NONE32);
+                            __builtin_amdgcn_wave_barrier();
+                            if (pend && jj == blk) {
+                                uint32_t p = 0;
+#pragma unroll
+                                for (int sft = 64; sft > 0; sft >>= 1)
+                                    if (scr[p + sft - 1] < d[u]) p += sft;
+                                if (scr[p] == d[u]) idx = p;
+                                pend = false;
+                            }
+                            __builtin_amdgcn_wave_barrier();
+                        }
+                        if (idx != NONE32) {
+                            const uint32_t nj = mm.w & 0xff, mdj = (mm.w >> 8) & 0xff, mtj = (mm.w >> 16) & 0xff;
+                            const uint8_t *tbody = cg->ix.blob + 8ull * mm.z + ((payload_bytes(mdj, nj) + 7u) & ~7u);
+                            const FieldAddr fa = field_addr(mtj, nj, idx);
+                            const uint32_t flo = *reinterpret_cast<const uint32_t *>(tbody + fa.off0);
+                            const uint32_t fhi = *reinterpret_cast<const uint32_t *>(tbody + fa.off1);
+                            const double tfd = (double)field_val(flo, fhi, fa);
+                            c = (tfd * ts0) / (tfd + ix.s1[cg->ix.post_fn[128ull * jj + idx]]);
+                        }
                     }
-                }
-                cs_stage = 3;
-            } else if (cs_stage == 3) {
-                // ---- stage 3: s1 of the posting's fieldnorm
-                if (cs_fl & 4u) {
-                    if (cs_fl & 2u) {
-                        const uint32_t sh = (cs_x & 1u) * 8u;
-                        cs_v[1] = (cs_v[0] >> (16u + sh)) & 0xffu;
-                        cs_v[0] = (cs_v[0] >> sh) & 0xffu;
-                    }
-                    const double s1v = ix.s1[cs_v[1]];
-                    cs_v[2] = (uint32_t)__double2loint(s1v);
-                    cs_v[3] = (uint32_t)__double2hiint(s1v);
-                }
-                cs_stage = 4;
-            } else {
-                // ---- stage 4: Cache::evaluate (bm25.rs:355-358); the document's terms summed in ascending key order
-                // (absent terms add 0.0, exact); the offer
-                const double s0 = __shfl(r_s0, (int)cs_t);
-                double c = 0.0;
-                if (cs_fl & 4u) {
-                    const double tfd = (double)cs_v[0];
-                    c = (tfd * s0) / (tfd + __hiloint2double((int)cs_v[3], (int)cs_v[2]));
-                }
-                double *cs = reinterpret_cast<double *>(scr);
-                __builtin_amdgcn_wave_barrier();
-                cs[lane] = c;
-                __builtin_amdgcn_wave_barrier();
-                double acc = 0.0;
-                const bool leader = cs_ci < cs_n && cs_t == 0;
-                if (leader)
-                    for (uint32_t u = 0; u < m; ++u) acc += cs[lane + u];
-                __builtin_amdgcn_wave_barrier();
-                {   // the offer: whole documents to this wave's list
-                    const unsigned long long th = TM_THETA_NOW();
-                    bool has = leader && (unsigned long long)__double_as_longlong(acc) >= th &&
-                               (rtop.cnt < k || better(acc, cs_d, rtop.kth_s, rtop.kth_d));
-                    if (__ballot(has)) {
-                        rtop.template offer<true>(has, acc, cs_d, k, lane);
-                        if (rtop.cnt >= k) {
-                            const unsigned long long kb = (unsigned long long)__double_as_longlong(rtop.kth_s);
-                            if (kb > published) {
-                                if (lane == 0) {
-                                    atomicMax(&S.theta, kb);
-                                    atomicMax(&bt.theta[q], kb);
+                    double *cs = reinterpret_cast<double *>(scr);
+                    __builtin_amdgcn_wave_barrier();
+                    cs[lane] = c;
+                    __builtin_amdgcn_wave_barrier();
+                    double acc = 0.0;
+                    const bool leader = task[u] && t == 0;
+                    if (leader)
+                        for (uint32_t i = 0; i < m; ++i) acc += cs[lane + i];
+                    __builtin_amdgcn_wave_barrier();
+                    {   // the offer: whole documents to this wave's list
+                        const unsigned long long th = TM_THETA_NOW();
+                        const bool has = leader && (unsigned long long)__double_as_longlong(acc) >= th &&
+                                         (rtop.cnt < k || better(acc, d[u], rtop.kth_s, rtop.kth_d));
+                        if (__ballot(has)) {
+                            rtop.template offer<true>(has, acc, d[u], k, lane);
+                            if (rtop.cnt >= k) {
+                                const unsigned long long kb = (unsigned long long)__double_as_longlong(rtop.kth_s);
+                                if (kb > published) {
+                                    if (lane == 0) {
+                                        atomicMax(&S.theta, kb);
+                                        atomicMax(&bt.theta[q], kb);
+                                    }
+                                    published = kb;
                                 }
-                                published = kb;
                             }
                         }
                     }
                 }
-                q_head += cs_n;
-                if (cs_from == 0) q0 -= cs_n;
-                else if (cs_from == 1) q1 -= cs_n;
-                else q2 -= cs_n;
-                cs_stage = 0;
             }
-                    } while (false);
         }
         if (failed && lane == 0) S.fail = 1;
         __syncthreads();  // (every wave's verdict is in)
@@ -745,10 +642,12 @@ __global__ void __launch_bounds__(TEAM * 64, 4) scan_team_kernel(DevIndex ix, De
             }
         if (lane == 0) {
             ce->bt.res_cnt[lst] = n;
-            if (wave == 0 && item_fails) ce->bt.item_failed[item] = 1u;
+            if (wave == 0 && item_fails) {
+                ce->bt.item_failed[item] = 1u;
+                *ce->bt.fail_any = 1u;
+            }
         }
     }
 }
 #undef TM_THETA_NOW
 #undef TM_ISSUE
-#undef TM_AFTER_GROUPS

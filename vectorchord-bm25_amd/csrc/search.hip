@@ -196,7 +196,7 @@ struct vbm25_index {
     std::vector<uint32_t> term_df_host;  // host copy for query routing
     vbm25_batch *scratch = nullptr;      // batch object re-used by vbm25_search_batch
     DeviceBuffer term_wand_tf, term_wand_fn, term_df, term_first_block, term_s0, blk_min_doc, blk_max_doc, blk_meta, blk_ub, blob,
-        post_fn, post_rel16, post_tfn, doc_payload, s1, term_idf, fn_len, term_kth_ub, blk_piv;
+        post_fn, post_rel16, post_tfn, doc_payload, s1, term_idf, fn_len, term_kth_ub, blk_piv, term_loc, blk_loc;
     double k1 = 1.2;
     uint64_t device_bytes = 0;
 };
@@ -212,10 +212,12 @@ struct Tuning {
     uint32_t dense_items = D_TARGET_ITEMS;
     uint32_t range_items = R_TARGET_ITEMS, range_min_chunk = R_MIN_CHUNK_POSTINGS;
     uint32_t range_grid = R_GRID, dense_grid = D_GRID;
-    int team = 1;                  // sparse queries on the general route take scan_team_kernel (0: scan_range_kernel)
+    int team = 0;                  // 1: sparse queries on the general route take scan_team_kernel (the round-4 alternative) instead of scan_range_kernel
     uint32_t team_size = 4;        // waves per team: 4 (four workgroups per CU) or 8 (two)
-    uint32_t team_items = 4096;    // work items of a batch on that route
+    uint32_t team_items = 2048;    // work items of a batch on that route
     uint32_t team_dbg = 0;         // timing experiments only
+    uint32_t fused_items = 128;    // the one-launch route takes batches of up to this many work items
+    int arith = 1;                 // batches of sparse queries beyond that: work items made by the scan kernel (no plan_kernel)
     uint32_t generation = 0;       // bumped by every vbm25_tuning_set / reset: vbm25_search_batch's batch object is rebuilt when it is stale
 };
 static Tuning g_tune;
@@ -225,7 +227,7 @@ struct vbm25_batch {
     int device = 0;  // the index's device ordinal: the batch can be destroyed after its index
     uint32_t max_queries = 0, max_terms = 0, k = 0, nq = 0, max_items = 0;
     DeviceBuffer term_ids, q_off, items, n_items, q_item_base, theta, res_score, res_doc, res_cnt,
-        hits, n_hits, error_flag, prof, q_dense, item_failed, item_order, work_ctr, hist, fused_state, dbg;
+        hits, n_hits, error_flag, prof, q_dense, item_failed, item_order, work_ctr, hist, fused_state, dbg, team_cand, fail_any, q_failed, theta_last;
     bool bigk = false;            // k > 1024: exhaustive path, one query at a time
     DeviceBuffer bk_acc, bk_keys, bk_iota, bk_docs, bk_tmp;
     size_t bk_tmp_bytes = 0;
@@ -244,6 +246,8 @@ struct vbm25_batch {
     uint32_t dense_c = 0;         // items per dense query of the current queries (0: chunks by postings, as the other queries)
     // vbm25_search_batch with a handful of sparse queries: ONE launch (scan_range_kernel plans, scans and merges)
     uint32_t fused_g = 0;         // items per query of the current queries on that route (0: general route)
+    uint32_t arith_g = 0;         // general route without plan_kernel (every query sparse): items per query, made by the scan kernel itself
+    bool need_many = true;        // the current queries have items for scan_many_kernel (more than 16 terms, 256 < k, dense without the dense kernel)
     bool fused_pinned = false;    // ... with queries and hits in pinned host memory (vbm25_search_batch, <= 8 queries); else device buffers
     bool state_clean = false;     // threshold / histogram / counters are zero (the fused route leaves them so; the general one does not)
     uint32_t target_items = TARGET_ITEMS;
@@ -359,6 +363,24 @@ static int vbm25_index_create_impl(const vbm25_index_desc *d, int device, vbm25_
                 if ((size_t(1) << i) <= top) kth[size_t(TM_KTH) * t + i] = tmp[(size_t(1) << i) - 1];
         }
     }
+    // bucket locator (scan_team_kernel's Cursor::seek_block): per term buckets of about one block span
+    std::vector<uint32_t> loc_off(2ull * d->n_terms), loc;
+    for (uint32_t t = 0; t < d->n_terms; ++t) {
+        const uint32_t b0 = d->term_first_block[t], b1 = d->term_first_block[t + 1];
+        const uint64_t nb = std::max<uint32_t>(b1 - b0, 1u);
+        uint32_t sh = 8;
+        while (sh < 31 && (uint64_t(d->n_docs) >> sh) > nb) ++sh;
+        const uint32_t n_buckets = (d->n_docs >> sh) + 2u;
+        loc_off[2ull * t] = uint32_t(loc.size());
+        loc_off[2ull * t + 1] = sh;
+        uint32_t j = b0;
+        for (uint32_t b = 0; b < n_buckets; ++b) {
+            const uint64_t start = uint64_t(b) << sh;
+            while (j < b1 && uint64_t(d->blk_max_doc[j]) < start) ++j;
+            loc.push_back(j);
+        }
+        if (loc.size() > 0xfffffff0ull) return set_error(VBM25_ERR_UNSUPPORTED, "block locator exceeds 2^32 entries");
+    }
     DeviceBuffer fieldnorm, err;
     int rc = 0;
     // slack: the scan kernels read whole 256-byte LDS-DMA slots / word pairs from a block's first byte
@@ -378,6 +400,8 @@ static int vbm25_index_create_impl(const vbm25_index_desc *d, int device, vbm25_
         (rc = ix->post_rel16.alloc(256ull * d->n_blocks)) ||
         (rc = ix->post_tfn.alloc(256ull * d->n_blocks)) ||
         (rc = ix->blk_piv.alloc(16ull * d->n_blocks)) ||
+        (rc = ix->term_loc.upload(loc_off.data(), 4ull * loc_off.size())) ||
+        (rc = ix->blk_loc.upload(loc.data(), 4ull * loc.size())) ||
         (rc = ix->doc_payload.upload(d->doc_payload, 6ull * d->n_docs)) ||
         (rc = ix->s1.upload(s1, sizeof s1)) ||
         (rc = fieldnorm.upload(d->doc_fieldnorm, d->n_docs)) || (rc = err.alloc(4)))
@@ -435,6 +459,8 @@ static int vbm25_index_create_impl(const vbm25_index_desc *d, int device, vbm25_
     ix->dev.post_rel16 = ix->post_rel16.as<uint32_t>();
     ix->dev.post_tfn = ix->post_tfn.as<uint32_t>();
     ix->dev.blk_piv = ix->blk_piv.as<uint4>();
+    ix->dev.term_loc = ix->term_loc.as<uint2>();
+    ix->dev.blk_loc = ix->blk_loc.as<uint32_t>();
     ix->dev.doc_payload = ix->doc_payload.as<uint16_t>();
     ix->dev.s1 = ix->s1.as<double>();
     ix->dev.blob_bytes = d->blob_bytes;
@@ -451,7 +477,7 @@ static int vbm25_index_create_impl(const vbm25_index_desc *d, int device, vbm25_
     }
     for (const DeviceBuffer *b : {&ix->term_df, &ix->term_first_block, &ix->term_s0, &ix->blk_min_doc,
                                   &ix->blk_max_doc, &ix->blk_meta, &ix->blk_ub, &ix->blob, &ix->post_fn,
-                                  &ix->post_rel16, &ix->post_tfn, &ix->blk_piv, &ix->term_kth_ub, &ix->doc_payload, &ix->s1})
+                                  &ix->post_rel16, &ix->post_tfn, &ix->blk_piv, &ix->term_loc, &ix->blk_loc, &ix->term_kth_ub, &ix->doc_payload, &ix->s1})
         ix->device_bytes += b->bytes;
     *out = ix.release();
     return VBM25_OK;
@@ -537,9 +563,14 @@ static int vbm25_batch_create_impl(vbm25_index *ix, uint32_t max_queries, uint32
         (rc = bt->n_hits.alloc(4ull * max_queries)) || (rc = bt->error_flag.alloc(4)) ||
         (rc = bt->q_dense.alloc(max_queries)) ||
         (rc = bt->item_failed.alloc(4ull * bt->max_items)) || (rc = bt->item_order.alloc(4ull * bt->max_items)) || (rc = bt->work_ctr.alloc(8)) ||
-        (rc = bt->hist.alloc(4ull * CUR_HB * max_queries)) || (rc = bt->fused_state.alloc(4ull * (max_queries + 1))))
+        (rc = bt->hist.alloc(4ull * CUR_HB * max_queries)) || (rc = bt->fused_state.alloc(4ull * (max_queries + 1))) ||
+        (rc = bt->fail_any.alloc(4)) || (rc = bt->q_failed.alloc(4ull * max_queries)) || (rc = bt->theta_last.alloc(8ull * max_queries)))
         return rc;
+    HIP_TRY(hipMemset(bt->fail_any.p, 0, 4));
+    HIP_TRY(hipMemset(bt->q_failed.p, 0, 4ull * max_queries));
     HIP_TRY(hipMemset(bt->error_flag.p, 0, 4));
+    if (bt->use_range && bt->tune.team)  // one candidate list per wave of scan_team_kernel's grid (1024 x 4 or 512 x 8 waves)
+        if (int rc2 = bt->team_cand.alloc(4ull * TM_CAND * 4096)) return rc2;
     if (int rc2 = bt->dbg.alloc(64)) return rc2;
     HIP_TRY(hipMemset(bt->dbg.p, 0, 64));
 #ifdef VBM25_PROFILE
@@ -617,8 +648,10 @@ static int vbm25_batch_set_queries_impl(vbm25_batch *bt, const uint32_t *term_id
     }
     bt->nq = nq;
     bt->fused_g = 0;
+    bt->arith_g = 0;
+    bt->need_many = many || !bt->use_range;
     bt->fused_pinned = false;
-    if (bt->tune.fused && bt->use_range && nq && !many && !has_dense && range_mt != 0) {  // every query sparse, <= 16 indexed terms: the one-launch route
+    if (bt->use_range && nq && !many && !has_dense && range_mt != 0) {  // every query sparse, <= 16 indexed terms: the one-launch route
         unsigned long long most = 0;
         bool all = true;
         for (uint32_t q = 0; q < nq; ++q) {
@@ -632,9 +665,11 @@ static int vbm25_batch_set_queries_impl(vbm25_batch *bt, const uint32_t *term_id
             g = std::min<unsigned long long>(std::max<unsigned long long>(g, 1), std::min<unsigned long long>(64, bt->index->n_docs));
             // only where the launches it saves matter: a batch that fills the GPU runs slower through the FUSED
             // instantiation (more live state in the tile loop) than plan + scan + merge cost
-            if (nq * g <= 128) {
+            if (bt->tune.fused && nq * g <= bt->tune.fused_items) {
                 bt->fused_g = uint32_t(g);
                 bt->fused_pinned = fast && nq <= 8 && !bt->timing;
+            } else if (bt->tune.arith && !bt->tune.team) {
+                bt->arith_g = uint32_t(g);  // the general route, items made in the kernel: no plan_kernel, merge_kernel cleans
             }
         }
     }
@@ -759,6 +794,12 @@ static int vbm25_batch_run_impl(vbm25_batch *bt, void *hip_stream) {
     db.ne_ratio = std::max(1u, bt->tune.ne_ratio);
     db.dense_on = bt->use_dense ? 1u : 0u;
     db.team_dbg = bt->tune.team_dbg;
+    db.team_cand = bt->team_cand.as<uint32_t>();
+    db.fail_any = bt->fail_any.as<uint32_t>();
+    db.q_failed = bt->q_failed.as<uint32_t>();
+    db.theta_last = bt->theta_last.as<unsigned long long>();
+    db.many_expected = bt->need_many ? 1u : 0u;
+    db.merge_clean = 0;
     const bool range = bt->use_range;
     const DevIndex &ix = bt->index->dev;
     db.fused_state = bt->fused_state.as<uint32_t>();
@@ -821,6 +862,41 @@ static int vbm25_batch_run_impl(vbm25_batch *bt, void *hip_stream) {
             return int(VBM25_OK);
         });
         if (rcf) return rcf;
+        HIP_TRY(hipGetLastError());
+        bt->state_clean = true;
+        return VBM25_OK;
+    }
+    if (bt->arith_g && bt->range_rt && bt->k <= (uint32_t)REG_K) {
+        // Every query sparse, <= 16 terms: the scan kernel makes the work items itself (no plan_kernel), scan_many_kernel is a
+        // small grid that leaves at once unless an item was given up, merge_kernel merges and leaves the per-launch state zero.
+        const bool clean = bt->state_clean;
+        bt->state_clean = false;
+        if (!clean) {
+            HIP_TRY(hipMemsetAsync(bt->hist.p, 0, 4ull * CUR_HB * bt->max_queries, st));
+            HIP_TRY(hipMemsetAsync(bt->theta.p, 0, 8ull * bt->max_queries, st));
+            HIP_TRY(hipMemsetAsync(bt->work_ctr.p, 0, 8, st));
+            HIP_TRY(hipMemsetAsync(bt->fail_any.p, 0, 4, st));
+            HIP_TRY(hipMemsetAsync(bt->item_failed.p, 0, 4ull * bt->max_items, st));
+            HIP_TRY(hipMemsetAsync(bt->res_cnt.p, 0, 4ull * bt->max_items * bt->lpi, st));
+        }
+        db.fused_g = bt->arith_g;
+        db.dense_on = 0;
+        db.many_expected = 0;
+        db.merge_clean = 1;
+        if (int rc = take_events()) return rc;
+        const uint32_t agrid = std::min<uint32_t>(bt->nq * bt->arith_g, std::max(1u, bt->tune.range_grid));
+        const int rca = dispatch_k(bt->k, [&](auto kmax) {
+            constexpr int KM = decltype(kmax)::value;
+            if constexpr (KM <= REG_K) {
+                if (bt->range_rt == 8) scan_range_kernel<KM, 8><<<agrid, RWG, 0, st>>>(ix, db);
+                else scan_range_kernel<KM, 16><<<agrid, RWG, 0, st>>>(ix, db);
+                scan_many_kernel<KM><<<64, WG, 0, st>>>(ix, db);
+                if (bt->timing) (void)hipEventRecord(e1, st);
+                merge_kernel<KM><<<bt->nq, 64, 0, st>>>(ix, db);
+            }
+            return int(VBM25_OK);
+        });
+        if (rca) return rca;
         HIP_TRY(hipGetLastError());
         bt->state_clean = true;
         return VBM25_OK;
@@ -998,6 +1074,8 @@ int vbm25_tuning_set(const char *name, long long value) {
     else if (n == "team_size") g_tune.team_size = value == 8 ? 8u : 4u;
     else if (n == "team_items") g_tune.team_items = (uint32_t)std::max(256ll, value);
     else if (n == "team_dbg") g_tune.team_dbg = (uint32_t)value;
+    else if (n == "fused_items") g_tune.fused_items = (uint32_t)std::max(0ll, value);
+    else if (n == "arith") g_tune.arith = value != 0;
     else return set_error(VBM25_ERR_INVALID, "unknown tuning switch %s", name);
     ++g_tune.generation;
     return VBM25_OK;
@@ -1014,6 +1092,14 @@ int vbm25_batch_debug_counts(vbm25_batch *bt, uint32_t *n_items, uint32_t *n_fai
     if (!bt || !n_items || !n_failed) return set_error(VBM25_ERR_INVALID, "NULL argument");
     if (int rc = use_device(bt->index->device)) return rc;
     HIP_TRY(hipDeviceSynchronize());
+    if (bt->arith_g && bt->state_clean) {  // merge_kernel has cleaned the flags and kept the counts per query
+        *n_items = bt->nq * bt->arith_g;
+        std::vector<uint32_t> qf(bt->nq);
+        if (bt->nq) HIP_TRY(hipMemcpy(qf.data(), bt->q_failed.p, 4ull * bt->nq, hipMemcpyDeviceToHost));
+        *n_failed = 0;
+        for (uint32_t x : qf) *n_failed += x;
+        return VBM25_OK;
+    }
     HIP_TRY(hipMemcpy(n_items, bt->n_items.p, 4, hipMemcpyDeviceToHost));
     std::vector<uint32_t> f(*n_items);
     if (*n_items) HIP_TRY(hipMemcpy(f.data(), bt->item_failed.p, 4ull * *n_items, hipMemcpyDeviceToHost));
@@ -1043,7 +1129,8 @@ int vbm25_batch_debug_theta(vbm25_batch *bt, unsigned long long *out) {
     if (!bt || !out) return set_error(VBM25_ERR_INVALID, "NULL argument");
     if (int rc = use_device(bt->index->device)) return rc;
     HIP_TRY(hipDeviceSynchronize());
-    if (bt->nq && bt->theta.p) HIP_TRY(hipMemcpy(out, bt->theta.p, 8ull * bt->nq, hipMemcpyDeviceToHost));
+    if (bt->nq && bt->theta.p)
+        HIP_TRY(hipMemcpy(out, bt->arith_g && bt->state_clean ? bt->theta_last.p : bt->theta.p, 8ull * bt->nq, hipMemcpyDeviceToHost));
     return VBM25_OK;
 }
 
