@@ -138,6 +138,11 @@ int vbm25_segment_load(const char *path, vbm25_segment **out);
 uint64_t vbm25_query_bytes(const vbm25_index_desc *, const uint32_t *term_ids, uint32_t n_terms,
                            uint32_t k);
 
+/* FIELDNORM_TO_LENGTH (bm25.rs:15-272; 256 entries) and the term-independent half of Cache::new, s1[f] = k1 * (1 - b +
+ * b * FIELDNORM_TO_LENGTH[f] / avgdl) with avgdl = sum_len / n_docs (bm25.rs:349-352), exactly as the library uses them. */
+int vbm25_fieldnorm_table(uint32_t *lengths256);
+int vbm25_cache_s1(uint32_t n_docs, uint64_t sum_len, double k1, double b, double *s1_256);
+
 /* ------------------------------------------------------------------------
  * Host side of the shim: the growing (unsealed) segment, search.rs:83-135.
  * Documents inserted since the last VACUUM live in VectorTuples, not in
@@ -288,6 +293,41 @@ int vbm25_batch_kernel_ms(vbm25_batch *, double *avg_ms, uint32_t *n_launches);
 int vbm25_evaluate_batch(vbm25_index *, const uint32_t *q_terms, uint32_t n_q_terms, uint32_t n_docs,
                          const uint64_t *doc_start, const uint32_t *doc_term, const uint32_t *doc_tf,
                          double *scores);
+
+/* ------------------------------------------------------------------------
+ * Several GPUs of one node: independent queries shard
+ * across the devices, the index is replicated.  vbm25_multi_create uploads the
+ * flattened segment to devices[0] ONCE and makes the other replicas GPU to GPU
+ * (hipMemcpyPeerAsync over xGMI, derived arrays included; a device may be
+ * listed more than once).  A batch is cut into contiguous, balanced shards --
+ * the first nq % n devices get one query more --, every device searches its
+ * shard on its own stream, and the 24-byte hit records go from every device
+ * straight into the caller's host arrays in query order (the caller is the
+ * host: a device-side gather would only add a hop).  Same results, record for
+ * record, as vbm25_search_batch on one device.  One host thread drives all
+ * devices; a handle may be used from one thread at a time.
+ * ---------------------------------------------------------------------- */
+typedef struct vbm25_multi vbm25_multi;
+typedef struct vbm25_multi_batch vbm25_multi_batch;
+int vbm25_multi_create(const vbm25_index_desc *desc, const int *devices, int n_devices,
+                       vbm25_multi **out);
+void vbm25_multi_destroy(vbm25_multi *);
+int vbm25_multi_device_count(const vbm25_multi *);
+/* The replica on devices[i] (borrowed: e.g. for vbm25_lookup_terms, which is the same on every replica). */
+int vbm25_multi_index(vbm25_multi *, int i, vbm25_index **out);
+/* bm25::search for nq queries, sharded; arguments and results as vbm25_search_batch.  Synchronous. */
+int vbm25_multi_search_batch(vbm25_multi *, const uint32_t *term_ids, const uint32_t *q_off,
+                             uint32_t nq, uint32_t k, vbm25_hit *hits, uint32_t *n_hits);
+/* The same with the shards resident on their devices: create once, set the queries, run (asynchronous:
+ * every device's scan and the download of its records are enqueued on that device's stream), fetch (waits for
+ * all devices and fills the caller's arrays).  run may be repeated. */
+int vbm25_multi_batch_create(vbm25_multi *, uint32_t max_queries, uint32_t max_total_terms, uint32_t k,
+                             vbm25_multi_batch **out);
+void vbm25_multi_batch_destroy(vbm25_multi_batch *);
+int vbm25_multi_batch_set_queries(vbm25_multi_batch *, const uint32_t *term_ids, const uint32_t *q_off,
+                                  uint32_t nq);
+int vbm25_multi_batch_run(vbm25_multi_batch *);
+int vbm25_multi_batch_fetch(vbm25_multi_batch *, vbm25_hit *hits, uint32_t *n_hits);
 
 #ifdef __cplusplus
 }

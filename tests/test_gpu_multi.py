@@ -1,0 +1,83 @@
+"""The N-GPU split behind the C ABI (vbm25_multi_*) on the one GPU of the test box: replicas made with
+hipMemcpyPeerAsync on device 0 itself, the batch sharded over them -- every record identical to the single-handle result.
+Also: the alternative scan kernel (scan_team_kernel, tuning team = 1) against the oracle.  -m gpu only."""
+import numpy as np
+import pytest
+
+import orc
+import vectorchord_bm25_amd as vb
+from corpus import make_corpus, make_queries
+from parity import assert_bit_exact
+
+pytestmark = pytest.mark.gpu
+
+
+def _setup(n_docs=120_000, vocab=3000, seed=11):
+    c = make_corpus(n_docs, vocab, seed=seed, length="lognormal", mean_len=60)
+    seg = vb.Segment.build(1.2, 0.75, c["doc_len"], c["doc_payload"], c["term_key"], c["term_start"], c["post_doc"], c["post_tf"])
+    return c, seg
+
+
+@pytest.mark.parametrize("n_rep,nq,k", [(2, 64, 10), (3, 101, 10), (2, 7, 10), (4, 3, 5), (2, 40, 300), (2, 6, 2000)])
+def test_multi_replicas_on_one_device_match_single_handle(n_rep, nq, k):
+    """Shard sizes that differ by one, fewer queries than replicas (empty shards), the one-launch route inside a shard
+    (<= 8 queries), k beyond the register top-k, the exhaustive k > 1024 path: byte-identical records."""
+    c, seg = _setup()
+    terms, off = make_queries(c, nq, 4, seed=5)
+    single = vb.GpuIndex(seg)
+    h1, n1 = vb.search_batch(single, terms, off, k)
+    multi = vb.MultiIndex(seg, [0] * n_rep)
+    assert multi.n_devices == n_rep
+    h2, n2 = multi.search_batch(terms, off, k)
+    assert np.array_equal(n1, n2)
+    assert h1.tobytes() == h2.tobytes()
+    # the resident form, run twice (state left clean by the first run), and a second query set on the same object
+    mb = vb.MultiBatch(multi, nq, len(terms), k)
+    mb.set_queries(terms, off)
+    for _ in range(2):
+        mb.run()
+        h3, n3 = mb.fetch()
+        assert np.array_equal(n1, n3) and h1.tobytes() == h3.tobytes()
+    terms2, off2 = make_queries(c, max(1, nq // 2), 3, seed=6)
+    mb.set_queries(terms2, off2)
+    mb.run()
+    h4, n4 = mb.fetch()
+    h5, n5 = vb.search_batch(single, terms2, off2, k)
+    assert np.array_equal(n4, n5) and h4.tobytes() == h5.tobytes()
+
+
+def test_multi_argument_errors():
+    c, seg = _setup(5000, 200)
+    with pytest.raises(vb.Vbm25Error) as e:
+        vb.MultiIndex(seg, [])
+    assert e.value.code == -1
+    with pytest.raises(vb.Vbm25Error) as e:
+        vb.MultiIndex(seg, [0, 99])
+    assert e.value.code == -1
+    multi = vb.MultiIndex(seg, [0, 0])
+    with pytest.raises(vb.Vbm25Error):  # k = 0: "number of needed rows is set to 0" (default.rs:114-116)
+        multi.search_batch(np.zeros(1, dtype=np.uint32), np.array([0, 1], dtype=np.uint32), 0)
+    h, n = multi.search_batch(np.zeros(0, dtype=np.uint32), np.array([0], dtype=np.uint32), 10)  # no queries
+    assert len(n) == 0
+
+
+@pytest.mark.parametrize("team_size", [4, 8])
+def test_team_kernel_matches_the_oracle(tuning, team_size):
+    """scan_team_kernel (tuning team = 1: the round-4 alternative to scan_range_kernel): bit-exact against the canonical
+    brute force on sparse queries of 1..16 terms, k up to 256, a corpus with tails and wide blocks."""
+    c, seg = _setup(300_000, 4000, seed=3)
+    oix = orc.OracleIndex.from_arrays(seg.meta(), seg.arrays())
+    gix = vb.GpuIndex(seg)
+    tuning(team=1, team_size=team_size, fused=0)
+    for nterms, k in ((1, 10), (2, 10), (5, 10), (8, 64), (16, 100), (5, 256)):
+        terms, off = make_queries(c, 96, nterms, seed=100 + nterms)
+        b = vb.Batch(gix, 96, len(terms), k)
+        b.set_queries(terms, off)
+        for _ in range(2):
+            b.run()
+            hits, nh = b.fetch()
+            ob, onb, _ = oix.search_batch(terms, off, k, mode="brute", threads=8)
+            assert np.array_equal(nh, onb)
+            for q in range(96):
+                assert_bit_exact(ob[q, :onb[q]], hits[q, :nh[q]], what=f"team {team_size} terms {nterms} k {k} q{q}")
+        assert b.debug_counts()[1] == 0

@@ -128,3 +128,20 @@ def test_heap_model_basic_properties():
     popped, _ = orc.heap_script(np.array([3, 3, 0], dtype=np.int64),
                                 np.array([0, 0, -1], dtype=np.int32))
     assert popped.tolist() == [0]
+
+
+def test_product_tables_match_the_reference():
+    """The PRODUCT's own FIELDNORM_TO_LENGTH (csrc/segment.cpp) against the table generated from bm25.rs:15-272 -- not only the
+    oracle's copy -- and its s1[256] (Cache::new, bm25.rs:349-352) bit for bit against the formula evaluated here in f64."""
+    import numpy as np
+    import vectorchord_bm25_amd as vb
+    table = json.load(open(os.path.join(GOLD, "fieldnorm_table.json")))
+    t = np.zeros(256, dtype=np.uint32)
+    vb._lib.check(vb.lib().vbm25_fieldnorm_table(t.ctypes.data))
+    assert t.tolist() == table
+    for n_docs, sum_len, k1, b in ((10_000_000, 958_123_457, 1.2, 0.75), (3, 7, 2.0, 0.0), (1000, 10 ** 12, 0.9, 1.0)):
+        s1 = np.zeros(256, dtype=np.float64)
+        vb._lib.check(vb.lib().vbm25_cache_s1(n_docs, sum_len, k1, b, s1.ctypes.data))
+        avgdl = float(sum_len) / float(n_docs)
+        want = np.array([k1 * (1.0 - b + b * float(x) / avgdl) for x in table], dtype=np.float64)
+        assert s1.view(np.uint64).tolist() == want.view(np.uint64).tolist()

@@ -116,6 +116,19 @@ def test_synth_corpus_is_a_valid_flush(len_mode, zipf):
     assert np.array_equal(seg.token_terms(toks), np.arange(len(keys), dtype=np.uint32))
 
 
+def test_synth_corpus_at_a_million_documents_is_the_oracles_flush():
+    """The generator of the bench corpora (C3 / C5 come from it) at 1 M documents -- 96 M postings, every codec width the bench
+    sees: decoded with the oracle's codec and flushed again by the oracle, array for array."""
+    seg = vb.Segment.synth(1_000_000, 30_000, mean_len=100, len_mode=1, zipf_s=0.0, seed=20260925, threads=0)
+    a = seg.arrays()
+    docs, tfs, ts = decode_all(a)
+    lens = np.zeros(seg.n_docs, dtype=np.int64)
+    np.add.at(lens, docs, tfs)
+    assert lens.sum() == seg.desc.sum_len
+    oix = orc.OracleIndex.build(1.2, 0.75, lens.astype(np.uint32), a["doc_payload"], a["term_key"], ts, docs, tfs)
+    assert_same_index(seg, oix)
+
+
 def test_segment_save_load_and_query_bytes():
     seg = vb.Segment.synth(5000, 100, mean_len=30, seed=3, threads=2)
     with tempfile.TemporaryDirectory() as d:

@@ -52,6 +52,8 @@ ABI = {
     "vbm25_segment_save": (i32, [vp, C.c_char_p]),
     "vbm25_segment_load": (i32, [C.c_char_p, vp]),
     "vbm25_query_bytes": (u64, [vp, vp, u32, u32]),
+    "vbm25_fieldnorm_table": (i32, [vp]),
+    "vbm25_cache_s1": (i32, [u32, u64, C.c_double, C.c_double, vp]),
     "vbm25_growing_search": (i32, [vp, vp, u32, u32, u32, vp, vp, vp, vp, vp, vp, vp, vp]),
     "vbm25_merge_hits": (i32, [vp, u32, vp, u32, u32, vp, vp]),
     "vbm25_evaluate": (i32, [vp, vp, vp, u32, vp, u32, vp]),
@@ -76,6 +78,16 @@ ABI = {
     "vbm25_batch_set_timing": (i32, [vp, i32]),
     "vbm25_batch_kernel_ms": (i32, [vp, vp, vp]),
     "vbm25_evaluate_batch": (i32, [vp, vp, u32, u32, vp, vp, vp, vp]),
+    "vbm25_multi_create": (i32, [vp, vp, i32, vp]),
+    "vbm25_multi_destroy": (None, [vp]),
+    "vbm25_multi_device_count": (i32, [vp]),
+    "vbm25_multi_index": (i32, [vp, i32, vp]),
+    "vbm25_multi_search_batch": (i32, [vp, vp, vp, u32, u32, vp, vp]),
+    "vbm25_multi_batch_create": (i32, [vp, u32, u32, u32, vp]),
+    "vbm25_multi_batch_destroy": (None, [vp]),
+    "vbm25_multi_batch_set_queries": (i32, [vp, vp, vp, u32]),
+    "vbm25_multi_batch_run": (i32, [vp]),
+    "vbm25_multi_batch_fetch": (i32, [vp, vp, vp]),
 }
 
 

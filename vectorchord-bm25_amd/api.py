@@ -300,10 +300,72 @@ class Batch:
         return tuple(int(x) for x in out)
 
 
+class MultiIndex:
+    """vbm25_multi_create: the sealed segment on several GPUs of one node -- uploaded once, replicated GPU to GPU.
+    `devices` may list a device more than once (two replicas on device 0: the single-GPU test of the N-GPU path)."""
+
+    def __init__(self, segment, devices):
+        self.segment = segment
+        devs = (C.c_int * len(devices))(*[int(d) for d in devices])
+        self.h = C.c_void_p()
+        check(lib().vbm25_multi_create(C.byref(segment.desc), devs, len(devices), C.byref(self.h)))
+        self.n_devices = lib().vbm25_multi_device_count(self.h)
+
+    def __del__(self):
+        try:
+            if self.h:
+                lib().vbm25_multi_destroy(self.h)
+        except Exception:
+            pass
+
+    def search_batch(self, term_ids, q_off, k):
+        """vbm25_multi_search_batch: as search_batch(), the batch cut into contiguous shards over the replicas."""
+        term_ids = np.ascontiguousarray(term_ids, dtype=np.uint32)
+        q_off = np.ascontiguousarray(q_off, dtype=np.uint32)
+        nq = len(q_off) - 1
+        hits = np.zeros((nq, max(k, 1)), dtype=HIT_DTYPE)
+        n_hits = np.zeros(nq, dtype=np.uint32)
+        check(lib().vbm25_multi_search_batch(self.h, _p(term_ids), q_off.ctypes.data_as(C.c_void_p), nq, k,
+                                             hits.ctypes.data_as(C.c_void_p), n_hits.ctypes.data_as(C.c_void_p)))
+        return hits, n_hits
+
+
+class MultiBatch:
+    """vbm25_multi_batch_*: the shards resident on their devices; run() is asynchronous on every device's stream
+    (scan + download of the records), fetch() waits for all of them."""
+
+    def __init__(self, multi, max_queries, max_total_terms, k):
+        self.multi, self.k, self.nq = multi, k, 0
+        self.h = C.c_void_p()
+        check(lib().vbm25_multi_batch_create(multi.h, max_queries, max(1, max_total_terms), k, C.byref(self.h)))
+
+    def __del__(self):
+        try:
+            if self.h:
+                lib().vbm25_multi_batch_destroy(self.h)
+        except Exception:
+            pass
+
+    def set_queries(self, term_ids, q_off):
+        term_ids = np.ascontiguousarray(term_ids, dtype=np.uint32)
+        q_off = np.ascontiguousarray(q_off, dtype=np.uint32)
+        check(lib().vbm25_multi_batch_set_queries(self.h, _p(term_ids), q_off.ctypes.data_as(C.c_void_p), len(q_off) - 1))
+        self.nq = len(q_off) - 1
+
+    def run(self):
+        check(lib().vbm25_multi_batch_run(self.h))
+
+    def fetch(self):
+        hits = np.zeros((self.nq, self.k), dtype=HIT_DTYPE)
+        n_hits = np.zeros(self.nq, dtype=np.uint32)
+        check(lib().vbm25_multi_batch_fetch(self.h, _p(hits) if self.nq else None, _p(n_hits) if self.nq else None))
+        return hits, n_hits
+
+
 def set_tuning(name, value):
     """test / tuning aid (vbm25_tuning_set, not in include/vbm25.h): process-wide switch read when a Batch / GpuIndex
     scratch batch is created.  Names: dense_x1000, dense, ne, fused, ne_ratio, dense_items, range_items,
-    range_min_chunk, range_grid, dense_grid."""
+    range_min_chunk, range_grid, dense_grid, team, team_size, team_items, fused_items, arith."""
     f = lib().vbm25_tuning_set
     f.restype = C.c_int
     f.argtypes = [C.c_char_p, C.c_longlong]

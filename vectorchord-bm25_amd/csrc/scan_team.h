@@ -52,7 +52,8 @@ constexpr int TM_TQ = 4;         // candidate blocks per term and round (16 term
 constexpr int TM_G = 4;          // blocks per group of the branch-free path
 constexpr int TM_KTH = 9;        // term_kth_ub entries per term: the 2^i-th largest block maximum, i = 0..8
 constexpr int TM_IL = 4;         // batches of the bulk completion in flight together
-constexpr uint32_t TM_CAND = 2048;  // candidate documents per wave and item (bt.team_cand)
+constexpr uint32_t TM_CAND = 8192;  // candidate documents a wave's list holds (bt.team_cand)
+constexpr uint32_t TM_FLUSH = 2048; // ... completed at the next round's start when it holds more than this
 
 template <int TEAM>
 struct TeamLds {
@@ -255,11 +256,236 @@ __global__ void __launch_bounds__(TEAM * 64, 4) scan_team_kernel(DevIndex ix, De
             ub = ix.blk_ub[j];
         }
 
-        for (uint32_t tlo = lo; tlo < hi;) {
-            const uint32_t thi = hi - tlo > W ? tlo + W : hi, span = thi - tlo;
+        RegTopK<RK> rtop;
+        rtop.init();
+        unsigned long long published = 0;
+        // (one pass more than there are windows: the last pass only completes what is left in the list)
+        for (uint32_t tlo = lo;;) {
+            const bool last_pass = tlo >= hi;
+            const uint32_t thi = last_pass ? tlo : hi - tlo > W ? tlo + W : hi, span = thi - tlo;
             unsigned long long poll = 0;  // the query's threshold as the other workgroups see it: asked for now, used at the window's end
-            if (wave == 0) poll = __hip_atomic_load(&bt.theta[q], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (wave == 0 && !last_pass) poll = __hip_atomic_load(&bt.theta[q], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             for (;;) {  // rounds: up to TM_TQ blocks per term each
+                if (cnt > TM_CAND) {
+                    failed = true;  // one round made more candidates than the list holds: the item is scan_many_kernel's
+                    cnt = 0;
+                }
+                if (cnt && (last_pass || cnt > TM_FLUSH) && !(bt.team_dbg & 1u)) {
+                    // ---- bulk completion of the wave's candidates: TM_IL batches of 64 / m candidates x m terms at a time, every
+                    // stage for all of them before the next stage (straight-line code: the loads of the four batches are in flight together)
+                    const uint32_t inv_m = (65536u + m - 1u) / m;  // p / m == (p * inv_m) >> 16 for p < 4096
+                    const uint32_t per_batch = 64u / m;
+                    const uint32_t ci = (lane * inv_m) >> 16, t = lane - ci * m;
+                    const uint32_t tb1 = (uint32_t)__shfl((int)r_b1, (int)t), tb0 = (uint32_t)__shfl((int)r_b0, (int)t);
+                    const uint32_t tloc = (uint32_t)__shfl((int)r_loc, (int)t), tsh = (uint32_t)__shfl((int)r_sh, (int)t);
+                    const double ts0 = __shfl(r_s0, (int)t);
+                    const TeamArgsP cb = cold_args();
+                    const uint32_t *blk_loc = cb->ix.blk_loc, *blk_max_doc = cb->ix.blk_max_doc;
+                    for (uint32_t c0 = 0; c0 < cnt; c0 += TM_IL * per_batch) {
+                        uint32_t d[TM_IL], jb[TM_IL], fl[TM_IL], xx[TM_IL];  // fl: 1 plane, 2 tfn, 4 block found, 8 redo from the generic decode
+                        uint32_t v[TM_IL][8];
+                        bool task[TM_IL];
+                        // ---- A: the candidates; the locator's bucket
+        #pragma unroll
+                        for (int u = 0; u < TM_IL; ++u) {
+                            task[u] = ci < per_batch && c0 + u * per_batch + ci < cnt;
+                            d[u] = task[u] ? gl[c0 + u * per_batch + ci] : 0u;
+                            fl[u] = 0;
+                            jb[u] = tb1;
+                            if (task[u]) {
+                                const uint32_t b = tloc + (d[u] >> tsh);
+                                v[u][0] = blk_loc[b];
+                                v[u][1] = blk_loc[b + 1];
+                            }
+                        }
+                        // ---- B: the last documents of the bucket's first four blocks
+        #pragma unroll
+                        for (int u = 0; u < TM_IL; ++u) {
+                            if (task[u]) {
+                                const uint32_t ja = v[u][0], last = tb1 - 1u;
+                                xx[u] = v[u][1];  // the bucket's last candidate block (tb1: none)
+                                jb[u] = ja;
+        #pragma unroll
+                                for (int i = 0; i < 4; ++i) v[u][4 + i] = blk_max_doc[min(ja + (uint32_t)i, last)];
+                            }
+                        }
+                        // ---- C: the block; its first document, flags and pivots
+        #pragma unroll
+                        for (int u = 0; u < TM_IL; ++u) {
+                            if (task[u]) {
+                                const uint32_t ja = jb[u], je = xx[u];
+                                uint32_t jj = tb1;
+        #pragma unroll
+                                for (int i = 3; i >= 0; --i)
+                                    if (ja + (uint32_t)i < tb1 && v[u][4 + i] >= d[u]) jj = ja + (uint32_t)i;
+                                if (jj == tb1 && ja + 4u <= je && ja + 4u < tb1) fl[u] = 8;  // more than four blocks in the bucket: redone below
+                                jb[u] = jj;
+                                if (jj < tb1) {
+                                    const uint4 mm = ix.blk_meta[jj];
+                                    const uint4 pv = ix.blk_piv[jj];
+                                    v[u][0] = mm.x;
+                                    v[u][1] = mm.y;
+                                    v[u][2] = mm.w;
+                                    v[u][4] = pv.x;
+                                    v[u][5] = pv.y;
+                                    v[u][6] = pv.z;
+                                    v[u][7] = pv.w;
+                                    fl[u] = 4;
+                                }
+                            }
+                        }
+                        // ---- D: the 16 ids that can hold the document
+        #pragma unroll
+                        for (int u = 0; u < TM_IL; ++u) {
+                            if (fl[u] & 4u) {
+                                const uint32_t mn = v[u][0];
+                                if (mn > d[u]) {
+                                    fl[u] = 0;  // the document lies between two blocks
+                                } else if (!rel16_block(mn, v[u][1], v[u][2])) {
+                                    fl[u] = 8;
+                                } else {
+                                    const uint32_t r = d[u] - mn;
+                                    uint32_t seg = 0;
+        #pragma unroll
+                                    for (int i = 4; i < 8; ++i) seg += ((v[u][i] & 0xffffu) < r ? 1u : 0u) + ((v[u][i] >> 16) < r ? 1u : 0u);
+                                    if (seg > 7u) {
+                                        fl[u] = 0;
+                                    } else if (!tfn_block(v[u][2])) {
+                                        fl[u] = 8;
+                                    } else {
+                                        xx[u] = r | (16u * seg) << 16;
+                                        const uint4 *pp = reinterpret_cast<const uint4 *>(reinterpret_cast<const uint16_t *>(ix.post_rel16) + 128ull * jb[u] + 16u * seg);
+                                        const uint4 a = pp[0], b = pp[1];
+                                        v[u][0] = a.x;
+                                        v[u][1] = a.y;
+                                        v[u][2] = a.z;
+                                        v[u][3] = a.w;
+                                        v[u][4] = b.x;
+                                        v[u][5] = b.y;
+                                        v[u][6] = b.z;
+                                        v[u][7] = b.w;
+                                    }
+                                }
+                            }
+                        }
+                        // ---- E: the posting's index; its tf / fieldnorm word
+        #pragma unroll
+                        for (int u = 0; u < TM_IL; ++u) {
+                            if (fl[u] & 4u) {
+                                const uint32_t r = xx[u] & 0xffffu, base = xx[u] >> 16;
+                                uint32_t idx = NONE32;
+        #pragma unroll
+                                for (int i = 0; i < 8; ++i) {
+                                    if ((v[u][i] & 0xffffu) == r) idx = base + 2 * i;
+                                    if ((v[u][i] >> 16) == r) idx = base + 2 * i + 1;
+                                }
+                                if (idx == NONE32) {
+                                    fl[u] = 0;
+                                } else {
+                                    xx[u] = idx;
+                                    v[u][0] = ix.post_tfn[64ull * jb[u] + (idx >> 1)];
+                                }
+                            }
+                        }
+                        // ---- F: s1 of the posting's fieldnorm
+        #pragma unroll
+                        for (int u = 0; u < TM_IL; ++u) {
+                            if (fl[u] & 4u) {
+                                const uint32_t sh = (xx[u] & 1u) * 8u;
+                                const uint32_t fn = (v[u][0] >> (16u + sh)) & 0xffu;
+                                v[u][0] = (v[u][0] >> sh) & 0xffu;
+                                const double s1v = ix.s1[fn];
+                                v[u][2] = (uint32_t)__double2loint(s1v);
+                                v[u][3] = (uint32_t)__double2hiint(s1v);
+                            }
+                        }
+                        // ---- G: Cache::evaluate (bm25.rs:355-358); the lookups the fast path could not serve; the document's terms summed
+                        // in ascending key order (absent terms add 0.0, exact); the offer
+        #pragma unroll
+                        for (int u = 0; u < TM_IL; ++u) {
+                            if (c0 + u * per_batch >= cnt) break;
+                            double c = 0.0;
+                            if (fl[u] & 4u) {
+                                const double tfd = (double)v[u][0];
+                                c = (tfd * ts0) / (tfd + __hiloint2double((int)v[u][3], (int)v[u][2]));
+                            }
+                            if (__ballot((fl[u] & 8u) != 0)) {  // from the generic decode, one block at a time (rare)
+                                const TeamArgsP cg = cold_args();
+                                uint32_t jj = tb1;
+                                uint4 mm = make_uint4(0, 0, 0, 0);
+                                bool pend = false;
+                                if (fl[u] & 8u) {
+                                    jj = tm_first_block_ge(blk_max_doc, tb0, tb1, d[u], inv_docs);
+                                    if (jj < tb1) {
+                                        mm = ix.blk_meta[jj];
+                                        pend = mm.x <= d[u];
+                                    }
+                                }
+                                uint32_t idx = NONE32;
+                                for (;;) {
+                                    const unsigned long long pmask = __ballot(pend);
+                                    if (!pmask) break;
+                                    const uint32_t blk = (uint32_t)__builtin_amdgcn_readlane((int)jj, __ffsll((long long)pmask) - 1);
+                                    const uint4 um = uni4(ix.blk_meta[blk]);
+                                    const uint32_t un = um.w & 0xff, umd = (um.w >> 8) & 0xff;
+                                    uint32_t a0, a1;
+                                    decode_doc_ids(cg->ix.blob + 8ull * um.z, umd, un, um.x, lane, a0, a1);
+                                    __builtin_amdgcn_wave_barrier();
+                                    *reinterpret_cast<uint2 *>(&scr[2 * lane]) = make_uint2(2 * lane < un ? a0 : NONE32, 2 * lane + 1 < un ? a1 : NONE32);
+                                    __builtin_amdgcn_wave_barrier();
+                                    if (pend && jj == blk) {
+                                        uint32_t p = 0;
+        #pragma unroll
+                                        for (int sft = 64; sft > 0; sft >>= 1)
+                                            if (scr[p + sft - 1] < d[u]) p += sft;
+                                        if (scr[p] == d[u]) idx = p;
+                                        pend = false;
+                                    }
+                                    __builtin_amdgcn_wave_barrier();
+                                }
+                                if (idx != NONE32) {
+                                    const uint32_t nj = mm.w & 0xff, mdj = (mm.w >> 8) & 0xff, mtj = (mm.w >> 16) & 0xff;
+                                    const uint8_t *tbody = cg->ix.blob + 8ull * mm.z + ((payload_bytes(mdj, nj) + 7u) & ~7u);
+                                    const FieldAddr fa = field_addr(mtj, nj, idx);
+                                    const uint32_t flo = *reinterpret_cast<const uint32_t *>(tbody + fa.off0);
+                                    const uint32_t fhi = *reinterpret_cast<const uint32_t *>(tbody + fa.off1);
+                                    const double tfd = (double)field_val(flo, fhi, fa);
+                                    c = (tfd * ts0) / (tfd + ix.s1[cg->ix.post_fn[128ull * jj + idx]]);
+                                }
+                            }
+                            double *cs = reinterpret_cast<double *>(scr);
+                            __builtin_amdgcn_wave_barrier();
+                            cs[lane] = c;
+                            __builtin_amdgcn_wave_barrier();
+                            double acc = 0.0;
+                            const bool leader = task[u] && t == 0;
+                            if (leader)
+                                for (uint32_t i = 0; i < m; ++i) acc += cs[lane + i];
+                            __builtin_amdgcn_wave_barrier();
+                            {   // the offer: whole documents to this wave's list
+                                const unsigned long long th = TM_THETA_NOW();
+                                const bool has = leader && (unsigned long long)__double_as_longlong(acc) >= th &&
+                                                 (rtop.cnt < k || better(acc, d[u], rtop.kth_s, rtop.kth_d));
+                                if (__ballot(has)) {
+                                    rtop.template offer<true>(has, acc, d[u], k, lane);
+                                    if (rtop.cnt >= k) {
+                                        const unsigned long long kb = (unsigned long long)__double_as_longlong(rtop.kth_s);
+                                        if (kb > published) {
+                                            if (lane == 0) {
+                                                atomicMax(&S.theta, kb);
+                                                atomicMax(&bt.theta[q], kb);
+                                            }
+                                            published = kb;
+                                        }
+                                    }
+                                }
+                            }
+                        }
+                    }
+                    cnt = 0;
+                }
+                if (bt.team_dbg & 1u) cnt = 0;
+                if (last_pass) break;
                 const double thd = __longlong_as_double((long long)TM_THETA_NOW());
                 const bool in_win = valid && meta.x < thi;
                 const bool plane = shift == 0u && rel16_block(meta.x, meta.y, meta.w);
@@ -385,6 +611,7 @@ __global__ void __launch_bounds__(TEAM * 64, 4) scan_team_kernel(DevIndex ix, De
                 if (!again) break;
             }
 
+            if (last_pass) break;
             // ---- the window's marks of this wave are in: the bitmap's life cycle
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             if (lane == 0) atomicAdd(&S.sync[0], 1u);
@@ -401,228 +628,6 @@ __global__ void __launch_bounds__(TEAM * 64, 4) scan_team_kernel(DevIndex ix, De
             }
             ++epoch;
             tlo = thi;
-        }
-        if (cnt > TM_CAND) {
-            failed = true;  // lists that intersect this densely: the item is scan_many_kernel's
-            cnt = 0;
-        }
-
-        // ================================================================================================================
-        // Bulk completion of the wave's candidates: TM_IL batches of 64 / m candidates x m terms at a time, every stage for
-        // all of them before the next stage (straight-line code: the loads of the four batches are in flight together).
-        // ================================================================================================================
-        RegTopK<RK> rtop;
-        rtop.init();
-        unsigned long long published = 0;
-        if (cnt && !(bt.team_dbg & 1u)) {
-            const uint32_t inv_m = (65536u + m - 1u) / m;  // p / m == (p * inv_m) >> 16 for p < 4096
-            const uint32_t per_batch = 64u / m;
-            const uint32_t ci = (lane * inv_m) >> 16, t = lane - ci * m;
-            const uint32_t tb1 = (uint32_t)__shfl((int)r_b1, (int)t), tb0 = (uint32_t)__shfl((int)r_b0, (int)t);
-            const uint32_t tloc = (uint32_t)__shfl((int)r_loc, (int)t), tsh = (uint32_t)__shfl((int)r_sh, (int)t);
-            const double ts0 = __shfl(r_s0, (int)t);
-            const uint32_t *blk_loc = ca->ix.blk_loc, *blk_max_doc = ca->ix.blk_max_doc;
-            for (uint32_t c0 = 0; c0 < cnt; c0 += TM_IL * per_batch) {
-                uint32_t d[TM_IL], jb[TM_IL], fl[TM_IL], xx[TM_IL];  // fl: 1 plane, 2 tfn, 4 block found, 8 redo from the generic decode
-                uint32_t v[TM_IL][8];
-                bool task[TM_IL];
-                // ---- A: the candidates; the locator's bucket
-#pragma unroll
-                for (int u = 0; u < TM_IL; ++u) {
-                    task[u] = ci < per_batch && c0 + u * per_batch + ci < cnt;
-                    d[u] = task[u] ? gl[c0 + u * per_batch + ci] : 0u;
-                    fl[u] = 0;
-                    jb[u] = tb1;
-                    if (task[u]) {
-                        const uint32_t b = tloc + (d[u] >> tsh);
-                        v[u][0] = blk_loc[b];
-                        v[u][1] = blk_loc[b + 1];
-                    }
-                }
-                // ---- B: the last documents of the bucket's first four blocks
-#pragma unroll
-                for (int u = 0; u < TM_IL; ++u) {
-                    if (task[u]) {
-                        const uint32_t ja = v[u][0], last = tb1 - 1u;
-                        xx[u] = v[u][1];  // the bucket's last candidate block (tb1: none)
-                        jb[u] = ja;
-#pragma unroll
-                        for (int i = 0; i < 4; ++i) v[u][4 + i] = blk_max_doc[min(ja + (uint32_t)i, last)];
-                    }
-                }
-                // ---- C: the block; its first document, flags and pivots
-#pragma unroll
-                for (int u = 0; u < TM_IL; ++u) {
-                    if (task[u]) {
-                        const uint32_t ja = jb[u], je = xx[u];
-                        uint32_t jj = tb1;
-#pragma unroll
-                        for (int i = 3; i >= 0; --i)
-                            if (ja + (uint32_t)i < tb1 && v[u][4 + i] >= d[u]) jj = ja + (uint32_t)i;
-                        if (jj == tb1 && ja + 4u <= je && ja + 4u < tb1) fl[u] = 8;  // more than four blocks in the bucket: redone below
-                        jb[u] = jj;
-                        if (jj < tb1) {
-                            const uint4 mm = ix.blk_meta[jj];
-                            const uint4 pv = ix.blk_piv[jj];
-                            v[u][0] = mm.x;
-                            v[u][1] = mm.y;
-                            v[u][2] = mm.w;
-                            v[u][4] = pv.x;
-                            v[u][5] = pv.y;
-                            v[u][6] = pv.z;
-                            v[u][7] = pv.w;
-                            fl[u] = 4;
-                        }
-                    }
-                }
-                // ---- D: the 16 ids that can hold the document
-#pragma unroll
-                for (int u = 0; u < TM_IL; ++u) {
-                    if (fl[u] & 4u) {
-                        const uint32_t mn = v[u][0];
-                        if (mn > d[u]) {
-                            fl[u] = 0;  // the document lies between two blocks
-                        } else if (!rel16_block(mn, v[u][1], v[u][2])) {
-                            fl[u] = 8;
-                        } else {
-                            const uint32_t r = d[u] - mn;
-                            uint32_t seg = 0;
-#pragma unroll
-                            for (int i = 4; i < 8; ++i) seg += ((v[u][i] & 0xffffu) < r ? 1u : 0u) + ((v[u][i] >> 16) < r ? 1u : 0u);
-                            if (seg > 7u) {
-                                fl[u] = 0;
-                            } else if (!tfn_block(v[u][2])) {
-                                fl[u] = 8;
-                            } else {
-                                xx[u] = r | (16u * seg) << 16;
-                                const uint4 *pp = reinterpret_cast<const uint4 *>(reinterpret_cast<const uint16_t *>(ix.post_rel16) + 128ull * jb[u] + 16u * seg);
-                                const uint4 a = pp[0], b = pp[1];
-                                v[u][0] = a.x;
-                                v[u][1] = a.y;
-                                v[u][2] = a.z;
-                                v[u][3] = a.w;
-                                v[u][4] = b.x;
-                                v[u][5] = b.y;
-                                v[u][6] = b.z;
-                                v[u][7] = b.w;
-                            }
-                        }
-                    }
-                }
-                // ---- E: the posting's index; its tf / fieldnorm word
-#pragma unroll
-                for (int u = 0; u < TM_IL; ++u) {
-                    if (fl[u] & 4u) {
-                        const uint32_t r = xx[u] & 0xffffu, base = xx[u] >> 16;
-                        uint32_t idx = NONE32;
-#pragma unroll
-                        for (int i = 0; i < 8; ++i) {
-                            if ((v[u][i] & 0xffffu) == r) idx = base + 2 * i;
-                            if ((v[u][i] >> 16) == r) idx = base + 2 * i + 1;
-                        }
-                        if (idx == NONE32) {
-                            fl[u] = 0;
-                        } else {
-                            xx[u] = idx;
-                            v[u][0] = ix.post_tfn[64ull * jb[u] + (idx >> 1)];
-                        }
-                    }
-                }
-                // ---- F: s1 of the posting's fieldnorm
-#pragma unroll
-                for (int u = 0; u < TM_IL; ++u) {
-                    if (fl[u] & 4u) {
-                        const uint32_t sh = (xx[u] & 1u) * 8u;
-                        const uint32_t fn = (v[u][0] >> (16u + sh)) & 0xffu;
-                        v[u][0] = (v[u][0] >> sh) & 0xffu;
-                        const double s1v = ix.s1[fn];
-                        v[u][2] = (uint32_t)__double2loint(s1v);
-                        v[u][3] = (uint32_t)__double2hiint(s1v);
-                    }
-                }
-                // ---- G: Cache::evaluate (bm25.rs:355-358); the lookups the fast path could not serve; the document's terms summed
-                // in ascending key order (absent terms add 0.0, exact); the offer
-#pragma unroll
-                for (int u = 0; u < TM_IL; ++u) {
-                    if (c0 + u * per_batch >= cnt) break;
-                    double c = 0.0;
-                    if (fl[u] & 4u) {
-                        const double tfd = (double)v[u][0];
-                        c = (tfd * ts0) / (tfd + __hiloint2double((int)v[u][3], (int)v[u][2]));
-                    }
-                    if (__ballot((fl[u] & 8u) != 0)) {  // from the generic decode, one block at a time (rare)
-                        const TeamArgsP cg = cold_args();
-                        uint32_t jj = tb1;
-                        uint4 mm = make_uint4(0, 0, 0, 0);
-                        bool pend = false;
-                        if (fl[u] & 8u) {
-                            jj = tm_first_block_ge(blk_max_doc, tb0, tb1, d[u], inv_docs);
-                            if (jj < tb1) {
-                                mm = ix.blk_meta[jj];
-                                pend = mm.x <= d[u];
-                            }
-                        }
-                        uint32_t idx = NONE32;
-                        for (;;) {
-                            const unsigned long long pmask = __ballot(pend);
-                            if (!pmask) break;
-                            const uint32_t blk = (uint32_t)__builtin_amdgcn_readlane((int)jj, __ffsll((long long)pmask) - 1);
-                            const uint4 um = uni4(ix.blk_meta[blk]);
-                            const uint32_t un = um.w & 0xff, umd = (um.w >> 8) & 0xff;
-                            uint32_t a0, a1;
-                            decode_doc_ids(cg->ix.blob + 8ull * um.z, umd, un, um.x, lane, a0, a1);
-                            __builtin_amdgcn_wave_barrier();
-                            *reinterpret_cast<uint2 *>(&scr[2 * lane]) = make_uint2(2 * lane < un ? a0 : NONE32, 2 * lane + 1 < un ? a1 : NONE32);
-                            __builtin_amdgcn_wave_barrier();
-                            if (pend && jj == blk) {
-                                uint32_t p = 0;
-#pragma unroll
-                                for (int sft = 64; sft > 0; sft >>= 1)
-                                    if (scr[p + sft - 1] < d[u]) p += sft;
-                                if (scr[p] == d[u]) idx = p;
-                                pend = false;
-                            }
-                            __builtin_amdgcn_wave_barrier();
-                        }
-                        if (idx != NONE32) {
-                            const uint32_t nj = mm.w & 0xff, mdj = (mm.w >> 8) & 0xff, mtj = (mm.w >> 16) & 0xff;
-                            const uint8_t *tbody = cg->ix.blob + 8ull * mm.z + ((payload_bytes(mdj, nj) + 7u) & ~7u);
-                            const FieldAddr fa = field_addr(mtj, nj, idx);
-                            const uint32_t flo = *reinterpret_cast<const uint32_t *>(tbody + fa.off0);
-                            const uint32_t fhi = *reinterpret_cast<const uint32_t *>(tbody + fa.off1);
-                            const double tfd = (double)field_val(flo, fhi, fa);
-                            c = (tfd * ts0) / (tfd + ix.s1[cg->ix.post_fn[128ull * jj + idx]]);
-                        }
-                    }
-                    double *cs = reinterpret_cast<double *>(scr);
-                    __builtin_amdgcn_wave_barrier();
-                    cs[lane] = c;
-                    __builtin_amdgcn_wave_barrier();
-                    double acc = 0.0;
-                    const bool leader = task[u] && t == 0;
-                    if (leader)
-                        for (uint32_t i = 0; i < m; ++i) acc += cs[lane + i];
-                    __builtin_amdgcn_wave_barrier();
-                    {   // the offer: whole documents to this wave's list
-                        const unsigned long long th = TM_THETA_NOW();
-                        const bool has = leader && (unsigned long long)__double_as_longlong(acc) >= th &&
-                                         (rtop.cnt < k || better(acc, d[u], rtop.kth_s, rtop.kth_d));
-                        if (__ballot(has)) {
-                            rtop.template offer<true>(has, acc, d[u], k, lane);
-                            if (rtop.cnt >= k) {
-                                const unsigned long long kb = (unsigned long long)__double_as_longlong(rtop.kth_s);
-                                if (kb > published) {
-                                    if (lane == 0) {
-                                        atomicMax(&S.theta, kb);
-                                        atomicMax(&bt.theta[q], kb);
-                                    }
-                                    published = kb;
-                                }
-                            }
-                        }
-                    }
-                }
-            }
         }
         if (failed && lane == 0) S.fail = 1;
         __syncthreads();  // (every wave's verdict is in)

@@ -257,6 +257,8 @@ struct vbm25_batch {
     // vbm25_search_batch's low-latency route: pinned staging buffers and a private stream -- queries go up and
     // hits come down with asynchronous copies and ONE stream synchronisation
     hipStream_t lat_stream = nullptr;
+    hipStream_t last_stream = nullptr;  // the stream of the last run: what fetch waits for (not the whole device)
+    bool download_enqueued = false;     // the last run's records are already on their way to pin_out (vbm25_multi_batch_run)
     uint8_t *pin_in = nullptr, *pin_out = nullptr;
     size_t pin_in_bytes = 0, pin_out_bytes = 0, pin_nt = 0;
     ~vbm25_batch() {
@@ -269,6 +271,41 @@ struct vbm25_batch {
         }
     }
 };
+
+
+namespace {
+// every device array of an index (vbm25_multi_create copies them from GPU to GPU)
+DeviceBuffer vbm25_index::*const INDEX_BUFFERS[] = {
+    &vbm25_index::term_wand_tf, &vbm25_index::term_wand_fn, &vbm25_index::term_df, &vbm25_index::term_first_block, &vbm25_index::term_s0,
+    &vbm25_index::blk_min_doc, &vbm25_index::blk_max_doc, &vbm25_index::blk_meta, &vbm25_index::blk_ub, &vbm25_index::blob,
+    &vbm25_index::post_fn, &vbm25_index::post_rel16, &vbm25_index::post_tfn, &vbm25_index::doc_payload, &vbm25_index::s1,
+    &vbm25_index::term_idf, &vbm25_index::fn_len, &vbm25_index::term_kth_ub, &vbm25_index::blk_piv, &vbm25_index::term_loc, &vbm25_index::blk_loc};
+
+void fill_dev(vbm25_index *ix) {
+    ix->dev.n_docs = ix->n_docs;
+    ix->dev.n_terms = ix->n_terms;
+    ix->dev.n_blocks = ix->n_blocks;
+    ix->dev.term_df = ix->term_df.as<uint32_t>();
+    ix->dev.term_first_block = ix->term_first_block.as<uint32_t>();
+    ix->dev.term_s0 = ix->term_s0.as<double>();
+    ix->dev.term_wand_tf = ix->term_wand_tf.as<uint32_t>();
+    ix->dev.term_wand_fn = ix->term_wand_fn.as<uint8_t>();
+    ix->dev.blk_min_doc = ix->blk_min_doc.as<uint32_t>();
+    ix->dev.blk_max_doc = ix->blk_max_doc.as<uint32_t>();
+    ix->dev.blk_meta = ix->blk_meta.as<uint4>();
+    ix->dev.blk_ub = ix->blk_ub.as<double>();
+    ix->dev.blob = ix->blob.as<uint8_t>();
+    ix->dev.post_fn = ix->post_fn.as<uint8_t>();
+    ix->dev.post_rel16 = ix->post_rel16.as<uint32_t>();
+    ix->dev.post_tfn = ix->post_tfn.as<uint32_t>();
+    ix->dev.blk_piv = ix->blk_piv.as<uint4>();
+    ix->dev.term_loc = ix->term_loc.as<uint2>();
+    ix->dev.blk_loc = ix->blk_loc.as<uint32_t>();
+    ix->dev.doc_payload = ix->doc_payload.as<uint16_t>();
+    ix->dev.s1 = ix->s1.as<double>();
+    ix->dev.term_kth_ub = ix->term_kth_ub.as<double>();  // (NULL when the block maxima are not attained)
+}
+}  // namespace
 
 namespace {
 
@@ -442,30 +479,15 @@ static int vbm25_index_create_impl(const vbm25_index_desc *d, int device, vbm25_
         return set_error(VBM25_ERR_CORRUPT,
                          "a posting scores above its block's / token's WAND pair "
                          "(search.rs:363,377-380 prune with those bounds)");
-    ix->dev.n_docs = d->n_docs;
-    ix->dev.n_terms = d->n_terms;
-    ix->dev.n_blocks = d->n_blocks;
-    ix->dev.term_df = ix->term_df.as<uint32_t>();
-    ix->dev.term_first_block = ix->term_first_block.as<uint32_t>();
-    ix->dev.term_s0 = ix->term_s0.as<double>();
-    ix->dev.term_wand_tf = ix->term_wand_tf.as<uint32_t>();
-    ix->dev.term_wand_fn = ix->term_wand_fn.as<uint8_t>();
-    ix->dev.blk_min_doc = ix->blk_min_doc.as<uint32_t>();
-    ix->dev.blk_max_doc = ix->blk_max_doc.as<uint32_t>();
-    ix->dev.blk_meta = ix->blk_meta.as<uint4>();
-    ix->dev.blk_ub = ix->blk_ub.as<double>();
-    ix->dev.blob = ix->blob.as<uint8_t>();
-    ix->dev.post_fn = ix->post_fn.as<uint8_t>();
-    ix->dev.post_rel16 = ix->post_rel16.as<uint32_t>();
-    ix->dev.post_tfn = ix->post_tfn.as<uint32_t>();
-    ix->dev.blk_piv = ix->blk_piv.as<uint4>();
-    ix->dev.term_loc = ix->term_loc.as<uint2>();
-    ix->dev.blk_loc = ix->blk_loc.as<uint32_t>();
-    ix->dev.doc_payload = ix->doc_payload.as<uint16_t>();
-    ix->dev.s1 = ix->s1.as<double>();
+    fill_dev(ix.get());
     ix->dev.blob_bytes = d->blob_bytes;
     ix->dev.blk_ub_attained = d->blk_wand_fn && d->blk_wand_tf && !(flag & 4u) ? 1u : 0u;
     ix->dev.term_kth_ub = ix->dev.blk_ub_attained && !kth.empty() ? ix->term_kth_ub.as<double>() : nullptr;
+    if (!ix->dev.term_kth_ub && ix->term_kth_ub.p) {  // (kept out of the replicas too)
+        (void)hipFree(ix->term_kth_ub.p);
+        ix->term_kth_ub.p = nullptr;
+        ix->term_kth_ub.bytes = 0;
+    }
     {   // for vbm25_evaluate_batch: per-term idf (host libm log, bm25.rs:285-289) and the fieldnorm table
         std::vector<double> idf(d->n_terms);
         for (uint32_t t = 0; t < d->n_terms; ++t)
@@ -739,6 +761,8 @@ static int vbm25_batch_run_impl(vbm25_batch *bt, void *hip_stream) {
     if (!bt->nq) return VBM25_OK;
     if (int rc = use_device(bt->index->device)) return rc;
     hipStream_t st = static_cast<hipStream_t>(hip_stream);
+    bt->last_stream = st;
+    bt->download_enqueued = false;
     if (bt->index->n_docs == 0) {  // empty sealed segment: no hits (the growing segment is the shim's, search.rs:83-135)
         HIP_TRY(hipMemsetAsync(bt->n_hits.p, 0, 4ull * bt->nq, st));
         return VBM25_OK;
@@ -931,6 +955,7 @@ static int vbm25_batch_run_impl(vbm25_batch *bt, void *hip_stream) {
     return VBM25_OK;
 }
 
+static int vbm25_batch_enqueue_download(vbm25_batch *bt);
 static int vbm25_batch_fetch_impl(vbm25_batch *bt, vbm25_hit *hits, uint32_t *n_hits, bool fast = false) {
     if (!bt || (!hits && bt->nq) || (!n_hits && bt->nq)) return set_error(VBM25_ERR_INVALID, "NULL argument");
     if (int rc = use_device(bt->index->device)) return rc;
@@ -946,17 +971,9 @@ static int vbm25_batch_fetch_impl(vbm25_batch *bt, vbm25_hit *hits, uint32_t *n_
     }
     if (fast && bt->lat_stream) {  // flag, counts and hits come down asynchronously; one synchronisation
         const size_t nh = sizeof(vbm25_hit) * size_t(bt->nq) * bt->k, nc = 4ull * bt->nq;
-        if (8 + nc + nh > bt->pin_out_bytes) {
-            if (bt->pin_out) HIP_TRY(hipHostFree(bt->pin_out));
-            bt->pin_out = nullptr;
-            bt->pin_out_bytes = 2 * (8 + nc + nh) + 256;
-            HIP_TRY(hipHostMalloc(reinterpret_cast<void **>(&bt->pin_out), bt->pin_out_bytes, hipHostMallocDefault));
-        }
-        HIP_TRY(hipMemcpyAsync(bt->pin_out, bt->error_flag.p, 4, hipMemcpyDeviceToHost, bt->lat_stream));
-        if (bt->nq) {
-            HIP_TRY(hipMemcpyAsync(bt->pin_out + 8, bt->n_hits.p, nc, hipMemcpyDeviceToHost, bt->lat_stream));
-            HIP_TRY(hipMemcpyAsync(bt->pin_out + 8 + nc, bt->hits.p, nh, hipMemcpyDeviceToHost, bt->lat_stream));
-        }
+        if (!bt->download_enqueued)
+            if (int rc = vbm25_batch_enqueue_download(bt)) return rc;
+        bt->download_enqueued = false;
         HIP_TRY(hipStreamSynchronize(bt->lat_stream));
         uint32_t flag = 0;
         std::memcpy(&flag, bt->pin_out, 4);
@@ -970,17 +987,41 @@ static int vbm25_batch_fetch_impl(vbm25_batch *bt, vbm25_hit *hits, uint32_t *n_
         }
         return VBM25_OK;
     }
-    HIP_TRY(hipDeviceSynchronize());
+    // the batch's own stream, not the device: other streams of the process (a gather, another batch) keep running
+    hipStream_t st = bt->last_stream;
     uint32_t flag = 0;
-    HIP_TRY(hipMemcpy(&flag, bt->error_flag.p, 4, hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpyAsync(&flag, bt->error_flag.p, 4, hipMemcpyDeviceToHost, st));
+    if (bt->nq) {
+        HIP_TRY(hipMemcpyAsync(hits, bt->hits.p, sizeof(vbm25_hit) * size_t(bt->nq) * bt->k, hipMemcpyDeviceToHost, st));
+        HIP_TRY(hipMemcpyAsync(n_hits, bt->n_hits.p, 4ull * bt->nq, hipMemcpyDeviceToHost, st));
+    }
+    HIP_TRY(hipStreamSynchronize(st));
     if (flag) {
-        HIP_TRY(hipMemset(bt->error_flag.p, 0, 4));
+        HIP_TRY(hipMemsetAsync(bt->error_flag.p, 0, 4, st));
+        HIP_TRY(hipStreamSynchronize(st));
         return set_error(VBM25_ERR_DEVICE, "device-side planner overflow (flag %u)", flag);
     }
-    if (bt->nq) {
-        HIP_TRY(hipMemcpy(hits, bt->hits.p, sizeof(vbm25_hit) * size_t(bt->nq) * bt->k, hipMemcpyDeviceToHost));
-        HIP_TRY(hipMemcpy(n_hits, bt->n_hits.p, 4ull * bt->nq, hipMemcpyDeviceToHost));
+    return VBM25_OK;
+}
+
+// the last run's flag, counts and records to the batch's pinned buffer, behind the run on its private stream (vbm25_search_batch's
+// and vbm25_multi_batch_run's general routes; the one-launch route has written them there itself)
+static int vbm25_batch_enqueue_download(vbm25_batch *bt) {
+    if (bt->bigk || !bt->lat_stream || (bt->fused_g && bt->fused_pinned)) return VBM25_OK;
+    if (int rc = use_device(bt->index->device)) return rc;
+    const size_t nh = sizeof(vbm25_hit) * size_t(bt->nq) * bt->k, nc = 4ull * bt->nq;
+    if (8 + nc + nh > bt->pin_out_bytes) {
+        if (bt->pin_out) HIP_TRY(hipHostFree(bt->pin_out));
+        bt->pin_out = nullptr;
+        bt->pin_out_bytes = 2 * (8 + nc + nh) + 256;
+        HIP_TRY(hipHostMalloc(reinterpret_cast<void **>(&bt->pin_out), bt->pin_out_bytes, hipHostMallocDefault));
     }
+    HIP_TRY(hipMemcpyAsync(bt->pin_out, bt->error_flag.p, 4, hipMemcpyDeviceToHost, bt->lat_stream));
+    if (bt->nq) {
+        HIP_TRY(hipMemcpyAsync(bt->pin_out + 8, bt->n_hits.p, nc, hipMemcpyDeviceToHost, bt->lat_stream));
+        HIP_TRY(hipMemcpyAsync(bt->pin_out + 8 + nc, bt->hits.p, nh, hipMemcpyDeviceToHost, bt->lat_stream));
+    }
+    bt->download_enqueued = true;
     return VBM25_OK;
 }
 
@@ -1091,7 +1132,7 @@ void vbm25_tuning_reset(void) {
 int vbm25_batch_debug_counts(vbm25_batch *bt, uint32_t *n_items, uint32_t *n_failed) {
     if (!bt || !n_items || !n_failed) return set_error(VBM25_ERR_INVALID, "NULL argument");
     if (int rc = use_device(bt->index->device)) return rc;
-    HIP_TRY(hipDeviceSynchronize());
+    HIP_TRY(hipStreamSynchronize(bt->last_stream));
     if (bt->arith_g && bt->state_clean) {  // merge_kernel has cleaned the flags and kept the counts per query
         *n_items = bt->nq * bt->arith_g;
         std::vector<uint32_t> qf(bt->nq);
@@ -1113,7 +1154,7 @@ int vbm25_batch_debug_counts(vbm25_batch *bt, uint32_t *n_items, uint32_t *n_fai
 int vbm25_batch_debug_check(vbm25_batch *bt, uint32_t *out4) {  // out4: 16 words
     if (!bt || !out4) return set_error(VBM25_ERR_INVALID, "NULL argument");
     if (int rc = use_device(bt->index->device)) return rc;
-    HIP_TRY(hipDeviceSynchronize());
+    HIP_TRY(hipStreamSynchronize(bt->last_stream));
     if (!bt->dbg.p) {
         std::memset(out4, 0, 64);
         return VBM25_OK;
@@ -1128,7 +1169,7 @@ int vbm25_batch_debug_check(vbm25_batch *bt, uint32_t *out4) {  // out4: 16 word
 int vbm25_batch_debug_theta(vbm25_batch *bt, unsigned long long *out) {
     if (!bt || !out) return set_error(VBM25_ERR_INVALID, "NULL argument");
     if (int rc = use_device(bt->index->device)) return rc;
-    HIP_TRY(hipDeviceSynchronize());
+    HIP_TRY(hipStreamSynchronize(bt->last_stream));
     if (bt->nq && bt->theta.p)
         HIP_TRY(hipMemcpy(out, bt->arith_g && bt->state_clean ? bt->theta_last.p : bt->theta.p, 8ull * bt->nq, hipMemcpyDeviceToHost));
     return VBM25_OK;
@@ -1218,6 +1259,224 @@ int vbm25_batch_fetch(vbm25_batch *bt, vbm25_hit *hits, uint32_t *n_hits) {
 int vbm25_search_batch(vbm25_index *ix, const uint32_t *term_ids, const uint32_t *q_off, uint32_t nq,
                        uint32_t k, vbm25_hit *hits, uint32_t *n_hits) {
     return guarded([&] { return vbm25_search_batch_impl(ix, term_ids, q_off, nq, k, hits, n_hits); });
+}
+
+// the shard's part of vbm25_multi_batch_fetch: wait for the part's stream, copy out; an item the one-launch route gave up is
+// redone on the general route, as in vbm25_search_batch
+static int vbm25_batch_finish_download(vbm25_batch *bt, vbm25_hit *hits, uint32_t *n_hits) {
+    const bool fast = !bt->bigk && bt->lat_stream;
+    int rc = vbm25_batch_fetch_impl(bt, hits, n_hits, fast);
+    if (rc == VBM25_RETRY_GENERAL) {
+        bt->fused_g = 0;
+        rc = upload_staged(bt);
+        if (!rc) rc = vbm25_batch_run_impl(bt, bt->lat_stream);
+        if (!rc) rc = vbm25_batch_fetch_impl(bt, hits, n_hits, fast);
+    }
+    return rc;
+}
+
+// ---------------------------------------------------------------------------
+// Several GPUs of one node behind the C ABI (BASELINE.json configs[3]).  The path shards by
+// independent queries: the index is replicated, a batch is cut into contiguous shards, nothing is exchanged between the
+// GPUs but the replicas themselves -- made ONCE, GPU to GPU (hipMemcpyPeerAsync over xGMI: one host upload, n - 1 peer
+// copies, derived arrays included).  The hit records go straight from every GPU to the caller's host buffer (pinned
+// staging, one asynchronous copy per device and run): the caller is the host, so a device-side gather (peer copies or
+// RCCL) would only add a hop.  One host thread drives all devices: every device has its own batch objects and stream,
+// the shards run concurrently, fetch waits for all of them.
+// ---------------------------------------------------------------------------
+}  // extern "C"
+
+struct vbm25_multi {
+    std::vector<vbm25_index *> replicas;  // [0] is the one uploaded from the host
+    vbm25_multi_batch *scratch = nullptr;  // batch object re-used by vbm25_multi_search_batch
+    ~vbm25_multi() {
+        for (vbm25_index *ix : replicas) vbm25_index_destroy(ix);
+    }
+};
+struct vbm25_multi_batch {
+    vbm25_multi *multi = nullptr;
+    uint32_t max_queries = 0, max_terms = 0, k = 0, nq = 0;
+    std::vector<vbm25_batch *> parts;      // one per replica
+    std::vector<uint32_t> lo;              // shard bounds: replica i has the queries [lo[i], lo[i + 1])
+    std::vector<uint32_t> off_scratch;
+    ~vbm25_multi_batch() {
+        for (vbm25_batch *b : parts) vbm25_batch_destroy(b);
+    }
+};
+
+namespace {
+
+int clone_index(const vbm25_index *src, int device, vbm25_index **out) {
+    int n_dev = 0;
+    HIP_TRY(hipGetDeviceCount(&n_dev));
+    if (device < 0 || device >= n_dev) return set_error(VBM25_ERR_INVALID, "device %d out of range (%d devices)", device, n_dev);
+    hipDeviceProp_t prop;
+    HIP_TRY(hipGetDeviceProperties(&prop, device));
+    if (!std::strstr(prop.gcnArchName, "gfx950"))
+        return set_error(VBM25_ERR_DEVICE, "device %d is %s; this library is built for gfx950 only", device, prop.gcnArchName);
+    if (int rc = use_device(device)) return rc;
+    if (device != src->device) {  // direct xGMI copies where the runtime allows them (staged through the host otherwise)
+        int can = 0;
+        if (hipDeviceCanAccessPeer(&can, device, src->device) == hipSuccess && can) {
+            const hipError_t e = hipDeviceEnablePeerAccess(src->device, 0);
+            if (e != hipSuccess && e != hipErrorPeerAccessAlreadyEnabled) (void)hipGetLastError();
+        }
+        (void)hipGetLastError();
+    }
+    auto ix = std::make_unique<vbm25_index>();
+    ix->device = device;
+    ix->n_docs = src->n_docs;
+    ix->n_terms = src->n_terms;
+    ix->n_blocks = src->n_blocks;
+    ix->term_key = src->term_key;
+    ix->term_df_host = src->term_df_host;
+    ix->k1 = src->k1;
+    ix->device_bytes = src->device_bytes;
+    for (auto member : INDEX_BUFFERS) {
+        const DeviceBuffer &from = src->*member;
+        if (!from.p) continue;
+        DeviceBuffer &to = (*ix).*member;
+        if (int rc = to.alloc(from.bytes)) return rc;
+        if (from.bytes) HIP_TRY(hipMemcpyPeerAsync(to.p, device, from.p, src->device, from.bytes, nullptr));
+    }
+    HIP_TRY(hipStreamSynchronize(nullptr));
+    fill_dev(ix.get());
+    ix->dev.blob_bytes = src->dev.blob_bytes;
+    ix->dev.blk_ub_attained = src->dev.blk_ub_attained;
+    *out = ix.release();
+    return VBM25_OK;
+}
+
+int multi_create_impl(const vbm25_index_desc *desc, const int *devices, int n_devices, vbm25_multi **out) {
+    if (!out) return set_error(VBM25_ERR_INVALID, "out is NULL");
+    *out = nullptr;
+    if (!devices || n_devices <= 0) return set_error(VBM25_ERR_INVALID, "no devices given");
+    auto m = std::make_unique<vbm25_multi>();
+    vbm25_index *first = nullptr;
+    if (int rc = vbm25_index_create(desc, devices[0], &first)) return rc;
+    m->replicas.push_back(first);
+    for (int i = 1; i < n_devices; ++i) {
+        vbm25_index *r = nullptr;
+        if (int rc = clone_index(first, devices[i], &r)) return rc;
+        m->replicas.push_back(r);
+    }
+    *out = m.release();
+    return VBM25_OK;
+}
+
+int multi_batch_create_impl(vbm25_multi *m, uint32_t max_queries, uint32_t max_total_terms, uint32_t k, vbm25_multi_batch **out) {
+    if (!out) return set_error(VBM25_ERR_INVALID, "out is NULL");
+    *out = nullptr;
+    if (!m) return set_error(VBM25_ERR_INVALID, "multi is NULL");
+    if (!max_queries) return set_error(VBM25_ERR_INVALID, "max_queries is 0");
+    auto mb = std::make_unique<vbm25_multi_batch>();
+    mb->multi = m;
+    mb->max_queries = max_queries;
+    mb->max_terms = max_total_terms;
+    mb->k = k;
+    const uint32_t n = uint32_t(m->replicas.size());
+    const uint32_t per = (max_queries + n - 1) / n;  // a shard is at most this many queries; it may hold all the terms
+    for (vbm25_index *ix : m->replicas) {
+        vbm25_batch *b = nullptr;
+        if (int rc = vbm25_batch_create(ix, per, std::max(max_total_terms, 1u), k, &b)) return rc;
+        mb->parts.push_back(b);
+    }
+    mb->lo.assign(n + 1, 0);
+    *out = mb.release();
+    return VBM25_OK;
+}
+
+int multi_batch_set_queries_impl(vbm25_multi_batch *mb, const uint32_t *term_ids, const uint32_t *q_off, uint32_t nq) {
+    if (!mb || !q_off) return set_error(VBM25_ERR_INVALID, "NULL argument");
+    if (nq > mb->max_queries) return set_error(VBM25_ERR_INVALID, "%u queries exceed the batch capacity %u", nq, mb->max_queries);
+    if (q_off[0] != 0) return set_error(VBM25_ERR_INVALID, "q_off[0] must be 0");
+    const uint32_t n = uint32_t(mb->parts.size());
+    mb->nq = nq;
+    for (uint32_t i = 0; i <= n; ++i) {  // contiguous, balanced shards (the first nq % n get one query more)
+        const uint32_t base = nq / n, rem = nq % n;
+        mb->lo[i] = i * base + std::min(i, rem);
+    }
+    for (uint32_t i = 0; i < n; ++i) {
+        const uint32_t a = mb->lo[i], b = mb->lo[i + 1];
+        if (q_off[b] < q_off[a]) return set_error(VBM25_ERR_INVALID, "q_off not monotone");
+        mb->off_scratch.resize(size_t(b - a) + 1);
+        for (uint32_t q = a; q <= b; ++q) mb->off_scratch[q - a] = q_off[q] - q_off[a];
+        // staged in the part's pinned memory, copied on its own stream: the devices' uploads overlap
+        if (int rc = vbm25_batch_set_queries_impl(mb->parts[i], term_ids ? term_ids + q_off[a] : nullptr, mb->off_scratch.data(), b - a, true))
+            return rc;
+    }
+    return VBM25_OK;
+}
+
+int multi_batch_run_impl(vbm25_multi_batch *mb) {
+    if (!mb) return set_error(VBM25_ERR_INVALID, "batch is NULL");
+    for (size_t i = 0; i < mb->parts.size(); ++i) {  // every device on its own stream: the shards run concurrently
+        vbm25_batch *b = mb->parts[i];
+        if (!b->nq) continue;
+        if (int rc = vbm25_batch_run_impl(b, b->bigk ? nullptr : b->lat_stream)) return rc;
+        if (int rc = vbm25_batch_enqueue_download(b)) return rc;  // the shard's records to pinned host memory, behind its scan
+    }
+    return VBM25_OK;
+}
+
+int multi_batch_fetch_impl(vbm25_multi_batch *mb, vbm25_hit *hits, uint32_t *n_hits) {
+    if (!mb || (!hits && mb->nq) || (!n_hits && mb->nq)) return set_error(VBM25_ERR_INVALID, "NULL argument");
+    for (size_t i = 0; i < mb->parts.size(); ++i) {
+        vbm25_batch *b = mb->parts[i];
+        if (!b->nq) continue;
+        if (int rc = vbm25_batch_finish_download(b, hits + size_t(mb->lo[i]) * mb->k, n_hits + mb->lo[i])) return rc;
+    }
+    return VBM25_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int vbm25_multi_create(const vbm25_index_desc *desc, const int *devices, int n_devices, vbm25_multi **out) {
+    return guarded([&] { return multi_create_impl(desc, devices, n_devices, out); });
+}
+void vbm25_multi_destroy(vbm25_multi *m) {
+    if (!m) return;
+    if (m->scratch) vbm25_multi_batch_destroy(m->scratch);
+    delete m;
+}
+int vbm25_multi_device_count(const vbm25_multi *m) { return m ? int(m->replicas.size()) : 0; }
+int vbm25_multi_index(vbm25_multi *m, int i, vbm25_index **out) {
+    if (!m || !out || i < 0 || size_t(i) >= m->replicas.size()) return set_error(VBM25_ERR_INVALID, "bad argument");
+    *out = m->replicas[size_t(i)];
+    return VBM25_OK;
+}
+int vbm25_multi_batch_create(vbm25_multi *m, uint32_t max_queries, uint32_t max_total_terms, uint32_t k, vbm25_multi_batch **out) {
+    return guarded([&] { return multi_batch_create_impl(m, max_queries, max_total_terms, k, out); });
+}
+void vbm25_multi_batch_destroy(vbm25_multi_batch *mb) { delete mb; }
+int vbm25_multi_batch_set_queries(vbm25_multi_batch *mb, const uint32_t *term_ids, const uint32_t *q_off, uint32_t nq) {
+    return guarded([&] { return multi_batch_set_queries_impl(mb, term_ids, q_off, nq); });
+}
+int vbm25_multi_batch_run(vbm25_multi_batch *mb) {
+    return guarded([&] { return multi_batch_run_impl(mb); });
+}
+int vbm25_multi_batch_fetch(vbm25_multi_batch *mb, vbm25_hit *hits, uint32_t *n_hits) {
+    return guarded([&] { return multi_batch_fetch_impl(mb, hits, n_hits); });
+}
+int vbm25_multi_search_batch(vbm25_multi *m, const uint32_t *term_ids, const uint32_t *q_off, uint32_t nq, uint32_t k,
+                             vbm25_hit *hits, uint32_t *n_hits) {
+    return guarded([&]() -> int {
+        if (!m || !q_off) return set_error(VBM25_ERR_INVALID, "NULL argument");
+        if (nq == 0) return k ? VBM25_OK : set_error(VBM25_ERR_INVALID, "number of needed rows is set to 0");
+        vbm25_multi_batch *mb = m->scratch;
+        const uint32_t n_terms = q_off[nq] ? q_off[nq] : 1;
+        if (!mb || mb->k != k || mb->max_queries < nq || mb->max_terms < n_terms) {
+            if (mb) vbm25_multi_batch_destroy(mb);
+            m->scratch = nullptr;
+            if (int rc = multi_batch_create_impl(m, std::max(nq, 16u), std::max(n_terms, 256u), k, &mb)) return rc;
+            m->scratch = mb;
+        }
+        if (int rc = multi_batch_set_queries_impl(mb, term_ids, q_off, nq)) return rc;
+        if (int rc = multi_batch_run_impl(mb)) return rc;
+        return multi_batch_fetch_impl(mb, hits, n_hits);
+    });
 }
 
 }  // extern "C"

@@ -738,6 +738,20 @@ static int vbm25_segment_load_impl(const char *path, vbm25_segment **out) {
     return VBM25_OK;
 }
 
+// The two tables every score goes through, as this library computes them (tests compare them with the reference's:
+// tests/golden/fieldnorm_table.json is generated from bm25.rs:15-272).
+int vbm25_fieldnorm_table(uint32_t *lengths256) {
+    if (!lengths256) return set_error(VBM25_ERR_INVALID, "NULL argument");
+    std::memcpy(lengths256, fieldnorm_lengths(), 256 * sizeof(uint32_t));
+    return VBM25_OK;
+}
+int vbm25_cache_s1(uint32_t n_docs, uint64_t sum_len, double k1, double b, double *s1_256) {
+    if (!s1_256) return set_error(VBM25_ERR_INVALID, "NULL argument");
+    if (n_docs == 0) return set_error(VBM25_ERR_INVALID, "no documents: the average length is 0 / 0");
+    bm25_tables(n_docs, sum_len, k1, b, s1_256);
+    return VBM25_OK;
+}
+
 uint64_t vbm25_query_bytes(const vbm25_index_desc *d, const uint32_t *term_ids, uint32_t n_terms,
                            uint32_t k) {
     uint64_t bytes = 0;
