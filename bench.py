@@ -76,6 +76,101 @@ def cpu_model():
     return "unknown"
 
 
+def lib_sha16(vb):
+    """First 16 hex digits of the sha256 of the libvbm25.so this process has loaded."""
+    import hashlib
+    h = hashlib.sha256()
+    with open(vb.library_path(), "rb") as f:
+        for chunk in iter(lambda: f.read(1 << 20), b""):
+            h.update(chunk)
+    return h.hexdigest()[:16]
+
+
+def committed_traffic(sha16, workload):
+    """HBM bytes per launch of the workload's dominant kernel from profiles/pmc_traffic.json -- rocprofv3 --pmc FETCH_SIZE /
+    WRITE_SIZE passes cannot run inside a timed process, so their summary is committed, keyed by the sha256 of the library
+    they were taken on.  None when the loaded library is another build (the number would not be this kernel's)."""
+    try:
+        table = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))
+        return int(table[sha16][workload]["hbm_bytes_per_launch"])
+    except Exception:
+        return None
+
+
+def extra_workload(vb, name, budget_s, sha16):
+    """The other single-GPU configurations of BASELINE.json inside the same driver-timed run, under a wall-clock budget:
+    C2 (single 3-term query, 1 M documents: C-ABI latencies) and C5 (50 M documents / 100 k Zipf vocabulary / 10-term / top-100:
+    scan_dense_kernel against the roofline).  Fewer steps than a dedicated run and no CPU baseline."""
+    import ctypes as C
+    t_start = time.perf_counter()
+    n_docs, vocab, mean_len, len_mode, zipf_s, nq, nterms, k = WORKLOADS[name]
+    need = {"C2": 15.0, "C5": 170.0}[name]  # build + upload + queries + steps on the round-4 box
+    if budget_s < need:
+        return {"skipped": f"{need:.0f} s needed, {max(0.0, budget_s):.0f} s of --extra-budget-s left"}
+    seg = vb.Segment.synth(n_docs, vocab, mean_len=mean_len, len_mode=len_mode, zipf_s=zipf_s, seed=20260925, threads=usable_cpus())
+    t_build = time.perf_counter() - t_start
+    gix = vb.GpuIndex(seg, device=0)
+    out = {"workload": f"{name}: {n_docs} docs / {vocab} vocab / {nq} x {nterms}-term / top-{k}", "build_s": round(t_build, 2),
+           "index_hbm_bytes": gix.device_bytes}
+    if name == "C2":
+        lt, lo = make_queries(seg, vocab, 400, nterms, seed=7, zipf_s=zipf_s)
+        one = np.array([0, nterms], dtype=np.uint32)
+        L = vb.lib()
+        hb = np.zeros((1, k), dtype=vb.HIT_DTYPE)
+        nbuf = np.zeros(1, dtype=np.uint32)
+        lt = np.ascontiguousarray(lt, dtype=np.uint32)
+        base, po = lt.ctypes.data, C.c_void_p(one.ctypes.data)
+        ph, pn = C.c_void_p(hb.ctypes.data), C.c_void_p(nbuf.ctypes.data)
+        uc = []
+        for q in range(400):
+            pt = C.c_void_p(base + 4 * int(lo[q]))
+            t0 = time.perf_counter()
+            rc = L.vbm25_search_batch(gix.h, pt, po, 1, k, ph, pn)
+            if q >= 20:
+                uc.append(1e6 * (time.perf_counter() - t0))
+            assert rc == 0 and nbuf[0] == k
+        uc.sort()
+        out.update({"c_abi_nq1_us_p50": round(uc[len(uc) // 2], 1), "c_abi_nq1_us_p99": round(uc[int(len(uc) * 0.99)], 1),
+                    "queries_timed": len(uc),
+                    "includes": "vbm25_search_batch(nq = 1) through the bare C entry point: query hand-over, ONE launch, stream synchronisation"})
+    else:
+        import torch
+        nb, steps, warmup = 2, 6, 2
+        shards = [make_queries(seg, vocab, nq, nterms, seed=1 + bi, zipf_s=zipf_s) for bi in range(nb)]
+        algo = [sum(seg.query_bytes(t[o[q]:o[q + 1]], k) for q in range(nq)) for t, o in shards]
+        batches = []
+        for t, o in shards:
+            b = vb.Batch(gix, nq, len(t), k)
+            b.set_queries(t, o)
+            batches.append(b)
+        stream = torch.cuda.current_stream().cuda_stream
+        for i in range(warmup):
+            batches[i % nb].run(stream)
+        torch.cuda.synchronize()
+        for b in batches:
+            b.set_timing(True)
+        t0 = time.perf_counter()
+        for i in range(steps):
+            batches[i % nb].run(stream)
+        torch.cuda.synchronize()
+        elapsed = time.perf_counter() - t0
+        parts = [b.kernel_ms() for b in batches]
+        n_launch = sum(n for _, n in parts)
+        kernel_ms = sum(ms * n for ms, n in parts) / max(1, n_launch)
+        for b in batches:
+            hits, n_hits = b.fetch()
+            assert (n_hits == k).all()
+        a = sum(algo) / len(algo)
+        achieved = a / (kernel_ms * 1e-3) / 1e9
+        out.update({"value": round(nq * steps / elapsed, 1), "unit": "queries/s", "steps": steps, "warmup": warmup,
+                    "ms_per_step": round(1e3 * elapsed / steps, 3),
+                    "roofline": {"bound": "hbm", "kernel": "scan_dense_kernel", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBPS,
+                                 "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": committed_traffic(sha16, name),
+                                 "algorithmic_bytes_per_launch": int(a), "kernel_ms": round(kernel_ms, 3), "launches_timed": n_launch}})
+    out["seconds"] = round(time.perf_counter() - t_start, 1)
+    return out
+
+
 def make_queries(seg, vocab, nq, nterms, seed, zipf_s):
     rng = np.random.default_rng(seed)
     if zipf_s > 0:
@@ -154,6 +249,8 @@ def run(argv=None, scorer_factory=None, backend="nccl"):
                     help="check every query of every batch bit-exact against the oracle (outside the timed region)")
     ap.add_argument("--build-threads", type=int, default=0)
     ap.add_argument("--cache", default="", help="segment file: load if present, else build and save")
+    ap.add_argument("--extra-budget-s", type=float, default=240.0,
+                    help="wall-clock budget for the C2 / C5 lines appended as `extra` (N = 1 only; 0 switches them off)")
     ap.add_argument("--tune", default="", help="development aid: library test switches, name=value[,name=value...] (vbm25_tuning_set)")
     args = ap.parse_args(argv)
 
@@ -165,6 +262,8 @@ def run(argv=None, scorer_factory=None, backend="nccl"):
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
+        if world == 1 and "WORLD_SIZE" not in os.environ and scorer_factory is None:
+            return run_single_process(args, vb)  # one process, --gpus devices behind the C ABI (vbm25_multi_*)
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run")
     on_gpu = scorer_factory is None
     if on_gpu:
@@ -284,15 +383,19 @@ def run(argv=None, scorer_factory=None, backend="nccl"):
     stream_ptr = s_scan.cuda_stream if on_gpu else None
     gather_events, gather_cpu_s = [], [0.0]
     last_gathered = [None]
+    gatherer = vb.sharded.RootGather(n_total, k, dev) if use_dist else None
+    gathered_ev = [None] * nb  # per batch object: its records have left (the scan that rewrites them waits for this)
 
     def step(i):
         b = batches[i % nb]
+        if on_gpu and use_dist and gathered_ev[i % nb] is not None:
+            s_scan.wait_event(gathered_ev[i % nb])  # the batch's result buffer is still being gathered from
         b.run(stream_ptr)
         if not use_dist:
             return
         if not on_gpu:
             t0 = time.perf_counter()
-            last_gathered[0] = vb.sharded.gather_to_root(locals_[i % nb], n_total, k)
+            last_gathered[0] = gatherer(locals_[i % nb])
             gather_cpu_s[0] += time.perf_counter() - t0
             return
         done = s_scan.record_event()
@@ -300,9 +403,10 @@ def run(argv=None, scorer_factory=None, backend="nccl"):
             s_gather.wait_event(done)
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
-            last_gathered[0] = vb.sharded.gather_to_root(locals_[i % nb], n_total, k)
+            last_gathered[0] = gatherer(locals_[i % nb])
             e1.record()
             gather_events.append((e0, e1))
+            gathered_ev[i % nb] = e1
 
     for i in range(args.warmup):
         step(i)
@@ -412,6 +516,7 @@ def run(argv=None, scorer_factory=None, backend="nccl"):
                                "written to pinned host memory), stream synchronisation; search_batch_* adds the Python wrapper"}
 
     result_line = None
+    sha16 = lib_sha16(vb) if on_gpu else None
     if rank == 0:
         ms_per_step = 1e3 * elapsed / args.steps
         dense = zipf_s > 0
@@ -446,14 +551,24 @@ def run(argv=None, scorer_factory=None, backend="nccl"):
             out["roofline"] = {"bound": "hbm", "kernel": "scan_dense_kernel" if dense else "scan_range_kernel",
                                "achieved": round(achieved, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                                "frac": round(achieved / HBM_PEAK_GBPS, 4),
-                               # HBM bytes per launch come from separate rocprofv3 --pmc passes (summaries under
-                               # profiles/); they are not collected inside this run
-                               "traffic": None,
+                               # HBM bytes per launch: separate rocprofv3 --pmc passes (FETCH_SIZE x 2 + WRITE_SIZE, the gfx950
+                               # correction of MI355X_MICROARCH.md), committed in profiles/pmc_traffic.json under the sha256 of
+                               # the library they were taken on; null when this run loaded another build
+                               "traffic": committed_traffic(sha16, args.workload if world == 1 else "C3"),
                                "algorithmic_bytes_per_launch": int(algo),
                                "kernel_ms": round(kernel_ms, 4), "launches_timed": n_launch}
         if world == 1 and not args.no_cpu_baseline and on_gpu:
             oix = oix or oracle_index(seg)
             out["cpu_baseline"] = cpu_baseline(oix, shards[0][0], shards[0][1], k)
+        if on_gpu:
+            out["config"]["libvbm25_sha256_16"] = sha16
+        if world == 1 and on_gpu and not use_dist and args.workload == "C3" and args.extra_budget_s > 0:
+            # the other single-GPU configurations, driver-timed in the same run (the C3 index is released first)
+            del batches, results, gix, oix, seg
+            t_extra = time.perf_counter()
+            extra = {"c2": extra_workload(vb, "C2", args.extra_budget_s, sha16)}
+            extra["c5"] = extra_workload(vb, "C5", args.extra_budget_s - (time.perf_counter() - t_extra), sha16)
+            out["extra"] = extra
         result_line = json.dumps(out)
     if use_dist:
         if rank == 0 and not args.cache and cache and os.path.exists(cache):
@@ -463,6 +578,68 @@ def run(argv=None, scorer_factory=None, backend="nccl"):
         sys.stdout.flush()
         print(result_line, flush=True)
     return use_dist
+
+
+def run_single_process(args, vb):
+    """`python bench.py --gpus N` WITHOUT torch.distributed.run: one process drives N devices through the C ABI
+    (vbm25_multi_*: one host upload, replicas made GPU to GPU, contiguous shards on per-device streams, records straight into
+    the caller's host arrays).  The driver's N > 1 runs come through torch.distributed.run, one rank per GPU; this is the same
+    split as a Rust / C host gets it."""
+    import torch
+    n = args.gpus
+    if not torch.cuda.is_available() or torch.cuda.device_count() < n:
+        raise SystemExit(f"--gpus {n}: {torch.cuda.device_count() if torch.cuda.is_available() else 0} device(s) visible")
+    n_docs, vocab, mean_len, len_mode, zipf_s, nq, nterms, k = WORKLOADS[args.workload]
+    if args.queries:
+        nq = args.queries
+    nb = max(1, args.batches)
+    t0 = time.perf_counter()
+    if args.cache and os.path.exists(args.cache):
+        seg = vb.Segment.load(args.cache)
+    else:
+        seg = vb.Segment.synth(n_docs, vocab, mean_len=mean_len, len_mode=len_mode, zipf_s=zipf_s, seed=20260925,
+                               threads=args.build_threads or usable_cpus())
+    t_build = time.perf_counter() - t0
+    t0 = time.perf_counter()
+    multi = vb.MultiIndex(seg, list(range(n)))
+    t_upload = time.perf_counter() - t0
+    n_total = n * nq
+    sets = [make_queries(seg, vocab, n_total, nterms, seed=1 + bi, zipf_s=zipf_s) for bi in range(nb)]
+    batches = []
+    for t, o in sets:
+        b = vb.MultiBatch(multi, n_total, len(t), k)
+        b.set_queries(t, o)
+        batches.append(b)
+    for i in range(args.warmup):
+        batches[i % nb].run()
+    for b in batches:
+        b.fetch()
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        batches[i % nb].run()
+    results = [b.fetch() for b in batches]  # waits for every device
+    elapsed = time.perf_counter() - t0
+    for hits, n_hits in results:
+        assert (n_hits == k).all(), "missing hits"
+    verified = None
+    if args.verify:
+        oix = oracle_index(seg)
+        for (t, o), (hits, n_hits) in zip(sets, results):
+            ob, onb, _ = oix.search_batch(t, o, k, mode="brute", threads=usable_cpus())
+            assert np.array_equal(n_hits, onb) and hits.tobytes() == ob.tobytes(), "records differ from the oracle"
+        verified = {"queries": int(n_total * nb), "batches": nb}
+    out = {"metric": METRIC, "value": round(n_total * args.steps / elapsed, 1), "unit": "queries/s", "n_gpus": n,
+           "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(1e3 * elapsed / args.steps, 4),
+           "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+           "config": {"workload": f"C4: {n_docs} docs / {vocab} vocab / {nq} x {nterms}-term queries per GPU / top-{k}",
+                      "parallelism": f"ONE process, {n} devices through vbm25_multi_*: {nb} batches of {n_total} queries, contiguous "
+                                     "shards, index replicated GPU to GPU, records downloaded to host arrays inside every step",
+                      "batches_rotated": nb, "build_s": round(t_build, 2), "upload_and_replicate_s": round(t_upload, 2),
+                      "libvbm25_sha256_16": lib_sha16(vb)}}
+    if verified:
+        out["config"]["verified_bit_exact_vs_oracle"] = verified
+    print(json.dumps(out), flush=True)
+    return False
 
 
 def main():

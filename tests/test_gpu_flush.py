@@ -106,6 +106,12 @@ def test_device_build_from_unsorted_mappings_rejects_bad_input():
     args = (1.2, 0.75, c["doc_len"], c["doc_payload"], c["term_key"])
     with pytest.raises(vb.Vbm25Error):  # a token rank beyond the keys
         vb.Segment.build_device_unsorted(*args, np.r_[term, np.uint32(len(c["term_key"]))], np.r_[doc, np.uint32(0)], np.r_[tf, np.uint32(1)])
+    for far in (len(c["term_key"]) + 1, 0x7fffffff, 0xffffffff):  # far beyond them (term_start has n_terms + 1 entries)
+        with pytest.raises(vb.Vbm25Error) as e:
+            vb.Segment.build_device_unsorted(*args, np.r_[term, np.uint32(far)], np.r_[doc, np.uint32(0)], np.r_[tf, np.uint32(1)])
+        assert e.value.code == -1
+    # ... and the device is still usable afterwards
+    vb.Segment.build_device_unsorted(*args, term, doc, tf)
     with pytest.raises(vb.Vbm25Error):  # the same (token, document) twice
         vb.Segment.build_device_unsorted(*args, np.r_[term, term[:1]], np.r_[doc, doc[:1]], np.r_[tf, tf[:1]])
     with pytest.raises(vb.Vbm25Error):  # a token without mappings

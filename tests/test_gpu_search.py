@@ -279,10 +279,10 @@ def test_corrupt_index_is_rejected():
 
 
 def test_correlated_terms_spill_and_abort_paths():
-    """Terms that co-occur in the same documents: almost every posting of a tile collides with
-    a partner, which exercises (a) the joiner's long-list path (more than 64 colliding postings
-    per tile, overflow kept in the HBM spill), (b) the give-up path (more than 512: the item is
-    redone by the dense-window kernel) and (c) documents with three and more addends."""
+    """Terms that co-occur in the same documents: almost every posting of a tile is a second arrival, which exercises
+    (a) scan_range_kernel's row overflow (the tile is undone and planned again with half the blocks), (b) its give-up path
+    (rows overflow even at one block per term: item_failed, the item is redone by scan_many_kernel) and (c) documents with
+    three and more addends."""
     n_docs = 600_000
     rng = np.random.default_rng(42)
     base = np.sort(rng.choice(n_docs, 9000, replace=False)).astype(np.uint32)

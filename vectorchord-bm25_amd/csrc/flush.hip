@@ -451,19 +451,22 @@ int build_device_impl(int device, double k1, double b, uint32_t n_docs, const ui
 __global__ void __launch_bounds__(256) mapping_keys_kernel(uint64_t n, uint32_t n_terms, const uint32_t *term, const uint32_t *doc,
                                                            unsigned long long *key, uint32_t *error_flag) {
     for (uint64_t i = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x) {
-        const uint32_t t = term[i];
-        if (t >= n_terms) atomicOr(error_flag, 1u);
+        uint32_t t = term[i];
+        if (t >= n_terms) {
+            atomicOr(error_flag, 1u);
+            t = n_terms ? n_terms - 1u : 0u;  // (clamped: nothing downstream may index with it; the host rejects the input)
+        }
         key[i] = (unsigned long long)t << 32 | doc[i];
     }
 }
 // sorted keys -> document column + the first mapping of every token (CSR starts)
-__global__ void __launch_bounds__(256) mapping_split_kernel(uint64_t n, const unsigned long long *key, uint32_t *doc,
+__global__ void __launch_bounds__(256) mapping_split_kernel(uint64_t n, uint32_t n_terms, const unsigned long long *key, uint32_t *doc,
                                                             unsigned long long *term_start) {
     for (uint64_t i = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x) {
         const unsigned long long k = key[i];
         doc[i] = (uint32_t)k;
         const uint32_t t = (uint32_t)(k >> 32);
-        if (i == 0 || (uint32_t)(key[i - 1] >> 32) != t) term_start[t] = i;
+        if (t < n_terms && (i == 0 || (uint32_t)(key[i - 1] >> 32) != t)) term_start[t] = i;
     }
 }
 
@@ -498,6 +501,11 @@ int build_device_unsorted_impl(int device, double k1, double b, uint32_t n_docs,
         mapping_keys_kernel<<<2048, 256>>>(n_map, n_terms, d_term.as<uint32_t>(), d_doc.as<uint32_t>(), d_key.as<unsigned long long>(),
                                            d_err.as<uint32_t>());
         FL_TRY(hipGetLastError());
+        {   // a token rank >= n_terms: rejected BEFORE the sort and the split (term_start has n_terms + 1 entries)
+            uint32_t bad = 0;
+            FL_TRY(hipMemcpy(&bad, d_err.p, 4, hipMemcpyDeviceToHost));
+            if (bad) return set_error(VBM25_ERR_INVALID, "a mapping names a token >= n_terms");
+        }
         int end_bit = 32;  // the bits of the key that can differ: the document and as much of the token as n_terms needs
         while (end_bit < 64 && (uint64_t(n_terms) >> (end_bit - 32)) != 0) ++end_bit;
         hipcub::DoubleBuffer<unsigned long long> keys(d_key.as<unsigned long long>(), d_key2.as<unsigned long long>());
@@ -506,7 +514,7 @@ int build_device_unsorted_impl(int device, double k1, double b, uint32_t n_docs,
         FL_TRY(hipcub::DeviceRadixSort::SortPairs(nullptr, tmp_bytes, keys, vals, (int)n_map, 0, end_bit));
         FL_TRY(d_tmp.alloc(tmp_bytes));
         FL_TRY(hipcub::DeviceRadixSort::SortPairs(d_tmp.p, tmp_bytes, keys, vals, (int)n_map, 0, end_bit));
-        mapping_split_kernel<<<2048, 256>>>(n_map, keys.Current(), d_doc.as<uint32_t>(), d_ts.as<unsigned long long>());
+        mapping_split_kernel<<<2048, 256>>>(n_map, n_terms, keys.Current(), d_doc.as<uint32_t>(), d_ts.as<unsigned long long>());
         FL_TRY(hipGetLastError());
         uint32_t flag = 0;
         FL_TRY(hipMemcpy(&flag, d_err.p, 4, hipMemcpyDeviceToHost));

@@ -122,7 +122,11 @@ __global__ void __launch_bounds__(PLAN_WG) plan_kernel(DevIndex ix, DevBatch bt,
     const uint32_t q0 = min(bt.nq, tid * per), q1 = min(bt.nq, q0 + per);
     // per-launch state of the scan kernels (saves two memset launches per step)
     for (uint32_t i = tid; i < bt.nq; i += PLAN_WG) bt.theta[i] = 0;
-    for (uint32_t i = tid; i < max_items; i += PLAN_WG) bt.item_failed[i] = 0;
+    for (uint32_t i = tid; i < max_items; i += PLAN_WG) {
+        bt.item_failed[i] = 0;
+        bt.item_order[i] = i;  // (every slot defined even when the item count overflows: error_flag 2)
+    }
+    __syncthreads();
     if (bt.lpi > 1)  // lists a kernel does not write must read as empty
         for (uint32_t i = tid; i < max_items * bt.lpi; i += PLAN_WG) bt.res_cnt[i] = 0;
     if (tid == 0) {

@@ -3,7 +3,7 @@
 // search.hip inside namespace vbm25, after scan_range.h (whose helpers it uses).
 //
 // One 8-wave workgroup per work item (query x doc range), persistent, items from bt.work_ctr[1].  The item is
-// cut into WINDOWS of <= D_W consecutive documents with one 32-bit FIXED-POINT accumulator per document in LDS
+// cut into WINDOWS of <= D_W consecutive documents with one 16-bit FIXED-POINT accumulator per document in LDS (two per word)
 // (integer LDS atomics run at full rate on gfx950; float LDS atomics measured three times slower than the
 // whole rest of a window).  A window is
 //
@@ -34,7 +34,7 @@
 // The integer sums only SELECT; every score that is compared, kept or returned is the exact f64 sum, so results
 // are bit-identical to the other kernels'.  Bounds: s0 is rounded up to f32 and carries a factor 1 + 2^-19
 // (five f32 roundings + v_rcp_f32's 1 ulp < 2^-21 relative), s1 is rounded down; the scale is a power of two with
-// scale x (sum of the token upper bounds) < 2^31; truncation to an integer is covered by the + 1; the integer sum is
+// scale x (sum of the token upper bounds) < 2^15 (the accumulators are 16 bits wide); truncation to an integer is covered by the + 1; the integer sum is
 // exact.  So  acc >= scale x score  and  score >= (acc - m) / (scale (1 + 2^-18)).
 // oracle/dense_model.inc is a scalar CPU model of this scheme (tests/test_dense_model.py).
 //

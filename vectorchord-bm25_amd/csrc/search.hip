@@ -26,6 +26,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <memory>
+#include <mutex>
 #include <string>
 #include <vector>
 
@@ -221,6 +222,11 @@ struct Tuning {
     uint32_t generation = 0;       // bumped by every vbm25_tuning_set / reset: vbm25_search_batch's batch object is rebuilt when it is stale
 };
 static Tuning g_tune;
+static std::mutex g_tune_mutex;  // (set / reset / the copy a new batch takes)
+static Tuning tuning_snapshot() {
+    std::lock_guard<std::mutex> g(g_tune_mutex);
+    return g_tune;
+}
 
 struct vbm25_batch {
     vbm25_index *index = nullptr;
@@ -544,7 +550,7 @@ static int vbm25_batch_create_impl(vbm25_index *ix, uint32_t max_queries, uint32
     bt->max_queries = max_queries;
     bt->max_terms = max_total_terms;
     bt->k = k;
-    bt->tune = g_tune;
+    bt->tune = tuning_snapshot();
     bt->h_dense.resize(max_queries);
     bt->h_postings.resize(max_queries);
     // Routing by k: k <= 256 -- sparse queries of <= 16 terms: scan_range_kernel, dense ones: scan_dense_kernel, the rest and
@@ -751,6 +757,9 @@ static int vbm25_batch_set_queries_impl(vbm25_batch *bt, const uint32_t *term_id
         }
         bt->range_grid = uint32_t(std::min<unsigned long long>(std::max<unsigned long long>(items, 1), bt->tune.team ? 1024u : std::max(1u, bt->tune.range_grid)));
         bt->dense_grid = uint32_t(std::min<unsigned long long>(std::max<unsigned long long>(items, 1), std::max(1u, bt->tune.dense_grid)));
+#ifdef VBM25_PROFILE
+        bt->range_grid = std::min<uint32_t>(bt->range_grid, R_GRID);  // (the phase counters are sized for R_GRID workgroups)
+#endif
     }
     return VBM25_OK;
 }
@@ -1100,6 +1109,7 @@ int vbm25_evaluate_batch(vbm25_index *ix, const uint32_t *q_terms, uint32_t n_q,
 // team_size, team_items.
 int vbm25_tuning_set(const char *name, long long value) {
     if (!name) return set_error(VBM25_ERR_INVALID, "NULL argument");
+    std::lock_guard<std::mutex> guard(g_tune_mutex);
     const std::string n(name);
     if (n == "dense_x1000") g_tune.dense_x1000 = value;
     else if (n == "dense") g_tune.dense = value != 0;
@@ -1122,6 +1132,7 @@ int vbm25_tuning_set(const char *name, long long value) {
     return VBM25_OK;
 }
 void vbm25_tuning_reset(void) {
+    std::lock_guard<std::mutex> guard(g_tune_mutex);
     const uint32_t gen = g_tune.generation + 1u;
     g_tune = Tuning();
     g_tune.generation = gen;
@@ -1215,7 +1226,7 @@ static int vbm25_search_batch_impl(vbm25_index *ix, const uint32_t *term_ids, co
     // the shape fits (device buffers of a batch are far more expensive to create than a search)
     vbm25_batch *bt = ix->scratch;
     const uint32_t n_terms = q_off[nq] ? q_off[nq] : 1;
-    if (!bt || bt->k != k || bt->max_queries < nq || bt->max_terms < n_terms || bt->tune.generation != g_tune.generation) {
+    if (!bt || bt->k != k || bt->max_queries < nq || bt->max_terms < n_terms || bt->tune.generation != tuning_snapshot().generation) {
         if (bt) vbm25_batch_destroy(bt);
         ix->scratch = nullptr;
         if (int rc = vbm25_batch_create(ix, std::max(nq, 16u), std::max(n_terms, 256u), k, &bt)) return rc;

@@ -233,10 +233,15 @@ void parallel_tasks(size_t n_tasks, int threads, F &&fn) {
         }
     };
     std::vector<std::thread> pool;
+    pool.reserve(size_t(threads > 1 ? threads - 1 : 0));  // (no reallocation -- no bad_alloc -- while joinable threads sit in it)
     try {
         for (int t = 1; t < threads; ++t) pool.emplace_back(worker, t);
     } catch (const std::system_error &) {
         // no more threads to be had (EAGAIN): not an error -- the ones that exist and this one drain the queue
+    } catch (...) {  // anything else: stop the queue, join what runs, pass it on (a joinable std::thread destroyed = std::terminate)
+        next.store(n_tasks, std::memory_order_relaxed);
+        for (auto &th : pool) th.join();
+        throw;
     }
     worker(0);
     for (auto &th : pool) th.join();
