@@ -104,12 +104,12 @@ def extra_workload(vb, name, budget_s, sha16):
     import ctypes as C
     t_start = time.perf_counter()
     n_docs, vocab, mean_len, len_mode, zipf_s, nq, nterms, k = WORKLOADS[name]
-    need = {"C2": 15.0, "C5": 170.0}[name]  # build + upload + queries + steps on the round-4 box
+    need = {"C2": 10.0, "C5": 60.0}[name]  # generation + index + queries + steps on the round-4 box
     if budget_s < need:
         return {"skipped": f"{need:.0f} s needed, {max(0.0, budget_s):.0f} s of --extra-budget-s left"}
-    seg = vb.Segment.synth(n_docs, vocab, mean_len=mean_len, len_mode=len_mode, zipf_s=zipf_s, seed=20260925, threads=usable_cpus())
+    seg = vb.DeviceSegment.synth(n_docs, vocab, mean_len=mean_len, len_mode=len_mode, zipf_s=zipf_s, seed=20260925, device=0)
     t_build = time.perf_counter() - t_start
-    gix = vb.GpuIndex(seg, device=0)
+    gix = vb.GpuIndex(seg)
     out = {"workload": f"{name}: {n_docs} docs / {vocab} vocab / {nq} x {nterms}-term / top-{k}", "build_s": round(t_build, 2),
            "index_hbm_bytes": gix.device_bytes}
     if name == "C2":
@@ -194,9 +194,12 @@ def make_queries(seg, vocab, nq, nterms, seed, zipf_s):
 
 
 def oracle_index(seg):
-    """The checker (oracle/): only --verify and the cpu_baseline leg use it."""
+    """The checker (oracle/): only --verify and the cpu_baseline leg use it.  A segment that lives in HBM is downloaded for it."""
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import orc
+
+    if hasattr(seg, "download"):
+        seg = seg.download()
 
     return orc.OracleIndex.from_arrays(seg.meta(), seg.arrays())
 
@@ -298,7 +301,10 @@ def run(argv=None, scorer_factory=None, backend="nccl"):
     threads = args.build_threads or usable_cpus()
     t0 = time.perf_counter()
     cache = args.cache
-    if use_dist and not cache:
+    device_build = on_gpu and not cache  # generated and sealed in HBM, every rank on its own device (deterministic: the same corpus)
+    if device_build:
+        seg = vb.DeviceSegment.synth(n_docs, vocab, mean_len=mean_len, len_mode=len_mode, zipf_s=zipf_s, seed=20260925, device=local_rank)
+    elif use_dist and not cache:
         # one node: rank 0 builds the (deterministic) segment once, the other ranks load it
         import shutil
         need = 6 * n_docs * mean_len  # generous bound of the segment file size
@@ -312,7 +318,9 @@ def run(argv=None, scorer_factory=None, backend="nccl"):
         if rank == 0 and os.path.exists(cache):
             os.remove(cache)
         dist.barrier()
-    if use_dist and rank != 0:
+    if device_build:
+        pass
+    elif use_dist and rank != 0:
         dist.barrier()  # rank 0 has written the file
         seg = vb.Segment.load(cache)
     else:
@@ -327,7 +335,7 @@ def run(argv=None, scorer_factory=None, backend="nccl"):
             dist.barrier()
     t_build = time.perf_counter() - t0
     t0 = time.perf_counter()
-    gix = vb.GpuIndex(seg, device=local_rank) if on_gpu else None
+    gix = (vb.GpuIndex(seg) if device_build else vb.GpuIndex(seg, device=local_rank)) if on_gpu else None
     t_upload = time.perf_counter() - t0
 
     # ---- the batches: rank 0 makes all world x nq queries of each, broadcasts the descriptors, every rank keeps its shard
@@ -534,7 +542,9 @@ def run(argv=None, scorer_factory=None, backend="nccl"):
                        "doc_length": "lognormal(ln 80, 0.6) clamp [8,2000]" if len_mode == 1 else f"fixed {mean_len}",
                        "token_distribution": f"zipf({zipf_s})" if zipf_s > 0 else "uniform",
                        "k1": 1.2, "b": 0.75, "index_hbm_bytes": gix.device_bytes if on_gpu else None,
-                       "postings": int(seg.arrays()["term_df"].astype(np.int64).sum()),
+                       "postings": int(seg.n_postings if device_build else seg.arrays()["term_df"].astype(np.int64).sum()),
+                       "corpus_built": "on the device (vbm25_device_segment_synth + vbm25_index_create_from_device)" if device_build
+                                       else "on the host (vbm25_segment_synth) and uploaded",
                        "parallelism": f"{nb} batches of {n_total} queries, each sharded over {world} GPU(s), index replicated",
                        "build_s": round(t_build, 2), "upload_s": round(t_upload, 2),
                        "scatter_ms": round(scatter_ms, 3), "gather_ms": round(gather_ms, 4),

@@ -295,6 +295,33 @@ int vbm25_evaluate_batch(vbm25_index *, const uint32_t *q_terms, uint32_t n_q_te
                          double *scores);
 
 /* ------------------------------------------------------------------------
+ * Device-resident build (SURVEY 8(f)-1 without the round trip): the sealed segment is encoded in HBM and STAYS there
+ * (vbm25_device_segment); vbm25_index_create_from_device makes the index of it with device-to-device copies and
+ * device-side derivation -- no posting crosses the PCIe link.  (flush.rs:40-158, io.rs:244-282.)
+ *
+ * vbm25_device_segment_build: arguments and result of vbm25_segment_build_device, kept on `device`.
+ * vbm25_device_segment_synth: the synthetic corpus of vbm25_segment_synth GENERATED on the device (same model, same
+ * counter-based generator; the device's log / exp round differently from libm's in a handful of draws per billion, so
+ * the corpus has the same distribution but is not bit for bit the host generator's).
+ * vbm25_device_segment_download: the host copy (a vbm25_segment like any other: byte-identical to what the host builder
+ * makes of the same mappings).  _token_terms / _query_bytes: as vbm25_segment_synth_token_terms / vbm25_query_bytes.
+ * ---------------------------------------------------------------------- */
+typedef struct vbm25_device_segment vbm25_device_segment;
+int vbm25_device_segment_build(int device, double k1, double b, uint32_t n_docs, const uint32_t *doc_len,
+                               const uint16_t *doc_payload, uint32_t n_terms, const uint8_t *term_key,
+                               const uint64_t *term_start, const uint32_t *post_doc, const uint32_t *post_tf,
+                               vbm25_device_segment **out);
+int vbm25_device_segment_synth(const vbm25_synth_params *params, int device, vbm25_device_segment **out);
+int vbm25_device_segment_download(const vbm25_device_segment *, vbm25_segment **out);
+int vbm25_device_segment_token_terms(const vbm25_device_segment *, const uint32_t *tokens, uint32_t n, uint32_t *term_ids);
+uint64_t vbm25_device_segment_query_bytes(const vbm25_device_segment *, const uint32_t *term_ids, uint32_t n_terms, uint32_t k);
+int vbm25_device_segment_info(const vbm25_device_segment *, uint32_t *n_docs, uint32_t *n_terms, uint32_t *n_blocks,
+                              uint64_t *n_postings);
+void vbm25_device_segment_free(vbm25_device_segment *);
+/* The index of a device segment, on the segment's device; the segment is left as it was. */
+int vbm25_index_create_from_device(const vbm25_device_segment *, vbm25_index **out);
+
+/* ------------------------------------------------------------------------
  * Several GPUs of one node: independent queries shard
  * across the devices, the index is replicated.  vbm25_multi_create uploads the
  * flattened segment to devices[0] ONCE and makes the other replicas GPU to GPU

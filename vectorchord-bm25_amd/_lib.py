@@ -78,6 +78,14 @@ ABI = {
     "vbm25_batch_set_timing": (i32, [vp, i32]),
     "vbm25_batch_kernel_ms": (i32, [vp, vp, vp]),
     "vbm25_evaluate_batch": (i32, [vp, vp, u32, u32, vp, vp, vp, vp]),
+    "vbm25_device_segment_build": (i32, [i32, C.c_double, C.c_double, u32, vp, vp, u32, vp, vp, vp, vp, vp]),
+    "vbm25_device_segment_synth": (i32, [vp, i32, vp]),
+    "vbm25_device_segment_download": (i32, [vp, vp]),
+    "vbm25_device_segment_token_terms": (i32, [vp, vp, u32, vp]),
+    "vbm25_device_segment_query_bytes": (u64, [vp, vp, u32, u32]),
+    "vbm25_device_segment_info": (i32, [vp, vp, vp, vp, vp]),
+    "vbm25_device_segment_free": (None, [vp]),
+    "vbm25_index_create_from_device": (i32, [vp, vp]),
     "vbm25_multi_create": (i32, [vp, vp, i32, vp]),
     "vbm25_multi_destroy": (None, [vp]),
     "vbm25_multi_device_count": (i32, [vp]),

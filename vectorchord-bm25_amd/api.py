@@ -182,6 +182,59 @@ class Segment:
         return int(lib().vbm25_query_bytes(C.byref(self.desc), _p(term_ids), len(term_ids), k))
 
 
+class DeviceSegment:
+    """A sealed segment that lives in HBM (vbm25_device_segment): built or generated on the device, never downloaded unless
+    asked (download() -> Segment).  GpuIndex(device_segment) makes the index of it without a round trip through the host."""
+
+    def __init__(self, handle):
+        self.h = handle
+        nd, nt, nb, npost = C.c_uint32(), C.c_uint32(), C.c_uint32(), C.c_uint64()
+        check(lib().vbm25_device_segment_info(self.h, C.byref(nd), C.byref(nt), C.byref(nb), C.byref(npost)))
+        self.n_docs, self.n_terms, self.n_blocks, self.n_postings = nd.value, nt.value, nb.value, npost.value
+
+    @classmethod
+    def synth(cls, n_docs, vocab, mean_len=100, len_mode=1, zipf_s=0.0, k1=1.2, b=0.75, seed=20260925, device=0):
+        p = SynthParams(n_docs, vocab, mean_len, len_mode, zipf_s, k1, b, seed, 0, 0)
+        out = C.c_void_p()
+        check(lib().vbm25_device_segment_synth(C.byref(p), device, C.byref(out)))
+        return cls(out)
+
+    @classmethod
+    def build(cls, k1, b, doc_len, doc_payload, term_key, term_start, post_doc, post_tf, device=0):
+        doc_len = np.ascontiguousarray(doc_len, dtype=np.uint32)
+        doc_payload = np.ascontiguousarray(doc_payload, dtype=np.uint16)
+        term_key = np.ascontiguousarray(term_key, dtype=np.uint8)
+        term_start = np.ascontiguousarray(term_start, dtype=np.uint64)
+        post_doc = np.ascontiguousarray(post_doc, dtype=np.uint32)
+        post_tf = np.ascontiguousarray(post_tf, dtype=np.uint32)
+        out = C.c_void_p()
+        check(lib().vbm25_device_segment_build(device, k1, b, len(doc_len), _p(doc_len), _p(doc_payload), len(term_start) - 1,
+                                               _p(term_key), _p(term_start), _p(post_doc), _p(post_tf), C.byref(out)))
+        return cls(out)
+
+    def download(self):
+        out = C.c_void_p()
+        check(lib().vbm25_device_segment_download(self.h, C.byref(out)))
+        return Segment(out)
+
+    def token_terms(self, tokens):
+        tokens = np.ascontiguousarray(tokens, dtype=np.uint32)
+        out = np.zeros(len(tokens), dtype=np.uint32)
+        check(lib().vbm25_device_segment_token_terms(self.h, _p(tokens), len(tokens), _p(out)))
+        return out
+
+    def query_bytes(self, term_ids, k):
+        term_ids = np.ascontiguousarray(term_ids, dtype=np.uint32)
+        return int(lib().vbm25_device_segment_query_bytes(self.h, _p(term_ids), len(term_ids), k))
+
+    def __del__(self):
+        try:
+            if self.h:
+                lib().vbm25_device_segment_free(self.h)
+        except Exception:
+            pass
+
+
 def desc_from_arrays(meta, arrays):
     """IndexDesc over caller-owned numpy arrays (returns (desc, keepalive))."""
     keep = {}
@@ -200,8 +253,12 @@ class GpuIndex:
     """HBM-resident sealed segment (vbm25_index)."""
 
     def __init__(self, segment_or_desc, device=0, keepalive=None):
-        desc = segment_or_desc.desc if isinstance(segment_or_desc, Segment) else segment_or_desc
         self.h = C.c_void_p()
+        if isinstance(segment_or_desc, DeviceSegment):  # already in HBM: vbm25_index_create_from_device (on the segment's device)
+            self.n_terms, self.n_docs = segment_or_desc.n_terms, segment_or_desc.n_docs
+            check(lib().vbm25_index_create_from_device(segment_or_desc.h, C.byref(self.h)))
+            return
+        desc = segment_or_desc.desc if isinstance(segment_or_desc, Segment) else segment_or_desc
         self.n_terms = desc.n_terms
         self.n_docs = desc.n_docs
         check(lib().vbm25_index_create(C.byref(desc), device, C.byref(self.h)))

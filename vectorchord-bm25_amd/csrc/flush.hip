@@ -18,11 +18,14 @@
 #include <hipcub/hipcub.hpp>
 
 #include <algorithm>
+#include <cmath>
+#include <cstdio>
 #include <cstring>
 #include <memory>
 #include <vector>
 
 #include "vbm25_internal.h"
+#include "device_segment.h"
 
 namespace {
 
@@ -45,6 +48,10 @@ struct DBuf {
     T *as() const {
         return static_cast<T *>(p);
     }
+};
+
+struct WidenU32 {
+    __host__ __device__ unsigned long long operator()(uint32_t v) const { return v; }
 };
 
 struct FlushArgs {
@@ -286,14 +293,27 @@ __global__ void __launch_bounds__(256) doc_kernel(uint32_t n_docs, const uint32_
     if ((threadIdx.x & 63) == 0) atomicAdd(sum_len, local);
 }
 
-// dev_doc / dev_tf != nullptr: the mappings are already on the device, sorted (vbm25_segment_build_device_unsorted);
-// post_doc / post_tf are not read then.
-int build_device_impl(int device, double k1, double b, uint32_t n_docs, const uint32_t *doc_len, const uint16_t *doc_payload,
-                      uint32_t n_terms, const uint8_t *term_key, const uint64_t *term_start, const uint32_t *post_doc,
-                      const uint32_t *post_tf, vbm25_segment **out, const uint32_t *dev_doc = nullptr, const uint32_t *dev_tf = nullptr) {
-    if (!out) return set_error(VBM25_ERR_INVALID, "out is NULL");
-    *out = nullptr;
-    if (!doc_len || !doc_payload || !term_start || (n_terms && (!term_key || ((!post_doc || !post_tf) && (!dev_doc || !dev_tf)))))
+__global__ void __launch_bounds__(256) gather_u32_kernel(uint32_t n, const uint32_t *idx, const uint32_t *src, uint32_t *dst) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) dst[i] = src[idx[i]];
+}
+// synthetic ctids (fetcher.rs:218-225's layout: 64 tuples per heap block)
+__global__ void __launch_bounds__(256) synth_payload_kernel(uint32_t n_docs, uint16_t *payload) {
+    for (uint32_t d = blockIdx.x * blockDim.x + threadIdx.x; d < n_docs; d += gridDim.x * blockDim.x) {
+        const uint32_t blk = d / 64;
+        payload[3ull * d + 0] = (uint16_t)(blk >> 16);
+        payload[3ull * d + 1] = (uint16_t)(blk & 0xffff);
+        payload[3ull * d + 2] = (uint16_t)(d % 64 + 1);
+    }
+}
+
+// The encode, everything left in HBM (vbm25_device_segment).  Inputs on the host, or already on the device: dev_len (document
+// lengths), dev_doc / dev_tf (the mappings, sorted by (token, document)); doc_payload == nullptr: synthetic ctids.
+int build_device_core(int device, double k1, double b, uint32_t n_docs, const uint32_t *doc_len, const uint32_t *dev_len,
+                      const uint16_t *doc_payload, uint32_t n_terms, const uint8_t *term_key, const uint64_t *term_start,
+                      const uint32_t *post_doc, const uint32_t *post_tf, const uint32_t *dev_doc, const uint32_t *dev_tf,
+                      std::unique_ptr<vbm25_device_segment> &out) {
+    if ((!doc_len && !dev_len) || !term_start || (n_terms && (!term_key || ((!post_doc || !post_tf) && (!dev_doc || !dev_tf)))))
         return set_error(VBM25_ERR_INVALID, "NULL argument");
     if (!n_docs) return set_error(VBM25_ERR_INVALID, "segment without documents");
     if (!(k1 >= 1.2 && k1 <= 2.0) || !(b >= 0.0 && b <= 1.0))  // types.rs:18-45
@@ -307,96 +327,102 @@ int build_device_impl(int device, double k1, double b, uint32_t n_docs, const ui
     if (device < 0 || device >= n_dev) return set_error(VBM25_ERR_INVALID, "device %d out of range (%d devices)", device, n_dev);
     FL_TRY(hipSetDevice(device));
 
-    auto seg = std::make_unique<vbm25_segment>();
-    seg->k1 = k1;
-    seg->b = b;
-    seg->n_docs = n_docs;
-    seg->n_terms = n_terms;
-    seg->term_key.assign(term_key, term_key + 16ull * n_terms);
-    seg->doc_payload.assign(doc_payload, doc_payload + 3ull * n_docs);
-    seg->term_first_block.resize(size_t(n_terms) + 1);
+    auto ds = std::make_unique<vbm25_device_segment>();
+    ds->device = device;
+    ds->k1 = k1;
+    ds->b = b;
+    ds->n_docs = n_docs;
+    ds->n_terms = n_terms;
+    ds->term_key.assign(term_key, term_key + 16ull * n_terms);
+    ds->term_first_block.resize(size_t(n_terms) + 1);
+    ds->term_df.resize(n_terms);
     uint64_t nb = 0;
     for (uint32_t t = 0; t < n_terms; ++t) {
         if (term_start[t + 1] <= term_start[t]) return set_error(VBM25_ERR_INVALID, "term %u has no postings", t);
-        seg->term_first_block[t] = uint32_t(nb);
+        if (term_start[t + 1] - term_start[t] > 0xffffffffull) return set_error(VBM25_ERR_UNSUPPORTED, "a token with more than 2^32 mappings");
+        ds->term_first_block[t] = uint32_t(nb);
+        ds->term_df[t] = uint32_t(term_start[t + 1] - term_start[t]);
         nb += (term_start[t + 1] - term_start[t] + 127) / 128;
         if (nb > 0xfffffff0ull) return set_error(VBM25_ERR_UNSUPPORTED, "more than 2^32 blocks");
     }
-    seg->term_first_block[n_terms] = uint32_t(nb);
-    const uint32_t n_blocks = seg->n_blocks = uint32_t(nb);
+    ds->term_first_block[n_terms] = uint32_t(nb);
+    const uint32_t n_blocks = ds->n_blocks = uint32_t(nb);
     const uint64_t n_post = n_terms ? term_start[n_terms] : 0;
 
-    DBuf d_len, d_fnlen, d_fn, d_sum, d_ts, d_tfb, d_pd, d_pt, d_denom, d_err;
-    DBuf b_min, b_max, b_wtf, b_len8, b_off8, b_n, b_wfn, b_md, b_mt, b_wval, t_wfn, t_wtf, t_df, d_tmp, d_blob;
-    FL_TRY(d_len.alloc(4ull * n_docs));
+    DBuf d_len, d_fnlen, d_sum, d_ts, d_pd, d_pt, d_denom, d_err, b_len8, b_wval, d_tmp, d_bnd;
     FL_TRY(d_fnlen.alloc(4 * 256));
-    FL_TRY(d_fn.alloc(n_docs));
+    FL_TRY(ds->d_doc_fieldnorm.alloc(n_docs));
+    FL_TRY(ds->d_doc_payload.alloc(6ull * n_docs));
     FL_TRY(d_sum.alloc(8));
     FL_TRY(d_err.alloc(4));
-    FL_TRY(hipMemcpy(d_len.p, doc_len, 4ull * n_docs, hipMemcpyHostToDevice));
+    if (!dev_len) {
+        FL_TRY(d_len.alloc(4ull * n_docs));
+        FL_TRY(hipMemcpy(d_len.p, doc_len, 4ull * n_docs, hipMemcpyHostToDevice));
+        dev_len = d_len.as<uint32_t>();
+    }
+    if (doc_payload) FL_TRY(hipMemcpy(ds->d_doc_payload.p, doc_payload, 6ull * n_docs, hipMemcpyHostToDevice));
+    else synth_payload_kernel<<<1024, 256>>>(n_docs, ds->d_doc_payload.as<uint16_t>());
     FL_TRY(hipMemcpy(d_fnlen.p, fieldnorm_lengths(), 4 * 256, hipMemcpyHostToDevice));
     FL_TRY(hipMemset(d_sum.p, 0, 8));
     FL_TRY(hipMemset(d_err.p, 0, 4));
-    doc_kernel<<<1024, 256>>>(n_docs, d_len.as<uint32_t>(), d_fnlen.as<uint32_t>(), d_fn.as<uint8_t>(), d_sum.as<unsigned long long>());
+    doc_kernel<<<1024, 256>>>(n_docs, dev_len, d_fnlen.as<uint32_t>(), ds->d_doc_fieldnorm.as<uint8_t>(), d_sum.as<unsigned long long>());
     FL_TRY(hipGetLastError());
     unsigned long long sum_len = 0;
     FL_TRY(hipMemcpy(&sum_len, d_sum.p, 8, hipMemcpyDeviceToHost));
-    seg->sum_len = sum_len;
-    seg->doc_fieldnorm.resize(n_docs);
-    FL_TRY(hipMemcpy(seg->doc_fieldnorm.data(), d_fn.p, n_docs, hipMemcpyDeviceToHost));
+    ds->sum_len = sum_len;
     double denom[256];
     bm25_tables(n_docs, sum_len, k1, b, denom);
 
     FL_TRY(d_ts.alloc(8ull * (n_terms + 1)));
-    FL_TRY(d_tfb.alloc(4ull * (n_terms + 1)));
+    FL_TRY(ds->d_term_first_block.alloc(4ull * (n_terms + 1)));
     if (!dev_doc) {
         FL_TRY(d_pd.alloc(4ull * n_post));
         FL_TRY(d_pt.alloc(4ull * n_post));
     }
     FL_TRY(d_denom.alloc(8 * 256));
     FL_TRY(hipMemcpy(d_ts.p, term_start, 8ull * (n_terms + 1), hipMemcpyHostToDevice));
-    FL_TRY(hipMemcpy(d_tfb.p, seg->term_first_block.data(), 4ull * (n_terms + 1), hipMemcpyHostToDevice));
+    FL_TRY(hipMemcpy(ds->d_term_first_block.p, ds->term_first_block.data(), 4ull * (n_terms + 1), hipMemcpyHostToDevice));
     if (n_post && !dev_doc) {
         FL_TRY(hipMemcpy(d_pd.p, post_doc, 4ull * n_post, hipMemcpyHostToDevice));
         FL_TRY(hipMemcpy(d_pt.p, post_tf, 4ull * n_post, hipMemcpyHostToDevice));
     }
     FL_TRY(hipMemcpy(d_denom.p, denom, 8 * 256, hipMemcpyHostToDevice));
-    FL_TRY(b_min.alloc(4ull * n_blocks));
-    FL_TRY(b_max.alloc(4ull * n_blocks));
-    FL_TRY(b_wtf.alloc(4ull * n_blocks));
+    FL_TRY(ds->d_blk_min.alloc(4ull * n_blocks));
+    FL_TRY(ds->d_blk_max.alloc(4ull * n_blocks));
+    FL_TRY(ds->d_blk_wand_tf.alloc(4ull * n_blocks));
     FL_TRY(b_len8.alloc(4ull * (n_blocks + 1)));
-    FL_TRY(b_off8.alloc(4ull * (n_blocks + 1)));
-    FL_TRY(b_n.alloc(n_blocks));
-    FL_TRY(b_wfn.alloc(n_blocks));
-    FL_TRY(b_md.alloc(n_blocks));
-    FL_TRY(b_mt.alloc(n_blocks));
+    FL_TRY(ds->d_blk_off8.alloc(4ull * (n_blocks + 1)));
+    FL_TRY(ds->d_blk_n.alloc(n_blocks));
+    FL_TRY(ds->d_blk_wand_fn.alloc(n_blocks));
+    FL_TRY(ds->d_blk_meta_doc.alloc(n_blocks));
+    FL_TRY(ds->d_blk_meta_tf.alloc(n_blocks));
     FL_TRY(b_wval.alloc(8ull * n_blocks));
-    FL_TRY(t_wfn.alloc(n_terms));
-    FL_TRY(t_wtf.alloc(4ull * n_terms));
-    FL_TRY(t_df.alloc(4ull * n_terms));
+    FL_TRY(ds->d_term_wand_fn.alloc(n_terms));
+    FL_TRY(ds->d_term_wand_tf.alloc(4ull * n_terms));
+    FL_TRY(ds->d_term_df.alloc(4ull * n_terms));
     FlushArgs a{};
     a.n_docs = n_docs;
     a.n_terms = n_terms;
     a.n_blocks = n_blocks;
     a.term_start = d_ts.as<uint64_t>();
-    a.term_first_block = d_tfb.as<uint32_t>();
+    a.term_first_block = ds->d_term_first_block.as<uint32_t>();
     a.post_doc = dev_doc ? dev_doc : d_pd.as<uint32_t>();
     a.post_tf = dev_tf ? dev_tf : d_pt.as<uint32_t>();
-    a.fieldnorm = d_fn.as<uint8_t>();
+    a.fieldnorm = ds->d_doc_fieldnorm.as<uint8_t>();
     a.denom = d_denom.as<double>();
     a.kp1 = k1 + 1.0;
-    a.min_doc = b_min.as<uint32_t>();
-    a.max_doc = b_max.as<uint32_t>();
-    a.wand_tf = b_wtf.as<uint32_t>();
+    a.min_doc = ds->d_blk_min.as<uint32_t>();
+    a.max_doc = ds->d_blk_max.as<uint32_t>();
+    a.wand_tf = ds->d_blk_wand_tf.as<uint32_t>();
     a.len8 = b_len8.as<uint32_t>();
-    a.off8 = b_off8.as<uint32_t>();
-    a.n = b_n.as<uint8_t>();
-    a.wand_fn = b_wfn.as<uint8_t>();
-    a.meta_doc = b_md.as<uint8_t>();
-    a.meta_tf = b_mt.as<uint8_t>();
+    a.off8 = ds->d_blk_off8.as<uint32_t>();
+    a.n = ds->d_blk_n.as<uint8_t>();
+    a.wand_fn = ds->d_blk_wand_fn.as<uint8_t>();
+    a.meta_doc = ds->d_blk_meta_doc.as<uint8_t>();
+    a.meta_tf = ds->d_blk_meta_tf.as<uint8_t>();
     a.wand_val = b_wval.as<double>();
     a.error_flag = d_err.as<uint32_t>();
-    seg->blk_off8.assign(size_t(n_blocks) + 1, 0);
+    ds->term_bytes.assign(n_terms, 0);
     if (n_blocks) {
         FL_TRY(hipMemset(b_len8.p, 0, 4ull * (n_blocks + 1)));
         block_stats_kernel<<<(n_blocks + 3) / 4, 256>>>(a);
@@ -405,41 +431,331 @@ int build_device_impl(int device, double k1, double b, uint32_t n_docs, const ui
         FL_TRY(hipcub::DeviceScan::ExclusiveSum(nullptr, tmp_bytes, a.len8, a.off8, (int)(n_blocks + 1)));
         FL_TRY(d_tmp.alloc(tmp_bytes));
         FL_TRY(hipcub::DeviceScan::ExclusiveSum(d_tmp.p, tmp_bytes, a.len8, a.off8, (int)(n_blocks + 1)));
-        FL_TRY(hipMemcpy(seg->blk_off8.data(), b_off8.p, 4ull * (n_blocks + 1), hipMemcpyDeviceToHost));
         uint32_t flag = 0;
         FL_TRY(hipMemcpy(&flag, d_err.p, 4, hipMemcpyDeviceToHost));
         if (flag) return set_error(VBM25_ERR_INVALID, "mappings must be sorted by (token, document), ids < n_docs, tf > 0");
-        // total body length: the scan would wrap silently beyond 2^32 units of 8 bytes
-        std::vector<uint32_t> len8(n_blocks);
-        FL_TRY(hipMemcpy(len8.data(), b_len8.p, 4ull * n_blocks, hipMemcpyDeviceToHost));
-        uint64_t total8 = 0;
-        for (uint32_t x : len8) total8 += x;
+        // total body length: a 32-bit scan would wrap silently beyond 2^32 units of 8 bytes -- summed in 64 bits as well
+        unsigned long long total8 = 0;
+        {
+            size_t rb = 0;
+            hipcub::TransformInputIterator<unsigned long long, WidenU32, const uint32_t *> wide(a.len8, WidenU32());
+            FL_TRY(hipcub::DeviceReduce::Sum(nullptr, rb, wide, d_sum.as<unsigned long long>(), (int)n_blocks));
+            DBuf d_rt;
+            FL_TRY(d_rt.alloc(rb));
+            FL_TRY(hipcub::DeviceReduce::Sum(d_rt.p, rb, wide, d_sum.as<unsigned long long>(), (int)n_blocks));
+            FL_TRY(hipMemcpy(&total8, d_sum.p, 8, hipMemcpyDeviceToHost));
+        }
         if (total8 > 0xffffffffull) return set_error(VBM25_ERR_UNSUPPORTED, "block bodies exceed 32 GiB");
-        const size_t blob_bytes = 8ull * total8;
-        FL_TRY(d_blob.alloc(blob_bytes));
-        a.blob = d_blob.as<uint8_t>();
+        ds->blob_bytes = 8ull * total8;
+        FL_TRY(ds->d_blob.alloc(ds->blob_bytes));
+        a.blob = ds->d_blob.as<uint8_t>();
         block_pack_kernel<<<(n_blocks + 3) / 4, 256>>>(a);
         FL_TRY(hipGetLastError());
-        term_wand_kernel<<<n_terms, 64>>>(a, t_wfn.as<uint8_t>(), t_wtf.as<uint32_t>(), t_df.as<uint32_t>());
+        term_wand_kernel<<<n_terms, 64>>>(a, ds->d_term_wand_fn.as<uint8_t>(), ds->d_term_wand_tf.as<uint32_t>(), ds->d_term_df.as<uint32_t>());
         FL_TRY(hipGetLastError());
-        seg->blob.resize(blob_bytes);
-        FL_TRY(hipMemcpy(seg->blob.data(), d_blob.p, blob_bytes, hipMemcpyDeviceToHost));
+        // the body offsets at the tokens' first blocks: the algorithmic bytes per token (vbm25_query_bytes)
+        FL_TRY(d_bnd.alloc(4ull * (n_terms + 1)));
+        gather_u32_kernel<<<(n_terms + 1 + 255) / 256, 256>>>(n_terms + 1, ds->d_term_first_block.as<uint32_t>(), a.off8, d_bnd.as<uint32_t>());
+        FL_TRY(hipGetLastError());
+        std::vector<uint32_t> bnd(size_t(n_terms) + 1);
+        FL_TRY(hipMemcpy(bnd.data(), d_bnd.p, 4ull * (n_terms + 1), hipMemcpyDeviceToHost));
+        for (uint32_t t = 0; t < n_terms; ++t)
+            ds->term_bytes[t] = 8ull * (bnd[t + 1] - bnd[t]) + 40ull * (ds->term_first_block[t + 1] - ds->term_first_block[t]) + ds->term_df[t];
+    } else {
+        FL_TRY(hipMemset(ds->d_blk_off8.p, 0, 4));
     }
-    auto fetch = [&](auto &vec, const DBuf &src, size_t n) -> hipError_t {
+    FL_TRY(hipDeviceSynchronize());
+    out = std::move(ds);
+    return VBM25_OK;
+}
+
+// the host copy of a device segment: the same vbm25_segment the host builder makes, byte for byte
+int download_device_segment(const vbm25_device_segment &ds, vbm25_segment **out) {
+    FL_TRY(hipSetDevice(ds.device));
+    auto seg = std::make_unique<vbm25_segment>();
+    seg->k1 = ds.k1;
+    seg->b = ds.b;
+    seg->n_docs = ds.n_docs;
+    seg->n_terms = ds.n_terms;
+    seg->n_blocks = ds.n_blocks;
+    seg->sum_len = ds.sum_len;
+    seg->term_key = ds.term_key;
+    seg->term_first_block = ds.term_first_block;
+    seg->token_term = ds.token_term;
+    auto fetch = [&](auto &vec, const HbmArray &src, size_t n) -> hipError_t {
         vec.resize(n);
         return n ? hipMemcpy(vec.data(), src.p, n * sizeof(vec[0]), hipMemcpyDeviceToHost) : hipSuccess;
     };
-    FL_TRY(fetch(seg->blk_min_doc, b_min, n_blocks));
-    FL_TRY(fetch(seg->blk_max_doc, b_max, n_blocks));
-    FL_TRY(fetch(seg->blk_wand_tf, b_wtf, n_blocks));
-    FL_TRY(fetch(seg->blk_n, b_n, n_blocks));
-    FL_TRY(fetch(seg->blk_wand_fn, b_wfn, n_blocks));
-    FL_TRY(fetch(seg->blk_meta_doc, b_md, n_blocks));
-    FL_TRY(fetch(seg->blk_meta_tf, b_mt, n_blocks));
-    FL_TRY(fetch(seg->term_wand_fn, t_wfn, n_terms));
-    FL_TRY(fetch(seg->term_wand_tf, t_wtf, n_terms));
-    FL_TRY(fetch(seg->term_df, t_df, n_terms));
+    FL_TRY(fetch(seg->doc_fieldnorm, ds.d_doc_fieldnorm, ds.n_docs));
+    FL_TRY(fetch(seg->doc_payload, ds.d_doc_payload, 3ull * ds.n_docs));
+    FL_TRY(fetch(seg->blk_off8, ds.d_blk_off8, size_t(ds.n_blocks) + 1));
+    FL_TRY(fetch(seg->blob, ds.d_blob, ds.blob_bytes));
+    FL_TRY(fetch(seg->blk_min_doc, ds.d_blk_min, ds.n_blocks));
+    FL_TRY(fetch(seg->blk_max_doc, ds.d_blk_max, ds.n_blocks));
+    FL_TRY(fetch(seg->blk_wand_tf, ds.d_blk_wand_tf, ds.n_blocks));
+    FL_TRY(fetch(seg->blk_n, ds.d_blk_n, ds.n_blocks));
+    FL_TRY(fetch(seg->blk_wand_fn, ds.d_blk_wand_fn, ds.n_blocks));
+    FL_TRY(fetch(seg->blk_meta_doc, ds.d_blk_meta_doc, ds.n_blocks));
+    FL_TRY(fetch(seg->blk_meta_tf, ds.d_blk_meta_tf, ds.n_blocks));
+    FL_TRY(fetch(seg->term_wand_fn, ds.d_term_wand_fn, ds.n_terms));
+    FL_TRY(fetch(seg->term_wand_tf, ds.d_term_wand_tf, ds.n_terms));
+    FL_TRY(fetch(seg->term_df, ds.d_term_df, ds.n_terms));
     *out = seg.release();
+    return VBM25_OK;
+}
+
+// dev_doc / dev_tf != nullptr: the mappings are already on the device, sorted (vbm25_segment_build_device_unsorted);
+// post_doc / post_tf are not read then.
+int build_device_impl(int device, double k1, double b, uint32_t n_docs, const uint32_t *doc_len, const uint16_t *doc_payload,
+                      uint32_t n_terms, const uint8_t *term_key, const uint64_t *term_start, const uint32_t *post_doc,
+                      const uint32_t *post_tf, vbm25_segment **out, const uint32_t *dev_doc = nullptr, const uint32_t *dev_tf = nullptr) {
+    if (!out) return set_error(VBM25_ERR_INVALID, "out is NULL");
+    *out = nullptr;
+    if (!doc_len || !doc_payload) return set_error(VBM25_ERR_INVALID, "NULL argument");
+    std::unique_ptr<vbm25_device_segment> ds;
+    if (int rc = build_device_core(device, k1, b, n_docs, doc_len, nullptr, doc_payload, n_terms, term_key, term_start, post_doc, post_tf,
+                                   dev_doc, dev_tf, ds))
+        return rc;
+    return download_device_segment(*ds, out);
+}
+
+// ---------------------------------------------------------------------------
+// The synthetic corpus of SURVEY section 8(d) generated ON the device (the model of vbm25_segment_synth, segment.cpp: every
+// draw slot of a document is token t with probability p_t, independently per token -- geometric gaps; tf = hits inside one
+// document; document length = sum of its tfs) and sealed there: no posting crosses the PCIe link.  The same counter-based
+// generator (splitmix64 seeded per (token, 65536-document chunk)) with the device's log / exp / cos: a corpus of the same
+// distribution, NOT bit for bit the host generator's (libm and ocml round differently in a handful of draws per billion).
+// ---------------------------------------------------------------------------
+struct DevRng {
+    unsigned long long s;
+    __device__ explicit DevRng(unsigned long long seed) : s(seed) {}
+    __device__ unsigned long long next() {  // splitmix64
+        unsigned long long z = (s += 0x9E3779B97F4A7C15ull);
+        z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+        z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+        return z ^ (z >> 31);
+    }
+    __device__ double unit() { return ((double)(next() >> 11) + 1.0) * (1.0 / 9007199254740992.0); }  // (0,1]
+};
+__host__ __device__ inline unsigned long long synth_mix(unsigned long long a, unsigned long long b, unsigned long long c) {
+    unsigned long long s = a ^ (b * 0xD6E8FEB86659FD93ull) ^ (c * 0xCA5A826395121157ull);
+    unsigned long long z = 0;
+    for (int i = 0; i < 2; ++i) {
+        z = (s += 0x9E3779B97F4A7C15ull);
+        z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+        z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+        z = z ^ (z >> 31);
+    }
+    return z;
+}
+constexpr uint32_t SYNTH_CHUNK = 1u << 16;
+
+// draws per document: mean_len, or clamp(round(LogNormal(ln(0.8 mean_len), 0.6)), 8, 2000) (two uniforms per document)
+__global__ void __launch_bounds__(256) synth_draws_kernel(uint32_t n_docs, uint32_t mean_len, uint32_t len_mode, unsigned long long seed0,
+                                                          uint32_t *draws) {
+    const double mu = log(0.8 * (double)mean_len);
+    for (uint32_t d = blockIdx.x * blockDim.x + threadIdx.x; d < n_docs; d += gridDim.x * blockDim.x) {
+        uint32_t len = mean_len;
+        if (len_mode == 1) {
+            DevRng rng(seed0 + 2ull * d * 0x9E3779B97F4A7C15ull);  // the state after 2 d draws of the sequential generator
+            const double u1 = rng.unit(), u2 = rng.unit();
+            const double z = sqrt(-2.0 * log(u1)) * cos(6.283185307179586 * u2);
+            const double v = nearbyint(exp(mu + 0.6 * z));
+            len = (uint32_t)fmin(2000.0, fmax(8.0, v));
+        }
+        draws[d] = len;
+    }
+}
+
+struct SynthArgs {
+    uint32_t n_docs, vocab, n_chunks;
+    unsigned long long seed;
+    const unsigned long long *slot;  // n_docs + 1: prefix sum of the draws per document
+    const double *log1mp;            // per token: log(1 - p_t)
+    const uint32_t *order;           // key position -> token number
+    uint32_t *count;                 // per (key position, chunk): postings
+    const unsigned long long *offset;  // their exclusive prefix sum
+    uint32_t *doc_len;               // sum of tf per document
+    uint32_t *post_doc, *post_tf;
+};
+template <bool EMIT>
+__global__ void __launch_bounds__(256) synth_gen_kernel(SynthArgs a) {
+    const unsigned long long task = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (task >= (unsigned long long)a.vocab * a.n_chunks) return;
+    const uint32_t pos_i = (uint32_t)(task / a.n_chunks), chunk = (uint32_t)(task - (unsigned long long)pos_i * a.n_chunks);
+    const uint32_t token = a.order[pos_i];
+    const uint32_t c0 = chunk * SYNTH_CHUNK, c1 = (uint32_t)min((unsigned long long)a.n_docs, (unsigned long long)c0 + SYNTH_CHUNK);
+    const double l1p = a.log1mp[token];
+    const unsigned long long *S = a.slot;
+    DevRng rng(synth_mix(a.seed, token, c0));
+    const unsigned long long begin = S[c0], end = S[c1];
+    unsigned long long pos = begin, out = EMIT ? a.offset[task] : 0ull;
+    uint32_t d = c0, cur_doc = 0xffffffffu, cur_tf = 0, n = 0;
+    for (;;) {
+        const double g = floor(log(rng.unit()) / l1p);
+        if (!(g < 1e18)) break;
+        pos += (unsigned long long)g;
+        if (pos >= end) break;
+        if (S[d + 1] <= pos) {  // slot -> document: interpolate inside the chunk, then walk
+            const uint32_t guess = c0 + (uint32_t)((pos - begin) * (unsigned long long)(c1 - c0) / (end - begin));
+            if (guess > d) d = guess;
+            while (S[d] > pos) --d;
+            while (S[d + 1] <= pos) ++d;
+        }
+        if (d == cur_doc) {
+            ++cur_tf;
+        } else {
+            if (cur_tf) {
+                if (EMIT) {
+                    a.post_doc[out] = cur_doc;
+                    a.post_tf[out] = cur_tf;
+                    ++out;
+                } else {
+                    atomicAdd(&a.doc_len[cur_doc], cur_tf);
+                    ++n;
+                }
+            }
+            cur_doc = d;
+            cur_tf = 1;
+        }
+        ++pos;
+    }
+    if (cur_tf) {
+        if (EMIT) {
+            a.post_doc[out] = cur_doc;
+            a.post_tf[out] = cur_tf;
+        } else {
+            atomicAdd(&a.doc_len[cur_doc], cur_tf);
+            ++n;
+        }
+    }
+    if (!EMIT) a.count[task] = n;
+}
+__global__ void __launch_bounds__(256) gather_u64_stride_kernel(uint32_t n, unsigned long long stride, const unsigned long long *src,
+                                                                unsigned long long last, unsigned long long *dst) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) dst[i] = src[(unsigned long long)i * stride];
+    if (i == n) dst[i] = last;
+}
+
+int synth_device_impl(const vbm25_synth_params *pr, int device, vbm25_device_segment **out) {
+    if (!pr || !out) return set_error(VBM25_ERR_INVALID, "NULL argument");
+    *out = nullptr;
+    if (!pr->n_docs || !pr->vocab || !pr->mean_len) return set_error(VBM25_ERR_INVALID, "n_docs, vocab and mean_len must be positive");
+    if (!(pr->k1 >= 1.2 && pr->k1 <= 2.0) || !(pr->b >= 0.0 && pr->b <= 1.0))
+        return set_error(VBM25_ERR_INVALID, "k1 must be in [1.2, 2] and b in [0, 1]");
+    int n_dev = 0;
+    if (hipGetDeviceCount(&n_dev) != hipSuccess || n_dev == 0)
+        return set_error(VBM25_ERR_DEVICE, "no HIP device: the device generator has no CPU fallback (vbm25_segment_synth is the host generator)");
+    if (device < 0 || device >= n_dev) return set_error(VBM25_ERR_INVALID, "device %d out of range (%d devices)", device, n_dev);
+    FL_TRY(hipSetDevice(device));
+    const uint32_t n_docs = pr->n_docs, vocab = pr->vocab, n_chunks = (n_docs + SYNTH_CHUNK - 1) / SYNTH_CHUNK;
+    const unsigned long long n_tasks = (unsigned long long)vocab * n_chunks;
+    if (n_tasks > 0x7fffffffull) return set_error(VBM25_ERR_UNSUPPORTED, "vocab x document chunks exceeds 2^31 generation tasks");
+    // token probabilities and the tokens in key order (bytewise order of their decimal strings): vocabulary-sized, on the host
+    std::vector<double> log1mp(vocab);
+    {
+        double norm = 0.0;
+        if (pr->zipf_s > 0)
+            for (uint32_t t = 0; t < vocab; ++t) norm += std::pow(double(t + 1), -pr->zipf_s);
+        for (uint32_t t = 0; t < vocab; ++t) {
+            const double p = pr->zipf_s > 0 ? std::pow(double(t + 1), -pr->zipf_s) / norm : 1.0 / double(vocab);
+            log1mp[t] = std::log1p(-std::min(p, 0.999999));
+        }
+    }
+    std::vector<uint8_t> keys(16ull * vocab, 0);
+    for (uint32_t t = 0; t < vocab; ++t) {
+        char buf[17];
+        const int n = std::snprintf(buf, sizeof buf, "%u", t);
+        std::memcpy(keys.data() + 16ull * t, buf, size_t(n));
+    }
+    std::vector<uint32_t> order(vocab);
+    for (uint32_t t = 0; t < vocab; ++t) order[t] = t;
+    std::sort(order.begin(), order.end(), [&](uint32_t x, uint32_t y) { return std::memcmp(keys.data() + 16ull * x, keys.data() + 16ull * y, 16) < 0; });
+
+    DBuf d_draws, d_slot, d_l1p, d_order, d_count, d_off, d_len, d_pd, d_pt, d_tmp, d_bnd;
+    FL_TRY(d_draws.alloc(4ull * n_docs));
+    FL_TRY(d_slot.alloc(8ull * (n_docs + 1ull)));
+    FL_TRY(d_l1p.alloc(8ull * vocab));
+    FL_TRY(d_order.alloc(4ull * vocab));
+    FL_TRY(d_count.alloc(4ull * n_tasks));
+    FL_TRY(d_off.alloc(8ull * n_tasks));
+    FL_TRY(d_len.alloc(4ull * n_docs));
+    FL_TRY(d_bnd.alloc(8ull * (vocab + 1ull)));
+    FL_TRY(hipMemcpy(d_l1p.p, log1mp.data(), 8ull * vocab, hipMemcpyHostToDevice));
+    FL_TRY(hipMemcpy(d_order.p, order.data(), 4ull * vocab, hipMemcpyHostToDevice));
+    FL_TRY(hipMemset(d_len.p, 0, 4ull * n_docs));
+    FL_TRY(hipMemset(d_slot.p, 0, 8));
+    synth_draws_kernel<<<2048, 256>>>(n_docs, pr->mean_len, pr->len_mode, synth_mix(pr->seed, 0xD0C5, 0), d_draws.as<uint32_t>());
+    FL_TRY(hipGetLastError());
+    {   // slot[d + 1] = draws[0] + ... + draws[d]
+        size_t tb = 0;
+        hipcub::TransformInputIterator<unsigned long long, WidenU32, const uint32_t *> wide(d_draws.as<uint32_t>(), WidenU32());
+        FL_TRY(hipcub::DeviceScan::InclusiveSum(nullptr, tb, wide, d_slot.as<unsigned long long>() + 1, (int)n_docs));
+        FL_TRY(d_tmp.alloc(tb));
+        FL_TRY(hipcub::DeviceScan::InclusiveSum(d_tmp.p, tb, wide, d_slot.as<unsigned long long>() + 1, (int)n_docs));
+    }
+    SynthArgs a{};
+    a.n_docs = n_docs;
+    a.vocab = vocab;
+    a.n_chunks = n_chunks;
+    a.seed = pr->seed;
+    a.slot = d_slot.as<unsigned long long>();
+    a.log1mp = d_l1p.as<double>();
+    a.order = d_order.as<uint32_t>();
+    a.count = d_count.as<uint32_t>();
+    a.offset = d_off.as<unsigned long long>();
+    a.doc_len = d_len.as<uint32_t>();
+    const uint32_t grid = (uint32_t)((n_tasks + 255) / 256);
+    synth_gen_kernel<false><<<grid, 256>>>(a);  // pass 1: postings per task, document lengths
+    FL_TRY(hipGetLastError());
+    unsigned long long n_post = 0;
+    {
+        size_t tb = 0;
+        hipcub::TransformInputIterator<unsigned long long, WidenU32, const uint32_t *> wide(d_count.as<uint32_t>(), WidenU32());
+        DBuf d_t2;
+        FL_TRY(hipcub::DeviceScan::ExclusiveSum(nullptr, tb, wide, d_off.as<unsigned long long>(), (int)n_tasks));
+        FL_TRY(d_t2.alloc(tb));
+        FL_TRY(hipcub::DeviceScan::ExclusiveSum(d_t2.p, tb, wide, d_off.as<unsigned long long>(), (int)n_tasks));
+        unsigned long long last_off = 0;
+        uint32_t last_cnt = 0;
+        FL_TRY(hipMemcpy(&last_off, d_off.as<unsigned long long>() + (n_tasks - 1), 8, hipMemcpyDeviceToHost));
+        FL_TRY(hipMemcpy(&last_cnt, d_count.as<uint32_t>() + (n_tasks - 1), 4, hipMemcpyDeviceToHost));
+        n_post = last_off + last_cnt;
+    }
+    // the first mapping of every token (key order); tokens that never occur are left out of the segment
+    gather_u64_stride_kernel<<<(vocab + 1 + 255) / 256, 256>>>(vocab, n_chunks, d_off.as<unsigned long long>(), n_post, d_bnd.as<unsigned long long>());
+    FL_TRY(hipGetLastError());
+    std::vector<uint64_t> bnd(size_t(vocab) + 1);
+    FL_TRY(hipMemcpy(bnd.data(), d_bnd.p, 8ull * (vocab + 1ull), hipMemcpyDeviceToHost));
+    std::vector<uint64_t> term_start;
+    std::vector<uint8_t> term_key;
+    std::vector<uint32_t> token_term(vocab, UINT32_MAX);
+    for (uint32_t i = 0; i < vocab; ++i) {
+        if (bnd[i + 1] == bnd[i]) continue;
+        token_term[order[i]] = uint32_t(term_start.size());
+        term_start.push_back(bnd[i]);
+        term_key.insert(term_key.end(), keys.begin() + 16ull * order[i], keys.begin() + 16ull * order[i] + 16);
+    }
+    const uint32_t n_terms = uint32_t(term_start.size());
+    term_start.push_back(n_post);
+    FL_TRY(d_pd.alloc(4ull * n_post));
+    FL_TRY(d_pt.alloc(4ull * n_post));
+    a.post_doc = d_pd.as<uint32_t>();
+    a.post_tf = d_pt.as<uint32_t>();
+    synth_gen_kernel<true><<<grid, 256>>>(a);  // pass 2: the mappings, in (token, document) order
+    FL_TRY(hipGetLastError());
+    // the generation buffers go before the encode's are made
+    (void)hipFree(d_count.p); d_count.p = nullptr;
+    (void)hipFree(d_off.p); d_off.p = nullptr;
+    (void)hipFree(d_slot.p); d_slot.p = nullptr;
+    (void)hipFree(d_draws.p); d_draws.p = nullptr;
+    std::unique_ptr<vbm25_device_segment> ds;
+    if (int rc = build_device_core(device, pr->k1, pr->b, n_docs, nullptr, d_len.as<uint32_t>(), nullptr, n_terms, term_key.data(), term_start.data(),
+                                   nullptr, nullptr, d_pd.as<uint32_t>(), d_pt.as<uint32_t>(), ds))
+        return rc;
+    ds->token_term = std::move(token_term);
+    *out = ds.release();
     return VBM25_OK;
 }
 
@@ -549,4 +865,59 @@ extern "C" int vbm25_segment_build_device(int device, double k1, double b, uint3
     return vbm25::guarded([&] {
         return build_device_impl(device, k1, b, n_docs, doc_len, doc_payload, n_terms, term_key, term_start, post_doc, post_tf, out);
     });
+}
+
+extern "C" int vbm25_device_segment_synth(const vbm25_synth_params *params, int device, vbm25_device_segment **out) {
+    return vbm25::guarded([&] { return synth_device_impl(params, device, out); });
+}
+extern "C" int vbm25_device_segment_build(int device, double k1, double b, uint32_t n_docs, const uint32_t *doc_len,
+                                          const uint16_t *doc_payload, uint32_t n_terms, const uint8_t *term_key, const uint64_t *term_start,
+                                          const uint32_t *post_doc, const uint32_t *post_tf, vbm25_device_segment **out) {
+    return vbm25::guarded([&]() -> int {
+        if (!out) return set_error(VBM25_ERR_INVALID, "out is NULL");
+        *out = nullptr;
+        if (!doc_len || !doc_payload) return set_error(VBM25_ERR_INVALID, "NULL argument");
+        std::unique_ptr<vbm25_device_segment> ds;
+        if (int rc = build_device_core(device, k1, b, n_docs, doc_len, nullptr, doc_payload, n_terms, term_key, term_start, post_doc, post_tf,
+                                       nullptr, nullptr, ds))
+            return rc;
+        *out = ds.release();
+        return VBM25_OK;
+    });
+}
+extern "C" int vbm25_device_segment_download(const vbm25_device_segment *ds, vbm25_segment **out) {
+    return vbm25::guarded([&]() -> int {
+        if (!ds || !out) return set_error(VBM25_ERR_INVALID, "NULL argument");
+        *out = nullptr;
+        return download_device_segment(*ds, out);
+    });
+}
+extern "C" int vbm25_device_segment_token_terms(const vbm25_device_segment *ds, const uint32_t *tokens, uint32_t n, uint32_t *term_ids) {
+    if (!ds || ds->token_term.empty() || (n && (!tokens || !term_ids)))
+        return set_error(VBM25_ERR_INVALID, "not a segment of vbm25_device_segment_synth / NULL argument");
+    for (uint32_t i = 0; i < n; ++i) term_ids[i] = tokens[i] < ds->token_term.size() ? ds->token_term[tokens[i]] : UINT32_MAX;
+    return VBM25_OK;
+}
+extern "C" uint64_t vbm25_device_segment_query_bytes(const vbm25_device_segment *ds, const uint32_t *term_ids, uint32_t n_terms, uint32_t k) {
+    uint64_t bytes = 0;
+    if (ds)
+        for (uint32_t i = 0; i < n_terms; ++i)
+            if (term_ids[i] < ds->n_terms) bytes += ds->term_bytes[term_ids[i]];
+    return bytes + 14ull * k;
+}
+extern "C" int vbm25_device_segment_info(const vbm25_device_segment *ds, uint32_t *n_docs, uint32_t *n_terms, uint32_t *n_blocks, uint64_t *n_postings) {
+    if (!ds) return set_error(VBM25_ERR_INVALID, "NULL argument");
+    if (n_docs) *n_docs = ds->n_docs;
+    if (n_terms) *n_terms = ds->n_terms;
+    if (n_blocks) *n_blocks = ds->n_blocks;
+    if (n_postings) {
+        *n_postings = 0;
+        for (uint32_t df : ds->term_df) *n_postings += df;
+    }
+    return VBM25_OK;
+}
+extern "C" void vbm25_device_segment_free(vbm25_device_segment *ds) {
+    if (!ds) return;
+    (void)hipSetDevice(ds->device);
+    delete ds;
 }

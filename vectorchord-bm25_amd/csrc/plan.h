@@ -86,6 +86,69 @@ __global__ void __launch_bounds__(256) post_fn_kernel(PostFnArgs a) {
 }
 
 // ---------------------------------------------------------------------------
+// Index creation: what the index derives from the raw block / token arrays, on the device (the arrays may never have been on
+// the host: vbm25_index_create_from_device)
+// ---------------------------------------------------------------------------
+struct DeriveArgs {
+    uint32_t n_blocks, n_terms, has_wand;
+    const uint32_t *term_first_block, *term_wand_tf, *blk_min_doc, *blk_max_doc, *blk_off8, *blk_wand_tf;
+    const uint8_t *term_wand_fn, *blk_n, *blk_meta_doc, *blk_meta_tf, *blk_wand_fn;
+    const double *term_s0, *s1;
+    uint4 *blk_meta;
+    double *blk_ub;   // Cache::evaluate(block WAND pair) x (1 + 1e-12) (search.rs:377-380 evaluates it per visited block; here once)
+    double *blk_raw;  // the same without the margin (has_wand): what the k-th largest block maxima of a term are taken from
+};
+__global__ void __launch_bounds__(256) blk_derive_kernel(DeriveArgs a) {
+    const uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= a.n_blocks) return;
+    uint32_t lo = 0, hi = a.n_terms;  // the term of block j: term_first_block[t] <= j < [t + 1]
+    while (hi - lo > 1) {
+        const uint32_t mid = (lo + hi) >> 1;
+        if (a.term_first_block[mid] <= j) lo = mid; else hi = mid;
+    }
+    const uint32_t wfn = a.has_wand ? a.blk_wand_fn[j] : 0u;
+    a.blk_meta[j] = make_uint4(a.blk_min_doc[j], a.blk_max_doc[j], a.blk_off8[j],
+                               (uint32_t)a.blk_n[j] | (uint32_t)a.blk_meta_doc[j] << 8 | (uint32_t)a.blk_meta_tf[j] << 16 | wfn << 24);
+    const double s0 = a.term_s0[lo];
+    double ub;
+    if (a.has_wand) {
+        const double tf = (double)a.blk_wand_tf[j];
+        ub = (tf * s0) / (tf + a.s1[wfn]);
+        a.blk_raw[j] = ub;
+    } else {
+        const double wtf = (double)a.term_wand_tf[lo];
+        ub = (wtf * s0) / (wtf + a.s1[a.term_wand_fn[lo]]);
+    }
+    a.blk_ub[j] = ub * (1.0 + 1e-12);  // margin: another posting's evaluate may round one ulp higher
+}
+// sorted: every term's block maxima in descending order (segmented sort) -> the 2^i-th largest, i = 0..8 (0 when fewer)
+__global__ void __launch_bounds__(256) kth_pick_kernel(uint32_t n_terms, const uint32_t *term_first_block, const double *sorted, double *kth) {
+    const uint32_t e = blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= n_terms * 9u) return;
+    const uint32_t t = e / 9u, i = e - 9u * t;
+    const uint32_t b0 = term_first_block[t], nb = term_first_block[t + 1] - b0, at = (1u << i) - 1u;
+    kth[e] = at < nb ? sorted[b0 + at] : 0.0;
+}
+// bucket locator: entry b of term t = its first block whose last document is >= b << shift (term_first_block[t + 1] if none)
+__global__ void __launch_bounds__(256) loc_kernel(uint32_t n_terms, uint32_t n_docs, const uint32_t *term_first_block, const uint2 *term_loc,
+                                                  const uint32_t *blk_max_doc, uint32_t *blk_loc) {
+    const uint32_t t = blockIdx.x;
+    if (t >= n_terms) return;
+    const uint32_t b0 = term_first_block[t], b1 = term_first_block[t + 1];
+    const uint2 tl = term_loc[t];
+    const uint32_t n_buckets = (n_docs >> tl.y) + 2u;
+    for (uint32_t b = threadIdx.x; b < n_buckets; b += blockDim.x) {
+        const unsigned long long start = (unsigned long long)b << tl.y;
+        uint32_t lo = b0, hi = b1;
+        while (lo < hi) {
+            const uint32_t mid = (lo + hi) >> 1;
+            if ((unsigned long long)blk_max_doc[mid] < start) lo = mid + 1; else hi = mid;
+        }
+        blk_loc[tl.x + b] = lo;
+    }
+}
+
+// ---------------------------------------------------------------------------
 // Planner
 // ---------------------------------------------------------------------------
 // Block-wide inclusive scan of one u64 per thread (PLAN_WG threads): wave scans + one LDS hop.

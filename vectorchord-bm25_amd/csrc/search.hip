@@ -31,6 +31,7 @@
 #include <vector>
 
 #include "vbm25_internal.h"
+#include "device_segment.h"
 
 namespace vbm25 {
 
@@ -337,10 +338,21 @@ extern "C" {
 const char *vbm25_last_error(void) { return g_error; }
 const char *vbm25_version(void) { return "vbm25-mi355x 0.1 (gfx950)"; }
 
-static int vbm25_index_create_impl(const vbm25_index_desc *d, int device, vbm25_index **out) {
-    if (!out) return set_error(VBM25_ERR_INVALID, "out is NULL");
-    *out = nullptr;
-    if (int rc = check_desc(d)) return rc;
+// A flattened sealed segment as index creation sees it: the big arrays on the host (vbm25_index_desc) or in the HBM of the
+// index's device (vbm25_device_segment); the vocabulary-sized ones the host computes with (libm log) always on the host.
+struct RawSegment {
+    bool on_device;
+    uint32_t n_docs, n_terms, n_blocks;
+    uint64_t sum_len, blob_bytes;
+    double k1, b;
+    const uint8_t *term_key;                                  // host
+    const uint32_t *term_df_host, *term_first_block_host;     // host
+    const uint32_t *term_df, *term_wand_tf, *term_first_block, *blk_min_doc, *blk_max_doc, *blk_wand_tf, *blk_off8;
+    const uint8_t *term_wand_fn, *blk_n, *blk_wand_fn, *blk_meta_doc, *blk_meta_tf, *blob, *doc_fieldnorm;
+    const uint16_t *doc_payload;
+};
+
+static int index_create_common(const RawSegment &r, int device, vbm25_index **out) {
     int n_dev = 0;
     if (hipGetDeviceCount(&n_dev) != hipSuccess || n_dev == 0)
         return set_error(VBM25_ERR_DEVICE, "no HIP device: the MI355X path has no CPU fallback");
@@ -355,112 +367,137 @@ static int vbm25_index_create_impl(const vbm25_index_desc *d, int device, vbm25_
 
     auto ix = std::make_unique<vbm25_index>();
     ix->device = device;
-    ix->n_docs = d->n_docs;
-    ix->n_terms = d->n_terms;
-    ix->n_blocks = d->n_blocks;
-    ix->term_key.assign(d->term_key, d->term_key + 16ull * d->n_terms);
-    ix->term_df_host.assign(d->term_df, d->term_df + d->n_terms);
+    ix->n_docs = r.n_docs;
+    ix->n_terms = r.n_terms;
+    ix->n_blocks = r.n_blocks;
+    ix->k1 = r.k1;
+    ix->term_key.assign(r.term_key, r.term_key + 16ull * r.n_terms);
+    ix->term_df_host.assign(r.term_df_host, r.term_df_host + r.n_terms);
+    const hipMemcpyKind kind = r.on_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice;
+    auto put = [&](DeviceBuffer &dst, const void *src, size_t bytes) -> int {
+        if (int rc = dst.alloc(bytes)) return rc;
+        if (bytes) HIP_TRY(hipMemcpy(dst.p, src, bytes, kind));
+        return VBM25_OK;
+    };
+    const bool has_wand = r.blk_wand_fn && r.blk_wand_tf;
 
-    std::vector<double> s0(d->n_terms);
-    for (uint32_t t = 0; t < d->n_terms; ++t) s0[t] = bm25_s0(d->n_docs, d->term_df[t], d->k1);
+    // per-term s0 = idf (k1 + 1), idf (vbm25_evaluate_batch) -- host libm log, bm25.rs:285-289,348 -- and the s1 table of
+    // bm25.rs:349-352; the bucket locator's geometry
+    std::vector<double> s0(r.n_terms), idf(r.n_terms);
+    for (uint32_t t = 0; t < r.n_terms; ++t) {
+        s0[t] = bm25_s0(r.n_docs, r.term_df_host[t], r.k1);
+        idf[t] = std::log((double(r.n_docs) + 1.0) / (double(r.term_df_host[t]) + 0.5));
+    }
     double s1[256];
-    bm25_tables(d->n_docs, d->sum_len, d->k1, d->b, s1);
-    std::vector<uint4> meta(d->n_blocks);
-    for (uint32_t j = 0; j < d->n_blocks; ++j) {
-        meta[j].x = d->blk_min_doc[j];
-        meta[j].y = d->blk_max_doc[j];
-        meta[j].z = d->blk_off8[j];
-        meta[j].w = uint32_t(d->blk_n[j]) | uint32_t(d->blk_meta_doc[j]) << 8 |
-                    uint32_t(d->blk_meta_tf[j]) << 16 | uint32_t(d->blk_wand_fn ? d->blk_wand_fn[j] : 0) << 24;
-    }
-    // block upper bounds (search.rs:377-380 evaluates the block WAND pair per visited block; here once)
-    std::vector<double> blk_ub(d->n_blocks);
-    for (uint32_t t = 0; t < d->n_terms; ++t) {
-        const double wtf = double(d->term_wand_tf[t]);
-        const double tub = (wtf * s0[t]) / (wtf + s1[d->term_wand_fn[t]]);
-        for (uint32_t j = d->term_first_block[t]; j < d->term_first_block[t + 1]; ++j) {
-            double ub = tub;
-            if (d->blk_wand_fn && d->blk_wand_tf) {
-                const double tf = double(d->blk_wand_tf[j]);
-                ub = (tf * s0[t]) / (tf + s1[d->blk_wand_fn[j]]);
-            }
-            blk_ub[j] = ub * (1.0 + 1e-12);  // margin: another posting's evaluate may round one ulp higher
-        }
-    }
-    // per term the 2^i-th largest block maximum, i = 0..8 (scan_team_kernel's first threshold: with block WAND pairs every
-    // block maximum is the score of a posting of its block -- post_fn_kernel verifies that -- so k distinct documents of
-    // the term score at least the k-th largest of them)
-    std::vector<double> kth;
-    if (d->blk_wand_fn && d->blk_wand_tf) {
-        kth.assign(size_t(TM_KTH) * d->n_terms, 0.0);
-        std::vector<double> tmp;
-        for (uint32_t t = 0; t < d->n_terms; ++t) {
-            tmp.clear();
-            for (uint32_t j = d->term_first_block[t]; j < d->term_first_block[t + 1]; ++j) {
-                const double tf = double(d->blk_wand_tf[j]);
-                tmp.push_back((tf * s0[t]) / (tf + s1[d->blk_wand_fn[j]]));
-            }
-            const size_t top = std::min<size_t>(tmp.size(), 256);
-            std::partial_sort(tmp.begin(), tmp.begin() + top, tmp.end(), std::greater<double>());
-            for (int i = 0; i < TM_KTH; ++i)
-                if ((size_t(1) << i) <= top) kth[size_t(TM_KTH) * t + i] = tmp[(size_t(1) << i) - 1];
-        }
-    }
-    // bucket locator (scan_team_kernel's Cursor::seek_block): per term buckets of about one block span
-    std::vector<uint32_t> loc_off(2ull * d->n_terms), loc;
-    for (uint32_t t = 0; t < d->n_terms; ++t) {
-        const uint32_t b0 = d->term_first_block[t], b1 = d->term_first_block[t + 1];
-        const uint64_t nb = std::max<uint32_t>(b1 - b0, 1u);
+    bm25_tables(r.n_docs, r.sum_len, r.k1, r.b, s1);
+    std::vector<uint32_t> loc_off(2ull * r.n_terms);
+    uint64_t n_loc = 0;
+    for (uint32_t t = 0; t < r.n_terms; ++t) {  // buckets of about one block span
+        const uint64_t nb = std::max<uint32_t>(r.term_first_block_host[t + 1] - r.term_first_block_host[t], 1u);
         uint32_t sh = 8;
-        while (sh < 31 && (uint64_t(d->n_docs) >> sh) > nb) ++sh;
-        const uint32_t n_buckets = (d->n_docs >> sh) + 2u;
-        loc_off[2ull * t] = uint32_t(loc.size());
+        while (sh < 31 && (uint64_t(r.n_docs) >> sh) > nb) ++sh;
+        loc_off[2ull * t] = uint32_t(n_loc);
         loc_off[2ull * t + 1] = sh;
-        uint32_t j = b0;
-        for (uint32_t b = 0; b < n_buckets; ++b) {
-            const uint64_t start = uint64_t(b) << sh;
-            while (j < b1 && uint64_t(d->blk_max_doc[j]) < start) ++j;
-            loc.push_back(j);
-        }
-        if (loc.size() > 0xfffffff0ull) return set_error(VBM25_ERR_UNSUPPORTED, "block locator exceeds 2^32 entries");
+        n_loc += (r.n_docs >> sh) + 2u;
+        if (n_loc > 0xfffffff0ull) return set_error(VBM25_ERR_UNSUPPORTED, "block locator exceeds 2^32 entries");
     }
-    DeviceBuffer fieldnorm, err;
+
+    // the raw per-block arrays the derivation reads: used where they are (device segment) or uploaded for its duration
+    DeviceBuffer t_n, t_wfn, t_wtf, t_md, t_mt, t_off8, t_fieldnorm, t_raw, t_sorted, t_tmp, err;
+    const uint8_t *p_n = r.blk_n, *p_wfn = r.blk_wand_fn, *p_md = r.blk_meta_doc, *p_mt = r.blk_meta_tf, *p_fieldnorm = r.doc_fieldnorm;
+    const uint32_t *p_wtf = r.blk_wand_tf, *p_off8 = r.blk_off8;
     int rc = 0;
+    if (!r.on_device) {
+        if ((rc = t_n.upload(r.blk_n, r.n_blocks)) || (rc = t_md.upload(r.blk_meta_doc, r.n_blocks)) ||
+            (rc = t_mt.upload(r.blk_meta_tf, r.n_blocks)) || (rc = t_off8.upload(r.blk_off8, 4ull * (r.n_blocks + 1ull))) ||
+            (rc = t_fieldnorm.upload(r.doc_fieldnorm, r.n_docs)) ||
+            (has_wand && ((rc = t_wfn.upload(r.blk_wand_fn, r.n_blocks)) || (rc = t_wtf.upload(r.blk_wand_tf, 4ull * r.n_blocks)))))
+            return rc;
+        p_n = t_n.as<uint8_t>();
+        p_md = t_md.as<uint8_t>();
+        p_mt = t_mt.as<uint8_t>();
+        p_off8 = t_off8.as<uint32_t>();
+        p_fieldnorm = t_fieldnorm.as<uint8_t>();
+        p_wfn = t_wfn.as<uint8_t>();
+        p_wtf = t_wtf.as<uint32_t>();
+    }
     // slack: the scan kernels read whole 256-byte LDS-DMA slots / word pairs from a block's first byte
-    const size_t blob_alloc = ((size_t(d->blob_bytes) + 15) & ~size_t(15)) + 512;
-    if ((rc = ix->term_df.upload(d->term_df, 4ull * d->n_terms)) ||
-        (rc = ix->term_first_block.upload(d->term_first_block, 4ull * (d->n_terms + 1))) ||
-        (rc = ix->term_s0.upload(s0.data(), 8ull * d->n_terms)) ||
-        (rc = ix->term_wand_tf.upload(d->term_wand_tf, 4ull * d->n_terms)) ||
-        (rc = ix->term_wand_fn.upload(d->term_wand_fn, d->n_terms)) ||
-        (rc = ix->blk_min_doc.upload(d->blk_min_doc, 4ull * d->n_blocks)) ||
-        (rc = ix->blk_max_doc.upload(d->blk_max_doc, 4ull * d->n_blocks)) ||
-        (rc = ix->blk_meta.upload(meta.data(), 16ull * d->n_blocks)) ||
-        (rc = ix->blk_ub.upload(blk_ub.data(), 8ull * d->n_blocks)) ||
-        (!kth.empty() && (rc = ix->term_kth_ub.upload(kth.data(), 8ull * kth.size()))) ||
+    const size_t blob_alloc = ((size_t(r.blob_bytes) + 15) & ~size_t(15)) + 512;
+    if ((rc = put(ix->term_df, r.term_df, 4ull * r.n_terms)) ||
+        (rc = put(ix->term_first_block, r.term_first_block, 4ull * (r.n_terms + 1ull))) ||
+        (rc = ix->term_s0.upload(s0.data(), 8ull * r.n_terms)) ||
+        (rc = ix->term_idf.upload(idf.data(), 8ull * r.n_terms)) ||
+        (rc = ix->fn_len.upload(fieldnorm_lengths(), 4ull * 256)) ||
+        (rc = put(ix->term_wand_tf, r.term_wand_tf, 4ull * r.n_terms)) ||
+        (rc = put(ix->term_wand_fn, r.term_wand_fn, r.n_terms)) ||
+        (rc = put(ix->blk_min_doc, r.blk_min_doc, 4ull * r.n_blocks)) ||
+        (rc = put(ix->blk_max_doc, r.blk_max_doc, 4ull * r.n_blocks)) ||
+        (rc = ix->blk_meta.alloc(16ull * r.n_blocks)) ||
+        (rc = ix->blk_ub.alloc(8ull * r.n_blocks)) ||
         (rc = ix->blob.alloc(blob_alloc)) ||
-        (rc = ix->post_fn.alloc(128ull * d->n_blocks)) ||
-        (rc = ix->post_rel16.alloc(256ull * d->n_blocks)) ||
-        (rc = ix->post_tfn.alloc(256ull * d->n_blocks)) ||
-        (rc = ix->blk_piv.alloc(16ull * d->n_blocks)) ||
+        (rc = ix->post_fn.alloc(128ull * r.n_blocks)) ||
+        (rc = ix->post_rel16.alloc(256ull * r.n_blocks)) ||
+        (rc = ix->post_tfn.alloc(256ull * r.n_blocks)) ||
+        (rc = ix->blk_piv.alloc(16ull * r.n_blocks)) ||
         (rc = ix->term_loc.upload(loc_off.data(), 4ull * loc_off.size())) ||
-        (rc = ix->blk_loc.upload(loc.data(), 4ull * loc.size())) ||
-        (rc = ix->doc_payload.upload(d->doc_payload, 6ull * d->n_docs)) ||
-        (rc = ix->s1.upload(s1, sizeof s1)) ||
-        (rc = fieldnorm.upload(d->doc_fieldnorm, d->n_docs)) || (rc = err.alloc(4)))
+        (rc = ix->blk_loc.alloc(4ull * n_loc)) ||
+        (rc = put(ix->doc_payload, r.doc_payload, 6ull * r.n_docs)) ||
+        (rc = ix->s1.upload(s1, sizeof s1)) || (rc = err.alloc(4)))
         return rc;
     HIP_TRY(hipMemset(err.p, 0, 4));
     HIP_TRY(hipMemset(ix->blob.p, 0, blob_alloc));
-    if (d->blob_bytes) HIP_TRY(hipMemcpy(ix->blob.p, d->blob, d->blob_bytes, hipMemcpyHostToDevice));
-    if (d->n_blocks) {
-        const uint32_t grid = (d->n_blocks + 3) / 4;
+    if (r.blob_bytes) HIP_TRY(hipMemcpy(ix->blob.p, r.blob, r.blob_bytes, kind));
+    if (r.n_blocks) {
+        if (has_wand && ((rc = t_raw.alloc(8ull * r.n_blocks)) || (rc = t_sorted.alloc(8ull * r.n_blocks)) ||
+                         (rc = ix->term_kth_ub.alloc(8ull * TM_KTH * r.n_terms))))
+            return rc;
+        DeriveArgs da{};
+        da.n_blocks = r.n_blocks;
+        da.n_terms = r.n_terms;
+        da.has_wand = has_wand ? 1u : 0u;
+        da.term_first_block = ix->term_first_block.as<uint32_t>();
+        da.term_wand_tf = ix->term_wand_tf.as<uint32_t>();
+        da.term_wand_fn = ix->term_wand_fn.as<uint8_t>();
+        da.blk_min_doc = ix->blk_min_doc.as<uint32_t>();
+        da.blk_max_doc = ix->blk_max_doc.as<uint32_t>();
+        da.blk_off8 = p_off8;
+        da.blk_wand_tf = p_wtf;
+        da.blk_n = p_n;
+        da.blk_meta_doc = p_md;
+        da.blk_meta_tf = p_mt;
+        da.blk_wand_fn = p_wfn;
+        da.term_s0 = ix->term_s0.as<double>();
+        da.s1 = ix->s1.as<double>();
+        da.blk_meta = ix->blk_meta.as<uint4>();
+        da.blk_ub = ix->blk_ub.as<double>();
+        da.blk_raw = t_raw.as<double>();
+        blk_derive_kernel<<<(r.n_blocks + 255) / 256, 256>>>(da);
+        HIP_TRY(hipGetLastError());
+        if (has_wand) {
+            // per term the 2^i-th largest block maximum, i = 0..8 (the scan kernels' first threshold: with block WAND pairs
+            // every block maximum is the score of a posting of its block -- post_fn_kernel verifies that -- so k distinct
+            // documents of the term score at least the k-th largest of them): a segmented sort of the maxima by term
+            size_t tb = 0;
+            const uint32_t *seg = ix->term_first_block.as<uint32_t>();
+            HIP_TRY(hipcub::DeviceSegmentedRadixSort::SortKeysDescending(nullptr, tb, t_raw.as<double>(), t_sorted.as<double>(), (int)r.n_blocks,
+                                                                        (int)r.n_terms, seg, seg + 1));
+            if ((rc = t_tmp.alloc(tb))) return rc;
+            HIP_TRY(hipcub::DeviceSegmentedRadixSort::SortKeysDescending(t_tmp.p, tb, t_raw.as<double>(), t_sorted.as<double>(), (int)r.n_blocks,
+                                                                        (int)r.n_terms, seg, seg + 1));
+            kth_pick_kernel<<<(r.n_terms * TM_KTH + 255) / 256, 256>>>(r.n_terms, seg, t_sorted.as<double>(), ix->term_kth_ub.as<double>());
+            HIP_TRY(hipGetLastError());
+        }
+        loc_kernel<<<r.n_terms, 256>>>(r.n_terms, r.n_docs, ix->term_first_block.as<uint32_t>(), ix->term_loc.as<uint2>(),
+                                       ix->blk_max_doc.as<uint32_t>(), ix->blk_loc.as<uint32_t>());
+        HIP_TRY(hipGetLastError());
+        const uint32_t grid = (r.n_blocks + 3) / 4;
         PostFnArgs pa{};
-        pa.n_blocks = d->n_blocks;
-        pa.n_docs = d->n_docs;
-        pa.n_terms = d->n_terms;
+        pa.n_blocks = r.n_blocks;
+        pa.n_docs = r.n_docs;
+        pa.n_terms = r.n_terms;
         pa.blk_meta = ix->blk_meta.as<uint4>();
         pa.blob = ix->blob.as<uint8_t>();
-        pa.doc_fieldnorm = fieldnorm.as<uint8_t>();
+        pa.doc_fieldnorm = p_fieldnorm;
         pa.post_fn = ix->post_fn.as<uint8_t>();
         pa.post_rel16 = ix->post_rel16.as<uint32_t>();
         pa.post_tfn = ix->post_tfn.as<uint32_t>();
@@ -485,30 +522,89 @@ static int vbm25_index_create_impl(const vbm25_index_desc *d, int device, vbm25_
         return set_error(VBM25_ERR_CORRUPT,
                          "a posting scores above its block's / token's WAND pair "
                          "(search.rs:363,377-380 prune with those bounds)");
-    fill_dev(ix.get());
-    ix->dev.blob_bytes = d->blob_bytes;
-    ix->dev.blk_ub_attained = d->blk_wand_fn && d->blk_wand_tf && !(flag & 4u) ? 1u : 0u;
-    ix->dev.term_kth_ub = ix->dev.blk_ub_attained && !kth.empty() ? ix->term_kth_ub.as<double>() : nullptr;
-    if (!ix->dev.term_kth_ub && ix->term_kth_ub.p) {  // (kept out of the replicas too)
+    ix->dev.blk_ub_attained = has_wand && !(flag & 4u) ? 1u : 0u;
+    if (!ix->dev.blk_ub_attained && ix->term_kth_ub.p) {  // the k-th largest maxima bound nothing then: kept out of the index (and its replicas)
         (void)hipFree(ix->term_kth_ub.p);
         ix->term_kth_ub.p = nullptr;
         ix->term_kth_ub.bytes = 0;
     }
-    {   // for vbm25_evaluate_batch: per-term idf (host libm log, bm25.rs:285-289) and the fieldnorm table
-        std::vector<double> idf(d->n_terms);
-        for (uint32_t t = 0; t < d->n_terms; ++t)
-            idf[t] = std::log((double(d->n_docs) + 1.0) / (double(d->term_df[t]) + 0.5));
-        if ((rc = ix->term_idf.upload(idf.data(), 8ull * d->n_terms)) ||
-            (rc = ix->fn_len.upload(fieldnorm_lengths(), 4ull * 256)))
-            return rc;
-        ix->k1 = d->k1;
-    }
+    fill_dev(ix.get());
+    ix->dev.blob_bytes = r.blob_bytes;
+    ix->dev.blk_ub_attained = has_wand && !(flag & 4u) ? 1u : 0u;
     for (const DeviceBuffer *b : {&ix->term_df, &ix->term_first_block, &ix->term_s0, &ix->blk_min_doc,
                                   &ix->blk_max_doc, &ix->blk_meta, &ix->blk_ub, &ix->blob, &ix->post_fn,
                                   &ix->post_rel16, &ix->post_tfn, &ix->blk_piv, &ix->term_loc, &ix->blk_loc, &ix->term_kth_ub, &ix->doc_payload, &ix->s1})
         ix->device_bytes += b->bytes;
     *out = ix.release();
     return VBM25_OK;
+}
+
+static int vbm25_index_create_impl(const vbm25_index_desc *d, int device, vbm25_index **out) {
+    if (!out) return set_error(VBM25_ERR_INVALID, "out is NULL");
+    *out = nullptr;
+    if (int rc = check_desc(d)) return rc;
+    RawSegment r{};
+    r.on_device = false;
+    r.n_docs = d->n_docs;
+    r.n_terms = d->n_terms;
+    r.n_blocks = d->n_blocks;
+    r.sum_len = d->sum_len;
+    r.blob_bytes = d->blob_bytes;
+    r.k1 = d->k1;
+    r.b = d->b;
+    r.term_key = d->term_key;
+    r.term_df_host = r.term_df = d->term_df;
+    r.term_first_block_host = r.term_first_block = d->term_first_block;
+    r.term_wand_tf = d->term_wand_tf;
+    r.term_wand_fn = d->term_wand_fn;
+    r.blk_min_doc = d->blk_min_doc;
+    r.blk_max_doc = d->blk_max_doc;
+    r.blk_n = d->blk_n;
+    r.blk_wand_fn = d->blk_wand_fn;
+    r.blk_wand_tf = d->blk_wand_tf;
+    r.blk_meta_doc = d->blk_meta_doc;
+    r.blk_meta_tf = d->blk_meta_tf;
+    r.blk_off8 = d->blk_off8;
+    r.blob = d->blob;
+    r.doc_fieldnorm = d->doc_fieldnorm;
+    r.doc_payload = d->doc_payload;
+    return index_create_common(r, device, out);
+}
+
+// The index of a segment that is already in HBM (vbm25_device_segment_synth / _build): device-to-device copies of the arrays the
+// index keeps as they are, everything else derived where it lies.  The segment is left as it was.
+static int vbm25_index_create_from_device_impl(const vbm25_device_segment *ds, vbm25_index **out) {
+    if (!out) return set_error(VBM25_ERR_INVALID, "out is NULL");
+    *out = nullptr;
+    if (!ds) return set_error(VBM25_ERR_INVALID, "segment is NULL");
+    RawSegment r{};
+    r.on_device = true;
+    r.n_docs = ds->n_docs;
+    r.n_terms = ds->n_terms;
+    r.n_blocks = ds->n_blocks;
+    r.sum_len = ds->sum_len;
+    r.blob_bytes = ds->blob_bytes;
+    r.k1 = ds->k1;
+    r.b = ds->b;
+    r.term_key = ds->term_key.data();
+    r.term_df_host = ds->term_df.data();
+    r.term_first_block_host = ds->term_first_block.data();
+    r.term_df = ds->d_term_df.as<uint32_t>();
+    r.term_first_block = ds->d_term_first_block.as<uint32_t>();
+    r.term_wand_tf = ds->d_term_wand_tf.as<uint32_t>();
+    r.term_wand_fn = ds->d_term_wand_fn.as<uint8_t>();
+    r.blk_min_doc = ds->d_blk_min.as<uint32_t>();
+    r.blk_max_doc = ds->d_blk_max.as<uint32_t>();
+    r.blk_n = ds->d_blk_n.as<uint8_t>();
+    r.blk_wand_fn = ds->d_blk_wand_fn.as<uint8_t>();
+    r.blk_wand_tf = ds->d_blk_wand_tf.as<uint32_t>();
+    r.blk_meta_doc = ds->d_blk_meta_doc.as<uint8_t>();
+    r.blk_meta_tf = ds->d_blk_meta_tf.as<uint8_t>();
+    r.blk_off8 = ds->d_blk_off8.as<uint32_t>();
+    r.blob = ds->d_blob.as<uint8_t>();
+    r.doc_fieldnorm = ds->d_doc_fieldnorm.as<uint8_t>();
+    r.doc_payload = ds->d_doc_payload.as<uint16_t>();
+    return index_create_common(r, ds->device, out);
 }
 
 void vbm25_index_destroy(vbm25_index *ix) {
@@ -1247,6 +1343,9 @@ static int vbm25_search_batch_impl(vbm25_index *ix, const uint32_t *term_ids, co
 
 int vbm25_index_create(const vbm25_index_desc *d, int device, vbm25_index **out) {
     return guarded([&] { return vbm25_index_create_impl(d, device, out); });
+}
+int vbm25_index_create_from_device(const vbm25_device_segment *ds, vbm25_index **out) {
+    return guarded([&] { return vbm25_index_create_from_device_impl(ds, out); });
 }
 
 int vbm25_batch_create(vbm25_index *ix, uint32_t max_queries, uint32_t max_total_terms, uint32_t k,
