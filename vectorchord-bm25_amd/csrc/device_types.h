@@ -91,6 +91,20 @@ struct DevBatch {
     uint32_t *dbg;             // -DVBM25_CHECK builds: [0] first violated check (0: none), [1] value, [2] item, [3] thread
 };
 
+// The arguments of the scan kernels (DevIndex ix, DevBatch bt) as they lie in the kernarg segment.  The pointers that only an
+// item's setup, its end and the rare paths need are read from there where they are used (cold_args): kept in SGPRs for the whole
+// kernel they push the loops' uniform state into VGPRs and the VGPRs into scratch.
+struct KernArgs {
+    DevIndex ix;
+    DevBatch bt;
+};
+typedef const __attribute__((address_space(4))) KernArgs *KernArgsP;
+__device__ __forceinline__ KernArgsP cold_args() {
+    KernArgsP p = (KernArgsP)__builtin_amdgcn_kernarg_segment_ptr();
+    asm volatile("" : "+s"(p));  // opaque: the loads stay where they are written
+    return p;
+}
+
 // Bounds / consistency assertions of the scan kernels, compiled in by -DVBM25_CHECK only (tools/dense_stress.py): the
 // first violation is recorded in bt.dbg and read back with vbm25_batch_debug_check.
 #ifdef VBM25_CHECK

@@ -98,7 +98,7 @@ __global__ void __launch_bounds__(DWG, KMAX > 128 ? 2 : 4) scan_dense_kernel(Dev
 
     const uint32_t tid = threadIdx.x, lane = tid & 63, wave = uni(tid >> 6);
     const uint32_t k = bt.k;
-    const uint32_t n_items = *bt.n_items;
+    const uint32_t n_items = *cold_args()->bt.n_items;
     for (uint32_t i = tid; i < 256; i += DWG) {
         const double v = ix.s1[i];
         S.s1[i] = v;
@@ -116,7 +116,7 @@ __global__ void __launch_bounds__(DWG, KMAX > 128 ? 2 : 4) scan_dense_kernel(Dev
     for (;;) {
         __syncthreads();  // previous item fully done with LDS
         if (tid == 0) {
-            S.item = atomicAdd(&bt.work_ctr[1], 1u);
+            S.item = atomicAdd(&cold_args()->bt.work_ctr[1], 1u);
             S.cover = 0;
             S.cflag = 0;
             S.fail = 0;
@@ -126,7 +126,7 @@ __global__ void __launch_bounds__(DWG, KMAX > 128 ? 2 : 4) scan_dense_kernel(Dev
         __syncthreads();
         const uint32_t item = uni(S.item);
         if (item >= n_items) break;
-        const Item it = bt.items[item];
+        const Item it = cold_args()->bt.items[item];
         if (!(it.m & ITEM_DENSE) || (it.m & ~ITEM_DENSE) > (uint32_t)D_T) continue;  // the other kernels'
         const uint32_t q = uni(it.q), lo = uni(it.doc_lo), hi = uni(it.doc_hi);
         uint32_t *hrow = bt.hist + (size_t)q * CUR_HB;
@@ -171,11 +171,12 @@ __global__ void __launch_bounds__(DWG, KMAX > 128 ? 2 : 4) scan_dense_kernel(Dev
         // ---- item setup (wave 0, lane t = term t): block ranges, first block at or after lo, bounds, order, scale
         if (wave == 0) {
             poll_request();
+            const KernArgsP ca = cold_args();  // (the item setup's pointers: not kept in registers over the window loop)
             uint32_t m = 0, term = NONE32;
             {
-                const uint32_t qb = uni(bt.q_off[q]), qe = uni(bt.q_off[q + 1]);
+                const uint32_t qb = uni(ca->bt.q_off[q]), qe = uni(ca->bt.q_off[q + 1]);
                 for (uint32_t base = qb; base < qe; base += 64) {  // compaction of the indexed terms (search.rs:59-61)
-                    const uint32_t tt = base + lane < qe ? bt.term_ids[base + lane] : NONE32;
+                    const uint32_t tt = base + lane < qe ? ca->bt.term_ids[base + lane] : NONE32;
                     const bool ok = tt < ix.n_terms;
                     const unsigned long long okm = __ballot(ok);
                     const uint32_t pos = m + __builtin_amdgcn_mbcnt_hi((uint32_t)(okm >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)okm, 0u));
@@ -188,18 +189,27 @@ __global__ void __launch_bounds__(DWG, KMAX > 128 ? 2 : 4) scan_dense_kernel(Dev
                 __builtin_amdgcn_wave_barrier();
             }
             const bool act = lane < m;
-            double s0 = 0.0, tub = 0.0;
+            double s0 = 0.0, tub = 0.0, kth = 0.0;
+            const double *kub = ca->ix.term_kth_ub;
+            if (act && kub) {  // theta0: the term's 2^i-th largest block maximum, 2^i >= k (k documents of the term score that much)
+                uint32_t kidx = 0;
+                while ((1u << kidx) < k) ++kidx;
+                kth = kub[(size_t)term * 9 + kidx];
+            }
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) kth = fmax(kth, __shfl_xor(kth, o));
+            const unsigned long long theta0 = (unsigned long long)__double_as_longlong(kth);
             if (act) {
-                const uint32_t b0 = ix.term_first_block[term], b1 = ix.term_first_block[term + 1];
-                s0 = ix.term_s0[term];
-                const double wtf = (double)ix.term_wand_tf[term];
-                tub = ((wtf * s0) / (wtf + S.s1[ix.term_wand_fn[term]])) * (1.0 + 1e-12);
+                const uint32_t b0 = ca->ix.term_first_block[term], b1 = ca->ix.term_first_block[term + 1];
+                s0 = ca->ix.term_s0[term];
+                const double wtf = (double)ca->ix.term_wand_tf[term];
+                tub = ((wtf * s0) / (wtf + S.s1[ca->ix.term_wand_fn[term]])) * (1.0 + 1e-12);
                 S.t_cur[lane] = r_first_block_ge(ix, b0, b1, lo);
                 S.t_b0[lane] = b0;
                 S.t_end[lane] = b1;
                 S.t_s0[lane] = s0;
                 S.t_ub[lane] = tub;
-                const uint32_t df = ix.term_df[term];
+                const uint32_t df = ca->ix.term_df[term];
                 S.t_cls[lane] = (uint8_t)(df >= ix.n_docs / 2 ? 2 : df >= ix.n_docs / 8 ? 1 : 0);
             }
             uint32_t rank = 0;  // position in ascending order of the token upper bounds
@@ -231,7 +241,7 @@ __global__ void __launch_bounds__(DWG, KMAX > 128 ? 2 : 4) scan_dense_kernel(Dev
             unsigned long long sumdf = 0;
             uint32_t maxdf = 1;
             for (uint32_t t = 0; t < m; ++t) {
-                const uint32_t dft = (uint32_t)__builtin_amdgcn_readlane((int)(act ? ix.term_df[term] : 0u), (int)t);
+                const uint32_t dft = (uint32_t)__builtin_amdgcn_readlane((int)(act ? ca->ix.term_df[term] : 0u), (int)t);
                 sumdf += dft;
                 maxdf = max(maxdf, dft);
             }
@@ -243,7 +253,8 @@ __global__ void __launch_bounds__(DWG, KMAX > 128 ? 2 : 4) scan_dense_kernel(Dev
                 S.wmax = wmax_item;
                 S.scale = scale;
                 S.hscale = (double)CUR_HB / sums0;  // score -> histogram bucket: linear in [0, sum of s0), as scan_range.h
-                S.theta = 0;
+                S.theta = theta0;  // a lower bound of the final k-th score before the first posting is read
+                if (theta0) atomicMax(&bt.theta[q], theta0);
             }
             __builtin_amdgcn_wave_barrier();
             poll_consume();
@@ -472,7 +483,7 @@ __global__ void __launch_bounds__(DWG, KMAX > 128 ? 2 : 4) scan_dense_kernel(Dev
                 const uint32_t b1 = S.t_end[t];
                 if (cand) {
                     const uint32_t b = r_first_block_ge(ix, S.t_b0[t], b1, d);
-                    if (b < b1 && ix.blk_min_doc[b] <= d) bound += ix.blk_ub[b];
+                    if (b < b1 && cold_args()->ix.blk_min_doc[b] <= d) bound += ix.blk_ub[b];
                 }
             }
             cand = cand && bound * (1.0 + 1e-12) >= thd;
@@ -490,7 +501,7 @@ __global__ void __launch_bounds__(DWG, KMAX > 128 ? 2 : 4) scan_dense_kernel(Dev
                 bool pend = false;
                 if (cand) {
                     b = r_first_block_ge(ix, S.t_b0[t], b1, d);
-                    pend = b < b1 && ix.blk_min_doc[b] <= d;
+                    pend = b < b1 && cold_args()->ix.blk_min_doc[b] <= d;
                 }
                 for (;;) {
                     const unsigned long long pmask = __ballot(pend);
@@ -500,7 +511,7 @@ __global__ void __launch_bounds__(DWG, KMAX > 128 ? 2 : 4) scan_dense_kernel(Dev
                     const uint4 bm = uni4(ix.blk_meta[blk]);
                     const uint32_t n = bm.w & 0xff, md = (bm.w >> 8) & 0xff, mt = (bm.w >> 16) & 0xff;
                     uint32_t a0, a1;
-                    decode_doc_ids(ix.blob + 8ull * bm.z, md, n, bm.x, lane, a0, a1);
+                    decode_doc_ids(cold_args()->ix.blob + 8ull * bm.z, md, n, bm.x, lane, a0, a1);
                     __builtin_amdgcn_wave_barrier();
                     *reinterpret_cast<uint2 *>(&scr[2 * lane]) = make_uint2(2 * lane < n ? a0 : NONE32, 2 * lane + 1 < n ? a1 : NONE32);
                     __builtin_amdgcn_wave_barrier();
@@ -510,11 +521,11 @@ __global__ void __launch_bounds__(DWG, KMAX > 128 ? 2 : 4) scan_dense_kernel(Dev
                         for (int sft = 64; sft > 0; sft >>= 1)
                             if (scr[idx + sft - 1] < d) idx += sft;
                         if (scr[idx] == d) {
-                            const uint8_t *tbody = ix.blob + 8ull * bm.z + ((payload_bytes(md, n) + 7u) & ~7u);
+                            const uint8_t *tbody = cold_args()->ix.blob + 8ull * bm.z + ((payload_bytes(md, n) + 7u) & ~7u);
                             const FieldAddr fa = field_addr(mt, n, idx);
                             const uint32_t flo = *reinterpret_cast<const uint32_t *>(tbody + fa.off0);
                             const uint32_t fhi = *reinterpret_cast<const uint32_t *>(tbody + fa.off1);
-                            const uint32_t fn = ix.post_fn[128ull * blk + idx];
+                            const uint32_t fn = cold_args()->ix.post_fn[128ull * blk + idx];
                             const double tf = (double)field_val(flo, fhi, fa);
                             c = (tf * S.t_s0[t]) / (tf + S.s1[fn]);  // Cache::evaluate, bm25.rs:355-358
                         }
@@ -649,7 +660,7 @@ __global__ void __launch_bounds__(DWG, KMAX > 128 ? 2 : 4) scan_dense_kernel(Dev
                 const double thd = __longlong_as_double((long long)S.theta);
                 const bool below = lane < m && S.t_cum[lane + 1u] < thd;  // a prefix of the lanes (t_cum ascends)
                 uint32_t pn = (uint32_t)__popcll(__ballot(below));
-                if (!bt.ne_on && pn < m) pn = 0;
+                if (!cold_args()->bt.ne_on && pn < m) pn = 0;
                 const bool head = lane < pn && pn < m && S.t_cls[S.t_ord[lane]] == 2;
                 const unsigned long long hm = __ballot(head);
                 const uint32_t h = (uint32_t)__ffsll((long long)~hm) - 1u;  // heads below the first other term
@@ -819,20 +830,21 @@ __global__ void __launch_bounds__(DWG, KMAX > 128 ? 2 : 4) scan_dense_kernel(Dev
         // ---- item result: one list per wave
         {
             const uint32_t n = failed ? 0u : rtop.cnt;
-            const size_t list = (size_t)item * bt.lpi + wave;
-            VCHK(item < bt.max_items && bt.lpi == (uint32_t)DNW, 9, item);
+            const KernArgsP ce = cold_args();
+            const size_t list = (size_t)item * ce->bt.lpi + wave;
+            VCHK(item < ce->bt.max_items && ce->bt.lpi == (uint32_t)DNW, 9, item);
             VCHK(n <= k, 14, n);
 #pragma unroll
             for (int r = 0; r < RK; ++r)
                 if (r * 64 + lane < n) {
-                    bt.res_score[list * k + r * 64 + lane] = rtop.score[r];
-                    bt.res_doc[list * k + r * 64 + lane] = rtop.doc[r];
+                    ce->bt.res_score[list * k + r * 64 + lane] = rtop.score[r];
+                    ce->bt.res_doc[list * k + r * 64 + lane] = rtop.doc[r];
                 }
             if (lane == 0) {
-                bt.res_cnt[list] = n;
+                ce->bt.res_cnt[list] = n;
                 if (wave == 0) {
-                    bt.item_failed[item] = failed ? 0x140u : 0u;
-                    if (failed) *bt.fail_any = 1u;
+                    ce->bt.item_failed[item] = failed ? 0x140u : 0u;
+                    if (failed) *ce->bt.fail_any = 1u;
                 }
             }
         }

@@ -122,19 +122,7 @@ __device__ __forceinline__ uint32_t tm_first_block_ge(const uint32_t *blk_max_do
         }                                                                                                       \
     } while (false)
 
-// The kernel's arguments as they lie in the kernarg segment.  The pointers that only the item setup, the item's end and the
-// rare paths need are read from there where they are used (cold_args): kept in SGPRs for the whole kernel they push the loop's
-// uniform state into VGPRs and the VGPRs into scratch.
-struct TeamArgs {
-    DevIndex ix;
-    DevBatch bt;
-};
-typedef const __attribute__((address_space(4))) TeamArgs *TeamArgsP;
-__device__ __forceinline__ TeamArgsP cold_args() {
-    TeamArgsP p = (TeamArgsP)__builtin_amdgcn_kernarg_segment_ptr();
-    asm volatile("" : "+s"(p));  // opaque: the loads stay where they are written
-    return p;
-}
+typedef KernArgsP TeamArgsP;  // (device_types.h: the cold arguments read from the kernarg segment where they are used)
 
 template <int KMAX, int TEAM>
 __global__ void __launch_bounds__(TEAM * 64, 4) scan_team_kernel(DevIndex ix, DevBatch bt) {
