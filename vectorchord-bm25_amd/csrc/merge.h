@@ -9,6 +9,8 @@ template <int KMAX>
 __global__ void __launch_bounds__(64) merge_kernel(DevIndex ix, DevBatch bt) {
     __shared__ TopK<(KMAX > REG_K ? KMAX : 1)> s_top;
     __shared__ uint32_t s_map[KMAX <= REG_K ? 16 * KMAX : 1];  // (list, entry) of the entries of 16 lists
+    __shared__ double s_sv_score[64];  // the entries at or above the threshold, while there are at most 64 of them (the usual case:
+    __shared__ uint32_t s_sv_doc[64];  // the threshold is the best k-th score any list reached) -- ranked by counting, below
     constexpr int RK = KMAX <= REG_K ? KMAX / 64 : 1;
     RegTopK<RK> rtop;
     rtop.init();
@@ -23,6 +25,8 @@ __global__ void __launch_bounds__(64) merge_kernel(DevIndex ix, DevBatch bt) {
     // the query's threshold is a lower bound of its k-th best score: entries below it cannot be among the hits (a
     // dense query's 32 lists of 100 entries mostly are)
     const unsigned long long theta = bt.theta[q];
+    uint32_t nsv = 0;      // survivors buffered in s_sv_*
+    bool ranked = true;    // ... and nothing has gone to the register top-k yet
     if constexpr (KMAX <= REG_K) {
         // all entries of 16 lists at a time: one round trip for the counts, one for the entries (a list after the other was
         // two dependent round trips per list -- most of this kernel's time)
@@ -43,6 +47,22 @@ __global__ void __launch_bounds__(64) merge_kernel(DevIndex ix, DevBatch bt) {
                     sc = bt.res_score[at];
                     d = bt.res_doc[at];
                     has = (unsigned long long)__double_as_longlong(sc) >= theta;
+                }
+                const unsigned long long hm = __ballot(has);
+                if (ranked && nsv + (uint32_t)__popcll(hm) <= 64u) {
+                    if (has) {
+                        const uint32_t at = nsv + __builtin_amdgcn_mbcnt_hi((uint32_t)(hm >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)hm, 0u));
+                        s_sv_score[at] = sc;
+                        s_sv_doc[at] = d;
+                    }
+                    nsv += (uint32_t)__popcll(hm);
+                    continue;
+                }
+                if (ranked) {  // more than 64 survivors: the buffered ones first, then everything through the register top-k
+                    ranked = false;
+                    __builtin_amdgcn_wave_barrier();
+                    const bool hb = lane < nsv;
+                    rtop.template offer<true>(hb, hb ? s_sv_score[lane] : 0.0, hb ? s_sv_doc[lane] : 0u, k, lane);
                 }
                 rtop.template offer<true>(has, sc, d, k, lane);  // (scan_team_kernel: a document may be in two waves' lists)
             }
@@ -75,7 +95,30 @@ __global__ void __launch_bounds__(64) merge_kernel(DevIndex ix, DevBatch bt) {
         out[2] = (unsigned long long)pl[2];
     };
     uint32_t n;
-    if constexpr (KMAX <= REG_K) {
+    if (KMAX <= REG_K && ranked) {
+        // at most 64 survivors, one per lane: an entry's place = the number of entries better than it (score descending, ties by
+        // ascending document); an entry that repeats an earlier one (same document, same score bits) is dropped and counts for nobody
+        __builtin_amdgcn_wave_barrier();
+        const bool mine = lane < nsv;
+        const double sc = mine ? s_sv_score[lane] : 0.0;
+        const uint32_t d = mine ? s_sv_doc[lane] : 0u;
+        bool rep = false;
+        for (uint32_t j = 0; j + 1 < nsv; ++j) {
+            const double sj = readlane_f64(sc, j);
+            const uint32_t dj = (uint32_t)__builtin_amdgcn_readlane((int)d, (int)j);
+            rep = rep || (lane > j && dj == d && sj == sc);
+        }
+        const unsigned long long live = __ballot(mine && !rep);
+        uint32_t place = 0;
+        for (uint32_t j = 0; j < nsv; ++j) {
+            if (!((live >> j) & 1ull)) continue;
+            const double sj = readlane_f64(sc, j);
+            const uint32_t dj = (uint32_t)__builtin_amdgcn_readlane((int)d, (int)j);
+            place += better(sj, dj, sc, d) ? 1u : 0u;
+        }
+        n = min((uint32_t)__popcll(live), k);
+        if (mine && !rep && place < k) emit(place, sc, d);
+    } else if constexpr (KMAX <= REG_K) {
         n = rtop.cnt;
 #pragma unroll
         for (int r = 0; r < RK; ++r)

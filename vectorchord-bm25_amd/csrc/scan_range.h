@@ -140,7 +140,7 @@ __global__ void __launch_bounds__(RWG, 4) scan_range_kernel(DevIndex ix, DevBatc
     // The general instantiation with bt.fused_g != 0 (every query of the batch sparse: vbm25_batch_run without plan_kernel):
     // the same items, made right here; merge_kernel merges and cleans.
     const uint32_t fused_g = bt.fused_g;
-    const uint32_t n_items = fused_g ? bt.nq * fused_g : *bt.n_items;
+    const uint32_t n_items = fused_g ? bt.nq * fused_g : *cold_args()->bt.n_items;
     for (uint32_t i = tid; i < 256; i += RWG) S.s1[i] = ix.s1[i];
 
 #ifdef VBM25_PROFILE
@@ -156,8 +156,9 @@ __global__ void __launch_bounds__(RWG, 4) scan_range_kernel(DevIndex ix, DevBatc
     for (;;) {
         __syncthreads();  // previous item fully done with LDS
         if (tid == 0) {
-            const uint32_t drawn = atomicAdd(bt.work_ctr, 1u);
-            S.item = !fused_g && drawn < n_items ? bt.item_order[drawn] : drawn;  // plan_kernel's order: longest first
+            const KernArgsP cd = cold_args();  // (the arguments only an item's setup and end need are read where they are used)
+            const uint32_t drawn = atomicAdd(cd->bt.work_ctr, 1u);
+            S.item = !fused_g && drawn < n_items ? cd->bt.item_order[drawn] : drawn;  // plan_kernel's order: longest first
         }
         for (uint32_t i = tid; i < R_HS; i += RWG) S.hkeys[i] = EMPTY;
         for (uint32_t i = tid; i < R_BM_WORDS + 4; i += RWG) S.bm[i] = 0;
@@ -175,7 +176,7 @@ __global__ void __launch_bounds__(RWG, 4) scan_range_kernel(DevIndex ix, DevBatc
             it.doc_hi = (uint32_t)((unsigned long long)ix.n_docs * (part + 1) / fused_g);
             it.m = 0;  // the host sends only sparse queries of <= RT indexed terms this way
         } else {
-            it = bt.items[item];
+            it = cold_args()->bt.items[item];
         }
         if (it.m > (uint32_t)RT) continue;  // more terms or dense (ITEM_DENSE): the other kernels'
         PROF_T(t_item);
@@ -379,11 +380,12 @@ __global__ void __launch_bounds__(RWG, 4) scan_range_kernel(DevIndex ix, DevBatc
         // ---- item setup (wave 0): terms, cursors, quotas, slot map; the first two plans
         if (wave == 0) {
             poll_request();
+            const KernArgsP ca = cold_args();
             uint32_t m = 0, term = NONE32;
             {
-                const uint32_t qb = uni(bt.q_off[q]), qe = uni(bt.q_off[q + 1]);
+                const uint32_t qb = uni(ca->bt.q_off[q]), qe = uni(ca->bt.q_off[q + 1]);
                 if (qe - qb <= 64) {  // one load per lane, compaction of the indexed terms through LDS
-                    const uint32_t tt = lane < qe - qb ? bt.term_ids[qb + lane] : NONE32;
+                    const uint32_t tt = lane < qe - qb ? ca->bt.term_ids[qb + lane] : NONE32;
                     const bool ok = tt < ix.n_terms;  // search.rs:59-61
                     const unsigned long long okm = __ballot(ok);
                     if (ok) S.scratch[__builtin_amdgcn_mbcnt_hi((uint32_t)(okm >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)okm, 0u))] = tt;
@@ -393,7 +395,7 @@ __global__ void __launch_bounds__(RWG, 4) scan_range_kernel(DevIndex ix, DevBatc
                     __builtin_amdgcn_wave_barrier();
                 } else {
                     for (uint32_t p = qb; p < qe; ++p) {
-                        const uint32_t tt = bt.term_ids[p];
+                        const uint32_t tt = ca->bt.term_ids[p];
                         if (tt >= ix.n_terms) continue;
                         if (m == lane) term = tt;
                         ++m;
@@ -405,18 +407,19 @@ __global__ void __launch_bounds__(RWG, 4) scan_range_kernel(DevIndex ix, DevBatc
             double s0 = 0.0, tub = 0.0, kth = 0.0;
             uint32_t df = 0, b0 = 0, b1 = 0;
             p_cur = p_end = 0;
-            if (act && ix.term_kth_ub) {  // (the smallest 2^i >= k: at least k documents of the term score that much)
+            const double *kub = ca->ix.term_kth_ub;
+            if (act && kub) {  // (the smallest 2^i >= k: at least k documents of the term score that much)
                 uint32_t kidx = 0;
                 while ((1u << kidx) < k) ++kidx;
-                kth = ix.term_kth_ub[(size_t)term * 9 + kidx];
+                kth = kub[(size_t)term * 9 + kidx];
             }
             if (act) {
-                b0 = ix.term_first_block[term];
-                b1 = ix.term_first_block[term + 1];
-                s0 = ix.term_s0[term];
-                df = ix.term_df[term];
-                const double wtf = (double)ix.term_wand_tf[term];
-                tub = ((wtf * s0) / (wtf + S.s1[ix.term_wand_fn[term]])) * (1.0 + 1e-12);
+                b0 = ca->ix.term_first_block[term];
+                b1 = ca->ix.term_first_block[term + 1];
+                s0 = ca->ix.term_s0[term];
+                df = ca->ix.term_df[term];
+                const double wtf = (double)ca->ix.term_wand_tf[term];
+                tub = ((wtf * s0) / (wtf + S.s1[ca->ix.term_wand_fn[term]])) * (1.0 + 1e-12);
                 // first block whose max_doc >= lo: guess by interpolation, gallop, then bisect
                 uint32_t lo_b = b0, hi_b = b1;
                 if (lo != 0 && b1 > b0) {
@@ -487,7 +490,7 @@ __global__ void __launch_bounds__(RWG, 4) scan_range_kernel(DevIndex ix, DevBatc
                     cum += readlane_f64(tub, owner);
                     const unsigned long long dfo = (uint32_t)__builtin_amdgcn_readlane((int)df, (int)owner);
                     head += dfo;
-                    if (pp + 1 < m && (dfo >= (unsigned long long)bt.ne_ratio * (sumdf - head) || dfo * 16ull >= ix.n_docs)) best = pp + 1;
+                    if (pp + 1 < m && (dfo >= (unsigned long long)ca->bt.ne_ratio * (sumdf - head) || dfo * 16ull >= ix.n_docs)) best = pp + 1;
                     if (lane == 0) {
                         S.t_cum[pp + 1] = cum;
                         S.t_best[pp + 1] = (uint8_t)best;
@@ -512,10 +515,10 @@ __global__ void __launch_bounds__(RWG, 4) scan_range_kernel(DevIndex ix, DevBatc
                     rec.doc_lo = lo;
                     rec.doc_hi = hi;
                     rec.m = m;
-                    bt.items[item] = rec;
-                    if (item == 0) *bt.n_items = n_items;
-                    if (item % fused_g == 0) bt.q_item_base[q] = item;
-                    if (item + 1 == n_items) bt.q_item_base[q + 1] = n_items;
+                    ca->bt.items[item] = rec;
+                    if (item == 0) *ca->bt.n_items = n_items;
+                    if (item % fused_g == 0) ca->bt.q_item_base[q] = item;
+                    if (item + 1 == n_items) ca->bt.q_item_base[q + 1] = n_items;
                 }
                 S.q = q;
                 S.lo = lo;
@@ -982,18 +985,23 @@ __global__ void __launch_bounds__(RWG, 4) scan_range_kernel(DevIndex ix, DevBatc
 #endif
         // ---- item result: one list per wave
         const uint32_t n = failed ? 0u : rtop.cnt;
-        const size_t list = (size_t)item * bt.lpi + wave;
+        const KernArgsP ce = cold_args();
+        const size_t list = (size_t)item * ce->bt.lpi + wave;
+        {
+            double *res_score = ce->bt.res_score;
+            uint32_t *res_doc = ce->bt.res_doc;
 #pragma unroll
-        for (int r = 0; r < RK; ++r)
-            if (r * 64 + lane < n) {
-                bt.res_score[list * k + r * 64 + lane] = rtop.score[r];
-                bt.res_doc[list * k + r * 64 + lane] = rtop.doc[r];
-            }
+            for (int r = 0; r < RK; ++r)
+                if (r * 64 + lane < n) {
+                    res_score[list * k + r * 64 + lane] = rtop.score[r];
+                    res_doc[list * k + r * 64 + lane] = rtop.doc[r];
+                }
+        }
         if (lane == 0) {
-            bt.res_cnt[list] = n;
+            ce->bt.res_cnt[list] = n;
             if (wave == 0) {
-                bt.item_failed[item] = failed ? (S.fail | 0x100u) : 0u;
-                if (failed) *bt.fail_any = 1u;
+                ce->bt.item_failed[item] = failed ? (S.fail | 0x100u) : 0u;
+                if (failed) *ce->bt.fail_any = 1u;
             }
         }
         if constexpr (FUSED) {
