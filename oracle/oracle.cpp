@@ -33,6 +33,10 @@ namespace {
 // being copied; tests/test_oracle_pins.py checks it against the reference
 // table when /root/reference is present.
 // ---------------------------------------------------------------------------
+// blocks the Block-WAND restatement decompressed on this thread (tools/wand_pruning.py: how much the reference's own
+// traversal skips on a query shape)
+static thread_local unsigned long long g_blocks_decoded = 0;
+
 struct FieldnormTable {
     uint32_t v[256];
     FieldnormTable() {
@@ -568,6 +572,7 @@ struct Cursor {
         filled = false;
     }
     void fill_block() {  // search.rs:498-518
+        ++g_blocks_decoded;
         uint32_t j = summary.blk;
         n_docs_dec = decompress_document_ids(summary.min_doc, ix->blk_meta_doc[j], ix->doc_ptr(j),
                                              ix->doc_bytes(j), docs);
@@ -970,6 +975,12 @@ void orc_index_get_view(const orc_index *ix, orc_index_view *v) {
 uint32_t orc_search_wand(const orc_index *ix, const uint32_t *terms, uint32_t n_terms, uint32_t k,
                          orc_hit *out) {
     return search_wand(ix, terms, n_terms, k, nullptr, out);
+}
+
+unsigned long long orc_wand_blocks_decoded(int reset) {
+    const unsigned long long v = g_blocks_decoded;
+    if (reset) g_blocks_decoded = 0;
+    return v;
 }
 
 uint32_t orc_search_brute(const orc_index *ix, const uint32_t *terms, uint32_t n_terms,

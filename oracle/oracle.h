@@ -117,6 +117,8 @@ uint32_t orc_search_wand(const orc_index *, const uint32_t *terms, uint32_t n_te
                          orc_hit *out);
 /* Canonical brute force: every document scored with Cache::evaluate summed in
  * ascending key order; ordered by (score desc, doc id asc). */
+/* blocks the calling thread's orc_search_wand calls have decompressed (fill_block, search.rs:498-518) since the last reset */
+unsigned long long orc_wand_blocks_decoded(int reset);
 uint32_t orc_search_brute(const orc_index *, const uint32_t *terms, uint32_t n_terms, uint32_t k,
                           orc_hit *out);
 /* Batch drivers (one query per thread, PostgreSQL's execution model).

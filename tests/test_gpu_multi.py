@@ -81,3 +81,24 @@ def test_team_kernel_matches_the_oracle(tuning, team_size):
             for q in range(96):
                 assert_bit_exact(ob[q, :onb[q]], hits[q, :nh[q]], what=f"team {team_size} terms {nterms} k {k} q{q}")
         assert b.debug_counts()[1] == 0
+
+
+def test_prefilter_by_over_fetch_matches_the_filtered_ranking():
+    """prefilter = on (default.rs:120-128): the shim's over-fetch loop (vb.search_batch_filtered) against the oracle's full ranking
+    with the same filter applied: the first k accepted hits, for filters that keep half, a tenth and one in 300 of the documents
+    (the last one forces the deeper rounds and exhausts some queries)."""
+    c, seg = _setup(200_000, 2000, seed=8)
+    oix = orc.OracleIndex.from_arrays(seg.meta(), seg.arrays())
+    gix = vb.GpuIndex(seg)
+    terms, off = make_queries(c, 24, 3, seed=12)
+    k = 10
+    for modulus in (2, 10, 300):
+        keep = lambda h, m=modulus: (h["doc_id"] % m) == 1  # noqa: E731
+        hits, nh, rounds = vb.search_batch_filtered(gix, terms, off, k, keep)
+        assert rounds >= (1 if modulus == 2 else 2)
+        for q in range(24):
+            t = terms[off[q]:off[q + 1]]
+            full = oix.search_brute(t, 65535)
+            want = full[keep(full)][:k]
+            assert nh[q] == len(want)
+            assert_bit_exact(want, hits[q, :nh[q]], what=f"filter 1/{modulus} q{q}")

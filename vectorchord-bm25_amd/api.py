@@ -357,6 +357,41 @@ class Batch:
         return tuple(int(x) for x in out)
 
 
+def search_batch_filtered(index, term_ids, q_off, k, keep, overfetch=2):
+    """`prefilter = on` (default.rs:120-128, fetcher.rs:180-216: a candidate enters Results only if filter(payload) holds -- a heap
+    visibility check the GPU cannot make) as the shim runs it: OVER-FETCH and filter on the host.  The GPU returns overfetch * k
+    hits per query; the host keeps those `keep(hits) -> bool array` accepts; a query left with fewer than k accepted hits although
+    the GPU delivered a full list is asked again, four times deeper, until k survive or its matches are exhausted (bm25.limit's
+    maximum, 65535, bounds the depth as it bounds the reference's k).  Exact: the accepted hits are the first k accepted of the
+    unfiltered ranking, which is what the reference's filtered search returns (ties aside).  Returns (hits[nq, k], n_hits[nq],
+    rounds)."""
+    term_ids = np.ascontiguousarray(term_ids, dtype=np.uint32)
+    q_off = np.ascontiguousarray(q_off, dtype=np.uint32)
+    nq = len(q_off) - 1
+    out = np.zeros((nq, max(k, 1)), dtype=HIT_DTYPE)
+    n_out = np.zeros(nq, dtype=np.uint32)
+    todo = np.arange(nq)
+    depth = min(65535, max(k, int(k * overfetch)))
+    rounds = 0
+    while len(todo):
+        rounds += 1
+        sub_terms = np.concatenate([term_ids[q_off[q]:q_off[q + 1]] for q in todo]) if len(todo) else term_ids[:0]
+        sub_off = np.concatenate([[0], np.cumsum([q_off[q + 1] - q_off[q] for q in todo])]).astype(np.uint32)
+        hits, n_hits = search_batch(index, sub_terms, sub_off, depth)
+        again = []
+        for i, q in enumerate(todo):
+            h = hits[i, :n_hits[i]]
+            ok = h[np.asarray(keep(h), dtype=bool)]
+            if len(ok) >= k or n_hits[i] < depth or depth == 65535:  # enough, or the query has no more matches to offer
+                n_out[q] = min(k, len(ok))
+                out[q, :n_out[q]] = ok[:k]
+            else:
+                again.append(q)
+        todo = np.array(again, dtype=np.int64)
+        depth = min(65535, depth * 4)
+    return out, n_out, rounds
+
+
 class MultiIndex:
     """vbm25_multi_create: the sealed segment on several GPUs of one node -- uploaded once, replicated GPU to GPU.
     `devices` may list a device more than once (two replicas on device 0: the single-GPU test of the N-GPU path)."""
