@@ -34,6 +34,7 @@ for f in re.split(r'\n(?=_ZN5vbm25\w+:)', txt):
         if op.startswith('scratch_'): sc[cur] += 1
     print(name, sum(tot.values()), "instructions;", sum(wl.values()), "v_writelane,", sum(rl.values()), "v_readlane,", sum(sc.values()), "scratch")
     print("v_writelane by source line:", wl.most_common(30))
+    print("v_readlane by source line:", rl.most_common(40))
     print("scratch by source line:", sc.most_common(30))
     reg = collections.Counter()
     for (fn, ln), v in tot.items():

@@ -2,7 +2,7 @@
 # One parametrised measurement script (replaces the round-3 tools/r3_*.sh one-offs).  Run through gpurun:
 #   gpurun -- 'bash tools/measure.sh <out-subdir> <step> [<step> ...]'
 # steps: tests (GPU search tests)  alltests (whole -m gpu suite)  c3 (verified bench line)  c3quick  c3stats (rocprofv3 kernel
-#        stats)  c3pmc (four counter passes)  c5  c2  ubench
+#        stats)  c3pmc (four counter passes + the pmc_traffic.json entry)  c5  c5stats  c5pmc  c2  ubench  ubenchpmc
 # TUNE="name=value,..." is passed to bench.py --tune.
 set -u
 R=$GRAFT_REPO_ROOT; SUB=${1:-r4}; shift; O=$R/gpurun_out/$SUB; mkdir -p $O; cd $R
@@ -26,8 +26,19 @@ for step in "$@"; do case $step in
       timeout 300 rocprofv3 --kernel-trace --pmc SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_VMEM_RD SQ_INSTS_SMEM SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_IFETCH --output-format csv -d $O/pmc_sq2 -- $B > $O/pmc_sq2.log 2>&1
       timeout 300 rocprofv3 --kernel-trace --pmc GRBM_GUI_ACTIVE FETCH_SIZE --output-format csv -d $O/pmc_fetch -- $B > $O/pmc_fetch.log 2>&1
       timeout 300 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $O/pmc_write -- $B > $O/pmc_write.log 2>&1)
-     python tools/pmc_summary.py ${KERNEL:-scan_team_kernel} sq1=$O/pmc_sq1 sq2=$O/pmc_sq2 fetch=$O/pmc_fetch write=$O/pmc_write > $O/pmc_summary.csv 2> $O/pmc_summary.err; cat $O/pmc_summary.csv
+     python tools/pmc_summary.py ${KERNEL:-scan_range_kernel} sq1=$O/pmc_sq1 sq2=$O/pmc_sq2 fetch=$O/pmc_fetch write=$O/pmc_write > $O/pmc_summary.csv 2> $O/pmc_summary.err; cat $O/pmc_summary.csv
+     python tools/pmc_traffic.py C3 ${KERNEL:-scan_range_kernel} $O/pmc_fetch $O/pmc_write > $O/pmc_traffic_c3.json; cat $O/pmc_traffic_c3.json
      find $O -name "*.csv" -size +5M -delete;;
+  c5stats) (cd /tmp; export TMPDIR=/tmp; timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats5 -- python $R/bench.py --workload C5 --steps 5 --warmup 1 --no-cpu-baseline --extra-budget-s 0 $TUNE_ARG > $O/stats5.log 2>&1); f=$(find $O/stats5 -name "*kernel_stats.csv" | head -1); [ -n "$f" ] && cp $f $O/c5_kernel_stats.csv && head -8 $O/c5_kernel_stats.csv; find $O/stats5 -name "*.csv" -size +5M -delete;;
+  c5pmc) B="python $R/bench.py --workload C5 --steps 3 --warmup 1 --no-cpu-baseline --extra-budget-s 0 $TUNE_ARG"
+     (cd /tmp; export TMPDIR=/tmp
+      timeout 400 rocprofv3 --kernel-trace --pmc SQ_WAVE_CYCLES SQ_BUSY_CU_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_WAIT_INST_LDS SQ_ACTIVE_INST_ANY SQ_INSTS_VALU SQ_INSTS_SALU --output-format csv -d $O/pmc5_sq1 -- $B > $O/pmc5_sq1.log 2>&1
+      timeout 400 rocprofv3 --kernel-trace --pmc GRBM_GUI_ACTIVE FETCH_SIZE --output-format csv -d $O/pmc5_fetch -- $B > $O/pmc5_fetch.log 2>&1
+      timeout 400 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $O/pmc5_write -- $B > $O/pmc5_write.log 2>&1)
+     python tools/pmc_summary.py scan_dense_kernel sq1=$O/pmc5_sq1 fetch=$O/pmc5_fetch write=$O/pmc5_write > $O/pmc5_summary.csv 2> $O/pmc5_summary.err; cat $O/pmc5_summary.csv
+     python tools/pmc_traffic.py C5 scan_dense_kernel $O/pmc5_fetch $O/pmc5_write > $O/pmc_traffic_c5.json; cat $O/pmc_traffic_c5.json
+     find $O -name "*.csv" -size +5M -delete;;
+  ubenchpmc) bash tools/ubench/pmc.sh > $O/mark_ceiling_pmc.txt 2>&1; tail -40 $O/mark_ceiling_pmc.txt;;
   ubench) (cd tools/ubench && ./mark_ceiling > $O/mark_ceiling.txt 2>&1; cat $O/mark_ceiling.txt);;
   *) echo "unknown step $step";;
 esac; done

@@ -200,17 +200,21 @@ __global__ void __launch_bounds__(DWG, KMAX > 128 ? 2 : 4) scan_dense_kernel(Dev
             for (int o = 32; o > 0; o >>= 1) kth = fmax(kth, __shfl_xor(kth, o));
             const unsigned long long theta0 = (unsigned long long)__double_as_longlong(kth);
             if (act) {
+                // (sl: the lane number, made opaque here -- the LDS addresses below are otherwise computed once at kernel
+                // entry, for every wave, and kept in scratch over the whole launch)
+                uint32_t sl = lane;
+                asm volatile("" : "+v"(sl));
                 const uint32_t b0 = ca->ix.term_first_block[term], b1 = ca->ix.term_first_block[term + 1];
                 s0 = ca->ix.term_s0[term];
                 const double wtf = (double)ca->ix.term_wand_tf[term];
                 tub = ((wtf * s0) / (wtf + S.s1[ca->ix.term_wand_fn[term]])) * (1.0 + 1e-12);
-                S.t_cur[lane] = r_first_block_ge(ix, b0, b1, lo);
-                S.t_b0[lane] = b0;
-                S.t_end[lane] = b1;
-                S.t_s0[lane] = s0;
-                S.t_ub[lane] = tub;
+                S.t_cur[sl] = r_first_block_ge(ix, b0, b1, lo);
+                S.t_b0[sl] = b0;
+                S.t_end[sl] = b1;
+                S.t_s0[sl] = s0;
+                S.t_ub[sl] = tub;
                 const uint32_t df = ca->ix.term_df[term];
-                S.t_cls[lane] = (uint8_t)(df >= ix.n_docs / 2 ? 2 : df >= ix.n_docs / 8 ? 1 : 0);
+                S.t_cls[sl] = (uint8_t)(df >= ix.n_docs / 2 ? 2 : df >= ix.n_docs / 8 ? 1 : 0);
             }
             uint32_t rank = 0;  // position in ascending order of the token upper bounds
             double sums0 = 0.0;
@@ -687,15 +691,17 @@ __global__ void __launch_bounds__(DWG, KMAX > 128 ? 2 : 4) scan_dense_kernel(Dev
                         const uint32_t before = (uint32_t)__builtin_amdgcn_readlane((int)wave_incl_scan_u32(lane < m && ru > rt ? cu : 0u), 63);
                         if (lane == 0) S.t_base[t] = before;
                         if (!uni(S.fail)) {
+                            uint32_t fl = lane, tb = t;
+                            asm volatile("" : "+v"(fl), "+s"(tb));  // (as sl in the item setup: nothing of this block hoisted to kernel entry)
 #pragma unroll
                             for (int ch = 0; ch < 2; ++ch) {
-                                const uint32_t i = 64u * ch + lane;
+                                const uint32_t i = 64u * ch + fl;
                                 if (i < ecnt[s]) {
                                     VCHK(before + i < (uint32_t)D_TCAP, 1, before + i);
                                     S.tmeta[before + i] = em[s][ch];
                                     S.tblk[before + i] = ecur[s] + i;
                                     S.tub[before + i] = __double2uint_ru(eub[s][ch] * scale) + 1u;
-                                    S.tterm[before + i] = (uint8_t)t;
+                                    S.tterm[before + i] = (uint8_t)tb;
                                 }
                             }
                         }
@@ -823,8 +829,11 @@ __global__ void __launch_bounds__(DWG, KMAX > 128 ? 2 : 4) scan_dense_kernel(Dev
 #endif
         if (failed) {  // hand the item to scan_many_kernel; leave LDS clean
             __syncthreads();
-            for (uint32_t i = tid; i < (uint32_t)D_W / 2; i += DWG) S.acc[i] = 0u;
-            if (tid < (uint32_t)D_W / 64) S.bmax[tid] = 0u;
+            // (the thread number rebuilt from the lane count: threadIdx.x itself would have to be kept -- in scratch -- for this path)
+            uint32_t t0 = wave * 64u + __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
+            asm volatile("" : "+v"(t0));
+            for (uint32_t i = t0; i < (uint32_t)D_W / 2; i += DWG) S.acc[i] = 0u;
+            if (t0 < (uint32_t)D_W / 64) S.bmax[t0] = 0u;
         }
 
         // ---- item result: one list per wave

@@ -391,7 +391,9 @@ __global__ void __launch_bounds__(RWG, 4) scan_range_kernel(DevIndex ix, DevBatc
                     if (ok) S.scratch[__builtin_amdgcn_mbcnt_hi((uint32_t)(okm >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)okm, 0u))] = tt;
                     __builtin_amdgcn_wave_barrier();
                     m = (uint32_t)__popcll(okm);
-                    if (lane < m) term = S.scratch[lane];
+                    uint32_t sl = lane;
+                    asm volatile("" : "+v"(sl));  // (the address below is otherwise computed at kernel entry and kept in scratch)
+                    if (lane < m) term = S.scratch[sl];
                     __builtin_amdgcn_wave_barrier();
                 } else {
                     for (uint32_t p = qb; p < qe; ++p) {
