@@ -21,7 +21,7 @@ n_docs, vocab, mean_len, len_mode, zipf_s, nq, nterms, k = WORKLOADS[wl]
 if cache and os.path.exists(cache):
     seg = vb.Segment.load(cache)
 else:
-    seg = vb.Segment.synth(n_docs, vocab, mean_len=mean_len, len_mode=len_mode, zipf_s=zipf_s, threads=16)
+    seg = vb.DeviceSegment.synth(n_docs, vocab, mean_len=mean_len, len_mode=len_mode, zipf_s=zipf_s, seed=20260925, device=0)
 gix = vb.GpuIndex(seg)
 terms, off = make_queries(seg, vocab, nq, nterms, seed=1, zipf_s=zipf_s)
 b = vb.Batch(gix, nq, len(terms), k)

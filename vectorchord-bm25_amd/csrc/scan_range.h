@@ -455,10 +455,12 @@ __global__ void __launch_bounds__(RWG, 4) scan_range_kernel(DevIndex ix, DevBatc
                 }
                 p_cur = lo_b;
                 p_end = b1;
-                S.t_s0[lane] = s0;
-                S.t_ub[lane] = tub;
-                S.t_b0[lane] = b0;
-                S.t_b1[lane] = b1;
+                uint32_t tl = lane;
+                asm volatile("" : "+v"(tl));  // (as sl above: none of these addresses hoisted to kernel entry)
+                S.t_s0[tl] = s0;
+                S.t_ub[tl] = tub;
+                S.t_b0[tl] = b0;
+                S.t_b1[tl] = b1;
             }
             // terms in ascending order of their token upper bound; prefix sums; admissible prefixes
             // theta0: the largest, over the terms, of the term's k-th largest block maximum -- a lower bound of the final k-th
@@ -633,7 +635,9 @@ __global__ void __launch_bounds__(RWG, 4) scan_range_kernel(DevIndex ix, DevBatc
 
             uint32_t nv = 0;  // this wave's entries: (wave - 1) + 7 i < np  <=>  i < nv
             if (wave == 0) {
-                // ---- planner: threshold poll, plan of the next tile (read by the others after barrier A)
+                // ---- planner: threshold poll, plan of the next tile (read by the others after barrier A).  (Issuing the poll's
+                // loads at the end of the previous turn, a tile ahead, was measured twice -- round 3 and, with the theta0
+                // bootstrap in place, round 4: 0.3813 against 0.3796 ms -- and is not worth the six registers it holds.)
                 poll_request();
                 pl_load();
                 poll_consume();
@@ -1013,15 +1017,19 @@ __global__ void __launch_bounds__(RWG, 4) scan_range_kernel(DevIndex ix, DevBatc
             // bypass this CU's vector cache, all entries of 16 lists at a time (one round trip, not one per list).
             uint32_t *tmp = S.stage;  // (free between items)
             bool last = true;
+            // (ml, zero: the lane number and a zero made opaque -- addresses built from the lane number in this block, and the
+            // zeros it stores, are otherwise computed at kernel entry and kept in scratch over the whole launch)
+            uint32_t ml = lane, zero = 0;
+            asm volatile("" : "+v"(ml), "+v"(zero));
             if (fused_g == 1u) {
                 __syncthreads();  // every wave is done with its stage rows (the cold pass of the last tile reads them)
                 const uint32_t base = wave * 3u * (uint32_t)KMAX;
 #pragma unroll
                 for (int r = 0; r < RK; ++r)
                     if (r * 64 + lane < n) {
-                        tmp[base + r * 64 + lane] = (uint32_t)__double2loint(rtop.score[r]);
-                        tmp[base + KMAX + r * 64 + lane] = (uint32_t)__double2hiint(rtop.score[r]);
-                        tmp[base + 2 * KMAX + r * 64 + lane] = rtop.doc[r];
+                        tmp[base + r * 64 + ml] = (uint32_t)__double2loint(rtop.score[r]);
+                        tmp[base + KMAX + r * 64 + ml] = (uint32_t)__double2hiint(rtop.score[r]);
+                        tmp[base + 2 * KMAX + r * 64 + ml] = rtop.doc[r];
                     }
                 if (lane == 0) S.lcnt[wave] = n;
                 __syncthreads();
@@ -1086,13 +1094,13 @@ __global__ void __launch_bounds__(RWG, 4) scan_range_kernel(DevIndex ix, DevBatc
                     if (r * 64 + lane < nh) {
                         const uint32_t d = rtop.doc[r];
                         const uint16_t *pl = ix.doc_payload + 3ull * d;
-                        unsigned long long *out = reinterpret_cast<unsigned long long *>(bt.hits + (size_t)q * k + r * 64 + lane);
+                        unsigned long long *out = reinterpret_cast<unsigned long long *>(bt.hits + (size_t)q * k + r * 64 + ml);
                         out[0] = (unsigned long long)__double_as_longlong(rtop.score[r]);
                         out[1] = (unsigned long long)d | (unsigned long long)pl[0] << 32 | (unsigned long long)pl[1] << 48;
                         out[2] = (unsigned long long)pl[2];
                     }
 #pragma unroll
-                for (int i = 0; i < 4; ++i) hrow[4 * lane + i] = 0;
+                for (int i = 0; i < 4; ++i) hrow[4 * ml + i] = zero;
                 if (lane == 0) {
                     bt.n_hits[q] = failed_any ? NONE32 : nh;  // NONE32: an item needs scan_many_kernel -- the host re-runs the batch on the general route
                     bt.theta[q] = 0;

@@ -693,6 +693,16 @@ static int vbm25_batch_create_impl(vbm25_index *ix, uint32_t max_queries, uint32
     HIP_TRY(hipMemset(bt->fail_any.p, 0, 4));
     HIP_TRY(hipMemset(bt->q_failed.p, 0, 4ull * max_queries));
     HIP_TRY(hipMemset(bt->error_flag.p, 0, 4));
+    // The per-launch state starts zero and every route that sets state_clean leaves ALL of it zero -- whichever route runs
+    // next (the plan-free route never touches fused_state: a one-launch run after it found the allocator's leftovers there
+    // and no workgroup took itself for a query's last one).
+    HIP_TRY(hipMemset(bt->fused_state.p, 0, 4ull * (max_queries + 1)));
+    HIP_TRY(hipMemset(bt->work_ctr.p, 0, 8));
+    HIP_TRY(hipMemset(bt->theta.p, 0, 8ull * max_queries));
+    HIP_TRY(hipMemset(bt->theta_last.p, 0, 8ull * max_queries));
+    HIP_TRY(hipMemset(bt->hist.p, 0, 4ull * CUR_HB * max_queries));
+    HIP_TRY(hipMemset(bt->item_failed.p, 0, 4ull * bt->max_items));
+    HIP_TRY(hipMemset(bt->res_cnt.p, 0, 4ull * bt->max_items * bt->lpi));
     if (bt->use_range && bt->tune.team)  // one candidate list per wave of scan_team_kernel's grid (1024 x 4 or 512 x 8 waves)
         if (int rc2 = bt->team_cand.alloc(4ull * TM_CAND * 4096)) return rc2;
     if (int rc2 = bt->dbg.alloc(64)) return rc2;
@@ -1004,6 +1014,7 @@ static int vbm25_batch_run_impl(vbm25_batch *bt, void *hip_stream) {
             HIP_TRY(hipMemsetAsync(bt->hist.p, 0, 4ull * CUR_HB * bt->max_queries, st));
             HIP_TRY(hipMemsetAsync(bt->theta.p, 0, 8ull * bt->max_queries, st));
             HIP_TRY(hipMemsetAsync(bt->work_ctr.p, 0, 8, st));
+            HIP_TRY(hipMemsetAsync(bt->fused_state.p, 0, 4ull * (bt->max_queries + 1), st));
             HIP_TRY(hipMemsetAsync(bt->fail_any.p, 0, 4, st));
             HIP_TRY(hipMemsetAsync(bt->item_failed.p, 0, 4ull * bt->max_items, st));
             HIP_TRY(hipMemsetAsync(bt->res_cnt.p, 0, 4ull * bt->max_items * bt->lpi, st));
