@@ -82,6 +82,7 @@ struct DevBatch {
     uint32_t merge_clean;      // merge_kernel leaves the per-launch state (thresholds, histogram, list counts, failure flags, item counters)
                                // zero for the next launch: the route without plan_kernel (fused_g != 0 in the general instantiations)
     uint32_t many_expected;    // scan_many_kernel: 0 = the host knows of no item for it; it looks at fail_any and leaves
+    uint32_t order_on;         // the route without plan_kernel: item_order holds the host's longest-first order of the items
     uint32_t *fail_any;        // != 0: a first-choice kernel gave an item up in this launch
     uint32_t *q_failed;        // per query: items the first-choice kernels gave up in the last launch (merge_kernel, merge_clean)
     unsigned long long *theta_last;  // per query: the threshold the last launch ended with (merge_kernel, merge_clean)

@@ -42,7 +42,7 @@
 // there: the number of candidates per window stays near k ln 2 while the threshold warms up.
 
 constexpr int DNW = 8;
-static_assert(DNW == RNW, "one result list per wave: bt.lpi is scan_range_kernel's");
+static_assert(DNW <= RNW, "one result list per wave: bt.lpi is scan_range_kernel's");
 constexpr int DWG = DNW * 64;
 constexpr int D_W = 16384;               // documents per window (at most; an item of very dense terms takes narrower ones)
 constexpr int D_W0 = 256;                // first window while the threshold is 0

@@ -33,9 +33,15 @@
 // item * lpi + wave; merge_kernel merges them.  A tile whose rows overflow hands the item to
 // scan_many_kernel (item_failed).
 
-constexpr int RNW = 8;               // waves per workgroup: planner + 7 workers (16 waves x 4 blocks measured 13 % slower)
+#ifndef VBM25_RNW
+#define VBM25_RNW 8
+#define VBM25_RB 8
+#define VBM25_RWPS 4
+#define VBM25_RLIST 128
+#endif
+constexpr int RNW = VBM25_RNW;       // waves per workgroup: planner + 7 workers (16 waves x 4 blocks measured 13 % slower)
 constexpr int RWG = RNW * 64;
-constexpr int RB = 8;                // blocks per worker per tile
+constexpr int RB = VBM25_RB;         // blocks per worker per tile
 constexpr int R_NBLK = (RNW - 1) * RB;  // blocks per tile (slots = lanes 0..R_NBLK-1 of the planner wave)
 static_assert(R_NBLK <= 64, "one planner lane per block of a tile");
 constexpr int R_BM_WORDS = 4096;     // 2^17 bits; word R_BM_WORDS is the trash word of out-of-range postings
@@ -48,7 +54,7 @@ constexpr uint32_t R_TARGET_ITEMS = 1024;
 constexpr uint32_t R_MIN_CHUNK_POSTINGS = 16384;
 constexpr uint32_t R_GRID = 512;      // persistent workgroups: 256 CUs x 2 (KMAX <= 64; 1 per CU above)
 constexpr int R_PLAN_RING = 3;
-constexpr int R_LIST = 128;           // second arrivals per wave per tile; more than that: scan_many_kernel
+constexpr int R_LIST = VBM25_RLIST;   // second arrivals per wave per tile; more than that: scan_many_kernel
 constexpr int R_STAGE_STRIDE = 130;   // words between staged rows: 128 would put the same column of every row on one LDS bank (S2 probes columns)
 
 template <int RT>
@@ -125,7 +131,7 @@ __device__ __forceinline__ uint32_t r_first_block_ge(const DevIndex &ix, uint32_
 }
 
 template <int KMAX, int RT, bool FUSED = false>
-__global__ void __launch_bounds__(RWG, 4) scan_range_kernel(DevIndex ix, DevBatch bt) {
+__global__ void __launch_bounds__(RWG, VBM25_RWPS) scan_range_kernel(DevIndex ix, DevBatch bt) {
     static_assert(KMAX <= REG_K, "register top-k only");
     static_assert(RT == 8 || RT == 16, "row stride");
     constexpr int RK = KMAX / 64;
@@ -158,7 +164,8 @@ __global__ void __launch_bounds__(RWG, 4) scan_range_kernel(DevIndex ix, DevBatc
         if (tid == 0) {
             const KernArgsP cd = cold_args();  // (the arguments only an item's setup and end need are read where they are used)
             const uint32_t drawn = atomicAdd(cd->bt.work_ctr, 1u);
-            S.item = !fused_g && drawn < n_items ? cd->bt.item_order[drawn] : drawn;  // plan_kernel's order: longest first
+            // plan_kernel's order, or (the route without plan_kernel) the host's: longest first -- the last items drawn decide when the launch ends
+            S.item = (!fused_g || (!FUSED && cd->bt.order_on)) && drawn < n_items ? cd->bt.item_order[drawn] : drawn;
         }
         for (uint32_t i = tid; i < R_HS; i += RWG) S.hkeys[i] = EMPTY;
         for (uint32_t i = tid; i < R_BM_WORDS + 4; i += RWG) S.bm[i] = 0;
@@ -785,8 +792,9 @@ __global__ void __launch_bounds__(RWG, 4) scan_range_kernel(DevIndex ix, DevBatc
 
             // ---- S2: wipe the filter; rows x terms: find the postings, score them
 #pragma unroll
-            for (int i = 0; i < R_BM_WORDS / 4 / RWG; ++i)
-                reinterpret_cast<uint4 *>(S.bm)[tid + i * RWG] = make_uint4(0, 0, 0, 0);
+            for (int i = 0; i < (R_BM_WORDS / 4 + RWG - 1) / RWG; ++i)
+                if (R_BM_WORDS / 4 % RWG == 0 || tid + i * RWG < (uint32_t)(R_BM_WORDS / 4))
+                    reinterpret_cast<uint4 *>(S.bm)[tid + i * RWG] = make_uint4(0, 0, 0, 0);
             if (tid == 0) S.nmulti[par ^ 1u] = 0;
             if (nm) {
                 // tasks = rows x the query's terms, packed: waves beyond nm * mq tasks skip the phase

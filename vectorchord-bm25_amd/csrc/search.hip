@@ -241,6 +241,7 @@ struct vbm25_batch {
     std::vector<uint32_t> h_terms, h_off;  // host copy of the queries (bigk launches per term)
     std::vector<uint8_t> h_dense;          // per query: dense (scratch of set_queries, sized once)
     std::vector<unsigned long long> h_postings;
+    std::vector<uint32_t> h_order, h_order_q;  // set_queries: the longest-first item order of the route without plan_kernel
     Tuning tune;                  // the switches of the moment the batch was created
     bool timing = false;
     bool use_range = false;       // k <= REG_K: sparse queries of <= 16 terms take scan_range_kernel, dense ones scan_dense_kernel
@@ -804,6 +805,17 @@ static int vbm25_batch_set_queries_impl(vbm25_batch *bt, const uint32_t *term_id
                 bt->fused_pinned = fast && nq <= 8 && !bt->timing;
             } else if (bt->tune.arith && !bt->tune.team) {
                 bt->arith_g = uint32_t(g);  // the general route, items made in the kernel: no plan_kernel, merge_kernel cleans
+                // ... handed out longest first, as plan_kernel would (the host has the posting counts): queries by
+                // descending postings, a query's g parts together
+                std::vector<uint32_t> &ord = bt->h_order;
+                ord.resize(size_t(nq) * g);
+                std::vector<uint32_t> &qs = bt->h_order_q;
+                qs.resize(nq);
+                for (uint32_t q = 0; q < nq; ++q) qs[q] = q;
+                std::stable_sort(qs.begin(), qs.end(), [&](uint32_t a, uint32_t b) { return q_postings[a] > q_postings[b]; });
+                for (uint32_t i = 0; i < nq; ++i)
+                    for (uint32_t part = 0; part < g; ++part) ord[size_t(i) * g + part] = qs[i] * uint32_t(g) + part;
+                HIP_TRY(hipMemcpy(bt->item_order.p, ord.data(), 4ull * ord.size(), hipMemcpyHostToDevice));
             }
         }
     }
@@ -939,6 +951,7 @@ static int vbm25_batch_run_impl(vbm25_batch *bt, void *hip_stream) {
     db.theta_last = bt->theta_last.as<unsigned long long>();
     db.many_expected = bt->need_many ? 1u : 0u;
     db.merge_clean = 0;
+    db.order_on = 0;
     const bool range = bt->use_range;
     const DevIndex &ix = bt->index->dev;
     db.fused_state = bt->fused_state.as<uint32_t>();
@@ -1023,6 +1036,7 @@ static int vbm25_batch_run_impl(vbm25_batch *bt, void *hip_stream) {
         db.dense_on = 0;
         db.many_expected = 0;
         db.merge_clean = 1;
+        db.order_on = 1;
         if (int rc = take_events()) return rc;
         const uint32_t agrid = std::min<uint32_t>(bt->nq * bt->arith_g, std::max(1u, bt->tune.range_grid));
         const int rca = dispatch_k(bt->k, [&](auto kmax) {
