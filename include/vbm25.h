@@ -301,8 +301,9 @@ int vbm25_evaluate_batch(vbm25_index *, const uint32_t *q_terms, uint32_t n_q_te
  *
  * vbm25_device_segment_build: arguments and result of vbm25_segment_build_device, kept on `device`.
  * vbm25_device_segment_synth: the synthetic corpus of vbm25_segment_synth GENERATED on the device (same model, same
- * counter-based generator; the device's log / exp round differently from libm's in a handful of draws per billion, so
- * the corpus has the same distribution but is not bit for bit the host generator's).
+ * counter-based generator; the device's log / exp round differently from libm's in a handful of draws per billion, and
+ * the head tokens of a Zipf law are drawn in several independent parts per chunk, so the corpus has the same distribution
+ * but is not bit for bit the host generator's).
  * vbm25_device_segment_download: the host copy (a vbm25_segment like any other: byte-identical to what the host builder
  * makes of the same mappings).  _token_terms / _query_bytes: as vbm25_segment_synth_token_terms / vbm25_query_bytes.
  * ---------------------------------------------------------------------- */

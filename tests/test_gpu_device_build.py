@@ -74,9 +74,11 @@ def test_device_generated_corpus_is_a_valid_flush(len_mode, zipf):
     toks = np.array([int(k) for k in keys], dtype=np.uint32)
     assert np.array_equal(dseg.token_terms(toks), np.arange(len(keys), dtype=np.uint32))
     assert np.array_equal(seg.token_terms(toks), np.arange(len(keys), dtype=np.uint32))
-    # the host generator makes the same corpus up to libm / ocml rounding: the same model, nearly the same postings
+    # the host generator makes the same corpus up to libm / ocml rounding: the same model, nearly the same postings.  (Zipf: the
+    # device draws a head token's chunk as several independent parts -- other streams, the same law: equal within sampling noise)
     host = vb.Segment.synth(n_docs, vocab, mean_len=mean, len_mode=len_mode, zipf_s=zipf, seed=7, threads=4)
-    assert abs(int(host.arrays()["term_df"].astype(np.int64).sum()) - len(docs)) <= max(50, len(docs) // 10_000)
+    tol = max(50, len(docs) // 10_000) if zipf == 0.0 else len(docs) // 500
+    assert abs(int(host.arrays()["term_df"].astype(np.int64).sum()) - len(docs)) <= tol
     # deterministic
     again = vb.DeviceSegment.synth(n_docs, vocab, mean_len=mean, len_mode=len_mode, zipf_s=zipf, seed=7).download()
     assert np.array_equal(again.arrays()["blob"], a["blob"])

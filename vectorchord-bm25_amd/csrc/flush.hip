@@ -567,8 +567,16 @@ __global__ void __launch_bounds__(256) synth_draws_kernel(uint32_t n_docs, uint3
     }
 }
 
+// A generation task is one token over one range of documents with its own random stream: a chunk of SYNTH_CHUNK documents, or
+// -- for the head tokens of a Zipf law, whose chunk would be a serial loop of 10^5 draws in one lane while the rest of the
+// device waits (C5: 14 s) -- one of 2^sub_log2 equal parts of it (about SYNTH_SUB_POSTINGS draws each).  Tokens in key order,
+// a token's tasks in document order: the mappings come out sorted by (token, document).
+constexpr uint32_t SYNTH_SUB_POSTINGS = 4096, SYNTH_SUB_MAX_LOG2 = 10;  // parts of >= 64 documents
 struct SynthArgs {
     uint32_t n_docs, vocab, n_chunks;
+    const unsigned long long *task_base;  // vocab + 1: first task of every key position
+    const uint8_t *sub_log2;              // per key position
+    unsigned long long n_tasks;
     unsigned long long seed;
     const unsigned long long *slot;  // n_docs + 1: prefix sum of the draws per document
     const double *log1mp;            // per token: log(1 - p_t)
@@ -581,10 +589,26 @@ struct SynthArgs {
 template <bool EMIT>
 __global__ void __launch_bounds__(256) synth_gen_kernel(SynthArgs a) {
     const unsigned long long task = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (task >= (unsigned long long)a.vocab * a.n_chunks) return;
-    const uint32_t pos_i = (uint32_t)(task / a.n_chunks), chunk = (uint32_t)(task - (unsigned long long)pos_i * a.n_chunks);
+    if (task >= a.n_tasks) return;
+    uint32_t pos_i = 0;
+    {   // the key position whose tasks hold this one: last i with task_base[i] <= task
+        uint32_t lo_i = 0, hi_i = a.vocab;
+        while (hi_i - lo_i > 1) {
+            const uint32_t mid = (lo_i + hi_i) >> 1;
+            if (a.task_base[mid] <= task) lo_i = mid; else hi_i = mid;
+        }
+        pos_i = lo_i;
+    }
+    const uint32_t sl2 = a.sub_log2[pos_i];
+    const unsigned long long local = task - a.task_base[pos_i];
+    const uint32_t chunk = (uint32_t)(local >> sl2), sub = (uint32_t)(local & ((1u << sl2) - 1u)), part = SYNTH_CHUNK >> sl2;
     const uint32_t token = a.order[pos_i];
-    const uint32_t c0 = chunk * SYNTH_CHUNK, c1 = (uint32_t)min((unsigned long long)a.n_docs, (unsigned long long)c0 + SYNTH_CHUNK);
+    const uint32_t c0 = (uint32_t)min((unsigned long long)a.n_docs, (unsigned long long)chunk * SYNTH_CHUNK + (unsigned long long)sub * part);
+    const uint32_t c1 = (uint32_t)min((unsigned long long)a.n_docs, (unsigned long long)c0 + part);
+    if (c0 >= c1) {
+        if (!EMIT) a.count[task] = 0;
+        return;
+    }
     const double l1p = a.log1mp[token];
     const unsigned long long *S = a.slot;
     DevRng rng(synth_mix(a.seed, token, c0));
@@ -631,10 +655,10 @@ __global__ void __launch_bounds__(256) synth_gen_kernel(SynthArgs a) {
     }
     if (!EMIT) a.count[task] = n;
 }
-__global__ void __launch_bounds__(256) gather_u64_stride_kernel(uint32_t n, unsigned long long stride, const unsigned long long *src,
-                                                                unsigned long long last, unsigned long long *dst) {
+__global__ void __launch_bounds__(256) gather_u64_at_kernel(uint32_t n, const unsigned long long *at, const unsigned long long *src,
+                                                            unsigned long long last, unsigned long long *dst) {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n) dst[i] = src[(unsigned long long)i * stride];
+    if (i < n) dst[i] = src[at[i]];
     if (i == n) dst[i] = last;
 }
 
@@ -650,8 +674,6 @@ int synth_device_impl(const vbm25_synth_params *pr, int device, vbm25_device_seg
     if (device < 0 || device >= n_dev) return set_error(VBM25_ERR_INVALID, "device %d out of range (%d devices)", device, n_dev);
     FL_TRY(hipSetDevice(device));
     const uint32_t n_docs = pr->n_docs, vocab = pr->vocab, n_chunks = (n_docs + SYNTH_CHUNK - 1) / SYNTH_CHUNK;
-    const unsigned long long n_tasks = (unsigned long long)vocab * n_chunks;
-    if (n_tasks > 0x7fffffffull) return set_error(VBM25_ERR_UNSUPPORTED, "vocab x document chunks exceeds 2^31 generation tasks");
     // token probabilities and the tokens in key order (bytewise order of their decimal strings): vocabulary-sized, on the host
     std::vector<double> log1mp(vocab);
     {
@@ -672,8 +694,24 @@ int synth_device_impl(const vbm25_synth_params *pr, int device, vbm25_device_seg
     std::vector<uint32_t> order(vocab);
     for (uint32_t t = 0; t < vocab; ++t) order[t] = t;
     std::sort(order.begin(), order.end(), [&](uint32_t x, uint32_t y) { return std::memcmp(keys.data() + 16ull * x, keys.data() + 16ull * y, 16) < 0; });
+    // tasks: one per (key position, chunk), or 2^sub_log2 per chunk where a chunk of the token holds more than
+    // 2 x SYNTH_SUB_POSTINGS draws on average (slots of a chunk ~ chunk documents x the mean draws per document)
+    std::vector<unsigned long long> task_base(size_t(vocab) + 1);
+    std::vector<uint8_t> sub_log2(vocab);
+    const double slots_per_chunk = double(std::min<uint32_t>(SYNTH_CHUNK, n_docs)) * double(pr->mean_len);
+    unsigned long long n_tasks = 0;
+    for (uint32_t i = 0; i < vocab; ++i) {
+        const double expect = -std::expm1(log1mp[order[i]]) * slots_per_chunk;  // p_t x slots
+        uint32_t l2 = 0;
+        while (l2 < SYNTH_SUB_MAX_LOG2 && expect > 2.0 * SYNTH_SUB_POSTINGS * double(1u << l2)) ++l2;
+        sub_log2[i] = uint8_t(l2);
+        task_base[i] = n_tasks;
+        n_tasks += (unsigned long long)n_chunks << l2;
+    }
+    task_base[vocab] = n_tasks;
+    if (n_tasks > 0x7fffffffull) return set_error(VBM25_ERR_UNSUPPORTED, "more than 2^31 generation tasks");
 
-    DBuf d_draws, d_slot, d_l1p, d_order, d_count, d_off, d_len, d_pd, d_pt, d_tmp, d_bnd;
+    DBuf d_draws, d_slot, d_l1p, d_order, d_count, d_off, d_len, d_pd, d_pt, d_tmp, d_bnd, d_tbase, d_sub;
     FL_TRY(d_draws.alloc(4ull * n_docs));
     FL_TRY(d_slot.alloc(8ull * (n_docs + 1ull)));
     FL_TRY(d_l1p.alloc(8ull * vocab));
@@ -684,6 +722,10 @@ int synth_device_impl(const vbm25_synth_params *pr, int device, vbm25_device_seg
     FL_TRY(d_bnd.alloc(8ull * (vocab + 1ull)));
     FL_TRY(hipMemcpy(d_l1p.p, log1mp.data(), 8ull * vocab, hipMemcpyHostToDevice));
     FL_TRY(hipMemcpy(d_order.p, order.data(), 4ull * vocab, hipMemcpyHostToDevice));
+    FL_TRY(d_tbase.alloc(8ull * (vocab + 1ull)));
+    FL_TRY(d_sub.alloc(vocab));
+    FL_TRY(hipMemcpy(d_tbase.p, task_base.data(), 8ull * (vocab + 1ull), hipMemcpyHostToDevice));
+    FL_TRY(hipMemcpy(d_sub.p, sub_log2.data(), vocab, hipMemcpyHostToDevice));
     FL_TRY(hipMemset(d_len.p, 0, 4ull * n_docs));
     FL_TRY(hipMemset(d_slot.p, 0, 8));
     synth_draws_kernel<<<2048, 256>>>(n_docs, pr->mean_len, pr->len_mode, synth_mix(pr->seed, 0xD0C5, 0), d_draws.as<uint32_t>());
@@ -699,6 +741,9 @@ int synth_device_impl(const vbm25_synth_params *pr, int device, vbm25_device_seg
     a.n_docs = n_docs;
     a.vocab = vocab;
     a.n_chunks = n_chunks;
+    a.task_base = d_tbase.as<unsigned long long>();
+    a.sub_log2 = d_sub.as<uint8_t>();
+    a.n_tasks = n_tasks;
     a.seed = pr->seed;
     a.slot = d_slot.as<unsigned long long>();
     a.log1mp = d_l1p.as<double>();
@@ -724,7 +769,7 @@ int synth_device_impl(const vbm25_synth_params *pr, int device, vbm25_device_seg
         n_post = last_off + last_cnt;
     }
     // the first mapping of every token (key order); tokens that never occur are left out of the segment
-    gather_u64_stride_kernel<<<(vocab + 1 + 255) / 256, 256>>>(vocab, n_chunks, d_off.as<unsigned long long>(), n_post, d_bnd.as<unsigned long long>());
+    gather_u64_at_kernel<<<(vocab + 1 + 255) / 256, 256>>>(vocab, d_tbase.as<unsigned long long>(), d_off.as<unsigned long long>(), n_post, d_bnd.as<unsigned long long>());
     FL_TRY(hipGetLastError());
     std::vector<uint64_t> bnd(size_t(vocab) + 1);
     FL_TRY(hipMemcpy(bnd.data(), d_bnd.p, 8ull * (vocab + 1ull), hipMemcpyDeviceToHost));
