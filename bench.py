@@ -246,6 +246,7 @@ def run(argv=None, scorer_factory=None, backend="nccl"):
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--workload", default="C3", choices=sorted(WORKLOADS))
     ap.add_argument("--queries", type=int, default=0, help="override queries per GPU")
+    ap.add_argument("--k", type=int, default=0, help="development aid: override the workload's k (the line then names that k; not a BASELINE.json configuration)")
     ap.add_argument("--batches", type=int, default=4, help="distinct query batches the timed loop rotates through")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--verify", action="store_true",
@@ -297,6 +298,8 @@ def run(argv=None, scorer_factory=None, backend="nccl"):
     n_docs, vocab, mean_len, len_mode, zipf_s, nq, nterms, k = WORKLOADS[args.workload]
     if args.queries:
         nq = args.queries
+    if args.k:
+        k = args.k
     nb = max(1, args.batches if args.workload != "C2" else 1)
     threads = args.build_threads or usable_cpus()
     t0 = time.perf_counter()

@@ -13,6 +13,10 @@
 // 38 k documents, 1024 x 5-term queries per launch, four batches rotated): the plane is 2.0 GB, far beyond the caches.
 // Variants (template switches) take the range test / the second-arrival collection out, to price them.
 //
+// Measurement trap found on the way: thousands of waves adding their counters to ONE cache line at kernel end cost more than
+// the kernel itself (the timings doubled); every wave writes its own 64-byte result slot, the host adds them up.
+// `./mark_ceiling team` runs only the team kernels (what tools/ubench/pmc.sh profiles).  Results: profiles/r4_mark_ceiling.txt.
+//
 // Build: hipcc --offload-arch=gfx950 -O3 -o mark_ceiling mark_ceiling.hip      Run: ./mark_ceiling
 #include <hip/hip_runtime.h>
 #include <cstdint>

@@ -131,7 +131,10 @@ __device__ __forceinline__ uint32_t r_first_block_ge(const DevIndex &ix, uint32_
 }
 
 template <int KMAX, int RT, bool FUSED = false>
-__global__ void __launch_bounds__(RWG, VBM25_RWPS) scan_range_kernel(DevIndex ix, DevBatch bt) {
+#ifndef VBM25_RWPS_BIGK
+#define VBM25_RWPS_BIGK VBM25_RWPS
+#endif
+__global__ void __launch_bounds__(RWG, KMAX > 64 ? VBM25_RWPS_BIGK : VBM25_RWPS) scan_range_kernel(DevIndex ix, DevBatch bt) {
     static_assert(KMAX <= REG_K, "register top-k only");
     static_assert(RT == 8 || RT == 16, "row stride");
     constexpr int RK = KMAX / 64;
