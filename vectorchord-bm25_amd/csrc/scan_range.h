@@ -829,9 +829,13 @@ __global__ void __launch_bounds__(RWG, KMAX > 64 ? VBM25_RWPS_BIGK : VBM25_RWPS)
                     const uint32_t nj = sj.w & 0xff, mdj = (sj.w >> 8) & 0xff, mtj = (sj.w >> 16) & 0xff;
                     const uint8_t *tbody = ix.blob + 8ull * sj.z + ((payload_bytes(mdj, nj) + 7u) & ~7u);
                     const FieldAddr fa = field_addr(mtj, nj, idx);
+#ifdef VBM25_S2_NOLOAD  // timing experiment only (wrong scores): what S2 costs without its round trip to HBM
+                    const uint32_t flo = (uint32_t)(size_t)(tbody + fa.off0) | 1u, fhi = flo, fn = idx & 255u;
+#else
                     const uint32_t flo = *reinterpret_cast<const uint32_t *>(tbody + fa.off0);
                     const uint32_t fhi = *reinterpret_cast<const uint32_t *>(tbody + fa.off1);
                     const uint32_t fn = ix.post_fn[128ull * S.pa[buf][eb].x + idx];
+#endif
                     const double tf = (double)field_val(flo, fhi, fa);
                     S.contrib[(r << LRT) + t] = (tf * S.t_s0[t]) / (tf + S.s1[fn]);  // Cache::evaluate, bm25.rs:355-358
                 }
