@@ -26,6 +26,17 @@ def both(c=None, seg=None, k1=1.2, b=0.75):
     return seg, vb.GpuIndex(seg), oix
 
 
+def _dirty_the_allocator():
+    """Fill 1 GiB of HBM with 0x0a bytes and hand it back: what the library allocates next is not zero by luck (round 4: the
+    one-launch route after a plan-free batch found the allocator's leftovers in a counter array nobody had initialised --
+    and passed for as long as fresh memory happened to be zero)."""
+    import torch
+    junk = torch.full((1 << 28,), 0x0a0a0a0a, dtype=torch.int32, device="cuda")
+    torch.cuda.synchronize()
+    del junk
+    torch.cuda.empty_cache()
+
+
 def check_batch(gix, oix, terms, off, k, wand=True):
     hits, nh = vb.search_batch(gix, terms, off, k)
     ob, onb, _ = oix.search_batch(terms, off, k, mode="brute", threads=8)
@@ -102,6 +113,44 @@ def test_tiny_and_large_batches_through_batch_run():
         for q in range(nq):
             want = oix.search_brute(terms[off[q]:off[q + 1]], 10)
             assert_bit_exact(want, hits[q, :nh[q]], what=f"nq={nq} q{q} vs brute")
+
+
+def test_route_transitions_on_one_handle():
+    """The three routes of a batch of sparse queries -- plan-free (every query sparse, many items), one-launch (a handful of
+    items; pinned through vbm25_search_batch, device buffers through vbm25_batch_run) and general (plan_kernel: a many-term
+    query in the batch) -- in every order on ONE batch object and ONE search handle, on memory that was not zero when it was
+    allocated: each route has to leave the per-launch state as every other route expects to find it."""
+    c = make_corpus(150_000, 3000, seed=14, length="lognormal", mean_len=60)
+    seg = vb.Segment.build(1.2, 0.75, c["doc_len"], c["doc_payload"], c["term_key"], c["term_start"], c["post_doc"], c["post_tf"])
+    oix = orc.OracleIndex.from_arrays(seg.meta(), seg.arrays())
+    _dirty_the_allocator()
+    gix = vb.GpuIndex(seg)
+    rng = np.random.default_rng(9)
+    n_terms = seg.meta()["n_terms"]
+    big_t, big_o = make_queries(c, 300, 4, seed=21)          # plan-free route
+    few_t, few_o = make_queries(c, 3, 4, seed=22)            # one-launch route
+    many = np.sort(rng.choice(n_terms, 30, replace=False)).astype(np.uint32)
+    gen_t = np.r_[big_t[:big_o[40]], many].astype(np.uint32)  # general route: 40 sparse queries + one of 30 terms
+    gen_o = np.r_[big_o[:41], big_o[40] + 30].astype(np.uint32)
+    shapes = {"free": (big_t, big_o), "one": (few_t, few_o), "gen": (gen_t, gen_o)}
+    want = {}
+    for name, (t, o) in shapes.items():
+        want[name] = [oix.search_brute(t[o[q]:o[q + 1]], 10) for q in range(len(o) - 1)]
+
+    def check(name, hits, nh):
+        for q, w in enumerate(want[name]):
+            assert_bit_exact(w, hits[q, :nh[q]], what=f"{name} q{q}")
+
+    order = ["free", "one", "free", "gen", "one", "gen", "free", "one", "one", "gen", "free"]
+    b = vb.Batch(gix, 300, int(max(big_o[-1], gen_o[-1])), 10)
+    for name in order:  # vbm25_batch_run (device buffers)
+        t, o = shapes[name]
+        b.set_queries(t, o)
+        b.run()
+        check(name, *b.fetch())
+    for name in order:  # vbm25_search_batch (its cached batch object; the one-launch route writes to pinned memory)
+        t, o = shapes[name]
+        check(name, *vb.search_batch(gix, t, o, 10))
 
 
 def test_mixed_batch_all_kernels():
@@ -219,17 +268,6 @@ def test_c2_1m_docs_single_3_term_query_top10():
     toks = np.stack([rng.choice(30000, 5, replace=False) for _ in range(256)]).astype(np.uint32)
     t = np.sort(seg.token_terms(toks.reshape(-1)).reshape(256, 5), axis=1).reshape(-1)
     check_batch(gix, oix, t, (np.arange(257) * 5).astype(np.uint32), 10, wand=False)
-
-
-def _dirty_the_allocator():
-    """Fill 1 GiB of HBM with 0x0a bytes and hand it back: what the library allocates next is not zero by luck (round 4: the
-    one-launch route after a plan-free batch found the allocator's leftovers in a counter array nobody had initialised --
-    and passed for as long as fresh memory happened to be zero)."""
-    import torch
-    junk = torch.full((1 << 28,), 0x0a0a0a0a, dtype=torch.int32, device="cuda")
-    torch.cuda.synchronize()
-    del junk
-    torch.cuda.empty_cache()
 
 
 def test_properties_idempotent_sorted_batch_invariant():
