@@ -39,6 +39,6 @@ for step in "$@"; do case $step in
      python tools/pmc_traffic.py C5 scan_dense_kernel $O/pmc5_fetch $O/pmc5_write > $O/pmc_traffic_c5.json; cat $O/pmc_traffic_c5.json
      find $O -name "*.csv" -size +5M -delete;;
   ubenchpmc) bash tools/ubench/pmc.sh > $O/mark_ceiling_pmc.txt 2>&1; tail -40 $O/mark_ceiling_pmc.txt;;
-  ubench) (cd tools/ubench && ./mark_ceiling > $O/mark_ceiling.txt 2>&1; cat $O/mark_ceiling.txt);;
+  ubench) (cd tools/ubench && { [ -x mark_ceiling ] || /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -o mark_ceiling mark_ceiling.hip; } && ./mark_ceiling > $O/mark_ceiling.txt 2>&1; cat $O/mark_ceiling.txt);;
   *) echo "unknown step $step";;
 esac; done
