@@ -794,8 +794,11 @@ static int vbm25_batch_set_queries_impl(vbm25_batch *bt, const uint32_t *term_id
             all = all && q_postings[q] != 0 && !dense[q];
         }
         if (all) {
-            // items per query: by the largest query's postings, within the batch's target (every query gets the same number)
-            unsigned long long g = (most + bt->min_chunk / 2) / bt->min_chunk;
+            // items per query: by the largest query's postings, within the batch's target (every query gets the same number).
+            // A handful of queries (the shim's nq = 1) is cut four times finer: its workgroups have the device to themselves,
+            // and a second document range in flight is worth more than the merge of its lists costs (C2: 39.8 -> 36.2 us)
+            const unsigned long long chunk = nq <= 8 ? std::max<unsigned long long>(bt->min_chunk / 4, 1) : bt->min_chunk;
+            unsigned long long g = (most + chunk / 2) / chunk;
             g = std::min<unsigned long long>(g, std::max<unsigned long long>((bt->target_items + nq / 2) / nq, 1));
             g = std::min<unsigned long long>(std::max<unsigned long long>(g, 1), std::min<unsigned long long>(64, bt->index->n_docs));
             // only where the launches it saves matter: a batch that fills the GPU runs slower through the FUSED
