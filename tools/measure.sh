@@ -3,6 +3,7 @@
 #   gpurun -- 'bash tools/measure.sh <out-subdir> <step> [<step> ...]'
 # steps: tests (GPU search tests)  alltests (whole -m gpu suite)  c3 (verified bench line)  c3quick  c3stats (rocprofv3 kernel
 #        stats)  c3pmc (four counter passes + the pmc_traffic.json entry)  c5  c5stats  c5pmc  c2  ubench  ubenchpmc
+#        sweep_items  sweep_grid  sweep_c2  sweep_bigk (the parameter sweeps of round 4)
 # TUNE="name=value,..." is passed to bench.py --tune.
 set -u
 R=$GRAFT_REPO_ROOT; SUB=${1:-r4}; shift; O=$R/gpurun_out/$SUB; mkdir -p $O; cd $R
@@ -40,5 +41,15 @@ for step in "$@"; do case $step in
      find $O -name "*.csv" -size +5M -delete;;
   ubenchpmc) bash tools/ubench/pmc.sh > $O/mark_ceiling_pmc.txt 2>&1; tail -40 $O/mark_ceiling_pmc.txt;;
   ubench) (cd tools/ubench && { [ -x mark_ceiling ] || /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -o mark_ceiling mark_ceiling.hip; } && ./mark_ceiling > $O/mark_ceiling.txt 2>&1; cat $O/mark_ceiling.txt);;
+  # ---- parameter sweeps of round 4 (DESIGN.md section 9 quotes their results)
+  sweep_items) for t in range_items=2048 range_items=1536 range_items=2048,range_min_chunk=8192; do TUNE=$t bash $0 ${SUB}_$(echo $t | tr '=,' '__') c3quick; done;;
+  sweep_grid) for t in range_grid=256 range_grid=384 range_grid=512; do TUNE=$t bash $0 ${SUB}_$(echo $t | tr '=,' '__') c3quick; done;;  # resident workgroups per CU: 1, 1.5, 2
+  sweep_c2) for t in range_min_chunk=16384 range_min_chunk=8192 range_min_chunk=4096 range_min_chunk=2048; do
+      timeout 300 python bench.py --workload C2 --no-cpu-baseline --steps 200 --tune $t 2>/dev/null |
+        python -c "import json,sys; d=json.loads(sys.stdin.read()); l=d['config']['latency']; print('$t', 'kernel_ms', d['roofline']['kernel_ms'], 'p50', l['c_abi_nq1_us_p50'], 'p99', l['c_abi_nq1_us_p99'])"; done;;
+  sweep_bigk)  # scan_range_kernel<128> / <256> (sparse queries, 64 < k <= 256): LIBS="libvbm25.so libvbm25_bigk.so" compares builds (-DVBM25_RWPS_BIGK=2)
+    for lib in ${LIBS:-libvbm25.so}; do for k in 100 200; do
+      VBM25_LIBRARY=$R/vectorchord-bm25_amd/csrc/$lib timeout 300 python bench.py --no-cpu-baseline --k $k --steps 50 --extra-budget-s 0 2>/dev/null |
+        python -c "import json,sys; d=json.loads(sys.stdin.read()); print('$lib', 'k=$k', d['value'], 'q/s', d['roofline']['kernel_ms'], 'ms')"; done; done;;
   *) echo "unknown step $step";;
 esac; done
