@@ -826,17 +826,26 @@ __global__ void __launch_bounds__(RWG, KMAX > 64 ? VBM25_RWPS_BIGK : VBM25_RWPS)
                         if (sb[idx + s - 1] < d) idx += s;
                     if (sb[idx] != d) continue;
                     atomicOr(&S.done[eb * 4 + (idx >> 5)], 1u << (idx & 31));
-                    const uint32_t nj = sj.w & 0xff, mdj = (sj.w >> 8) & 0xff, mtj = (sj.w >> 16) & 0xff;
-                    const uint8_t *tbody = ix.blob + 8ull * sj.z + ((payload_bytes(mdj, nj) + 7u) & ~7u);
-                    const FieldAddr fa = field_addr(mtj, nj, idx);
+                    double tf;
+                    uint32_t fn;
 #ifdef VBM25_S2_NOLOAD  // timing experiment only (wrong scores): what S2 costs without its round trip to HBM
-                    const uint32_t flo = (uint32_t)(size_t)(tbody + fa.off0) | 1u, fhi = flo, fn = idx & 255u;
+                    tf = (double)((idx & 3u) + 1u);
+                    fn = idx & 255u;
 #else
-                    const uint32_t flo = *reinterpret_cast<const uint32_t *>(tbody + fa.off0);
-                    const uint32_t fhi = *reinterpret_cast<const uint32_t *>(tbody + fa.off1);
-                    const uint32_t fn = ix.post_fn[128ull * S.pa[buf][eb].x + idx];
+                    if (tfn_block(sj.w)) {  // term frequency and fieldnorm of the posting from ONE word of the derived plane
+                        const uint32_t ww = ix.post_tfn[64ull * S.pa[buf][eb].x + (idx >> 1)] >> ((idx & 1u) * 8u);
+                        tf = (double)(ww & 0xffu);
+                        fn = (ww >> 16) & 0xffu;
+                    } else {  // tails, tf fields wider than 7 bits: the field out of the blob, the fieldnorm from its own plane
+                        const uint32_t nj = sj.w & 0xff, mdj = (sj.w >> 8) & 0xff, mtj = (sj.w >> 16) & 0xff;
+                        const uint8_t *tbody = ix.blob + 8ull * sj.z + ((payload_bytes(mdj, nj) + 7u) & ~7u);
+                        const FieldAddr fa = field_addr(mtj, nj, idx);
+                        const uint32_t flo = *reinterpret_cast<const uint32_t *>(tbody + fa.off0);
+                        const uint32_t fhi = *reinterpret_cast<const uint32_t *>(tbody + fa.off1);
+                        fn = ix.post_fn[128ull * S.pa[buf][eb].x + idx];
+                        tf = (double)field_val(flo, fhi, fa);
+                    }
 #endif
-                    const double tf = (double)field_val(flo, fhi, fa);
                     S.contrib[(r << LRT) + t] = (tf * S.t_s0[t]) / (tf + S.s1[fn]);  // Cache::evaluate, bm25.rs:355-358
                 }
             }
@@ -969,16 +978,26 @@ __global__ void __launch_bounds__(RWG, KMAX > 64 ? VBM25_RWPS_BIGK : VBM25_RWPS)
                             const uint4 sj = uni4(S.pm[buf][e]);
                             const uint2 aux = S.pa[buf][e];
                             const uint32_t blkj = uni(aux.x), t = uni(aux.y);
-                            const uint32_t nj = sj.w & 0xff, mdj = (sj.w >> 8) & 0xff, mtj = (sj.w >> 16) & 0xff;
-                            const uint8_t *tbody = ix.blob + 8ull * sj.z + ((payload_bytes(mdj, nj) + 7u) & ~7u);
-                            const FieldAddr f0 = field_addr(mtj, nj, 2 * lane), f1 = field_addr(mtj, nj, 2 * lane + 1);
-                            const uint32_t l0 = *reinterpret_cast<const uint32_t *>(tbody + f0.off0);
-                            const uint32_t h0 = *reinterpret_cast<const uint32_t *>(tbody + f0.off1);
-                            const uint32_t l1 = *reinterpret_cast<const uint32_t *>(tbody + f1.off0);
-                            const uint32_t h1 = *reinterpret_cast<const uint32_t *>(tbody + f1.off1);
-                            const uint32_t fnp = reinterpret_cast<const uint16_t *>(ix.post_fn + 128ull * blkj)[lane];
+                            double tf0, tf1;
+                            uint32_t fnp;  // the two fieldnorm bytes
+                            if (tfn_block(sj.w)) {  // (uniform: one block) the lane's two postings in ONE word of the derived plane
+                                const uint32_t ww = ix.post_tfn[64ull * blkj + lane];
+                                tf0 = (double)(ww & 0xffu);
+                                tf1 = (double)((ww >> 8) & 0xffu);
+                                fnp = ww >> 16;
+                            } else {
+                                const uint32_t nj = sj.w & 0xff, mdj = (sj.w >> 8) & 0xff, mtj = (sj.w >> 16) & 0xff;
+                                const uint8_t *tbody = ix.blob + 8ull * sj.z + ((payload_bytes(mdj, nj) + 7u) & ~7u);
+                                const FieldAddr f0 = field_addr(mtj, nj, 2 * lane), f1 = field_addr(mtj, nj, 2 * lane + 1);
+                                const uint32_t l0 = *reinterpret_cast<const uint32_t *>(tbody + f0.off0);
+                                const uint32_t h0 = *reinterpret_cast<const uint32_t *>(tbody + f0.off1);
+                                const uint32_t l1 = *reinterpret_cast<const uint32_t *>(tbody + f1.off0);
+                                const uint32_t h1 = *reinterpret_cast<const uint32_t *>(tbody + f1.off1);
+                                fnp = reinterpret_cast<const uint16_t *>(ix.post_fn + 128ull * blkj)[lane];
+                                tf0 = (double)field_val(l0, h0, f0);
+                                tf1 = (double)field_val(l1, h1, f1);
+                            }
                             const double s0t = S.t_s0[t];
-                            const double tf0 = (double)field_val(l0, h0, f0), tf1 = (double)field_val(l1, h1, f1);
                             const double p0 = (tf0 * s0t) / (tf0 + S.s1[fnp & 0xff]);
                             const double p1 = (tf1 * s0t) / (tf1 + S.s1[fnp >> 8]);
 #pragma nounroll
