@@ -44,6 +44,7 @@ constexpr int RWG = RNW * 64;
 constexpr int RB = VBM25_RB;         // blocks per worker per tile
 constexpr int R_NBLK = (RNW - 1) * RB;  // blocks per tile (slots = lanes 0..R_NBLK-1 of the planner wave)
 static_assert(R_NBLK <= 64, "one planner lane per block of a tile");
+static_assert(RB % 2 == 0, "a worker row of the plan is read two entries at a time");
 constexpr int R_BM_WORDS = 4096;     // 2^17 bits; word R_BM_WORDS is the trash word of out-of-range postings
 constexpr uint32_t R_BM_EXACT = 1u << 17;
 constexpr int R_HS_LOG2 = 10;  // > rows + every lane of the workers inserting at once: the table never fills
@@ -68,6 +69,10 @@ struct RangeLds {
     uint16_t mslot[2][R_ROWS];
     uint4 pm[R_PLAN_RING][R_NBLK];     // {min_doc, max_doc, off8, n | md << 8 | mt << 16 | wand_fn << 24}
     uint2 pa[R_PLAN_RING][R_NBLK];     // {block index, term}
+    // the same plan by worker: row w - 1 = the RB entries (w - 1) + (RNW - 1) i of worker w as {block index, first document}, slots
+    // beyond the plan filled with its last block -- a worker reads its row with four 16-byte loads (the prefetch of the
+    // plane words and S1 read eight entries one by one before: 12 LDS instructions and their address arithmetic per wave and tile)
+    alignas(16) uint2 pw[R_PLAN_RING][RNW - 1][RB];
     uint32_t coldw[R_PLAN_RING][RNW];  // per worker: its entries whose upper bound reaches the threshold
     double pub[R_PLAN_RING][R_NBLK];   // block upper bound (read for the entries marked cold only)
     uint4 hdr[R_PLAN_RING];            // {tlo, thi, blocks, -}
@@ -368,6 +373,14 @@ __global__ void __launch_bounds__(RWG, KMAX > 64 ? VBM25_RWPS_BIGK : VBM25_RWPS)
                 S.pm[buf][pos] = meta;
                 S.pa[buf][pos] = make_uint2(j, p_st);
                 S.pub[buf][pos] = ub;
+                S.pw[buf][pos % (RNW - 1)][pos / (RNW - 1)] = make_uint2(j, meta.x);
+            }
+            {   // slots beyond the plan: its last block (block 0 for a plan of no blocks); lane = slot
+                const uint32_t npl = (uint32_t)__popcll(mask);
+                const int lastl = mask ? 63 - (int)__builtin_clzll(mask) : 0;
+                const uint32_t jl = mask ? (uint32_t)__builtin_amdgcn_readlane((int)j, lastl) : 0u;
+                const uint32_t xl = mask ? (uint32_t)__builtin_amdgcn_readlane((int)meta.x, lastl) : 0u;
+                if (lane >= npl && lane < (uint32_t)R_NBLK) S.pw[buf][lane % (RNW - 1)][lane / (RNW - 1)] = make_uint2(jl, xl);
             }
             // cold blocks (search.rs:203): upper bound at or above the threshold -- the threshold only rises, so
             // deciding here, one tile early, errs on the safe side.  Bit i of word w: entry (w - 1) + (RNW - 1) i
@@ -623,12 +636,17 @@ __global__ void __launch_bounds__(RWG, KMAX > 64 ? VBM25_RWPS_BIGK : VBM25_RWPS)
         auto fetch_rel = [&](uint32_t b) {
             // branch-free (a branch per load made the compiler wait for every load at the join): entries beyond the plan
             // read the plan's last block, a plan of no blocks reads block 0; S1 masks those entries
-            const uint32_t npn = uni(S.hdr[b].z), last = npn ? npn - 1u : 0u, bmax = ix.n_blocks - 1u;
+            const uint4 *row = reinterpret_cast<const uint4 *>(&S.pw[b][wave ? wave - 1u : 0u][0]);
+            const uint32_t bmax = ix.n_blocks - 1u;
             uint32_t blk[RB];
 #pragma unroll
-            for (int i = 0; i < RB; ++i) blk[i] = S.pa[b][min((wave - 1u) + (RNW - 1) * i, last)].x;
+            for (int i = 0; i < RB / 2; ++i) {
+                const uint4 two = row[i];  // {block, first document} of two entries
+                blk[2 * i] = two.x;
+                blk[2 * i + 1] = two.z;
+            }
 #pragma unroll
-            for (int i = 0; i < RB; ++i) reln[i] = ix.post_rel16[64ull * min(uni(blk[i]), bmax) + lane];
+            for (int i = 0; i < RB; ++i) reln[i] = ix.post_rel16[64ull * min(uni(blk[i]), bmax) + lane];  // (a plan of no blocks leaves its rows as they were: clamped)
         };
         fetch_rel(0);
 
@@ -660,10 +678,15 @@ __global__ void __launch_bounds__(RWG, KMAX > 64 ? VBM25_RWPS_BIGK : VBM25_RWPS)
                 if (nv > (uint32_t)RB) nv = RB;
                 uint4 c[RB];
                 const bool allfast = (hdr.w & 0x100u) != 0;  // (the planner's test of every block of the tile)
+                {
+                    const uint4 *row = reinterpret_cast<const uint4 *>(&S.pw[buf][wave - 1u][0]);
 #pragma unroll
-                for (int i = 0; i < RB; ++i) c[i] = S.pm[buf][(wave - 1u) + (RNW - 1) * i];
-#pragma unroll
-                for (int i = 0; i < RB; ++i) c[i].x = uni(c[i].x);  // the first document is all the plane blocks need here
+                    for (int i = 0; i < RB / 2; ++i) {
+                        const uint4 two = row[i];
+                        c[2 * i].x = uni(two.y);  // the first document is all the plane blocks need here
+                        c[2 * i + 1].x = uni(two.w);
+                    }
+                }
                 asm volatile("; MARK_S1_DECODE");
                 // ids of the rel16 blocks: min_doc + the two halves of the lane's word (fetched one tile ahead); entries
                 // beyond nv are masked below
