@@ -1,0 +1,87 @@
+#!/usr/bin/env python3
+"""check_inflight.py -- scan_win_kernel issues its loop-carried loads with inline asm and waits for them by hand (scan_win.h): the
+compiler takes the loaded registers for valid the moment the asm statement ends.  This script compiles scan_win.hip to ISA and
+checks, instruction by instruction in layout order, that no compiler-generated instruction READS a register whose hand-issued
+load may still be in flight (issued by an asm global_load and not yet covered by an asm s_waitcnt that leaves fewer loads
+outstanding than were issued after it).  A violation means the register allocator inserted a copy / spill of an arriving
+register: restructure until it does not.  Exit status 1 on a violation.  (Layout order is not control flow: the check is
+conservative at branches -- it keeps a load in flight until a wait in layout order retires it -- which is the safe direction.)"""
+import os
+import re
+import subprocess
+import sys
+import tempfile
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+SRC = os.path.join(ROOT, "vectorchord-bm25_amd", "csrc", "scan_win.hip")
+
+
+def regs(tok):
+    out = []
+    for m in re.finditer(r"v\[(\d+):(\d+)\]|\bv(\d+)\b", tok):
+        if m.group(1):
+            out += list(range(int(m.group(1)), int(m.group(2)) + 1))
+        else:
+            out.append(int(m.group(3)))
+    return out
+
+
+def check(asm_text):
+    bad = []
+    kernel = "?"
+    inasm = False
+    flight = {}  # register -> serial number of the load that writes it
+    serial = 0
+    for i, line in enumerate(asm_text.split("\n")):
+        t = line.strip()
+        m = re.match(r"^(_ZN5vbm25\w+):", t)
+        if m:
+            kernel, flight, serial = m.group(1), {}, 0
+            continue
+        if t.startswith(";;#ASMSTART"):
+            inasm = True
+            continue
+        if t.startswith(";;#ASMEND"):
+            inasm = False
+            continue
+        if not t or t.startswith(";") or t.startswith("."):
+            continue
+        if inasm:
+            for part in t.split("\\n"):
+                part = part.strip()
+                if part.startswith("global_load"):
+                    serial += 1
+                    for r in regs(part.split()[1].rstrip(",")):
+                        flight[r] = serial
+                mm = re.search(r"vmcnt\((\d+)\)", part)
+                if mm:  # at most k loads outstanding: the k newest
+                    k = int(mm.group(1))
+                    flight = {r: s for r, s in flight.items() if s > serial - k}
+            continue
+        parts = t.split(None, 1)
+        if len(parts) < 2:
+            continue
+        ops = parts[1].split(",")
+        srcs = ",".join(ops[1:]) if not parts[0].startswith(("ds_write", "ds_or", "global_store", "global_atomic", "v_cmp", "s_")) else parts[1]
+        for r in regs(srcs):
+            if r in flight:
+                bad.append((kernel, i + 1, t))
+                break
+    return bad
+
+
+def main():
+    hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+    with tempfile.TemporaryDirectory() as d:
+        out = os.path.join(d, "scan_win.s")
+        subprocess.check_call([hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-S",
+                               "--cuda-device-only", SRC, "-o", out], stderr=subprocess.DEVNULL)
+        bad = check(open(out).read())
+    for k, ln, t in bad[:40]:
+        print(f"{k}: line {ln}: {t}   <-- reads a register whose load may be in flight")
+    print(f"{len(bad)} violation(s)")
+    return 1 if bad else 0
+
+
+if __name__ == "__main__":
+    sys.exit(main())

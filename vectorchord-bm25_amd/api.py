@@ -333,6 +333,13 @@ class Batch:
         check(f(self.h, C.byref(ni), C.byref(nf)))
         return ni.value, nf.value
 
+    def debug_route(self):
+        """test aid: 0 general route (plan_kernel), 1 one launch, 2 plan-free scan_range_kernel, 3 scan_win_kernel, 4 exhaustive"""
+        f = lib().vbm25_batch_debug_route
+        f.restype = C.c_int
+        f.argtypes = [C.c_void_p]
+        return int(f(self.h))
+
     def debug_theta(self, nq):
         """test aid: the thresholds (as float64 scores) the last run ended with; None if the library lacks the entry"""
         f = getattr(lib(), "vbm25_batch_debug_theta", None)

@@ -32,6 +32,13 @@ struct DevIndex {
                                  // (tfn_block), undefined for the others
     const uint16_t *doc_payload;
     const double *s1;            // 256 entries
+    // scan_win_kernel's planes (derived; the window-major view of the same postings):
+    const uint32_t *post_id16;   // 64 words per block: word l = (id[2l + 1] & 0xffff) << 16 | (id[2l] & 0xffff) -- the low 16 bits of EVERY
+                                 // posting's document id in posting order (tails included): the bit a posting owns in the filter of
+                                 // its 2^16-document window.  A term's postings are contiguous (only its last block is short)
+    const uint32_t *win_off;     // per qualifying term n_win + 1 entries: entry w = postings of the term with document < w << 16
+    const uint32_t *term_win;    // per term: first entry in win_off, NONE32 when the term has no table (too few postings)
+    uint32_t n_win;              // windows of 2^16 documents: ceil(n_docs / 65536)
     unsigned long long blob_bytes;  // bytes of blob that hold block bodies (the allocation has slack behind them)
     uint32_t blk_ub_attained;    // 1: every blk_ub is the score of a posting of its block (the index came with block WAND pairs)
 };
@@ -87,6 +94,7 @@ struct DevBatch {
     uint32_t *q_failed;        // per query: items the first-choice kernels gave up in the last launch (merge_kernel, merge_clean)
     unsigned long long *theta_last;  // per query: the threshold the last launch ended with (merge_kernel, merge_clean)
     uint32_t max_items;        // capacity of items / item_failed; res_* hold max_items * lpi lists of k entries
+    uint32_t win_g;            // scan_win_kernel: items (equal runs of 2^16-document windows) per query, one result list per item
     uint32_t *team_cand;       // scan_team_kernel: TM_CAND candidate documents per wave of its grid
     uint32_t team_dbg;         // development switch of scan_team_kernel (timing only, wrong results): 1 = candidates are not completed
     uint32_t *dbg;             // -DVBM25_CHECK builds: [0] first violated check (0: none), [1] value, [2] item, [3] thread

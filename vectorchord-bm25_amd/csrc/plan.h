@@ -12,6 +12,9 @@ struct PostFnArgs {
     uint8_t *post_fn;
     uint32_t *post_rel16, *post_tfn;
     uint4 *blk_piv;
+    uint32_t *post_id16, *win_off;   // scan_win_kernel's planes (device_types.h); term_win says which terms have a table
+    const uint32_t *term_win;
+    uint32_t n_win;
     uint32_t *error_flag;
     // upper bounds to verify: the scan kernels prune with them
     const uint32_t *term_first_block, *term_wand_tf;
@@ -62,13 +65,42 @@ __global__ void __launch_bounds__(256) post_fn_kernel(PostFnArgs a) {
         const uint32_t mid = (lo + hi) >> 1;
         if (a.term_first_block[mid] <= j) lo = mid; else hi = mid;
     }
+    // The window-major planes (scan_win_kernel): the low 16 bits of every id in posting order, and -- for the terms that have a
+    // table -- the number of the term's postings below every multiple of 2^16 documents.  Posting i of block j is posting
+    // 128 (j - first block) + i of its term: only a term's last block is short (flag 8 otherwise: the index then goes without
+    // these planes).  Every boundary w << 16 lies between two consecutive postings of the term (or before its first / after its
+    // last one): the later of the two writes entry w.
+    if (a.post_id16) {
+        a.post_id16[64ull * j + lane] = (d1 & 0xffffu) << 16 | (d0 & 0xffffu);
+        const uint32_t fb = a.term_first_block[lo], fe = a.term_first_block[lo + 1];
+        if (j + 1 < fe && n != 128u) atomicOr(a.error_flag, 8u);
+        const uint32_t wb = a.term_win[lo];
+        if (wb != NONE32 && !bad) {
+            const long long before = j == fb ? -1ll : (long long)a.blk_meta[j - 1].y;  // last document of the term before this block
+            if (lane == 0 && before >= (long long)d0) atomicOr(a.error_flag, 1u);  // a term's blocks must ascend
+            const long long p0 = lane == 0 ? before : (long long)prev;
+            const long long nw = (long long)a.n_win;
+            const uint32_t at = 128u * (j - fb);
+            if (i0 < n)
+                for (long long w = (p0 >> 16) + 1; w <= min((long long)(d0 >> 16), nw); ++w) a.win_off[wb + w] = at + i0;
+            if (i1 < n)
+                for (long long w = (long long)(d0 >> 16) + 1; w <= min((long long)(d1 >> 16), nw); ++w) a.win_off[wb + w] = at + i1;
+            if (j + 1 == fe && lane == (n - 1u) >> 1) {  // behind the term's last posting: all of them
+                const uint32_t dl = ((n - 1u) & 1u) ? d1 : d0;
+                for (long long w = (long long)(dl >> 16) + 1; w <= nw; ++w) a.win_off[wb + w] = at + n;
+            }
+        }
+    }
     const double s0 = a.term_s0[lo];
     const double wtf = (double)a.term_wand_tf[lo];
     const double tub = ((wtf * s0) / (wtf + a.s1[a.term_wand_fn[lo]])) * (1.0 + 1e-12);
     const double bub = a.blk_ub[j];
     uint32_t t0, t1;
     decode_fields(body + ((payload_bytes(md, n) + 7u) & ~7u), mt, n, lane, t0, t1);
-    a.post_tfn[64ull * j + lane] = tfn_block(m.w) ? t0 | t1 << 8 | (uint32_t)f0 << 16 | (uint32_t)f1 << 24 : 0u;
+    // (the two term frequencies and fieldnorm bytes of the lane's postings.  scan_range_kernel / scan_dense_kernel read the word of
+    // tfn_block blocks only; scan_win_kernel reads it for every posting -- tails included -- and takes a zero term frequency for
+    // "wider than a byte")
+    a.post_tfn[64ull * j + lane] = t0 <= 255u && t1 <= 255u ? t0 | t1 << 8 | (uint32_t)f0 << 16 | (uint32_t)f1 << 24 : 0u;
     bool loose = false, attained = false;  // attained: the block's bound is the score of one of its postings (flag 4 if not: no error,
                                            // but the k-th largest block maxima are then no lower bound of anything)
     if (i0 < n) {

@@ -1,0 +1,586 @@
+// scan_win.h -- scan_win_kernel: the document-WINDOW formulation of the sparse posting scan (queries of <= WN_T indexed terms
+// whose lists are of comparable length, k <= 64): the dominant kernel of C3.
+// Part of libvbm25's device code: included inside namespace vbm25 after device_types, decode, topk_lds, block_fetch, topk_reg.
+//
+// Replaces the traversal of search.rs:149-280 (the WAND main loop) for these queries.  What the loop computes -- the k best sums of
+// Cache::evaluate over the query's terms (bm25.rs:355-358), ties by ascending document -- is reached differently:
+//
+//   * The document space is cut into WINDOWS of 2^16 documents.  post_id16 holds the low 16 bits of every posting's document id in
+//     posting order and win_off[t][w] the number of term t's postings below document w << 16 (both derived at index creation,
+//     plan.h): the postings of term t in window w are ONE contiguous run of 16-bit values whose value IS the posting's bit in the
+//     window's filter.  No block metadata is read, no id is rebuilt, no tile is planned: a (term, window) pair is one coalesced
+//     8-byte load per lane (four postings) and four LDS atomics.
+//   * A WAVE owns its work item (a run of windows of one query) and everything it touches: an exact filter of 2^16 bits, the staged
+//     ids of the current window, a list of second arrivals, its top-k in registers.  There is no workgroup barrier anywhere; a
+//     workgroup is four independent waves.  The next window's runs are in flight while this one is marked.
+//   * A mark that finds its bit set is a SECOND ARRIVAL: the document has postings in two of the query's lists.  After the window's
+//     marks every (second arrival, term) pair is one lane: bisection of the term's staged run, the posting's tf / fieldnorm from
+//     ONE word of post_tfn, Cache::evaluate; the entry of the LAST term that holds the document sums the row in ascending key
+//     order (evaluate.rs:43-72) and offers it -- entries of earlier terms see a later one and drop out, so a document is offered once.
+//   * Documents with a single posting matter only where a block's upper bound (search.rs:377-380; blk_ub, evaluated once per
+//     index) reaches the threshold.  That is decided at the item's END, against the threshold the windows have raised by then (the
+//     COLD pass): the item's blocks whose bound still reaches it are decoded, their postings scored on their own, and a posting
+//     that would enter the list is offered unless its document has a posting in another list of the query (the completion's).
+//   * The threshold: theta0 from term_kth_ub (the item starts with a valid bound), the wave's own k-th score, the query's shared
+//     64-bit atomicMax word polled once per window.  Filtering on score < threshold is exact (a lower bound of the final k-th
+//     score; ties are kept).
+//
+// The window loop holds no vector memory operation under a branch: the compiler's count of the loads in flight stays exact, and
+// the runs of the next window, the boundaries after them, the shared threshold and the tf / fieldnorm words of the last window's
+// second arrivals are all in flight while a window is marked.
+//
+// Results: one list per item at res_*[item] (bt.lpi == 1 on this route); merge_kernel merges a query's lists.  An item with a
+// window that collects more than WN_LIST second arrivals, a run thicker than one load per lane (WN_SLOT postings) or a term
+// frequency above 255 in a second arrival is handed to scan_many_kernel (item_failed).
+
+constexpr int WN_T = 8;               // indexed terms per query
+constexpr int WN_WAVES = 4;           // independent waves per workgroup
+constexpr int WN_WG = WN_WAVES * 64;
+constexpr int WN_WPS = 3;             // waves per SIMD: 168 VGPRs, 12 waves x 12.8 KB of LDS (+ the s1 table per workgroup) per CU
+constexpr int WN_BM_WORDS = 2048;     // 2^16 bits
+constexpr int WN_SLOT = 256;          // staged ids per term: what one 8-byte load per lane covers
+constexpr int WN_LIST = 80;           // second arrivals per window
+constexpr uint32_t WN_GRID = 768;     // persistent workgroups: 256 CUs x 3
+
+struct WinWave {
+    alignas(16) uint32_t bm[WN_BM_WORDS];
+    alignas(16) uint16_t stage[WN_T * WN_SLOT];
+    uint32_t list[WN_LIST];           // x | term << 16
+    double contrib[64];
+};
+
+__device__ __forceinline__ uint32_t wn_mbcnt(unsigned long long mask) {
+    return __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
+}
+
+// The lane's four postings of a (term, window) pair: ids in v (two per word), posting r0 + j of the run's n is the lane's j-th.
+// Marks them in the window's filter; RET: the ones whose bit was already there go to the list of second arrivals.
+template <bool RET>
+__device__ __forceinline__ void wn_pair(WinWave &S, const uint2 v, const uint32_t r0, const uint32_t n, const uint32_t t,
+                                        uint32_t &nd) {
+    const uint32_t x0 = v.x & 0xffffu, x1 = v.x >> 16, x2 = v.y & 0xffffu, x3 = v.y >> 16;
+    const uint32_t b0 = r0 < n ? 1u << (x0 & 31u) : 0u;
+    const uint32_t b1 = r0 + 1u < n ? 1u << (x1 & 31u) : 0u;
+    const uint32_t b2 = r0 + 2u < n ? 1u << (x2 & 31u) : 0u;
+    const uint32_t b3 = r0 + 3u < n ? 1u << (x3 & 31u) : 0u;
+    if (!RET) {  // the window's first term: the filter is empty, nothing can be there yet
+        atomicOr(&S.bm[x0 >> 5], b0);
+        atomicOr(&S.bm[x1 >> 5], b1);
+        atomicOr(&S.bm[x2 >> 5], b2);
+        atomicOr(&S.bm[x3 >> 5], b3);
+        return;
+    }
+    const uint32_t h0 = atomicOr(&S.bm[x0 >> 5], b0) & b0;
+    const uint32_t h1 = atomicOr(&S.bm[x1 >> 5], b1) & b1;
+    const uint32_t h2 = atomicOr(&S.bm[x2 >> 5], b2) & b2;
+    const uint32_t h3 = atomicOr(&S.bm[x3 >> 5], b3) & b3;
+    if (__ballot((h0 | h1 | h2 | h3) != 0u)) {
+        uint32_t hm = (h0 ? 1u : 0u) | (h1 ? 2u : 0u) | (h2 ? 4u : 0u) | (h3 ? 8u : 0u);
+        do {
+            const bool has = hm != 0u;
+            const uint32_t j = (uint32_t)__ffs((int)hm) - 1u;
+            hm &= hm - 1u;
+            const uint32_t x = j == 0u ? x0 : j == 1u ? x1 : j == 2u ? x2 : x3;
+            const unsigned long long mk = __ballot(has);
+            const uint32_t pos = nd + wn_mbcnt(mk);
+            if (has && pos < (uint32_t)WN_LIST) S.list[pos] = x | t << 16;
+            nd += (uint32_t)__popcll(mk);
+        } while (__ballot(hm != 0u));
+    }
+}
+
+// The loads that stay in flight across the window loop's iterations -- the runs of the window after next, the tf / fieldnorm word of
+// the last window's second arrivals, the query's shared threshold -- are issued and waited for BY HAND.  Left to the compiler
+// every one of them was waited for too early: its count of the loads in flight is merged conservatively where paths join (the
+// loop header, every rare branch with a load inside), and `s_waitcnt vmcnt(n)` with too small an n waits for the newest loads
+// too.  An asm load is invisible to that count, which only makes the compiler's own waits stricter (vmcnt counts every load);
+// the waits below name the registers as in/out operands, so nothing that reads them can be scheduled above the wait.
+// Issue order at the end of every window w: P(w) the threshold, G(w) the word, R(w + 2) the eight runs.
+__device__ __forceinline__ void wn_load_run(unsigned long long &dst, const uint32_t voff, const unsigned long long sbase) {
+    asm volatile("global_load_dwordx2 %0, %1, %2" : "=v"(dst) : "v"(voff), "s"(sbase));
+}
+__device__ __forceinline__ void wn_load_word(uint32_t &dst, const uint32_t *addr) {
+    asm volatile("global_load_dword %0, %1, off" : "=v"(dst) : "v"(addr));
+}
+__device__ __forceinline__ void wn_load_theta(unsigned long long &dst, const uint32_t vzero, const unsigned long long *sbase) {
+    asm volatile("global_load_dwordx2 %0, %1, %2 sc1" : "=v"(dst) : "v"(vzero), "s"(sbase));  // (sc1: an agent-scope load, as __hip_atomic_load makes it)
+}
+// The kernel is compiled for MT run loads per window (MT = the most indexed terms of a query of the batch: 2, 4, 5 or 8; a query of
+// fewer terms loads the plane's first bytes for the others -- every load of the loop is unconditional: a conditional one made the
+// compiler COPY the arriving registers, i.e. read them before their loads had landed).  R(w + 1) complete: the MT + 2 loads issued
+// after it -- P(w), G(w), R(w + 2) -- may still be in flight; G(w): the MT of R(w + 2) behind it; P(w - 1): G(w - 1) and R(w + 1).
+#define WN_STR2(x) #x
+#define WN_STR(x) WN_STR2(x)
+#define WN_OPS2(b) "+v"(b[0]), "+v"(b[1])
+#define WN_OPS4(b) WN_OPS2(b), "+v"(b[2]), "+v"(b[3])
+#define WN_OPS5(b) WN_OPS4(b), "+v"(b[4])
+#define WN_OPS8(b) WN_OPS5(b), "+v"(b[5]), "+v"(b[6]), "+v"(b[7])
+template <int MT>
+__device__ __forceinline__ void wn_wait_runs(unsigned long long (&b)[MT]) {
+    static_assert(MT == 2 || MT == 4 || MT == 5 || MT == 8, "operand lists");
+    if constexpr (MT == 2) asm volatile("s_waitcnt vmcnt(4)" : WN_OPS2(b));
+    if constexpr (MT == 4) asm volatile("s_waitcnt vmcnt(6)" : WN_OPS4(b));
+    if constexpr (MT == 5) asm volatile("s_waitcnt vmcnt(7)" : WN_OPS5(b));
+    if constexpr (MT == 8) asm volatile("s_waitcnt vmcnt(10)" : WN_OPS8(b));
+}
+template <int MT>
+__device__ __forceinline__ void wn_wait_word(uint32_t &g) {
+    if constexpr (MT == 2) asm volatile("s_waitcnt vmcnt(2)" : "+v"(g));
+    if constexpr (MT == 4) asm volatile("s_waitcnt vmcnt(4)" : "+v"(g));
+    if constexpr (MT == 5) asm volatile("s_waitcnt vmcnt(5)" : "+v"(g));
+    if constexpr (MT == 8) asm volatile("s_waitcnt vmcnt(8)" : "+v"(g));
+}
+template <int MT>
+__device__ __forceinline__ void wn_wait_theta(unsigned long long &p) {
+    if constexpr (MT == 2) asm volatile("s_waitcnt vmcnt(3)" : "+v"(p));
+    if constexpr (MT == 4) asm volatile("s_waitcnt vmcnt(5)" : "+v"(p));
+    if constexpr (MT == 5) asm volatile("s_waitcnt vmcnt(6)" : "+v"(p));
+    if constexpr (MT == 8) asm volatile("s_waitcnt vmcnt(9)" : "+v"(p));
+}
+__device__ __forceinline__ void wn_wait_all(uint32_t &g) { asm volatile("s_waitcnt vmcnt(0)" : "+v"(g)); }
+// the rare paths inside the loop (a run thicker than one load per lane) load by hand too, and wait for everything: a load the
+// compiler knows of under a branch would cost every window its exact waits
+__device__ __forceinline__ unsigned long long wn_load_run_now(const uint16_t *addr) {
+    unsigned long long v;
+    asm volatile("global_load_dwordx2 %0, %1, off\n\ts_waitcnt vmcnt(0)" : "=v"(v) : "v"(addr));
+    return v;
+}
+__device__ __forceinline__ uint32_t wn_load_u16_now(const uint16_t *addr) {
+    uint32_t v;
+    asm volatile("global_load_ushort %0, %1, off\n\ts_waitcnt vmcnt(0)" : "=v"(v) : "v"(addr));
+    return v;
+}
+// every load issued by hand has landed: their registers are the compiler's again (they stay allocated up to here)
+template <int MT>
+__device__ __forceinline__ void wn_drain(unsigned long long (&a)[MT], unsigned long long (&b)[MT], uint32_t &g, unsigned long long &p) {
+    if constexpr (MT == 2) asm volatile("s_waitcnt vmcnt(0)" : WN_OPS2(a), WN_OPS2(b), "+v"(g), "+v"(p));
+    if constexpr (MT == 4) asm volatile("s_waitcnt vmcnt(0)" : WN_OPS4(a), WN_OPS4(b), "+v"(g), "+v"(p));
+    if constexpr (MT == 5) asm volatile("s_waitcnt vmcnt(0)" : WN_OPS5(a), WN_OPS5(b), "+v"(g), "+v"(p));
+    if constexpr (MT == 8) asm volatile("s_waitcnt vmcnt(0)" : WN_OPS8(a), WN_OPS8(b), "+v"(g), "+v"(p));
+}
+
+template <int MT>
+__global__ void __launch_bounds__(WN_WG, WN_WPS) scan_win_kernel(DevIndex ix, DevBatch bt) {
+    __shared__ WinWave SW[WN_WAVES];
+    __shared__ double S1[256];  // k1 (1 - b + b len(f) / avgdl) per fieldnorm (bm25.rs:349-352)
+    const uint32_t lane = threadIdx.x & 63;
+    WinWave &S = SW[uni(threadIdx.x >> 6)];
+    const uint32_t k = bt.k, g = bt.win_g, n_items = bt.nq * g, NWIN = ix.n_win;
+    const uint32_t dbg = bt.team_dbg;  // timing experiments (wrong results): 1 no cold pass, 2 no completion, 4 no second arrivals
+    const uint16_t *ids16 = reinterpret_cast<const uint16_t *>(ix.post_id16);
+    for (uint32_t i = threadIdx.x; i < 256u; i += WN_WG) S1[i] = ix.s1[i];
+#pragma unroll
+    for (int i = 0; i < WN_BM_WORDS / 4 / 64; ++i) reinterpret_cast<uint4 *>(S.bm)[lane + 64 * i] = make_uint4(0, 0, 0, 0);
+    __syncthreads();  // (the table; the only workgroup barrier of the kernel -- from here on the waves go their own ways)
+
+    for (;;) {
+        uint32_t item = 0;
+        {
+            const KernArgsP ca = cold_args();
+            if (lane == 0) item = atomicAdd(ca->bt.work_ctr, 1u);
+            item = uni(item);
+            if (item >= n_items) break;
+            if (ca->bt.order_on) item = uni(ca->bt.item_order[item]);  // the host's longest-first order
+        }
+        const uint32_t q = item / g, part = item - q * g;
+        const uint32_t w_lo = (uint32_t)((unsigned long long)NWIN * part / g), w_hi = (uint32_t)((unsigned long long)NWIN * (part + 1u) / g);
+
+        // ---- item setup: lane t = term t of the query (ascending key order)
+        uint32_t m = 0, term = NONE32;
+        {
+            const KernArgsP ca = cold_args();
+            const uint32_t qb = uni(ca->bt.q_off[q]), qe = uni(ca->bt.q_off[q + 1]);  // (the host sends queries of <= 64 terms this way)
+            const uint32_t tt = lane < qe - qb ? ca->bt.term_ids[qb + lane] : NONE32;
+            const bool ok = tt < ix.n_terms;  // search.rs:59-61
+            const unsigned long long okm = __ballot(ok);
+            if (ok) S.list[wn_mbcnt(okm)] = tt;
+            m = (uint32_t)__popcll(okm);
+            __builtin_amdgcn_wave_barrier();
+            if (lane < min(m, (uint32_t)MT)) term = S.list[lane];
+            __builtin_amdgcn_wave_barrier();
+        }
+        const bool act = lane < min(m, (uint32_t)MT);
+        uint32_t fb = 0, wb = 0;
+        double s0 = 0.0, kth = 0.0;
+        {
+            const KernArgsP ca = cold_args();
+            const double *kub = ca->ix.term_kth_ub;
+            if (act) {
+                fb = ca->ix.term_first_block[term];
+                s0 = ca->ix.term_s0[term];
+                wb = ca->ix.term_win[term];
+                if (kub) {  // (the smallest 2^i >= k: at least k documents of the term score that much)
+                    uint32_t kidx = 0;
+                    while ((1u << kidx) < k) ++kidx;
+                    kth = kub[(size_t)term * 9 + kidx];
+                }
+            }
+        }
+        // (the host routes only queries of <= WN_T indexed terms that all have a table this way)
+        bool failed = m > (uint32_t)MT || __ballot(act && wb == NONE32) != 0ull;
+        if (failed) m = 0;
+        const uint32_t wbs = act && !failed ? wb : 0u;  // (lanes without a term read the first table: every load below is unconditional)
+        // the term's postings as bytes (lane = term), and per term the numbers of its postings below the item's window boundaries
+        // (lane i = boundary w_lo + i; the host cuts items of at most 63 windows): no boundary is loaded inside the window loop
+        const unsigned long long pbase = (unsigned long long)ids16 + (act && !failed ? 256ull * fb : 0ull);
+        const uint32_t nw = w_hi - w_lo;
+        failed = failed || nw > 63u;
+        uint32_t wo[MT];
+#pragma unroll
+        for (int t = 0; t < MT; ++t)
+            wo[t] = ix.win_off[(uint32_t)__builtin_amdgcn_readlane((int)wbs, t) + min(w_lo + lane, NWIN)];
+        uint32_t wS = 0, wE = 0;  // lane = term: its postings below the item's two ends
+#pragma unroll
+        for (int t = 0; t < MT; ++t) {
+            if (lane == (uint32_t)t) {
+                wS = (uint32_t)__builtin_amdgcn_readlane((int)wo[t], 0);
+                wE = (uint32_t)__builtin_amdgcn_readlane((int)wo[t], (int)min(nw, 63u));
+            }
+        }
+        uint32_t wA = 0, wB = wS;  // lane = term: the boundaries of the window being worked on (its upper ones written with its marks)
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) kth = fmax(kth, __shfl_xor(kth, o));
+        unsigned long long th = (unsigned long long)__double_as_longlong(kth);  // theta0
+        {
+            unsigned long long pg = __hip_atomic_load(&bt.theta[q], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            pg = ((unsigned long long)uni((uint32_t)(pg >> 32)) << 32) | uni((uint32_t)pg);
+            if (lane == 0 && th > pg) atomicMax(&bt.theta[q], th);
+            if (pg > th) th = pg;
+        }
+        if (lane == 0) {
+            // the records plan_kernel would have made: scan_many_kernel (items this kernel gives up) reads them
+            const KernArgsP ca = cold_args();
+            Item rec;
+            rec.q = q;
+            rec.doc_lo = w_lo << 16;
+            rec.doc_hi = (uint32_t)min((unsigned long long)w_hi << 16, (unsigned long long)ix.n_docs);
+            rec.m = m;
+            ca->bt.items[item] = rec;
+            if (item == 0) *ca->bt.n_items = n_items;
+            if (part == 0) ca->bt.q_item_base[q] = item;
+            if (item + 1 == n_items) ca->bt.q_item_base[q + 1] = n_items;
+        }
+
+        RegTopK<1> rtop;
+        rtop.init();
+        unsigned long long published = 0;
+        auto offer = [&](bool has, double sc, uint32_t d) {
+            has = has && (unsigned long long)__double_as_longlong(sc) >= th && (rtop.cnt < k || better(sc, d, rtop.kth_s, rtop.kth_d));
+            if (!__ballot(has)) return;
+            rtop.offer(has, sc, d, k, lane);
+            if (rtop.cnt >= k) {
+                const unsigned long long kb = (unsigned long long)__double_as_longlong(rtop.kth_s);
+                if (kb > th) th = kb;
+            }
+        };
+
+        // the run of every term in window w_lo + i, four postings per lane: R(w_lo + i)
+        const uint32_t lane8 = 8u * lane;
+        auto load_runs = [&](unsigned long long (&dst)[MT], const uint32_t i) {
+            const uint32_t ic = min(i, 63u);
+#pragma unroll
+            for (int t = 0; t < MT; ++t) {
+                // (exactly MT loads, whatever the query's number of terms: the waits count them)
+                const unsigned long long a = (((unsigned long long)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(pbase >> 32), t) << 32) |
+                                              (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)pbase, t)) +
+                                             2ull * ((uint32_t)__builtin_amdgcn_readlane((int)wo[t], (int)ic) & ~3u);
+                wn_load_run(dst[t], lane8, a);
+            }
+        };
+        uint32_t d_gw = 0;
+        unsigned long long pgv = 0;  // the query's shared threshold, polled a window ahead
+        uint32_t vzero = 0;
+        asm volatile("" : "+v"(vzero));
+        // the loop's steady state from its first window on: R(w_lo), then a P and a G, then R(w_lo + 1) -- ten loads behind R(w_lo)
+        unsigned long long bufa[MT], bufb[MT];
+#pragma unroll
+        for (int t = 0; t < MT; ++t) bufa[t] = bufb[t] = 0;
+        load_runs(bufa, 0u);
+        wn_load_theta(pgv, vzero, &bt.theta[q]);
+        wn_load_word(d_gw, ix.post_tfn);
+        load_runs(bufb, 1u);
+        // (landed before the loop is entered: the compiler may move these registers on the way in -- a copy of a register whose
+        // load is still in flight would copy what was there before.  One exposed round trip per item; inside the loop a buffer is
+        // written by its loads and read by its marks only)
+        wn_drain<MT>(bufa, bufb, d_gw, pgv);
+
+        // ---- completion of the second arrivals in two halves: C1 (after a window's marks) finds the postings -- lane = (entry, term),
+        // bisection of the term's staged run -- and requests their tf / fieldnorm words; C2 scores, sums and offers.  The first
+        // pass of a window is finished only after the NEXT window's marks: the round trip to HBM hides behind them.
+        const uint32_t inv_m = m ? (65536u + m - 1u) / m : 0u, epp = m ? 64u / m : 0u;
+        const uint32_t el = (lane * inv_m) >> 16, tl = m ? lane - el * m : 0u;  // the lane's entry of a pass and its term
+        const uint32_t fbl = (uint32_t)__shfl((int)fb, (int)tl);
+        const double s0l = __shfl(s0, (int)tl);
+        bool d_valid = false, d_found = false, d_task = false, notf = false;
+        uint32_t d_x = 0, d_te = 0, d_p = 0, d_w = 0;
+        auto c1 = [&](const uint32_t e0, const uint32_t nd, const uint32_t w) {
+            const bool task = el < epp && e0 + el < nd;
+            const uint32_t ent = S.list[task ? e0 + el : 0u];
+            const uint32_t x = ent & 0xffffu;
+            const uint32_t plo = (uint32_t)__shfl((int)wA, (int)tl), phi = (uint32_t)__shfl((int)wB, (int)tl);
+            const uint32_t pal = plo & ~3u, len = phi - plo;
+            const uint16_t *sb = &S.stage[tl * WN_SLOT + (plo - pal)];
+            uint32_t base = 0;  // the last posting of the run whose id is <= x
+            const uint32_t slen = min(len, (uint32_t)WN_SLOT - (plo - pal));  // the staged part of the run
+            uint32_t n2 = task ? slen : 0u;
+#pragma unroll
+            for (int it = 0; it < 8; ++it) {
+                const uint32_t half = n2 >> 1;
+                if ((uint32_t)sb[base + half] <= x) base += half;
+                n2 -= half;
+            }
+            bool found = task && len != 0u && (uint32_t)sb[base] == x;
+            // a run thicker than its stage row and a document beyond the staged part: the rest of the run, in memory
+            bool more = task && !found && slen < len && (uint32_t)sb[slen - 1u] < x;
+            if (__ballot(more)) {
+                const uint16_t *gb = ids16 + 128ull * fbl + plo;
+                uint32_t lo = slen, hi = len;
+                while (__ballot(more && lo < hi)) {  // first posting of [slen, len) with id >= x
+                    const uint32_t mid = (lo + hi) >> 1;
+                    const uint32_t v = wn_load_u16_now(gb + (more ? mid : 0u));
+                    if (more && lo < hi) {
+                        if (v < x) lo = mid + 1u;
+                        else hi = mid;
+                    }
+                }
+                more = more && lo < len;
+                const uint32_t v = wn_load_u16_now(gb + (more ? lo : 0u));
+                if (more && v == x) {
+                    found = true;
+                    base = lo;
+                }
+            }
+            d_task = task;
+            d_found = found;
+            d_x = x;
+            d_te = ent >> 16;
+            d_p = plo + base;
+            d_w = w;
+        };
+        // the word of post_tfn that holds the posting C1 found (word 0 for the lanes that found none: the load is unconditional)
+        auto c1_request = [&]() { wn_load_word(d_gw, ix.post_tfn + (d_found ? 64ull * fbl + (d_p >> 1) : 0ull)); };
+        auto c2 = [&]() {
+            double c = 0.0;
+            if (d_found) {
+                const uint32_t ww = d_gw >> ((d_p & 1u) * 8u);
+                const uint32_t tfv = ww & 0xffu, fn = (ww >> 16) & 0xffu;
+                notf = notf || tfv == 0u;  // (a term frequency above 255: the word holds zeros -- not this kernel's item)
+                const double tf = (double)tfv;
+                c = (tf * s0l) / (tf + S1[fn]);  // Cache::evaluate, bm25.rs:355-358
+            }
+            S.contrib[lane] = c;
+            const unsigned long long fm = __ballot(d_found);
+            __builtin_amdgcn_wave_barrier();
+            bool okd = false;
+            double acc = 0.0;
+            if (d_task && tl == 0u) {
+                const uint32_t my = (uint32_t)(fm >> lane) & ((1u << m) - 1u);
+                // the entry of the LAST term that holds the document completes it (one offer per document)
+                okd = (my >> (d_te + 1u)) == 0u && (my & (my - 1u)) != 0u;
+                for (uint32_t t = 0; t < m; ++t) acc += S.contrib[lane + t];  // ascending key order; absent terms add 0.0
+            }
+            __builtin_amdgcn_wave_barrier();
+            offer(okd, acc, d_w << 16 | d_x);
+        };
+
+        // One window: `cur` holds its runs (requested two windows ago) and takes the runs of the window after next at the end.  Two
+        // buffers in fixed roles, the loop below alternates them: a run is loaded into the very registers it is marked from (a
+        // rotation of the buffers made the compiler copy every arriving run, one load at a time).  False: the item is given up.
+        auto window = [&](unsigned long long (&cur)[MT], const uint32_t w) -> bool {
+            // ---- marks of window w (its runs arrived while the last window was worked on).  Two phases per group of five pairs: ALL
+            // the group's atomics are issued before the first returned word is looked at -- the LDS executes a wave's operations in
+            // order, so every returned word already reflects the marks issued before it, and the group costs one round trip to the
+            // LDS instead of five.  The last window's open pass of second arrivals (C2) is finished between the two phases.
+            uint32_t nd = 0;
+            wA = wB;  // (the last window's upper boundaries)
+            wn_wait_runs<MT>(cur);
+#pragma unroll
+            for (int gq = 0; gq < 2; ++gq) {
+                uint32_t hb[5][4], ho[5][4];  // the bit of every posting of the group (0: not a posting of the run), the word that came back
+                if (gq == 0 || MT > 5) {
+#pragma unroll
+                    for (int u = 0; u < 5; ++u) {
+                        const int t = 5 * gq + u;
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) hb[u][j] = ho[u][j] = 0;
+                        if (t < MT && (uint32_t)t < m) {
+                            const uint32_t o_lo = (uint32_t)__builtin_amdgcn_readlane((int)wo[t < MT ? t : 0], (int)(w - w_lo));
+                            const uint32_t o_hi = (uint32_t)__builtin_amdgcn_readlane((int)wo[t < MT ? t : 0], (int)(w - w_lo + 1u));
+                            const uint32_t n = o_hi - o_lo, o_al = o_lo & ~3u, r0 = o_al + 4u * lane - o_lo;
+                            wB = lane == (uint32_t)t ? o_hi : wB;
+                            const uint2 run = make_uint2((uint32_t)cur[t < MT ? t : 0], (uint32_t)(cur[t < MT ? t : 0] >> 32));
+                            *reinterpret_cast<uint2 *>(&S.stage[t * WN_SLOT + 4u * lane]) = run;
+                            const uint32_t x0 = run.x & 0xffffu, x1 = run.x >> 16, x2 = run.y & 0xffffu, x3 = run.y >> 16;
+                            hb[u][0] = r0 < n ? 1u << (x0 & 31u) : 0u;
+                            hb[u][1] = r0 + 1u < n ? 1u << (x1 & 31u) : 0u;
+                            hb[u][2] = r0 + 2u < n ? 1u << (x2 & 31u) : 0u;
+                            hb[u][3] = r0 + 3u < n ? 1u << (x3 & 31u) : 0u;
+                            if (t == 0) {  // the window's first term: the filter is empty, nothing can be there yet
+                                atomicOr(&S.bm[x0 >> 5], hb[u][0]);
+                                atomicOr(&S.bm[x1 >> 5], hb[u][1]);
+                                atomicOr(&S.bm[x2 >> 5], hb[u][2]);
+                                atomicOr(&S.bm[x3 >> 5], hb[u][3]);
+                            } else {
+                                ho[u][0] = atomicOr(&S.bm[x0 >> 5], hb[u][0]);
+                                ho[u][1] = atomicOr(&S.bm[x1 >> 5], hb[u][1]);
+                                ho[u][2] = atomicOr(&S.bm[x2 >> 5], hb[u][2]);
+                                ho[u][3] = atomicOr(&S.bm[x3 >> 5], hb[u][3]);
+                            }
+                            if (o_hi - o_al > (uint32_t)WN_SLOT) {  // a run that one load per lane does not hold: the rest, not staged (C1 reads it from memory)
+                                const uint16_t *rest = ids16 + 128ull * (uint32_t)__builtin_amdgcn_readlane((int)fb, t) + 4u * lane;
+#pragma nounroll
+                                for (uint32_t o = o_al + (uint32_t)WN_SLOT; o < o_hi; o += (uint32_t)WN_SLOT) {
+                                    const unsigned long long mv = wn_load_run_now(rest + o);
+                                    const uint2 more = make_uint2((uint32_t)mv, (uint32_t)(mv >> 32));
+                                    if (t == 0) wn_pair<false>(S, more, o + 4u * lane - o_lo, n, (uint32_t)t, nd);
+                                    else wn_pair<true>(S, more, o + 4u * lane - o_lo, n, (uint32_t)t, nd);
+                                }
+                            }
+                        }
+                    }
+                }
+                if (gq == 0) {  // ---- the last window's first pass of second arrivals: its words have arrived behind these marks
+                    wn_wait_word<MT>(d_gw);
+                    if (d_valid) c2();
+                    d_valid = false;
+                }
+                if (gq == 0 || MT > 5) {
+#pragma unroll
+                    for (int u = 0; u < 5; ++u) {
+                        const int t = 5 * gq + u;
+                        if (t >= 1 && t < MT && (uint32_t)t < m) {
+                            const unsigned long long cv = cur[t < MT ? t : 0];
+#pragma unroll
+                            for (int j = 0; j < 4; ++j) {
+                                const bool hit = (ho[u][j] & hb[u][j]) != 0u;  // the bit was there: a second arrival
+                                const unsigned long long mk = __ballot(hit);
+                                if (mk) {
+                                    const uint32_t xj = (uint32_t)(cv >> (16 * j)) & 0xffffu;
+                                    const uint32_t pos = nd + wn_mbcnt(mk);
+                                    if (hit && pos < (uint32_t)WN_LIST) S.list[pos] = xj | (uint32_t)t << 16;
+                                    nd += (uint32_t)__popcll(mk);
+                                }
+                            }
+                        }
+                    }
+                }
+            }
+            __builtin_amdgcn_wave_barrier();
+            // more second arrivals than the list holds: the lists are too dense here for this kernel
+            if (nd > (uint32_t)WN_LIST) failed = true;
+            if (dbg & 4u) nd = 0;
+#pragma unroll
+            for (int i = 0; i < WN_BM_WORDS / 4 / 64; ++i) reinterpret_cast<uint4 *>(S.bm)[lane + 64 * i] = make_uint4(0, 0, 0, 0);
+
+            // ---- this window's second arrivals: passes beyond the first at once (rare), the first one left open
+            d_found = false;
+            if (nd != 0u && !failed && !(dbg & 2u)) {
+                for (uint32_t e0 = ((nd - 1u) / epp) * epp; e0 != 0u; e0 -= epp) {
+                    c1(e0, nd, w);
+                    c1_request();
+                    wn_wait_all(d_gw);
+                    c2();
+                }
+                c1(0u, nd, w);
+                d_valid = true;
+            }
+            // ---- the shared threshold polled a window ago; then, in this order: the next poll P(w), the word of this window's open
+            // pass G(w), the runs of the window after next R(w + 2)
+            {
+                wn_wait_theta<MT>(pgv);
+                const unsigned long long pg = ((unsigned long long)uni((uint32_t)(pgv >> 32)) << 32) | uni((uint32_t)pgv);
+                if (pg > th) th = pg;
+            }
+            wn_load_theta(pgv, vzero, &bt.theta[q]);
+            c1_request();
+            load_runs(cur, w - w_lo + 2u);
+            if (failed) return false;
+            return true;
+        };
+        for (uint32_t w = w_lo; w < w_hi; w += 2u) {
+            if (!window(bufa, w)) break;
+            if (w + 1u < w_hi && !window(bufb, w + 1u)) break;
+        }
+        wn_drain<MT>(bufa, bufb, d_gw, pgv);
+        if (d_valid && !failed) c2();
+        failed = failed || __ballot(notf) != 0ull;
+
+        // ---- cold pass (search.rs:203): the item's blocks whose upper bound reaches the threshold of now.  Their postings are scored
+        // on their own; one that would enter the list is offered unless its document has a posting in another list of the query --
+        // those documents are the completion's (never offered with a partial score).  Everything here is rare: the windows have
+        // raised the threshold above most blocks' bounds by now.
+        if (!failed && !(dbg & 1u)) {
+            for (uint32_t t = 0; t < m; ++t) {
+                const uint32_t pS = (uint32_t)__builtin_amdgcn_readlane((int)wS, (int)t), pE = (uint32_t)__builtin_amdgcn_readlane((int)wE, (int)t);
+                if (pE == pS) continue;
+                const uint32_t fbt = (uint32_t)__builtin_amdgcn_readlane((int)fb, (int)t);
+                const double s0t = readlane_f64(s0, t);
+                const uint32_t bS = pS >> 7, bE = (pE - 1u) >> 7;  // the item's blocks of the term: bS .. bE
+                for (uint32_t b0 = bS; b0 <= bE; b0 += 64u) {
+                    const bool in = b0 + lane <= bE;
+                    double ub = 0.0;
+                    if (in) ub = ix.blk_ub[fbt + b0 + lane];
+                    for (unsigned long long hm = __ballot(in && (unsigned long long)__double_as_longlong(ub) >= th); hm != 0ull; hm &= hm - 1ull) {
+                        const uint32_t blk = fbt + b0 + (uint32_t)__ffsll((long long)hm) - 1u;
+                        const unsigned long long ubb = (unsigned long long)__double_as_longlong(ix.blk_ub[blk]);
+                        if ((((unsigned long long)uni((uint32_t)(ubb >> 32)) << 32) | uni((uint32_t)ubb)) < th) continue;  // (the threshold of now)
+                        const uint4 bm = uni4(ix.blk_meta[blk]);
+                        const uint32_t n = bm.w & 0xff, md = (bm.w >> 8) & 0xff, mt = (bm.w >> 16) & 0xff;
+                        const uint8_t *body = ix.blob + 8ull * bm.z;
+                        uint32_t dd0, dd1, tt0, tt1;
+                        decode_doc_ids(body, md, n, bm.x, lane, dd0, dd1);
+                        decode_fields(body + ((payload_bytes(md, n) + 7u) & ~7u), mt, n, lane, tt0, tt1);
+                        const uchar2 fnn = reinterpret_cast<const uchar2 *>(ix.post_fn + 128ull * blk)[lane];
+#pragma nounroll
+                        for (uint32_t j = 0; j < 2u; ++j) {
+                            const uint32_t d = j ? dd1 : dd0, wd = d >> 16;
+                            const double tf = (double)(2u * lane + j < n ? (j ? tt1 : tt0) : 1u);
+                            const double sc = (tf * s0t) / (tf + S1[j ? fnn.y : fnn.x]);
+                            // a posting of the block inside the item's windows that would enter the list
+                            bool cand = 2u * lane + j < n && wd >= w_lo && wd < w_hi && (unsigned long long)__double_as_longlong(sc) >= th &&
+                                        (rtop.cnt < k || better(sc, d, rtop.kth_s, rtop.kth_d));
+                            if (!__ballot(cand)) continue;
+                            for (uint32_t t2 = 0; t2 < m; ++t2) {  // ... unless another list of the query holds the document
+                                if (t2 == t) continue;
+                                const uint32_t wb2 = (uint32_t)__builtin_amdgcn_readlane((int)wb, (int)t2);
+                                const uint16_t *run = ids16 + 128ull * (uint32_t)__builtin_amdgcn_readlane((int)fb, (int)t2);
+                                uint32_t lo = 0, hi = 0;
+                                if (cand) {
+                                    lo = ix.win_off[wb2 + wd];
+                                    hi = ix.win_off[wb2 + wd + 1u];
+                                }
+                                while (__ballot(lo < hi)) {  // first posting of the window's run with id >= the document's
+                                    const uint32_t mid = (lo + hi) >> 1;
+                                    if (lo < hi) {
+                                        if ((uint32_t)run[mid] < (d & 0xffffu)) lo = mid + 1u;
+                                        else hi = mid;
+                                    }
+                                }
+                                if (cand && lo < ix.win_off[wb2 + wd + 1u] && (uint32_t)run[lo] == (d & 0xffffu)) cand = false;
+                            }
+                            offer(cand, sc, d);
+                        }
+                    }
+                }
+            }
+        }
+        if (rtop.cnt >= k) {  // the item's k-th score to the query's shared threshold
+            const unsigned long long kb = (unsigned long long)__double_as_longlong(rtop.kth_s);
+            if (kb > published && lane == 0) atomicMax(&bt.theta[q], kb);
+        }
+
+        // ---- item result: one list
+        const uint32_t nres = failed ? 0u : rtop.cnt;
+        const KernArgsP ce = cold_args();
+        const size_t list = (size_t)item * ce->bt.lpi;
+        if (lane < nres) {
+            ce->bt.res_score[list * k + lane] = rtop.score[0];
+            ce->bt.res_doc[list * k + lane] = rtop.doc[0];
+        }
+        if (lane == 0) {
+            ce->bt.res_cnt[list] = nres;
+            ce->bt.item_failed[item] = failed ? 0x101u : 0u;
+            if (failed) *ce->bt.fail_any = 1u;
+        }
+    }
+}

@@ -1,0 +1,28 @@
+// scan_win.hip -- translation unit of scan_win_kernel (scan_win.h): the device types and helpers of search.hip, the kernel, and the
+// launcher search.hip calls.  A unit of its own so that the dominant kernel of C3 compiles in seconds, not with the other eight.
+#include <hip/hip_runtime.h>
+
+#include "vbm25_internal.h"
+
+namespace vbm25 {
+#include "device_types.h"
+#include "decode.h"
+#include "topk_lds.h"
+#include "block_fetch.h"
+#include "topk_reg.h"
+#include "scan_win.h"
+#include "scan_win_launch.h"
+
+// mt: the most indexed terms of a query of the batch -- the kernel is compiled for 2, 4, 5 and 8 run loads per window
+hipError_t scan_win_launch(const DevIndex &ix, const DevBatch &bt, uint32_t mt, uint32_t grid, hipStream_t st) {
+    if (mt <= 2) scan_win_kernel<2><<<grid, WN_WG, 0, st>>>(ix, bt);
+    else if (mt <= 4) scan_win_kernel<4><<<grid, WN_WG, 0, st>>>(ix, bt);
+    else if (mt <= 5) scan_win_kernel<5><<<grid, WN_WG, 0, st>>>(ix, bt);
+    else scan_win_kernel<8><<<grid, WN_WG, 0, st>>>(ix, bt);
+    return hipGetLastError();
+}
+uint32_t scan_win_resident_waves() { return WN_GRID * WN_WAVES; }
+uint32_t scan_win_max_terms() { return WN_T; }
+uint32_t scan_win_max_k() { return 64; }
+uint32_t scan_win_wg() { return WN_WAVES; }
+}  // namespace vbm25

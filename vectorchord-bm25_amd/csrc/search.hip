@@ -60,6 +60,7 @@ int set_error(int code, const char *fmt, ...) {
 #include "block_fetch.h"
 #include "topk_reg.h"
 #include "scan_range.h"
+#include "scan_win_launch.h"
 #include "scan_team.h"
 #include "scan_dense.h"
 #include "scan_many.h"
@@ -198,7 +199,9 @@ struct vbm25_index {
     std::vector<uint32_t> term_df_host;  // host copy for query routing
     vbm25_batch *scratch = nullptr;      // batch object re-used by vbm25_search_batch
     DeviceBuffer term_wand_tf, term_wand_fn, term_df, term_first_block, term_s0, blk_min_doc, blk_max_doc, blk_meta, blk_ub, blob,
-        post_fn, post_rel16, post_tfn, doc_payload, s1, term_idf, fn_len, term_kth_ub, blk_piv, term_loc, blk_loc;
+        post_fn, post_rel16, post_tfn, doc_payload, s1, term_idf, fn_len, term_kth_ub, blk_piv, term_loc, blk_loc, post_id16, win_off, term_win;
+    std::vector<uint32_t> term_win_host;  // host copy of term_win (query routing); empty: the index has no window planes
+    uint32_t n_win = 0;
     double k1 = 1.2;
     uint64_t device_bytes = 0;
 };
@@ -220,6 +223,10 @@ struct Tuning {
     uint32_t team_dbg = 0;         // timing experiments only
     uint32_t fused_items = 128;    // the one-launch route takes batches of up to this many work items
     int arith = 1;                 // batches of sparse queries beyond that: work items made by the scan kernel (no plan_kernel)
+    int win = 1;                   // batches of sparse queries of <= 8 comparable terms, k <= 64: scan_win_kernel (the window formulation)
+    int win_force = 0;             // tests: that route whatever the lists' lengths
+    uint32_t win_items = 0;        // work items of a batch on that route (0: twice the resident waves)
+    int win_planes = 1;            // read at index creation: derive the window planes (post_id16, win_off)
     uint32_t generation = 0;       // bumped by every vbm25_tuning_set / reset: vbm25_search_batch's batch object is rebuilt when it is stale
 };
 static Tuning g_tune;
@@ -255,6 +262,8 @@ struct vbm25_batch {
     // vbm25_search_batch with a handful of sparse queries: ONE launch (scan_range_kernel plans, scans and merges)
     uint32_t fused_g = 0;         // items per query of the current queries on that route (0: general route)
     uint32_t arith_g = 0;         // general route without plan_kernel (every query sparse): items per query, made by the scan kernel itself
+    uint32_t win_mt = 8;          // scan_win_kernel: the most indexed terms of a query of the current batch
+    uint32_t win_g = 0;           // ... and scan_win_kernel's flavour of it (items = runs of 2^16-document windows, one result list each)
     bool need_many = true;        // the current queries have items for scan_many_kernel (more than 16 terms, 256 < k, dense without the dense kernel)
     bool fused_pinned = false;    // ... with queries and hits in pinned host memory (vbm25_search_batch, <= 8 queries); else device buffers
     bool state_clean = false;     // threshold / histogram / counters are zero (the fused route leaves them so; the general one does not)
@@ -287,7 +296,8 @@ DeviceBuffer vbm25_index::*const INDEX_BUFFERS[] = {
     &vbm25_index::term_wand_tf, &vbm25_index::term_wand_fn, &vbm25_index::term_df, &vbm25_index::term_first_block, &vbm25_index::term_s0,
     &vbm25_index::blk_min_doc, &vbm25_index::blk_max_doc, &vbm25_index::blk_meta, &vbm25_index::blk_ub, &vbm25_index::blob,
     &vbm25_index::post_fn, &vbm25_index::post_rel16, &vbm25_index::post_tfn, &vbm25_index::doc_payload, &vbm25_index::s1,
-    &vbm25_index::term_idf, &vbm25_index::fn_len, &vbm25_index::term_kth_ub, &vbm25_index::blk_piv, &vbm25_index::term_loc, &vbm25_index::blk_loc};
+    &vbm25_index::term_idf, &vbm25_index::fn_len, &vbm25_index::term_kth_ub, &vbm25_index::blk_piv, &vbm25_index::term_loc, &vbm25_index::blk_loc,
+    &vbm25_index::post_id16, &vbm25_index::win_off, &vbm25_index::term_win};
 
 void fill_dev(vbm25_index *ix) {
     ix->dev.n_docs = ix->n_docs;
@@ -312,6 +322,10 @@ void fill_dev(vbm25_index *ix) {
     ix->dev.doc_payload = ix->doc_payload.as<uint16_t>();
     ix->dev.s1 = ix->s1.as<double>();
     ix->dev.term_kth_ub = ix->term_kth_ub.as<double>();  // (NULL when the block maxima are not attained)
+    ix->dev.post_id16 = ix->post_id16.as<uint32_t>();    // (the three of them NULL when the index has no window planes)
+    ix->dev.win_off = ix->win_off.as<uint32_t>();
+    ix->dev.term_win = ix->term_win.as<uint32_t>();
+    ix->dev.n_win = ix->n_win;
 }
 }  // namespace
 
@@ -403,6 +417,18 @@ static int index_create_common(const RawSegment &r, int device, vbm25_index **ou
         if (n_loc > 0xfffffff0ull) return set_error(VBM25_ERR_UNSUPPORTED, "block locator exceeds 2^32 entries");
     }
 
+    // scan_win_kernel's planes: the low 16 bits of every id in posting order, and for every term with at least a posting per four
+    // windows the table of its n_win + 1 window offsets (a rarer term's table would be larger than its list)
+    const bool win_planes = tuning_snapshot().win_planes != 0 && r.n_blocks != 0;
+    const uint32_t n_win = uint32_t((uint64_t(r.n_docs) + 65535u) >> 16);
+    std::vector<uint32_t> term_win(win_planes ? r.n_terms : 0u, UINT32_MAX);
+    uint64_t n_woff = 0;
+    if (win_planes)
+        for (uint32_t t = 0; t < r.n_terms; ++t) {
+            if (uint64_t(r.term_df_host[t]) * 4u < n_win || n_woff + n_win + 1u > 0xfffffff0ull) continue;
+            term_win[t] = uint32_t(n_woff);
+            n_woff += n_win + 1u;
+        }
     // the raw per-block arrays the derivation reads: used where they are (device segment) or uploaded for its duration
     DeviceBuffer t_n, t_wfn, t_wtf, t_md, t_mt, t_off8, t_fieldnorm, t_raw, t_sorted, t_tmp, err;
     const uint8_t *p_n = r.blk_n, *p_wfn = r.blk_wand_fn, *p_md = r.blk_meta_doc, *p_mt = r.blk_meta_tf, *p_fieldnorm = r.doc_fieldnorm;
@@ -438,7 +464,9 @@ static int index_create_common(const RawSegment &r, int device, vbm25_index **ou
         (rc = ix->blob.alloc(blob_alloc)) ||
         (rc = ix->post_fn.alloc(128ull * r.n_blocks)) ||
         (rc = ix->post_rel16.alloc(256ull * r.n_blocks)) ||
-        (rc = ix->post_tfn.alloc(256ull * r.n_blocks)) ||
+        (rc = ix->post_tfn.alloc(256ull * r.n_blocks + 1024)) ||  // (slack: scan_win_kernel's cold pass reads whole runs)
+        (win_planes && ((rc = ix->post_id16.alloc(256ull * r.n_blocks + 1024)) || (rc = ix->win_off.alloc(4ull * n_woff)) ||
+                        (rc = ix->term_win.upload(term_win.data(), 4ull * r.n_terms)))) ||
         (rc = ix->blk_piv.alloc(16ull * r.n_blocks)) ||
         (rc = ix->term_loc.upload(loc_off.data(), 4ull * loc_off.size())) ||
         (rc = ix->blk_loc.alloc(4ull * n_loc)) ||
@@ -503,6 +531,11 @@ static int index_create_common(const RawSegment &r, int device, vbm25_index **ou
         pa.post_rel16 = ix->post_rel16.as<uint32_t>();
         pa.post_tfn = ix->post_tfn.as<uint32_t>();
         pa.blk_piv = ix->blk_piv.as<uint4>();
+        pa.post_id16 = ix->post_id16.as<uint32_t>();
+        pa.win_off = ix->win_off.as<uint32_t>();
+        pa.term_win = ix->term_win.as<uint32_t>();
+        pa.n_win = n_win;
+        if (win_planes) HIP_TRY(hipMemset(ix->win_off.p, 0, 4ull * n_woff));
         pa.error_flag = err.as<uint32_t>();
         pa.term_first_block = ix->term_first_block.as<uint32_t>();
         pa.term_wand_tf = ix->term_wand_tf.as<uint32_t>();
@@ -523,6 +556,16 @@ static int index_create_common(const RawSegment &r, int device, vbm25_index **ou
         return set_error(VBM25_ERR_CORRUPT,
                          "a posting scores above its block's / token's WAND pair "
                          "(search.rs:363,377-380 prune with those bounds)");
+    if (win_planes && !(flag & 8u)) {  // (flag 8: a short block inside a term -- postings are not at 128 block + i: no window planes)
+        ix->term_win_host = std::move(term_win);
+        ix->n_win = n_win;
+    } else {
+        for (DeviceBuffer *b : {&ix->post_id16, &ix->win_off, &ix->term_win}) {
+            if (b->p) (void)hipFree(b->p);
+            b->p = nullptr;
+            b->bytes = 0;
+        }
+    }
     ix->dev.blk_ub_attained = has_wand && !(flag & 4u) ? 1u : 0u;
     if (!ix->dev.blk_ub_attained && ix->term_kth_ub.p) {  // the k-th largest maxima bound nothing then: kept out of the index (and its replicas)
         (void)hipFree(ix->term_kth_ub.p);
@@ -534,7 +577,8 @@ static int index_create_common(const RawSegment &r, int device, vbm25_index **ou
     ix->dev.blk_ub_attained = has_wand && !(flag & 4u) ? 1u : 0u;
     for (const DeviceBuffer *b : {&ix->term_df, &ix->term_first_block, &ix->term_s0, &ix->blk_min_doc,
                                   &ix->blk_max_doc, &ix->blk_meta, &ix->blk_ub, &ix->blob, &ix->post_fn,
-                                  &ix->post_rel16, &ix->post_tfn, &ix->blk_piv, &ix->term_loc, &ix->blk_loc, &ix->term_kth_ub, &ix->doc_payload, &ix->s1})
+                                  &ix->post_rel16, &ix->post_tfn, &ix->blk_piv, &ix->term_loc, &ix->blk_loc, &ix->term_kth_ub, &ix->doc_payload, &ix->s1,
+                                  &ix->post_id16, &ix->win_off, &ix->term_win})
         ix->device_bytes += b->bytes;
     *out = ix.release();
     return VBM25_OK;
@@ -658,6 +702,9 @@ static int vbm25_batch_create_impl(vbm25_index *ix, uint32_t max_queries, uint32
     bt->target_items = bt->use_range ? std::max(256u, bt->tune.team ? bt->tune.team_items : bt->tune.range_items) : TARGET_ITEMS;
     bt->min_chunk = bt->use_range ? std::max(128u, bt->tune.range_min_chunk) : MIN_CHUNK_POSTINGS;
     bt->max_items = max_queries + bt->target_items + (bt->use_dense ? std::max(256u, bt->tune.dense_items) : 0u);
+    // scan_win_kernel's items are one wave's work each (a few per query): room for them
+    if (bt->use_range && k <= scan_win_max_k() && bt->tune.win && !ix->term_win_host.empty())
+        bt->max_items = std::max(bt->max_items, std::max(8192u, 8u * max_queries));
     int rc = 0;
     if (k > 1024) {  // exhaustive path: query buffers, results and an accumulator per document
         bt->bigk = true;
@@ -784,6 +831,7 @@ static int vbm25_batch_set_queries_impl(vbm25_batch *bt, const uint32_t *term_id
     bt->nq = nq;
     bt->fused_g = 0;
     bt->arith_g = 0;
+    bt->win_g = 0;
     bt->need_many = many || !bt->use_range;
     bt->fused_pinned = false;
     if (bt->use_range && nq && !many && !has_dense && range_mt != 0) {  // every query sparse, <= 16 indexed terms: the one-launch route
@@ -803,10 +851,58 @@ static int vbm25_batch_set_queries_impl(vbm25_batch *bt, const uint32_t *term_id
             g = std::min<unsigned long long>(std::max<unsigned long long>(g, 1), std::min<unsigned long long>(64, bt->index->n_docs));
             // only where the launches it saves matter: a batch that fills the GPU runs slower through the FUSED
             // instantiation (more live state in the tile loop) than plan + scan + merge cost
+            // scan_win_kernel (the window formulation): every query of <= 8 indexed terms, all with a window table, the lists of
+            // comparable length (the MaxScore split of scan_range_kernel has nothing to skip) and neither too thin nor too thick
+            // per 2^16-document window (32 .. 232 postings on average: one 8-byte load per lane holds a run)
+            uint32_t win_g = 0;
+            const vbm25_index *ixh = bt->index;
+            if (bt->tune.win && bt->k <= scan_win_max_k() && !ixh->term_win_host.empty() && !bt->tune.team) {
+                const double wins = std::max(1.0, double(ixh->n_docs) / 65536.0);
+                double e_max = 1.0;
+                bool ok = true;
+                for (uint32_t q = 0; q < nq && ok; ++q) {
+                    uint64_t dfs[8];
+                    uint32_t n = 0;
+                    ok = q_off[q + 1] - q_off[q] <= 64u;
+                    for (uint32_t p = q_off[q]; p < q_off[q + 1] && ok; ++p) {
+                        const uint32_t t = term_ids[p];
+                        if (t >= ixh->n_terms) continue;
+                        ok = n < scan_win_max_terms() && ixh->term_win_host[t] != UINT32_MAX;
+                        if (!ok) break;
+                        const double e = double(ixh->term_df_host[t]) / wins;
+                        ok = bt->tune.win_force || (e >= 32.0 && e <= 232.0);
+                        e_max = std::max(e_max, e);
+                        dfs[n++] = ixh->term_df_host[t];
+                    }
+                    if (ok && !bt->tune.win_force && bt->tune.ne) {  // a prefix of the longest lists that scan_range_kernel would look up instead of scanning?
+                        std::sort(dfs, dfs + n, [](uint64_t a, uint64_t b) { return a > b; });
+                        uint64_t rest = 0;
+                        for (uint32_t i = 0; i < n; ++i) rest += dfs[i];
+                        for (uint32_t i = 0; i + 1 < n && ok; ++i) {
+                            rest -= dfs[i];
+                            ok = !(dfs[i] >= uint64_t(std::max(1u, bt->tune.ne_ratio)) * rest || dfs[i] * 16u >= ixh->n_docs);
+                        }
+                    }
+                }
+                if (ok) {
+                    // items per query: about twice the resident waves in all; an item's blocks per term should fit the 64-bit mask
+                    // of its hot blocks (8192 postings per term)
+                    const uint32_t target = bt->tune.win_items ? bt->tune.win_items : 2u * scan_win_resident_waves();
+                    const uint32_t nw_max = std::max(1u, uint32_t(8192.0 / std::max(32.0, e_max)));
+                    const uint32_t g_min = (ixh->n_win + nw_max - 1u) / nw_max;
+                    uint32_t gw = std::max(std::max(1u, (target + nq / 2) / nq), g_min);
+                    gw = std::min(std::min(gw, ixh->n_win), bt->max_items / nq);
+                    if (gw >= g_min && gw >= 1u) win_g = gw;
+                }
+            }
             if (bt->tune.fused && nq * g <= bt->tune.fused_items) {
                 bt->fused_g = uint32_t(g);
                 bt->fused_pinned = fast && nq <= 8 && !bt->timing;
-            } else if (bt->tune.arith && !bt->tune.team) {
+            } else if (win_g || (bt->tune.arith && !bt->tune.team)) {
+                if (win_g) {
+                    bt->win_g = win_g;
+                    g = win_g;
+                } else
                 bt->arith_g = uint32_t(g);  // the general route, items made in the kernel: no plan_kernel, merge_kernel cleans
                 // ... handed out longest first, as plan_kernel would (the host has the posting counts): queries by
                 // descending postings, a query's g parts together
@@ -854,6 +950,7 @@ static int vbm25_batch_set_queries_impl(vbm25_batch *bt, const uint32_t *term_id
     }
     bt->has_dense = has_dense;
     bt->range_rt = !bt->use_range || range_mt == 0 ? 0u : (range_mt <= 8u ? 8u : 16u);
+    bt->win_mt = range_mt;
     {   // the number of work items plan_kernel will make (same integer arithmetic): the persistent grids need not be
         // larger (a single query is a handful of items); with the dense-window kernel every dense query gets the same
         // number of items (equal document counts)
@@ -1017,6 +1114,38 @@ static int vbm25_batch_run_impl(vbm25_batch *bt, void *hip_stream) {
             return int(VBM25_OK);
         });
         if (rcf) return rcf;
+        HIP_TRY(hipGetLastError());
+        bt->state_clean = true;
+        return VBM25_OK;
+    }
+    if (bt->win_g && bt->k <= scan_win_max_k()) {
+        // Every query sparse, <= 8 terms of comparable length: scan_win_kernel (its waves make their work items themselves), then as
+        // on the route below: scan_many_kernel leaves at once unless an item was given up, merge_kernel merges and cleans.
+        const bool clean = bt->state_clean;
+        bt->state_clean = false;
+        if (!clean) {
+            HIP_TRY(hipMemsetAsync(bt->hist.p, 0, 4ull * CUR_HB * bt->max_queries, st));
+            HIP_TRY(hipMemsetAsync(bt->theta.p, 0, 8ull * bt->max_queries, st));
+            HIP_TRY(hipMemsetAsync(bt->work_ctr.p, 0, 8, st));
+            HIP_TRY(hipMemsetAsync(bt->fused_state.p, 0, 4ull * (bt->max_queries + 1), st));
+            HIP_TRY(hipMemsetAsync(bt->fail_any.p, 0, 4, st));
+            HIP_TRY(hipMemsetAsync(bt->item_failed.p, 0, 4ull * bt->max_items, st));
+            HIP_TRY(hipMemsetAsync(bt->res_cnt.p, 0, 4ull * bt->max_items * bt->lpi, st));
+        }
+        db.fused_g = bt->win_g;  // (merge_kernel: a query's lists are those of its win_g items)
+        db.win_g = bt->win_g;
+        db.lpi = 1;
+        db.hist = nullptr;       // (this kernel keeps no histogram of accepted documents: merge_kernel has none to clean)
+        db.dense_on = 0;
+        db.many_expected = 0;
+        db.merge_clean = 1;
+        db.order_on = 1;
+        if (int rc = take_events()) return rc;
+        const uint32_t wgrid = std::min<uint32_t>((bt->nq * bt->win_g + scan_win_wg() - 1u) / scan_win_wg(), scan_win_resident_waves() / scan_win_wg());
+        HIP_TRY(scan_win_launch(ix, db, bt->range_rt == 8 ? bt->win_mt : 8u, wgrid, st));
+        scan_many_kernel<64><<<64, WG, 0, st>>>(ix, db);
+        if (bt->timing) (void)hipEventRecord(e1, st);
+        merge_kernel<64><<<bt->nq, 64, 0, st>>>(ix, db);
         HIP_TRY(hipGetLastError());
         bt->state_clean = true;
         return VBM25_OK;
@@ -1251,6 +1380,10 @@ int vbm25_tuning_set(const char *name, long long value) {
     else if (n == "team_dbg") g_tune.team_dbg = (uint32_t)value;
     else if (n == "fused_items") g_tune.fused_items = (uint32_t)std::max(0ll, value);
     else if (n == "arith") g_tune.arith = value != 0;
+    else if (n == "win") g_tune.win = value != 0;
+    else if (n == "win_force") g_tune.win_force = value != 0;
+    else if (n == "win_items") g_tune.win_items = (uint32_t)std::max(0ll, value);
+    else if (n == "win_planes") g_tune.win_planes = value != 0;
     else return set_error(VBM25_ERR_INVALID, "unknown tuning switch %s", name);
     ++g_tune.generation;
     return VBM25_OK;
@@ -1268,8 +1401,8 @@ int vbm25_batch_debug_counts(vbm25_batch *bt, uint32_t *n_items, uint32_t *n_fai
     if (!bt || !n_items || !n_failed) return set_error(VBM25_ERR_INVALID, "NULL argument");
     if (int rc = use_device(bt->index->device)) return rc;
     HIP_TRY(hipStreamSynchronize(bt->last_stream));
-    if (bt->arith_g && bt->state_clean) {  // merge_kernel has cleaned the flags and kept the counts per query
-        *n_items = bt->nq * bt->arith_g;
+    if ((bt->arith_g || bt->win_g) && bt->state_clean) {  // merge_kernel has cleaned the flags and kept the counts per query
+        *n_items = bt->nq * (bt->win_g ? bt->win_g : bt->arith_g);
         std::vector<uint32_t> qf(bt->nq);
         if (bt->nq) HIP_TRY(hipMemcpy(qf.data(), bt->q_failed.p, 4ull * bt->nq, hipMemcpyDeviceToHost));
         *n_failed = 0;
@@ -1282,6 +1415,13 @@ int vbm25_batch_debug_counts(vbm25_batch *bt, uint32_t *n_items, uint32_t *n_fai
     *n_failed = 0;
     for (uint32_t x : f) *n_failed += x != 0;
     return VBM25_OK;
+}
+
+// test aid (not declared in include/vbm25.h): the route the current queries take -- 0 general (plan_kernel), 1 one launch,
+// 2 plan-free scan_range_kernel, 3 scan_win_kernel, 4 exhaustive k > 1024
+int vbm25_batch_debug_route(vbm25_batch *bt) {
+    if (!bt) return -1;
+    return bt->bigk ? 4 : bt->fused_g ? 1 : bt->win_g ? 3 : bt->arith_g ? 2 : 0;
 }
 
 // -DVBM25_CHECK builds (not declared in include/vbm25.h): the first violated assertion of the scan kernels, then reset.
@@ -1306,7 +1446,7 @@ int vbm25_batch_debug_theta(vbm25_batch *bt, unsigned long long *out) {
     if (int rc = use_device(bt->index->device)) return rc;
     HIP_TRY(hipStreamSynchronize(bt->last_stream));
     if (bt->nq && bt->theta.p)
-        HIP_TRY(hipMemcpy(out, bt->arith_g && bt->state_clean ? bt->theta_last.p : bt->theta.p, 8ull * bt->nq, hipMemcpyDeviceToHost));
+        HIP_TRY(hipMemcpy(out, (bt->arith_g || bt->win_g) && bt->state_clean ? bt->theta_last.p : bt->theta.p, 8ull * bt->nq, hipMemcpyDeviceToHost));
     return VBM25_OK;
 }
 
@@ -1468,6 +1608,8 @@ int clone_index(const vbm25_index *src, int device, vbm25_index **out) {
     ix->n_blocks = src->n_blocks;
     ix->term_key = src->term_key;
     ix->term_df_host = src->term_df_host;
+    ix->term_win_host = src->term_win_host;
+    ix->n_win = src->n_win;
     ix->k1 = src->k1;
     ix->device_bytes = src->device_bytes;
     for (auto member : INDEX_BUFFERS) {
