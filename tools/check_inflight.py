@@ -75,7 +75,7 @@ def main():
     with tempfile.TemporaryDirectory() as d:
         out = os.path.join(d, "scan_win.s")
         subprocess.check_call([hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-S",
-                               "--cuda-device-only", SRC, "-o", out], stderr=subprocess.DEVNULL)
+                               "--cuda-device-only", SRC, "-o", out] + sys.argv[1:], stderr=subprocess.DEVNULL)
         bad = check(open(out).read())
     for k, ln, t in bad[:40]:
         print(f"{k}: line {ln}: {t}   <-- reads a register whose load may be in flight")

@@ -94,7 +94,10 @@ struct DevBatch {
     uint32_t *q_failed;        // per query: items the first-choice kernels gave up in the last launch (merge_kernel, merge_clean)
     unsigned long long *theta_last;  // per query: the threshold the last launch ended with (merge_kernel, merge_clean)
     uint32_t max_items;        // capacity of items / item_failed; res_* hold max_items * lpi lists of k entries
-    uint32_t win_g;            // scan_win_kernel: items (equal runs of 2^16-document windows) per query, one result list per item
+    uint32_t win_g;            // scan_win_kernel: items (runs of 2^16-document windows) per query, one result list per item
+    uint32_t win_cut[17];      // ... item `part` of a query = the windows [win_cut[part], win_cut[part + 1]) when win_g <= 16 and
+                               // win_cut[win_g] != 0 (runs of decreasing length, handed out longest first: the last items drawn
+                               // are the short ones); equal runs n_win part / win_g otherwise
     uint32_t *team_cand;       // scan_team_kernel: TM_CAND candidate documents per wave of its grid
     uint32_t team_dbg;         // development switch of scan_team_kernel (timing only, wrong results): 1 = candidates are not completed
     uint32_t *dbg;             // -DVBM25_CHECK builds: [0] first violated check (0: none), [1] value, [2] item, [3] thread

@@ -39,7 +39,7 @@ constexpr int WN_WG = WN_WAVES * 64;
 constexpr int WN_WPS = 3;             // waves per SIMD: 168 VGPRs, 12 waves x 12.8 KB of LDS (+ the s1 table per workgroup) per CU
 constexpr int WN_BM_WORDS = 2048;     // 2^16 bits
 constexpr int WN_SLOT = 256;          // staged ids per term: what one 8-byte load per lane covers
-constexpr int WN_LIST = 80;           // second arrivals per window
+constexpr int WN_LIST = 64;           // second arrivals per window (the LDS is handed out in 512-byte granules: 106 per workgroup, three workgroups per CU)
 constexpr uint32_t WN_GRID = 768;     // persistent workgroups: 256 CUs x 3
 
 struct WinWave {
@@ -172,18 +172,41 @@ __global__ void __launch_bounds__(WN_WG, WN_WPS) scan_win_kernel(DevIndex ix, De
 #pragma unroll
     for (int i = 0; i < WN_BM_WORDS / 4 / 64; ++i) reinterpret_cast<uint4 *>(S.bm)[lane + 64 * i] = make_uint4(0, 0, 0, 0);
     __syncthreads();  // (the table; the only workgroup barrier of the kernel -- from here on the waves go their own ways)
+#ifdef VBM25_PROFILE
+    unsigned long long prof[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    const unsigned long long prof_t0 = __builtin_readcyclecounter();
+#endif
 
+    // Items come from one counter; the next one is drawn at the END of the item before (the round trip hides behind the cold pass).
+    // The first one too: thousands of waves queueing at that address at kernel start costs them up to tens of microseconds -- and
+    // is worth it (measured: 0.377 ms when every wave starts on its own number, 0.342 ms through the counter): the queue staggers
+    // the waves, and waves in lockstep meet at the same pipes at the same time.
+    uint32_t drawn = 0;
+    {
+        uint32_t d0 = 0;
+        if (lane == 0) d0 = atomicAdd(cold_args()->bt.work_ctr, 1u);
+        drawn = uni(d0);
+    }
     for (;;) {
-        uint32_t item = 0;
+        uint32_t item = drawn;
+        if (item >= n_items) break;
+        uint32_t w_lo, w_hi;
         {
             const KernArgsP ca = cold_args();
-            if (lane == 0) item = atomicAdd(ca->bt.work_ctr, 1u);
-            item = uni(item);
-            if (item >= n_items) break;
-            if (ca->bt.order_on) item = uni(ca->bt.item_order[item]);  // the host's longest-first order
+            if (ca->bt.order_on) item = uni(ca->bt.item_order[item]);  // the host's order: longest items first
         }
+        PROF_T(t_item);
         const uint32_t q = item / g, part = item - q * g;
-        const uint32_t w_lo = (uint32_t)((unsigned long long)NWIN * part / g), w_hi = (uint32_t)((unsigned long long)NWIN * (part + 1u) / g);
+        {
+            const KernArgsP ca = cold_args();
+            if (g <= 16u && ca->bt.win_cut[g] != 0u) {
+                w_lo = ca->bt.win_cut[part];
+                w_hi = ca->bt.win_cut[part + 1u];
+            } else {
+                w_lo = (uint32_t)((unsigned long long)NWIN * part / g);
+                w_hi = (uint32_t)((unsigned long long)NWIN * (part + 1u) / g);
+            }
+        }
 
         // ---- item setup: lane t = term t of the query (ascending key order)
         uint32_t m = 0, term = NONE32;
@@ -393,7 +416,10 @@ __global__ void __launch_bounds__(WN_WG, WN_WPS) scan_win_kernel(DevIndex ix, De
             // LDS instead of five.  The last window's open pass of second arrivals (C2) is finished between the two phases.
             uint32_t nd = 0;
             wA = wB;  // (the last window's upper boundaries)
+            PROF_T(t_0);
             wn_wait_runs<MT>(cur);
+            PROF_T(t_1);
+            PROF_ADD(1, t_0, t_1);
 #pragma unroll
             for (int gq = 0; gq < 2; ++gq) {
                 uint32_t hb[5][4], ho[5][4];  // the bit of every posting of the group (0: not a posting of the run), the word that came back
@@ -440,9 +466,15 @@ __global__ void __launch_bounds__(WN_WG, WN_WPS) scan_win_kernel(DevIndex ix, De
                     }
                 }
                 if (gq == 0) {  // ---- the last window's first pass of second arrivals: its words have arrived behind these marks
+                    PROF_T(t_2);
+                    PROF_ADD(2, t_1, t_2);
                     wn_wait_word<MT>(d_gw);
+                    PROF_T(t_2b);
+                    PROF_ADD(3, t_2, t_2b);
                     if (d_valid) c2();
                     d_valid = false;
+                    PROF_T(t_3);
+                    PROF_ADD(4, t_2b, t_3);
                 }
                 if (gq == 0 || MT > 5) {
 #pragma unroll
@@ -466,8 +498,14 @@ __global__ void __launch_bounds__(WN_WG, WN_WPS) scan_win_kernel(DevIndex ix, De
                 }
             }
             __builtin_amdgcn_wave_barrier();
+            PROF_T(t_4);
+            PROF_ADD(5, t_1, t_4);
             // more second arrivals than the list holds: the lists are too dense here for this kernel
             if (nd > (uint32_t)WN_LIST) failed = true;
+#ifdef VBM25_PROFILE
+            prof[0] += 1;
+            prof[10] += nd;
+#endif
             if (dbg & 4u) nd = 0;
 #pragma unroll
             for (int i = 0; i < WN_BM_WORDS / 4 / 64; ++i) reinterpret_cast<uint4 *>(S.bm)[lane + 64 * i] = make_uint4(0, 0, 0, 0);
@@ -484,6 +522,8 @@ __global__ void __launch_bounds__(WN_WG, WN_WPS) scan_win_kernel(DevIndex ix, De
                 c1(0u, nd, w);
                 d_valid = true;
             }
+            PROF_T(t_5);
+            PROF_ADD(6, t_4, t_5);
             // ---- the shared threshold polled a window ago; then, in this order: the next poll P(w), the word of this window's open
             // pass G(w), the runs of the window after next R(w + 2)
             {
@@ -494,14 +534,20 @@ __global__ void __launch_bounds__(WN_WG, WN_WPS) scan_win_kernel(DevIndex ix, De
             wn_load_theta(pgv, vzero, &bt.theta[q]);
             c1_request();
             load_runs(cur, w - w_lo + 2u);
+            PROF_T(t_6);
+            PROF_ADD(7, t_5, t_6);
             if (failed) return false;
             return true;
         };
+        PROF_T(t_loop);
         for (uint32_t w = w_lo; w < w_hi; w += 2u) {
             if (!window(bufa, w)) break;
             if (w + 1u < w_hi && !window(bufb, w + 1u)) break;
         }
+        PROF_T(t_loop_end);
         wn_drain<MT>(bufa, bufb, d_gw, pgv);
+        uint32_t next_draw = 0;
+        if (lane == 0) next_draw = atomicAdd(cold_args()->bt.work_ctr, 1u);  // (consumed at the item's very end)
         if (d_valid && !failed) c2();
         failed = failed || __ballot(notf) != 0ull;
 
@@ -510,6 +556,21 @@ __global__ void __launch_bounds__(WN_WG, WN_WPS) scan_win_kernel(DevIndex ix, De
         // those documents are the completion's (never offered with a partial score).  Everything here is rare: the windows have
         // raised the threshold above most blocks' bounds by now.
         if (!failed && !(dbg & 1u)) {
+            // the first 64 blocks of every term at once (one round trip for all the terms, not one each): lane = block
+            uint32_t hm0l = 0, hm0h = 0;  // lane = term: the mask of its hot blocks among them
+#pragma unroll
+            for (int t = 0; t < MT; ++t) {
+                const uint32_t pS = (uint32_t)__builtin_amdgcn_readlane((int)wS, t), pE = (uint32_t)__builtin_amdgcn_readlane((int)wE, t);
+                const uint32_t fbt = (uint32_t)__builtin_amdgcn_readlane((int)fb, t);
+                const bool in = (uint32_t)t < m && pE != pS && (pS >> 7) + lane <= ((pE - 1u) >> 7);
+                double ub = 0.0;
+                if (in) ub = ix.blk_ub[fbt + (pS >> 7) + lane];
+                const unsigned long long hm = __ballot(in && (unsigned long long)__double_as_longlong(ub) >= th);
+                if (lane == (uint32_t)t) {
+                    hm0l = (uint32_t)hm;
+                    hm0h = (uint32_t)(hm >> 32);
+                }
+            }
             for (uint32_t t = 0; t < m; ++t) {
                 const uint32_t pS = (uint32_t)__builtin_amdgcn_readlane((int)wS, (int)t), pE = (uint32_t)__builtin_amdgcn_readlane((int)wE, (int)t);
                 if (pE == pS) continue;
@@ -517,10 +578,15 @@ __global__ void __launch_bounds__(WN_WG, WN_WPS) scan_win_kernel(DevIndex ix, De
                 const double s0t = readlane_f64(s0, t);
                 const uint32_t bS = pS >> 7, bE = (pE - 1u) >> 7;  // the item's blocks of the term: bS .. bE
                 for (uint32_t b0 = bS; b0 <= bE; b0 += 64u) {
-                    const bool in = b0 + lane <= bE;
-                    double ub = 0.0;
-                    if (in) ub = ix.blk_ub[fbt + b0 + lane];
-                    for (unsigned long long hm = __ballot(in && (unsigned long long)__double_as_longlong(ub) >= th); hm != 0ull; hm &= hm - 1ull) {
+                    unsigned long long hm = (unsigned long long)(uint32_t)__builtin_amdgcn_readlane((int)hm0h, (int)t) << 32 |
+                                            (uint32_t)__builtin_amdgcn_readlane((int)hm0l, (int)t);
+                    if (b0 != bS) {  // (an item of more than 64 blocks of the term)
+                        const bool in = b0 + lane <= bE;
+                        double ub = 0.0;
+                        if (in) ub = ix.blk_ub[fbt + b0 + lane];
+                        hm = __ballot(in && (unsigned long long)__double_as_longlong(ub) >= th);
+                    }
+                    for (; hm != 0ull; hm &= hm - 1ull) {
                         const uint32_t blk = fbt + b0 + (uint32_t)__ffsll((long long)hm) - 1u;
                         const unsigned long long ubb = (unsigned long long)__double_as_longlong(ix.blk_ub[blk]);
                         if ((((unsigned long long)uni((uint32_t)(ubb >> 32)) << 32) | uni((uint32_t)ubb)) < th) continue;  // (the threshold of now)
@@ -569,6 +635,15 @@ __global__ void __launch_bounds__(WN_WG, WN_WPS) scan_win_kernel(DevIndex ix, De
             if (kb > published && lane == 0) atomicMax(&bt.theta[q], kb);
         }
 
+#ifdef VBM25_PROFILE
+        {
+            const unsigned long long t_end = __builtin_readcyclecounter();
+            prof[12] += 1;
+            prof[9] += t_loop_end - t_loop;
+            prof[8] += t_loop - t_item;
+            prof[13] += t_end - t_loop_end;
+        }
+#endif
         // ---- item result: one list
         const uint32_t nres = failed ? 0u : rtop.cnt;
         const KernArgsP ce = cold_args();
@@ -582,5 +657,13 @@ __global__ void __launch_bounds__(WN_WG, WN_WPS) scan_win_kernel(DevIndex ix, De
             ce->bt.item_failed[item] = failed ? 0x101u : 0u;
             if (failed) *ce->bt.fail_any = 1u;
         }
+        drawn = uni(next_draw);
     }
+#ifdef VBM25_PROFILE
+    if (bt.prof && lane == 0) {
+        unsigned long long *o = bt.prof + ((size_t)blockIdx.x * WN_WAVES + (threadIdx.x >> 6)) * 16;
+        for (int i = 0; i < 16; ++i) o[i] = prof[i];
+        o[15] = __builtin_readcyclecounter() - prof_t0;
+    }
+#endif
 }

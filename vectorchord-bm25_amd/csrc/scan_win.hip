@@ -1,6 +1,7 @@
 // scan_win.hip -- translation unit of scan_win_kernel (scan_win.h): the device types and helpers of search.hip, the kernel, and the
 // launcher search.hip calls.  A unit of its own so that the dominant kernel of C3 compiles in seconds, not with the other eight.
 #include <hip/hip_runtime.h>
+#include <cstdio>
 
 #include "vbm25_internal.h"
 

@@ -227,6 +227,7 @@ struct Tuning {
     int win_force = 0;             // tests: that route whatever the lists' lengths
     uint32_t win_items = 0;        // work items of a batch on that route (0: twice the resident waves)
     int win_planes = 1;            // read at index creation: derive the window planes (post_id16, win_off)
+    int win_guided = 1;            // scan_win_kernel's items of a query of decreasing length (0: equal)
     uint32_t generation = 0;       // bumped by every vbm25_tuning_set / reset: vbm25_search_batch's batch object is rebuilt when it is stale
 };
 static Tuning g_tune;
@@ -756,7 +757,7 @@ static int vbm25_batch_create_impl(vbm25_index *ix, uint32_t max_queries, uint32
     if (int rc2 = bt->dbg.alloc(64)) return rc2;
     HIP_TRY(hipMemset(bt->dbg.p, 0, 64));
 #ifdef VBM25_PROFILE
-    if (int rc2 = bt->prof.alloc(8ull * 16 * RNW * R_GRID)) return rc2;
+    if (int rc2 = bt->prof.alloc(8ull * 16 * RNW * R_GRID)) return rc2;  // (scan_win_kernel: 768 x 4 waves -- fewer)
     HIP_TRY(hipMemset(bt->prof.p, 0, 8ull * 16 * RNW * R_GRID));
 #endif
     *out = bt.release();
@@ -888,8 +889,7 @@ static int vbm25_batch_set_queries_impl(vbm25_batch *bt, const uint32_t *term_id
                     // items per query: about twice the resident waves in all; an item's blocks per term should fit the 64-bit mask
                     // of its hot blocks (8192 postings per term)
                     const uint32_t target = bt->tune.win_items ? bt->tune.win_items : 2u * scan_win_resident_waves();
-                    const uint32_t nw_max = std::max(1u, uint32_t(8192.0 / std::max(32.0, e_max)));
-                    const uint32_t g_min = (ixh->n_win + nw_max - 1u) / nw_max;
+                    const uint32_t g_min = (ixh->n_win + 62u) / 63u;  // (an item holds at most 63 windows)
                     uint32_t gw = std::max(std::max(1u, (target + nq / 2) / nq), g_min);
                     gw = std::min(std::min(gw, ixh->n_win), bt->max_items / nq);
                     if (gw >= g_min && gw >= 1u) win_g = gw;
@@ -912,6 +912,10 @@ static int vbm25_batch_set_queries_impl(vbm25_batch *bt, const uint32_t *term_id
                 qs.resize(nq);
                 for (uint32_t q = 0; q < nq; ++q) qs[q] = q;
                 std::stable_sort(qs.begin(), qs.end(), [&](uint32_t a, uint32_t b) { return q_postings[a] > q_postings[b]; });
+                if (win_g)  // (parts of decreasing length: every query's first part, then every query's second one, ...)
+                    for (uint32_t part = 0; part < g; ++part)
+                        for (uint32_t i = 0; i < nq; ++i) ord[size_t(part) * nq + i] = qs[i] * uint32_t(g) + part;
+                else
                 for (uint32_t i = 0; i < nq; ++i)
                     for (uint32_t part = 0; part < g; ++part) ord[size_t(i) * g + part] = qs[i] * uint32_t(g) + part;
                 HIP_TRY(hipMemcpy(bt->item_order.p, ord.data(), 4ull * ord.size(), hipMemcpyHostToDevice));
@@ -1134,6 +1138,25 @@ static int vbm25_batch_run_impl(vbm25_batch *bt, void *hip_stream) {
         }
         db.fused_g = bt->win_g;  // (merge_kernel: a query's lists are those of its win_g items)
         db.win_g = bt->win_g;
+        {
+            // a query's items: runs of windows of decreasing length (weights g + 1, g, ..., 2), handed out longest first -- the
+            // last items drawn, which decide when the launch ends, are the short ones.  Equal runs when a run would exceed the
+            // 63 windows an item can hold, or with more than 16 items per query.
+            const uint32_t gq = bt->win_g, nwin = bt->index->n_win;
+            std::memset(db.win_cut, 0, sizeof db.win_cut);
+            if (gq <= 16u && bt->tune.win_guided) {
+                const uint64_t total = uint64_t(gq) * (gq + 3u) / 2u;
+                uint64_t cum = 0;
+                bool fits = true;
+                for (uint32_t p = 0; p < gq; ++p) {
+                    db.win_cut[p] = uint32_t(uint64_t(nwin) * cum / total);
+                    cum += gq + 1u - p;
+                }
+                db.win_cut[gq] = nwin;
+                for (uint32_t p = 0; p < gq; ++p) fits = fits && db.win_cut[p + 1] - db.win_cut[p] <= 63u;
+                if (!fits) std::memset(db.win_cut, 0, sizeof db.win_cut);
+            }
+        }
         db.lpi = 1;
         db.hist = nullptr;       // (this kernel keeps no histogram of accepted documents: merge_kernel has none to clean)
         db.dense_on = 0;
@@ -1384,6 +1407,7 @@ int vbm25_tuning_set(const char *name, long long value) {
     else if (n == "win_force") g_tune.win_force = value != 0;
     else if (n == "win_items") g_tune.win_items = (uint32_t)std::max(0ll, value);
     else if (n == "win_planes") g_tune.win_planes = value != 0;
+    else if (n == "win_guided") g_tune.win_guided = value != 0;
     else return set_error(VBM25_ERR_INVALID, "unknown tuning switch %s", name);
     ++g_tune.generation;
     return VBM25_OK;
