@@ -247,6 +247,7 @@ def run(argv=None, scorer_factory=None, backend="nccl"):
     ap.add_argument("--workload", default="C3", choices=sorted(WORKLOADS))
     ap.add_argument("--queries", type=int, default=0, help="override queries per GPU")
     ap.add_argument("--k", type=int, default=0, help="development aid: override the workload's k (the line then names that k; not a BASELINE.json configuration)")
+    ap.add_argument("--no-verify-sample", action="store_true", help="skip the 64-query parity sample against the oracle (it downloads the segment)")
     ap.add_argument("--batches", type=int, default=4, help="distinct query batches the timed loop rotates through")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--verify", action="store_true",
@@ -460,14 +461,34 @@ def run(argv=None, scorer_factory=None, backend="nccl"):
         elapsed = float(t.item())
 
     # ---- outside the timed region ----
-    pcie_qps = None
-    if on_gpu:  # the first batch through the host-buffer boundary (upload queries, run, download hits)
+    pcie_qps = pcie_sync_qps = None
+    route = None
+    if on_gpu:
+        route = {0: "general (plan_kernel)", 1: "one launch", 2: "plan-free scan_range_kernel", 3: "scan_win_kernel", 4: "exhaustive"}.get(
+            batches[0].debug_route(), "?")
+        # the boundary as the reference's caller sees it -- host buffers in, host buffers out (search.rs:28-36 returns a Vec):
+        # (1) one batch at a time: upload, scan, download, each waited for; (2) PIPELINED (vbm25_stream_*: three batches in
+        # flight on their own streams with pinned staging -- upload n + 1 and download n - 1 overlap scan n)
         t0 = time.perf_counter()
         for _ in range(5):
             batches[0].set_queries(*shards[0])
             batches[0].run(stream_ptr)
             batches[0].fetch()
-        pcie_qps = 5 * nq_local / (time.perf_counter() - t0)
+        pcie_sync_qps = 5 * nq_local / (time.perf_counter() - t0)
+        depth, n_pipe = 3, max(20, min(args.steps, 200))
+        st = vb.Stream(gix, depth, nq_local, max(len(t) for t, _ in shards), k)
+        outs = [(np.zeros((nq_local, k), dtype=vb.HIT_DTYPE), np.zeros(nq_local, dtype=np.uint32)) for _ in range(depth)]
+        for phase in ("warm", "timed"):
+            if phase == "timed":
+                t0 = time.perf_counter()
+            for i in range(n_pipe if phase == "timed" else 2 * depth):
+                if st.in_flight == depth:
+                    st.collect(outs[i % depth])
+                st.submit(*shards[i % nb])
+            while st.in_flight:
+                st.collect(outs[0])
+        pcie_qps = n_pipe * nq_local / (time.perf_counter() - t0)
+        del st
     results = [b.fetch() for b in batches]
     for hits, n_hits in (results if "team_dbg" not in args.tune else []):  # (timing experiments switch parts of the kernel off)
         assert (n_hits == k).all() or args.workload in ("C1",), "missing hits"
@@ -480,6 +501,27 @@ def run(argv=None, scorer_factory=None, backend="nccl"):
 
     oix = None
     verified = None
+    verified_sample = None
+    if on_gpu and world == 1 and not args.verify and not args.no_verify_sample and "team_dbg" not in args.tune:
+        # ties the number to parity: a sample of 64 queries of the first batch, bit-exact against the oracle's brute force
+        # (outside the timed region; --verify checks every query of every batch)
+        t0 = time.perf_counter()
+        oix = oracle_index(seg)
+        t_oix = time.perf_counter() - t0
+        t0 = time.perf_counter()
+        ns = min(64, nq_local)
+        pick = np.linspace(0, nq_local - 1, ns).astype(np.int64)
+        t_all, o_all = shards[0]
+        st_ = np.concatenate([t_all[o_all[q]:o_all[q + 1]] for q in pick]).astype(np.uint32)
+        so_ = np.concatenate([[0], np.cumsum([o_all[q + 1] - o_all[q] for q in pick])]).astype(np.uint32)
+        ob, onb, _ = oix.search_batch(st_, so_, k, mode="brute", threads=usable_cpus())
+        hits0, n0 = results[0]
+        assert np.array_equal(n0[pick], onb), "hit counts differ from the oracle"
+        for f in ("doc_id", "payload"):
+            assert np.array_equal(hits0[f][pick], ob[f]), f"{f} differs from the oracle"
+        assert np.array_equal(hits0["score"][pick].view(np.uint64), ob["score"].view(np.uint64)), "score bits differ from the oracle"
+        verified_sample = {"queries": int(ns), "of_batch": 0, "bit_exact_vs_oracle_brute_force": True,
+                           "oracle_index_s": round(t_oix, 1), "seconds": round(time.perf_counter() - t0, 2)}
     if args.verify:  # full parity of this rank's batches, bit-exact against the oracle's brute force
         oix = oracle_index(seg)
         t0 = time.perf_counter()
@@ -552,16 +594,21 @@ def run(argv=None, scorer_factory=None, backend="nccl"):
                        "build_s": round(t_build, 2), "upload_s": round(t_upload, 2),
                        "scatter_ms": round(scatter_ms, 3), "gather_ms": round(gather_ms, 4),
                        "gather_exposed_ms": round(gather_exposed_ms, 4),
-                       "host_buffer_inclusive_qps_per_gpu": None if pcie_qps is None else round(pcie_qps, 1)},
+                       "route": route,
+                       "host_buffer_inclusive_qps_per_gpu": None if pcie_qps is None else round(pcie_qps, 1),
+                       "host_buffer_inclusive": "vbm25_stream_*: three batches in flight, pinned staging (queries up, 24-byte records down every step)",
+                       "host_buffer_one_batch_at_a_time_qps_per_gpu": None if pcie_sync_qps is None else round(pcie_sync_qps, 1)},
         }
         if verified:
             out["config"]["verified_bit_exact_vs_oracle"] = verified
+        if verified_sample:
+            out["config"]["verified_sample"] = verified_sample
         if latency:
             out["config"]["latency"] = latency
         if on_gpu:
             algo = sum(algo_bytes) / len(algo_bytes)
             achieved = algo / (kernel_ms * 1e-3) / 1e9 if kernel_ms > 0 else 0.0
-            out["roofline"] = {"bound": "hbm", "kernel": "scan_dense_kernel" if dense else "scan_range_kernel",
+            out["roofline"] = {"bound": "hbm", "kernel": "scan_dense_kernel" if dense else ("scan_win_kernel" if route == "scan_win_kernel" else "scan_range_kernel"),
                                "achieved": round(achieved, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                                "frac": round(achieved / HBM_PEAK_GBPS, 4),
                                # HBM bytes per launch: separate rocprofv3 --pmc passes (FETCH_SIZE x 2 + WRITE_SIZE, the gfx950

@@ -283,6 +283,24 @@ int vbm25_batch_device_results(vbm25_batch *, void **hits, void **n_hits);
 int vbm25_batch_set_timing(vbm25_batch *, int enabled);
 int vbm25_batch_kernel_ms(vbm25_batch *, double *avg_ms, uint32_t *n_launches);
 
+/* The same boundary PIPELINED (the caller hands over host buffers and gets host buffers back, as bm25::search
+ * returns a Vec, search.rs:28-36): up to `depth` batches are in flight at once, each on its own stream with its
+ * own pinned staging -- the upload of batch n + 1 and the download of batch n - 1 overlap the scan of batch n, and
+ * the host never waits for the device between a submit and the matching collect.
+ *   vbm25_stream_submit   copies the queries into pinned memory and enqueues upload, scan and download; returns at
+ *                         once.  VBM25_ERR_INVALID when `depth` batches are already in flight (collect first).
+ *   vbm25_stream_collect  waits for the OLDEST batch in flight and writes its records (nq x k hits, nq counts, in
+ *                         submission order -- first in, first out); *nq_out = its number of queries.
+ *                         VBM25_ERR_INVALID when nothing is in flight.
+ * Records are byte-identical to vbm25_search_batch's. */
+typedef struct vbm25_stream vbm25_stream;
+int vbm25_stream_create(vbm25_index *, uint32_t depth, uint32_t max_queries, uint32_t max_total_terms, uint32_t k,
+                        vbm25_stream **out);
+void vbm25_stream_destroy(vbm25_stream *);
+int vbm25_stream_submit(vbm25_stream *, const uint32_t *term_ids, const uint32_t *q_off, uint32_t nq);
+int vbm25_stream_collect(vbm25_stream *, vbm25_hit *hits, uint32_t *n_hits, uint32_t *nq_out);
+int vbm25_stream_in_flight(const vbm25_stream *);
+
 /* bm25::evaluate (evaluate.rs:22-74) for n_docs documents against ONE query on the device: the seq-scan
  * form of `tsvector <&> bm25query` (src/index/operators.rs:22-55), batched.  Everything is in term-id space
  * (vbm25_lookup_terms): q_terms = the query's ids, strictly ascending; ids >= the index's term count (tokens

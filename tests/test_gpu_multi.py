@@ -102,3 +102,35 @@ def test_prefilter_by_over_fetch_matches_the_filtered_ranking():
             want = full[keep(full)][:k]
             assert nh[q] == len(want)
             assert_bit_exact(want, hits[q, :nh[q]], what=f"filter 1/{modulus} q{q}")
+
+
+def test_pipelined_boundary_returns_the_single_batch_records():
+    """vbm25_stream_*: batches of different shapes interleaved through a ring of three slots (upload of one, scan of another and
+    download of a third in flight at once) come back first in first out with the records vbm25_search_batch gives for each
+    alone; submitting beyond the depth and collecting from an empty ring are argument errors."""
+    seg = vb.Segment.synth(400_000, 33_000, mean_len=100, len_mode=1, seed=9)
+    gix = vb.GpuIndex(seg)
+    rng = np.random.default_rng(2)
+    batches = []
+    for i, (nq, nt) in enumerate([(300, 5), (7, 3), (512, 5), (1, 4), (64, 8), (300, 2), (33, 5)]):
+        toks = np.stack([rng.choice(33_000, nt, replace=False) for _ in range(nq)]).astype(np.uint32)
+        ids = np.sort(seg.token_terms(toks.reshape(-1)).reshape(nq, nt), axis=1).reshape(-1)
+        batches.append((ids, (np.arange(nq + 1) * nt).astype(np.uint32)))
+    want = [vb.search_batch(gix, t, o, 10) for t, o in batches]
+    st = vb.Stream(gix, 3, 512, 4096, 10)
+    got = []
+    with pytest.raises(vb.Vbm25Error):
+        st.collect_raw()
+    for i, (t, o) in enumerate(batches):
+        if st.in_flight == 3:
+            got.append(st.collect())
+        st.submit(t, o)
+    assert st.in_flight == 3
+    with pytest.raises(vb.Vbm25Error):
+        st.submit(*batches[0])
+    st._nq.pop()  # (the refused submit was never in flight)
+    while st.in_flight:
+        got.append(st.collect())
+    assert len(got) == len(want)
+    for (h, n), (hw, nw) in zip(got, want):
+        assert np.array_equal(n, nw) and h.tobytes() == hw.tobytes()

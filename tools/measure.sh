@@ -16,12 +16,12 @@ for step in "$@"; do case $step in
   tests) timeout 1200 python -m pytest tests/test_gpu_search.py -x -q -m gpu -k "not c5_full and not bench_distributed" > $O/pytest_search.log 2>&1; tail -5 $O/pytest_search.log;;
   alltests) timeout 2400 python -m pytest tests -x -q -m gpu > $O/pytest_all.log 2>&1; tail -5 $O/pytest_all.log;;
   c3) seg C3; timeout 600 python bench.py --no-cpu-baseline --verify --steps 100 --extra-budget-s 0 $TUNE_ARG > $O/bench_c3.json 2> $O/bench_c3.err; show $O/bench_c3.json;;
-  c3quick) seg C3; timeout 600 python bench.py --no-cpu-baseline --steps 100 --extra-budget-s 0 $TUNE_ARG > $O/bench_c3q.json 2> $O/bench_c3q.err; show $O/bench_c3q.json;;
+  c3quick) seg C3; timeout 600 python bench.py --no-cpu-baseline --no-verify-sample --steps 100 --extra-budget-s 0 $TUNE_ARG > $O/bench_c3q.json 2> $O/bench_c3q.err; show $O/bench_c3q.json;;
   c3full) seg C3; timeout 900 python bench.py $TUNE_ARG > $O/bench_c3_full.json 2> $O/bench_c3_full.err; show $O/bench_c3_full.json;;
   c5) seg C5; timeout 900 python bench.py --workload C5 --no-cpu-baseline --steps 10 --warmup 2 $TUNE_ARG > $O/bench_c5.json 2> $O/bench_c5.err; show $O/bench_c5.json;;
   c2) seg C2; timeout 600 python bench.py --workload C2 --no-cpu-baseline --steps 200 $TUNE_ARG > $O/bench_c2.json 2> $O/bench_c2.err; show $O/bench_c2.json;;
-  c3stats) seg C3; (cd /tmp; export TMPDIR=/tmp; timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats -- python $R/bench.py --steps 20 --warmup 3 --no-cpu-baseline --extra-budget-s 0 $TUNE_ARG > $O/stats.log 2>&1); f=$(find $O/stats -name "*kernel_stats.csv" | head -1); [ -n "$f" ] && cp $f $O/c3_kernel_stats.csv && head -8 $O/c3_kernel_stats.csv; find $O/stats -name "*.csv" -size +5M -delete;;
-  c3pmc) seg C3; B="python $R/bench.py --steps 20 --warmup 3 --no-cpu-baseline --extra-budget-s 0 $TUNE_ARG"
+  c3stats) seg C3; (cd /tmp; export TMPDIR=/tmp; timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats -- python $R/bench.py --steps 20 --warmup 3 --no-cpu-baseline --no-verify-sample --extra-budget-s 0 $TUNE_ARG > $O/stats.log 2>&1); f=$(find $O/stats -name "*kernel_stats.csv" | head -1); [ -n "$f" ] && cp $f $O/c3_kernel_stats.csv && head -8 $O/c3_kernel_stats.csv; find $O/stats -name "*.csv" -size +5M -delete;;
+  c3pmc) seg C3; B="python $R/bench.py --steps 20 --warmup 3 --no-cpu-baseline --no-verify-sample --extra-budget-s 0 $TUNE_ARG"
      (cd /tmp; export TMPDIR=/tmp
       timeout 300 rocprofv3 --kernel-trace --pmc SQ_WAVE_CYCLES SQ_BUSY_CU_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_WAIT_INST_LDS SQ_ACTIVE_INST_ANY SQ_INSTS_VALU SQ_INSTS_SALU --output-format csv -d $O/pmc_sq1 -- $B > $O/pmc_sq1.log 2>&1
       timeout 300 rocprofv3 --kernel-trace --pmc SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_VMEM_RD SQ_INSTS_SMEM SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_IFETCH --output-format csv -d $O/pmc_sq2 -- $B > $O/pmc_sq2.log 2>&1

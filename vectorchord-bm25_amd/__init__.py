@@ -8,5 +8,5 @@ used by the tests and bench.py; it never touches oracle/.
 from ._lib import build, lib, library_path, Vbm25Error  # noqa: F401
 from .api import (  # noqa: F401
     HIT_DTYPE, Segment, DeviceSegment, GpuIndex, Batch, Query, intern, search, search_batch, search_batch_filtered, growing_search, merge_hits,
-    segment_from_pages, growing_from_pages, evaluate, evaluate_batch, set_tuning, reset_tuning, MultiIndex, MultiBatch)
+    segment_from_pages, growing_from_pages, evaluate, evaluate_batch, set_tuning, reset_tuning, MultiIndex, MultiBatch, Stream)
 from . import api, sharded  # noqa: F401,E402

@@ -96,6 +96,11 @@ ABI = {
     "vbm25_multi_batch_set_queries": (i32, [vp, vp, vp, u32]),
     "vbm25_multi_batch_run": (i32, [vp]),
     "vbm25_multi_batch_fetch": (i32, [vp, vp, vp]),
+    "vbm25_stream_create": (i32, [vp, u32, u32, u32, u32, vp]),
+    "vbm25_stream_destroy": (None, [vp]),
+    "vbm25_stream_submit": (i32, [vp, vp, vp, u32]),
+    "vbm25_stream_collect": (i32, [vp, vp, vp, vp]),
+    "vbm25_stream_in_flight": (i32, [vp]),
 }
 
 

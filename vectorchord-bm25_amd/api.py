@@ -364,6 +364,48 @@ class Batch:
         return tuple(int(x) for x in out)
 
 
+class Stream:
+    """The pipelined host-buffer boundary (vbm25_stream_*): up to `depth` batches in flight, first in first out."""
+
+    def __init__(self, index, depth, max_queries, max_total_terms, k):
+        self.index, self.k = index, k
+        self.h = C.c_void_p()
+        L = lib()
+        check(L.vbm25_stream_create(index.h, depth, max_queries, max(1, max_total_terms), k, C.byref(self.h)))
+        self._nq = []
+
+    def __del__(self):
+        try:
+            if self.h:
+                lib().vbm25_stream_destroy(self.h)
+        except Exception:
+            pass
+
+    def submit(self, term_ids, q_off):
+        term_ids = np.ascontiguousarray(term_ids, dtype=np.uint32)
+        q_off = np.ascontiguousarray(q_off, dtype=np.uint32)
+        self._nq.append(len(q_off) - 1)
+        check(lib().vbm25_stream_submit(self.h, term_ids.ctypes.data if len(term_ids) else None, q_off.ctypes.data, len(q_off) - 1))
+
+    def collect_raw(self):
+        """collect without this object's bookkeeping (tests: the library's own error on an empty ring)"""
+        got = C.c_uint32()
+        check(lib().vbm25_stream_collect(self.h, None, None, C.byref(got)))
+
+    def collect(self, out=None):
+        """The oldest batch in flight: (hits [nq, k], n_hits [nq]).  `out` = (hits, n_hits) arrays to write into."""
+        nq = self._nq.pop(0)
+        hits, n_hits = out if out is not None else (np.zeros((nq, self.k), dtype=HIT_DTYPE), np.zeros(nq, dtype=np.uint32))
+        got = C.c_uint32()
+        check(lib().vbm25_stream_collect(self.h, hits.ctypes.data, n_hits.ctypes.data, C.byref(got)))
+        assert got.value == nq
+        return hits, n_hits
+
+    @property
+    def in_flight(self):
+        return int(lib().vbm25_stream_in_flight(self.h))
+
+
 def search_batch_filtered(index, term_ids, q_off, k, keep, overfetch=2):
     """`prefilter = on` (default.rs:120-128, fetcher.rs:180-216: a candidate enters Results only if filter(payload) holds -- a heap
     visibility check the GPU cannot make) as the shim runs it: OVER-FETCH and filter on the host.  The GPU returns overfetch * k

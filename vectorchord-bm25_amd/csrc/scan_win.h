@@ -34,17 +34,25 @@
 // frequency above 255 in a second arrival is handed to scan_many_kernel (item_failed).
 
 constexpr int WN_T = 8;               // indexed terms per query
-constexpr int WN_WAVES = 4;           // independent waves per workgroup
-constexpr int WN_WG = WN_WAVES * 64;
-constexpr int WN_WPS = 3;             // waves per SIMD: 168 VGPRs, 12 waves x 12.8 KB of LDS (+ the s1 table per workgroup) per CU
+// Independent waves per workgroup: ONE workgroup per CU holds all the LDS its waves need (three workgroups of four waves, 3 x 54 KB,
+// were never resident together: the third one ran after the others).  As many waves as the LDS holds -- a wave's share grows with
+// the run loads MT it is compiled for -- and the registers allow: up to 12 waves have 168 VGPRs each, 13 to 16 have 128.
+#ifndef VBM25_WIN_WAVES_MAX
+#define VBM25_WIN_WAVES_MAX 12
+#endif
+constexpr int wn_waves(int mt) {
+    const int by_lds = (163840 - 2048) / (8192 + 512 * mt + 256 + 512);
+    return by_lds < VBM25_WIN_WAVES_MAX ? by_lds : VBM25_WIN_WAVES_MAX;
+}
 constexpr int WN_BM_WORDS = 2048;     // 2^16 bits
 constexpr int WN_SLOT = 256;          // staged ids per term: what one 8-byte load per lane covers
 constexpr int WN_LIST = 64;           // second arrivals per window (the LDS is handed out in 512-byte granules: 106 per workgroup, three workgroups per CU)
-constexpr uint32_t WN_GRID = 768;     // persistent workgroups: 256 CUs x 3
+constexpr uint32_t WN_GRID = 256;     // persistent workgroups: one per CU
 
+template <int MT>
 struct WinWave {
     alignas(16) uint32_t bm[WN_BM_WORDS];
-    alignas(16) uint16_t stage[WN_T * WN_SLOT];
+    alignas(16) uint16_t stage[MT * WN_SLOT];
     uint32_t list[WN_LIST];           // x | term << 16
     double contrib[64];
 };
@@ -55,8 +63,8 @@ __device__ __forceinline__ uint32_t wn_mbcnt(unsigned long long mask) {
 
 // The lane's four postings of a (term, window) pair: ids in v (two per word), posting r0 + j of the run's n is the lane's j-th.
 // Marks them in the window's filter; RET: the ones whose bit was already there go to the list of second arrivals.
-template <bool RET>
-__device__ __forceinline__ void wn_pair(WinWave &S, const uint2 v, const uint32_t r0, const uint32_t n, const uint32_t t,
+template <bool RET, int MT>
+__device__ __forceinline__ void wn_pair(WinWave<MT> &S, const uint2 v, const uint32_t r0, const uint32_t n, const uint32_t t,
                                         uint32_t &nd) {
     const uint32_t x0 = v.x & 0xffffu, x1 = v.x >> 16, x2 = v.y & 0xffffu, x3 = v.y >> 16;
     const uint32_t b0 = r0 < n ? 1u << (x0 & 31u) : 0u;
@@ -160,11 +168,13 @@ __device__ __forceinline__ void wn_drain(unsigned long long (&a)[MT], unsigned l
 }
 
 template <int MT>
-__global__ void __launch_bounds__(WN_WG, WN_WPS) scan_win_kernel(DevIndex ix, DevBatch bt) {
-    __shared__ WinWave SW[WN_WAVES];
+__global__ void __launch_bounds__(wn_waves(MT) * 64, (wn_waves(MT) + 3) / 4) scan_win_kernel(DevIndex ix, DevBatch bt) {
+    constexpr int WN_WAVES = wn_waves(MT), WN_WG = WN_WAVES * 64;
+    static_assert(sizeof(WinWave<MT>) == 8192 + 512 * MT + 256 + 512, "wn_waves() knows the size");
+    __shared__ WinWave<MT> SW[WN_WAVES];
     __shared__ double S1[256];  // k1 (1 - b + b len(f) / avgdl) per fieldnorm (bm25.rs:349-352)
     const uint32_t lane = threadIdx.x & 63;
-    WinWave &S = SW[uni(threadIdx.x >> 6)];
+    WinWave<MT> &S = SW[uni(threadIdx.x >> 6)];
     const uint32_t k = bt.k, g = bt.win_g, n_items = bt.nq * g, NWIN = ix.n_win;
     const uint32_t dbg = bt.team_dbg;  // timing experiments (wrong results): 1 no cold pass, 2 no completion, 4 no second arrivals
     const uint16_t *ids16 = reinterpret_cast<const uint16_t *>(ix.post_id16);
@@ -458,8 +468,8 @@ __global__ void __launch_bounds__(WN_WG, WN_WPS) scan_win_kernel(DevIndex ix, De
                                 for (uint32_t o = o_al + (uint32_t)WN_SLOT; o < o_hi; o += (uint32_t)WN_SLOT) {
                                     const unsigned long long mv = wn_load_run_now(rest + o);
                                     const uint2 more = make_uint2((uint32_t)mv, (uint32_t)(mv >> 32));
-                                    if (t == 0) wn_pair<false>(S, more, o + 4u * lane - o_lo, n, (uint32_t)t, nd);
-                                    else wn_pair<true>(S, more, o + 4u * lane - o_lo, n, (uint32_t)t, nd);
+                                    if (t == 0) wn_pair<false, MT>(S, more, o + 4u * lane - o_lo, n, (uint32_t)t, nd);
+                                    else wn_pair<true, MT>(S, more, o + 4u * lane - o_lo, n, (uint32_t)t, nd);
                                 }
                             }
                         }

@@ -16,14 +16,16 @@ namespace vbm25 {
 
 // mt: the most indexed terms of a query of the batch -- the kernel is compiled for 2, 4, 5 and 8 run loads per window
 hipError_t scan_win_launch(const DevIndex &ix, const DevBatch &bt, uint32_t mt, uint32_t grid, hipStream_t st) {
-    if (mt <= 2) scan_win_kernel<2><<<grid, WN_WG, 0, st>>>(ix, bt);
-    else if (mt <= 4) scan_win_kernel<4><<<grid, WN_WG, 0, st>>>(ix, bt);
-    else if (mt <= 5) scan_win_kernel<5><<<grid, WN_WG, 0, st>>>(ix, bt);
-    else scan_win_kernel<8><<<grid, WN_WG, 0, st>>>(ix, bt);
+    // (grid: workgroups; a workgroup is wn_waves(MT) independent waves)
+    if (mt <= 2) scan_win_kernel<2><<<grid, wn_waves(2) * 64, 0, st>>>(ix, bt);
+    else if (mt <= 4) scan_win_kernel<4><<<grid, wn_waves(4) * 64, 0, st>>>(ix, bt);
+    else if (mt <= 5) scan_win_kernel<5><<<grid, wn_waves(5) * 64, 0, st>>>(ix, bt);
+    else scan_win_kernel<8><<<grid, wn_waves(8) * 64, 0, st>>>(ix, bt);
     return hipGetLastError();
 }
-uint32_t scan_win_resident_waves() { return WN_GRID * WN_WAVES; }
+static uint32_t waves_of(uint32_t mt) { return uint32_t(mt <= 2 ? wn_waves(2) : mt <= 4 ? wn_waves(4) : mt <= 5 ? wn_waves(5) : wn_waves(8)); }
+uint32_t scan_win_resident_waves(uint32_t mt) { return WN_GRID * waves_of(mt); }
 uint32_t scan_win_max_terms() { return WN_T; }
 uint32_t scan_win_max_k() { return 64; }
-uint32_t scan_win_wg() { return WN_WAVES; }
+uint32_t scan_win_wg(uint32_t mt) { return waves_of(mt); }
 }  // namespace vbm25

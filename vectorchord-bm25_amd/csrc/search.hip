@@ -228,6 +228,7 @@ struct Tuning {
     uint32_t win_items = 0;        // work items of a batch on that route (0: twice the resident waves)
     int win_planes = 1;            // read at index creation: derive the window planes (post_id16, win_off)
     int win_guided = 1;            // scan_win_kernel's items of a query of decreasing length (0: equal)
+    uint32_t win_grid = 0;         // its persistent workgroups (0: three per CU)
     uint32_t generation = 0;       // bumped by every vbm25_tuning_set / reset: vbm25_search_batch's batch object is rebuilt when it is stale
 };
 static Tuning g_tune;
@@ -278,7 +279,7 @@ struct vbm25_batch {
     hipStream_t last_stream = nullptr;  // the stream of the last run: what fetch waits for (not the whole device)
     bool download_enqueued = false;     // the last run's records are already on their way to pin_out (vbm25_multi_batch_run)
     uint8_t *pin_in = nullptr, *pin_out = nullptr;
-    size_t pin_in_bytes = 0, pin_out_bytes = 0, pin_nt = 0;
+    size_t pin_in_bytes = 0, pin_out_bytes = 0, pin_nt = 0, pin_order_bytes = 0;
     ~vbm25_batch() {
         if (lat_stream) (void)hipStreamDestroy(lat_stream);
         if (pin_in) (void)hipHostFree(pin_in);
@@ -711,7 +712,7 @@ static int vbm25_batch_create_impl(vbm25_index *ix, uint32_t max_queries, uint32
         bt->bigk = true;
         bt->use_range = bt->use_dense = false;
         const size_t n = ix->n_docs ? ix->n_docs : 1;
-        hipcub::DeviceRadixSort::SortPairsDescending(nullptr, bt->bk_tmp_bytes, (const unsigned long long *)nullptr,
+        (void)hipcub::DeviceRadixSort::SortPairsDescending(nullptr, bt->bk_tmp_bytes, (const unsigned long long *)nullptr,
                                                      (unsigned long long *)nullptr, (const uint32_t *)nullptr,
                                                      (uint32_t *)nullptr, (int)n);
         if ((rc = bt->hits.alloc(sizeof(vbm25_hit) * size_t(max_queries) * k)) || (rc = bt->n_hits.alloc(4ull * max_queries)) ||
@@ -777,6 +778,9 @@ static int upload_staged(vbm25_batch *bt) {
     if (nt) HIP_TRY(hipMemcpyAsync(bt->term_ids.p, bt->pin_in, nt, hipMemcpyHostToDevice, bt->lat_stream));
     HIP_TRY(hipMemcpyAsync(bt->q_off.p, bt->pin_in + nt, no, hipMemcpyHostToDevice, bt->lat_stream));
     if (bt->nq) HIP_TRY(hipMemcpyAsync(bt->q_dense.p, bt->pin_in + nt + no, bt->nq, hipMemcpyHostToDevice, bt->lat_stream));
+    if (bt->pin_order_bytes)  // the host's item order of the routes without plan_kernel
+        HIP_TRY(hipMemcpyAsync(bt->item_order.p, bt->pin_in + nt + no + ((size_t(bt->nq) + 7) & ~size_t(7)), bt->pin_order_bytes,
+                               hipMemcpyHostToDevice, bt->lat_stream));
     return VBM25_OK;
 }
 
@@ -888,7 +892,7 @@ static int vbm25_batch_set_queries_impl(vbm25_batch *bt, const uint32_t *term_id
                 if (ok) {
                     // items per query: about twice the resident waves in all; an item's blocks per term should fit the 64-bit mask
                     // of its hot blocks (8192 postings per term)
-                    const uint32_t target = bt->tune.win_items ? bt->tune.win_items : 2u * scan_win_resident_waves();
+                    const uint32_t target = bt->tune.win_items ? bt->tune.win_items : 2u * scan_win_resident_waves(range_mt);
                     const uint32_t g_min = (ixh->n_win + 62u) / 63u;  // (an item holds at most 63 windows)
                     uint32_t gw = std::max(std::max(1u, (target + nq / 2) / nq), g_min);
                     gw = std::min(std::min(gw, ixh->n_win), bt->max_items / nq);
@@ -918,7 +922,8 @@ static int vbm25_batch_set_queries_impl(vbm25_batch *bt, const uint32_t *term_id
                 else
                 for (uint32_t i = 0; i < nq; ++i)
                     for (uint32_t part = 0; part < g; ++part) ord[size_t(i) * g + part] = qs[i] * uint32_t(g) + part;
-                HIP_TRY(hipMemcpy(bt->item_order.p, ord.data(), 4ull * ord.size(), hipMemcpyHostToDevice));
+                // (the fast path stages the order with the queries and copies it on the batch's own stream: upload_staged)
+                if (!fast) HIP_TRY(hipMemcpy(bt->item_order.p, ord.data(), 4ull * ord.size(), hipMemcpyHostToDevice));
             }
         }
     }
@@ -927,10 +932,12 @@ static int vbm25_batch_set_queries_impl(vbm25_batch *bt, const uint32_t *term_id
         // into the pinned output buffer -- no copy is enqueued at all.  General route: copied on the batch's own stream,
         // nothing waits here.
         const size_t nt = 4ull * q_off[nq], no = 4ull * (nq + 1);
-        if (nt + no + nq > bt->pin_in_bytes) {
+        const bool with_order = bt->arith_g || bt->win_g;
+        const size_t nd8 = (size_t(nq) + 7) & ~size_t(7), nord = with_order ? 4ull * bt->h_order.size() : 0;
+        if (nt + no + nd8 + nord > bt->pin_in_bytes) {
             if (bt->pin_in) HIP_TRY(hipHostFree(bt->pin_in));
             bt->pin_in = nullptr;
-            bt->pin_in_bytes = 2 * (nt + no + nq) + 256;
+            bt->pin_in_bytes = 2 * (nt + no + nd8 + nord) + 256;
             HIP_TRY(hipHostMalloc(reinterpret_cast<void **>(&bt->pin_in), bt->pin_in_bytes, hipHostMallocDefault));
         }
         const size_t nh = sizeof(vbm25_hit) * size_t(nq) * bt->k, nc = (4ull * nq + 7) & ~size_t(7);
@@ -944,7 +951,9 @@ static int vbm25_batch_set_queries_impl(vbm25_batch *bt, const uint32_t *term_id
         if (nt) std::memcpy(bt->pin_in, term_ids, nt);
         std::memcpy(bt->pin_in + nt, q_off, no);
         if (nq) std::memcpy(bt->pin_in + nt + no, dense, nq);
+        if (nord) std::memcpy(bt->pin_in + nt + no + nd8, bt->h_order.data(), nord);
         bt->pin_nt = nt;
+        bt->pin_order_bytes = nord;
         if (!(bt->fused_g && bt->fused_pinned))
             if (int rc = upload_staged(bt)) return rc;
     } else {
@@ -1164,8 +1173,9 @@ static int vbm25_batch_run_impl(vbm25_batch *bt, void *hip_stream) {
         db.merge_clean = 1;
         db.order_on = 1;
         if (int rc = take_events()) return rc;
-        const uint32_t wgrid = std::min<uint32_t>((bt->nq * bt->win_g + scan_win_wg() - 1u) / scan_win_wg(), scan_win_resident_waves() / scan_win_wg());
-        HIP_TRY(scan_win_launch(ix, db, bt->range_rt == 8 ? bt->win_mt : 8u, wgrid, st));
+        const uint32_t wmt = bt->range_rt == 8 ? bt->win_mt : 8u, wpw = scan_win_wg(wmt);
+        const uint32_t wgrid = std::min<uint32_t>((bt->nq * bt->win_g + wpw - 1u) / wpw, bt->tune.win_grid ? bt->tune.win_grid : scan_win_resident_waves(wmt) / wpw);
+        HIP_TRY(scan_win_launch(ix, db, wmt, wgrid, st));
         scan_many_kernel<64><<<64, WG, 0, st>>>(ix, db);
         if (bt->timing) (void)hipEventRecord(e1, st);
         merge_kernel<64><<<bt->nq, 64, 0, st>>>(ix, db);
@@ -1408,6 +1418,7 @@ int vbm25_tuning_set(const char *name, long long value) {
     else if (n == "win_items") g_tune.win_items = (uint32_t)std::max(0ll, value);
     else if (n == "win_planes") g_tune.win_planes = value != 0;
     else if (n == "win_guided") g_tune.win_guided = value != 0;
+    else if (n == "win_grid") g_tune.win_grid = (uint32_t)std::max(0ll, value);
     else return set_error(VBM25_ERR_INVALID, "unknown tuning switch %s", name);
     ++g_tune.generation;
     return VBM25_OK;
@@ -1576,6 +1587,69 @@ static int vbm25_batch_finish_download(vbm25_batch *bt, vbm25_hit *hits, uint32_
     }
     return rc;
 }
+
+// ---------------------------------------------------------------------------
+// The pipelined boundary (include/vbm25.h): a ring of batch objects, each with its own stream and pinned staging.  submit =
+// set_queries (staged) + run + download, all enqueued on the slot's stream; collect = the oldest slot's stream synchronisation
+// and one copy out of its pinned buffer.
+// ---------------------------------------------------------------------------
+}  // extern "C"
+struct vbm25_stream {
+    std::vector<vbm25_batch *> slots;
+    uint32_t head = 0, in_flight = 0;  // the oldest batch in flight, their number
+    ~vbm25_stream() {
+        for (vbm25_batch *b : slots) vbm25_batch_destroy(b);
+    }
+};
+static int stream_create_impl(vbm25_index *ix, uint32_t depth, uint32_t max_queries, uint32_t max_total_terms, uint32_t k, vbm25_stream **out) {
+    if (!out) return set_error(VBM25_ERR_INVALID, "out is NULL");
+    *out = nullptr;
+    if (!ix) return set_error(VBM25_ERR_INVALID, "index is NULL");
+    if (depth == 0 || depth > 16) return set_error(VBM25_ERR_INVALID, "depth must be 1..16");
+    auto s = std::make_unique<vbm25_stream>();
+    for (uint32_t i = 0; i < depth; ++i) {
+        vbm25_batch *b = nullptr;
+        if (int rc = vbm25_batch_create(ix, max_queries, std::max(max_total_terms, 1u), k, &b)) return rc;
+        s->slots.push_back(b);
+    }
+    *out = s.release();
+    return VBM25_OK;
+}
+static int stream_submit_impl(vbm25_stream *s, const uint32_t *term_ids, const uint32_t *q_off, uint32_t nq) {
+    if (!s || !q_off) return set_error(VBM25_ERR_INVALID, "NULL argument");
+    if (s->in_flight == s->slots.size()) return set_error(VBM25_ERR_INVALID, "%u batches in flight: collect one first", s->in_flight);
+    vbm25_batch *b = s->slots[(s->head + s->in_flight) % s->slots.size()];
+    const bool fast = !b->bigk;
+    if (int rc = vbm25_batch_set_queries_impl(b, term_ids, q_off, nq, fast)) return rc;
+    if (int rc = vbm25_batch_run_impl(b, fast ? b->lat_stream : nullptr)) return rc;
+    if (int rc = vbm25_batch_enqueue_download(b)) return rc;
+    ++s->in_flight;
+    return VBM25_OK;
+}
+static int stream_collect_impl(vbm25_stream *s, vbm25_hit *hits, uint32_t *n_hits, uint32_t *nq_out) {
+    if (!s) return set_error(VBM25_ERR_INVALID, "stream is NULL");
+    if (!s->in_flight) return set_error(VBM25_ERR_INVALID, "no batch in flight");
+    vbm25_batch *b = s->slots[s->head];
+    if ((!hits || !n_hits) && b->nq) return set_error(VBM25_ERR_INVALID, "NULL argument");
+    const int rc = vbm25_batch_finish_download(b, hits, n_hits);
+    if (nq_out) *nq_out = b->nq;
+    s->head = (s->head + 1) % uint32_t(s->slots.size());
+    --s->in_flight;
+    return rc;
+}
+extern "C" {
+int vbm25_stream_create(vbm25_index *ix, uint32_t depth, uint32_t max_queries, uint32_t max_total_terms, uint32_t k, vbm25_stream **out) {
+    return guarded([&] { return stream_create_impl(ix, depth, max_queries, max_total_terms, k, out); });
+}
+void vbm25_stream_destroy(vbm25_stream *s) { delete s; }
+int vbm25_stream_submit(vbm25_stream *s, const uint32_t *term_ids, const uint32_t *q_off, uint32_t nq) {
+    return guarded([&] { return stream_submit_impl(s, term_ids, q_off, nq); });
+}
+int vbm25_stream_collect(vbm25_stream *s, vbm25_hit *hits, uint32_t *n_hits, uint32_t *nq_out) {
+    return guarded([&] { return stream_collect_impl(s, hits, n_hits, nq_out); });
+}
+int vbm25_stream_in_flight(const vbm25_stream *s) { return s ? int(s->in_flight) : 0; }
+
 
 // ---------------------------------------------------------------------------
 // Several GPUs of one node behind the C ABI (BASELINE.json configs[3]).  The path shards by
