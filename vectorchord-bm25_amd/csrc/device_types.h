@@ -95,6 +95,7 @@ struct DevBatch {
     unsigned long long *theta_last;  // per query: the threshold the last launch ended with (merge_kernel, merge_clean)
     uint32_t max_items;        // capacity of items / item_failed; res_* hold max_items * lpi lists of k entries
     uint32_t win_g;            // scan_win_kernel: items (runs of 2^16-document windows) per query, one result list per item
+    uint32_t q_stride;         // != 0: every query of the batch has this many terms -- query q is term_ids[q_stride q ..): nobody loads q_off
     uint32_t win_cut[17];      // ... item `part` of a query = the windows [win_cut[part], win_cut[part + 1]) when win_g <= 16 and
                                // win_cut[win_g] != 0 (runs of decreasing length, handed out longest first: the last items drawn
                                // are the short ones); equal runs n_win part / win_g otherwise

@@ -49,9 +49,21 @@ constexpr int WN_SLOT = 256;          // staged ids per term: what one 8-byte lo
 constexpr int WN_LIST = 64;           // second arrivals per window (the LDS is handed out in 512-byte granules: 106 per workgroup, three workgroups per CU)
 constexpr uint32_t WN_GRID = 256;     // persistent workgroups: one per CU
 
+// A wave's filter lives in its own array, 8 KB-aligned: the address of a posting's word is `base | offset` -- one v_and_or_b32 --
+// where a sum would take an instruction more per posting (BM below).
+typedef __attribute__((address_space(3))) uint32_t wn_lds_u32;
+// (the mask 0x1ffc travels in a VGPR: v_and_or_b32 takes no literal on gfx9, and one scalar operand -- the base -- at most)
+struct WnBm {
+    uint32_t base, mask;
+};
+__device__ __forceinline__ uint32_t wn_or_rtn(const WnBm bm, const uint32_t x, const uint32_t bit) {
+    return __hip_atomic_fetch_or((wn_lds_u32 *)(((x >> 3) & bm.mask) | bm.base), bit, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+}
+__device__ __forceinline__ void wn_or(const WnBm bm, const uint32_t x, const uint32_t bit) {
+    (void)__hip_atomic_fetch_or((wn_lds_u32 *)(((x >> 3) & bm.mask) | bm.base), bit, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+}
 template <int MT>
 struct WinWave {
-    alignas(16) uint32_t bm[WN_BM_WORDS];
     alignas(16) uint16_t stage[MT * WN_SLOT];
     uint32_t list[WN_LIST];           // x | term << 16
     double contrib[64];
@@ -64,24 +76,24 @@ __device__ __forceinline__ uint32_t wn_mbcnt(unsigned long long mask) {
 // The lane's four postings of a (term, window) pair: ids in v (two per word), posting r0 + j of the run's n is the lane's j-th.
 // Marks them in the window's filter; RET: the ones whose bit was already there go to the list of second arrivals.
 template <bool RET, int MT>
-__device__ __forceinline__ void wn_pair(WinWave<MT> &S, const uint2 v, const uint32_t r0, const uint32_t n, const uint32_t t,
-                                        uint32_t &nd) {
+__device__ __forceinline__ void wn_pair(WinWave<MT> &S, const WnBm bmbase, const uint2 v, const uint32_t r0, const uint32_t n,
+                                        const uint32_t t, uint32_t &nd) {
     const uint32_t x0 = v.x & 0xffffu, x1 = v.x >> 16, x2 = v.y & 0xffffu, x3 = v.y >> 16;
     const uint32_t b0 = r0 < n ? 1u << (x0 & 31u) : 0u;
     const uint32_t b1 = r0 + 1u < n ? 1u << (x1 & 31u) : 0u;
     const uint32_t b2 = r0 + 2u < n ? 1u << (x2 & 31u) : 0u;
     const uint32_t b3 = r0 + 3u < n ? 1u << (x3 & 31u) : 0u;
     if (!RET) {  // the window's first term: the filter is empty, nothing can be there yet
-        atomicOr(&S.bm[x0 >> 5], b0);
-        atomicOr(&S.bm[x1 >> 5], b1);
-        atomicOr(&S.bm[x2 >> 5], b2);
-        atomicOr(&S.bm[x3 >> 5], b3);
+        wn_or(bmbase, x0, b0);
+        wn_or(bmbase, x1, b1);
+        wn_or(bmbase, x2, b2);
+        wn_or(bmbase, x3, b3);
         return;
     }
-    const uint32_t h0 = atomicOr(&S.bm[x0 >> 5], b0) & b0;
-    const uint32_t h1 = atomicOr(&S.bm[x1 >> 5], b1) & b1;
-    const uint32_t h2 = atomicOr(&S.bm[x2 >> 5], b2) & b2;
-    const uint32_t h3 = atomicOr(&S.bm[x3 >> 5], b3) & b3;
+    const uint32_t h0 = wn_or_rtn(bmbase, x0, b0) & b0;
+    const uint32_t h1 = wn_or_rtn(bmbase, x1, b1) & b1;
+    const uint32_t h2 = wn_or_rtn(bmbase, x2, b2) & b2;
+    const uint32_t h3 = wn_or_rtn(bmbase, x3, b3) & b3;
     if (__ballot((h0 | h1 | h2 | h3) != 0u)) {
         uint32_t hm = (h0 ? 1u : 0u) | (h1 ? 2u : 0u) | (h2 ? 4u : 0u) | (h3 ? 8u : 0u);
         do {
@@ -104,14 +116,17 @@ __device__ __forceinline__ void wn_pair(WinWave<MT> &S, const uint2 v, const uin
 // too.  An asm load is invisible to that count, which only makes the compiler's own waits stricter (vmcnt counts every load);
 // the waits below name the registers as in/out operands, so nothing that reads them can be scheduled above the wait.
 // Issue order at the end of every window w: P(w) the threshold, G(w) the word, R(w + 2) the eight runs.
+// (s_nop 4: a vector memory instruction must not read an SGPR within five wait states of a VALU instruction writing it -- v_readlane
+// does, and so does the restore of a spilled SGPR.  The compiler pads its own loads; it cannot see into an asm statement: without
+// the padding the kernel of eight run loads, which spills the pointer of the threshold word, faulted on a stale address.)
 __device__ __forceinline__ void wn_load_run(unsigned long long &dst, const uint32_t voff, const unsigned long long sbase) {
-    asm volatile("global_load_dwordx2 %0, %1, %2" : "=v"(dst) : "v"(voff), "s"(sbase));
+    asm volatile("s_nop 4\n\tglobal_load_dwordx2 %0, %1, %2" : "=v"(dst) : "v"(voff), "s"(sbase));
 }
 __device__ __forceinline__ void wn_load_word(uint32_t &dst, const uint32_t *addr) {
     asm volatile("global_load_dword %0, %1, off" : "=v"(dst) : "v"(addr));
 }
 __device__ __forceinline__ void wn_load_theta(unsigned long long &dst, const uint32_t vzero, const unsigned long long *sbase) {
-    asm volatile("global_load_dwordx2 %0, %1, %2 sc1" : "=v"(dst) : "v"(vzero), "s"(sbase));  // (sc1: an agent-scope load, as __hip_atomic_load makes it)
+    asm volatile("s_nop 4\n\tglobal_load_dwordx2 %0, %1, %2 sc1" : "=v"(dst) : "v"(vzero), "s"(sbase));  // (sc1: an agent-scope load, as __hip_atomic_load makes it)
 }
 // The kernel is compiled for MT run loads per window (MT = the most indexed terms of a query of the batch: 2, 4, 5 or 8; a query of
 // fewer terms loads the plane's first bytes for the others -- every load of the loop is unconditional: a conditional one made the
@@ -170,17 +185,23 @@ __device__ __forceinline__ void wn_drain(unsigned long long (&a)[MT], unsigned l
 template <int MT>
 __global__ void __launch_bounds__(wn_waves(MT) * 64, (wn_waves(MT) + 3) / 4) scan_win_kernel(DevIndex ix, DevBatch bt) {
     constexpr int WN_WAVES = wn_waves(MT), WN_WG = WN_WAVES * 64;
-    static_assert(sizeof(WinWave<MT>) == 8192 + 512 * MT + 256 + 512, "wn_waves() knows the size");
+    static_assert(sizeof(WinWave<MT>) == 512 * MT + 256 + 512, "wn_waves() knows the size");
+    __shared__ alignas(8192) uint32_t BM[WN_WAVES * WN_BM_WORDS];  // the waves' filters, 2^16 bits each
     __shared__ WinWave<MT> SW[WN_WAVES];
     __shared__ double S1[256];  // k1 (1 - b + b len(f) / avgdl) per fieldnorm (bm25.rs:349-352)
     const uint32_t lane = threadIdx.x & 63;
     WinWave<MT> &S = SW[uni(threadIdx.x >> 6)];
+    uint32_t *const bm = &BM[uni(threadIdx.x >> 6) * WN_BM_WORDS];
+    WnBm bmbase;
+    bmbase.base = uni((uint32_t)(uintptr_t)(wn_lds_u32 *)bm);
+    bmbase.mask = 0x1ffcu;
+    asm volatile("" : "+v"(bmbase.mask));
     const uint32_t k = bt.k, g = bt.win_g, n_items = bt.nq * g, NWIN = ix.n_win;
-    const uint32_t dbg = bt.team_dbg;  // timing experiments (wrong results): 1 no cold pass, 2 no completion, 4 no second arrivals
+    const uint32_t dbg = bt.team_dbg;  // timing experiments (wrong results): 1 no cold pass, 2 no completion, 4 no second arrivals, 32 no marks, 64 no wipe
     const uint16_t *ids16 = reinterpret_cast<const uint16_t *>(ix.post_id16);
     for (uint32_t i = threadIdx.x; i < 256u; i += WN_WG) S1[i] = ix.s1[i];
 #pragma unroll
-    for (int i = 0; i < WN_BM_WORDS / 4 / 64; ++i) reinterpret_cast<uint4 *>(S.bm)[lane + 64 * i] = make_uint4(0, 0, 0, 0);
+    for (int i = 0; i < WN_BM_WORDS / 4 / 64; ++i) reinterpret_cast<uint4 *>(bm)[lane + 64 * i] = make_uint4(0, 0, 0, 0);
     __syncthreads();  // (the table; the only workgroup barrier of the kernel -- from here on the waves go their own ways)
 #ifdef VBM25_PROFILE
     unsigned long long prof[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
@@ -191,8 +212,9 @@ __global__ void __launch_bounds__(wn_waves(MT) * 64, (wn_waves(MT) + 3) / 4) sca
     // The first one too: thousands of waves queueing at that address at kernel start costs them up to tens of microseconds -- and
     // is worth it (measured: 0.377 ms when every wave starts on its own number, 0.342 ms through the counter): the queue staggers
     // the waves, and waves in lockstep meet at the same pipes at the same time.
-    uint32_t drawn = 0;
-    {
+    const uint32_t n_waves = gridDim.x * (uint32_t)WN_WAVES;
+    uint32_t drawn = blockIdx.x * (uint32_t)WN_WAVES + uni(threadIdx.x >> 6);
+    if (dbg & 8u) {
         uint32_t d0 = 0;
         if (lane == 0) d0 = atomicAdd(cold_args()->bt.work_ctr, 1u);
         drawn = uni(d0);
@@ -222,7 +244,9 @@ __global__ void __launch_bounds__(wn_waves(MT) * 64, (wn_waves(MT) + 3) / 4) sca
         uint32_t m = 0, term = NONE32;
         {
             const KernArgsP ca = cold_args();
-            const uint32_t qb = uni(ca->bt.q_off[q]), qe = uni(ca->bt.q_off[q + 1]);  // (the host sends queries of <= 64 terms this way)
+            // (the host sends queries of <= 64 terms this way; when they all have the same number of terms nobody waits for q_off)
+            const uint32_t qs = ca->bt.q_stride;
+            const uint32_t qb = qs ? qs * q : uni(ca->bt.q_off[q]), qe = qs ? qs * (q + 1u) : uni(ca->bt.q_off[q + 1]);
             const uint32_t tt = lane < qe - qb ? ca->bt.term_ids[qb + lane] : NONE32;
             const bool ok = tt < ix.n_terms;  // search.rs:59-61
             const unsigned long long okm = __ballot(ok);
@@ -433,7 +457,7 @@ __global__ void __launch_bounds__(wn_waves(MT) * 64, (wn_waves(MT) + 3) / 4) sca
 #pragma unroll
             for (int gq = 0; gq < 2; ++gq) {
                 uint32_t hb[5][4], ho[5][4];  // the bit of every posting of the group (0: not a posting of the run), the word that came back
-                if (gq == 0 || MT > 5) {
+                if ((gq == 0 || MT > 5) && !(dbg & 128u)) {
 #pragma unroll
                     for (int u = 0; u < 5; ++u) {
                         const int t = 5 * gq + u;
@@ -451,16 +475,17 @@ __global__ void __launch_bounds__(wn_waves(MT) * 64, (wn_waves(MT) + 3) / 4) sca
                             hb[u][1] = r0 + 1u < n ? 1u << (x1 & 31u) : 0u;
                             hb[u][2] = r0 + 2u < n ? 1u << (x2 & 31u) : 0u;
                             hb[u][3] = r0 + 3u < n ? 1u << (x3 & 31u) : 0u;
-                            if (t == 0) {  // the window's first term: the filter is empty, nothing can be there yet
-                                atomicOr(&S.bm[x0 >> 5], hb[u][0]);
-                                atomicOr(&S.bm[x1 >> 5], hb[u][1]);
-                                atomicOr(&S.bm[x2 >> 5], hb[u][2]);
-                                atomicOr(&S.bm[x3 >> 5], hb[u][3]);
+                            if (dbg & 32u) {
+                            } else if (t == 0) {  // the window's first term: the filter is empty, nothing can be there yet
+                                wn_or(bmbase, x0, hb[u][0]);
+                                wn_or(bmbase, x1, hb[u][1]);
+                                wn_or(bmbase, x2, hb[u][2]);
+                                wn_or(bmbase, x3, hb[u][3]);
                             } else {
-                                ho[u][0] = atomicOr(&S.bm[x0 >> 5], hb[u][0]);
-                                ho[u][1] = atomicOr(&S.bm[x1 >> 5], hb[u][1]);
-                                ho[u][2] = atomicOr(&S.bm[x2 >> 5], hb[u][2]);
-                                ho[u][3] = atomicOr(&S.bm[x3 >> 5], hb[u][3]);
+                                ho[u][0] = wn_or_rtn(bmbase, x0, hb[u][0]);
+                                ho[u][1] = wn_or_rtn(bmbase, x1, hb[u][1]);
+                                ho[u][2] = wn_or_rtn(bmbase, x2, hb[u][2]);
+                                ho[u][3] = wn_or_rtn(bmbase, x3, hb[u][3]);
                             }
                             if (o_hi - o_al > (uint32_t)WN_SLOT) {  // a run that one load per lane does not hold: the rest, not staged (C1 reads it from memory)
                                 const uint16_t *rest = ids16 + 128ull * (uint32_t)__builtin_amdgcn_readlane((int)fb, t) + 4u * lane;
@@ -468,25 +493,14 @@ __global__ void __launch_bounds__(wn_waves(MT) * 64, (wn_waves(MT) + 3) / 4) sca
                                 for (uint32_t o = o_al + (uint32_t)WN_SLOT; o < o_hi; o += (uint32_t)WN_SLOT) {
                                     const unsigned long long mv = wn_load_run_now(rest + o);
                                     const uint2 more = make_uint2((uint32_t)mv, (uint32_t)(mv >> 32));
-                                    if (t == 0) wn_pair<false, MT>(S, more, o + 4u * lane - o_lo, n, (uint32_t)t, nd);
-                                    else wn_pair<true, MT>(S, more, o + 4u * lane - o_lo, n, (uint32_t)t, nd);
+                                    if (t == 0) wn_pair<false, MT>(S, bmbase, more, o + 4u * lane - o_lo, n, (uint32_t)t, nd);
+                                    else wn_pair<true, MT>(S, bmbase, more, o + 4u * lane - o_lo, n, (uint32_t)t, nd);
                                 }
                             }
                         }
                     }
                 }
-                if (gq == 0) {  // ---- the last window's first pass of second arrivals: its words have arrived behind these marks
-                    PROF_T(t_2);
-                    PROF_ADD(2, t_1, t_2);
-                    wn_wait_word<MT>(d_gw);
-                    PROF_T(t_2b);
-                    PROF_ADD(3, t_2, t_2b);
-                    if (d_valid) c2();
-                    d_valid = false;
-                    PROF_T(t_3);
-                    PROF_ADD(4, t_2b, t_3);
-                }
-                if (gq == 0 || MT > 5) {
+                if ((gq == 0 || MT > 5) && !(dbg & 128u)) {
 #pragma unroll
                     for (int u = 0; u < 5; ++u) {
                         const int t = 5 * gq + u;
@@ -517,9 +531,15 @@ __global__ void __launch_bounds__(wn_waves(MT) * 64, (wn_waves(MT) + 3) / 4) sca
             prof[10] += nd;
 #endif
             if (dbg & 4u) nd = 0;
+            if (!(dbg & 64u))
 #pragma unroll
-            for (int i = 0; i < WN_BM_WORDS / 4 / 64; ++i) reinterpret_cast<uint4 *>(S.bm)[lane + 64 * i] = make_uint4(0, 0, 0, 0);
+            for (int i = 0; i < WN_BM_WORDS / 4 / 64; ++i) reinterpret_cast<uint4 *>(bm)[lane + 64 * i] = make_uint4(0, 0, 0, 0);
 
+            // ---- the last window's open pass of second arrivals: its tf / fieldnorm words were requested a whole window ago (between the
+            // two phases of the marks, right behind the request, the wait for them was still exposed)
+            wn_wait_word<MT>(d_gw);
+            if (d_valid) c2();
+            d_valid = false;
             // ---- this window's second arrivals: passes beyond the first at once (rare), the first one left open
             d_found = false;
             if (nd != 0u && !failed && !(dbg & 2u)) {
@@ -667,7 +687,7 @@ __global__ void __launch_bounds__(wn_waves(MT) * 64, (wn_waves(MT) + 3) / 4) sca
             ce->bt.item_failed[item] = failed ? 0x101u : 0u;
             if (failed) *ce->bt.fail_any = 1u;
         }
-        drawn = uni(next_draw);
+        drawn = ((dbg & 8u) ? 0u : n_waves) + uni(next_draw);
     }
 #ifdef VBM25_PROFILE
     if (bt.prof && lane == 0) {

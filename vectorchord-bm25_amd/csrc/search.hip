@@ -227,7 +227,8 @@ struct Tuning {
     int win_force = 0;             // tests: that route whatever the lists' lengths
     uint32_t win_items = 0;        // work items of a batch on that route (0: twice the resident waves)
     int win_planes = 1;            // read at index creation: derive the window planes (post_id16, win_off)
-    int win_guided = 1;            // scan_win_kernel's items of a query of decreasing length (0: equal)
+    int win_guided = 0;            // scan_win_kernel's items of a query of decreasing length, handed out longest first (0: equal runs; measured
+                                   // no better on C3 -- an item's setup costs more than the shorter tail saves)
     uint32_t win_grid = 0;         // its persistent workgroups (0: three per CU)
     uint32_t generation = 0;       // bumped by every vbm25_tuning_set / reset: vbm25_search_batch's batch object is rebuilt when it is stale
 };
@@ -265,6 +266,8 @@ struct vbm25_batch {
     uint32_t fused_g = 0;         // items per query of the current queries on that route (0: general route)
     uint32_t arith_g = 0;         // general route without plan_kernel (every query sparse): items per query, made by the scan kernel itself
     uint32_t win_mt = 8;          // scan_win_kernel: the most indexed terms of a query of the current batch
+    uint32_t q_stride = 0;        // != 0: every query of the current batch has this many terms
+    bool order_useful = true;     // the current queries differ enough in length for the longest-first order to matter
     uint32_t win_g = 0;           // ... and scan_win_kernel's flavour of it (items = runs of 2^16-document windows, one result list each)
     bool need_many = true;        // the current queries have items for scan_many_kernel (more than 16 terms, 256 < k, dense without the dense kernel)
     bool fused_pinned = false;    // ... with queries and hits in pinned host memory (vbm25_search_batch, <= 8 queries); else device buffers
@@ -890,9 +893,9 @@ static int vbm25_batch_set_queries_impl(vbm25_batch *bt, const uint32_t *term_id
                     }
                 }
                 if (ok) {
-                    // items per query: about twice the resident waves in all; an item's blocks per term should fit the 64-bit mask
-                    // of its hot blocks (8192 postings per term)
-                    const uint32_t target = bt->tune.win_items ? bt->tune.win_items : 2u * scan_win_resident_waves(range_mt);
+                    // items: one per resident wave (an item's setup is a chain of six round trips to memory: on C3 3072 items of 51
+                    // windows take 0.270 ms, 6144 of 25 windows 0.287 ms)
+                    const uint32_t target = bt->tune.win_items ? bt->tune.win_items : scan_win_resident_waves(range_mt);
                     const uint32_t g_min = (ixh->n_win + 62u) / 63u;  // (an item holds at most 63 windows)
                     uint32_t gw = std::max(std::max(1u, (target + nq / 2) / nq), g_min);
                     gw = std::min(std::min(gw, ixh->n_win), bt->max_items / nq);
@@ -916,6 +919,8 @@ static int vbm25_batch_set_queries_impl(vbm25_batch *bt, const uint32_t *term_id
                 qs.resize(nq);
                 for (uint32_t q = 0; q < nq; ++q) qs[q] = q;
                 std::stable_sort(qs.begin(), qs.end(), [&](uint32_t a, uint32_t b) { return q_postings[a] > q_postings[b]; });
+                // (queries of about the same length: the order buys nothing and costs every work item a dependent load)
+                bt->order_useful = !win_g || !bt->tune.win_guided ? q_postings[qs[0]] * 4 > q_postings[qs[nq - 1]] * 5 : true;
                 if (win_g)  // (parts of decreasing length: every query's first part, then every query's second one, ...)
                     for (uint32_t part = 0; part < g; ++part)
                         for (uint32_t i = 0; i < nq; ++i) ord[size_t(part) * nq + i] = qs[i] * uint32_t(g) + part;
@@ -964,6 +969,12 @@ static int vbm25_batch_set_queries_impl(vbm25_batch *bt, const uint32_t *term_id
     bt->has_dense = has_dense;
     bt->range_rt = !bt->use_range || range_mt == 0 ? 0u : (range_mt <= 8u ? 8u : 16u);
     bt->win_mt = range_mt;
+    bt->q_stride = 0;
+    if (nq && q_off[1] != 0) {
+        bt->q_stride = q_off[1];
+        for (uint32_t q = 0; q < nq && bt->q_stride; ++q)
+            if (q_off[q + 1] - q_off[q] != bt->q_stride) bt->q_stride = 0;
+    }
     {   // the number of work items plan_kernel will make (same integer arithmetic): the persistent grids need not be
         // larger (a single query is a handful of items); with the dense-window kernel every dense query gets the same
         // number of items (equal document counts)
@@ -1171,7 +1182,8 @@ static int vbm25_batch_run_impl(vbm25_batch *bt, void *hip_stream) {
         db.dense_on = 0;
         db.many_expected = 0;
         db.merge_clean = 1;
-        db.order_on = 1;
+        db.order_on = bt->order_useful ? 1u : 0u;
+        db.q_stride = bt->q_stride;
         if (int rc = take_events()) return rc;
         const uint32_t wmt = bt->range_rt == 8 ? bt->win_mt : 8u, wpw = scan_win_wg(wmt);
         const uint32_t wgrid = std::min<uint32_t>((bt->nq * bt->win_g + wpw - 1u) / wpw, bt->tune.win_grid ? bt->tune.win_grid : scan_win_resident_waves(wmt) / wpw);
