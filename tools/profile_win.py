@@ -39,7 +39,18 @@ win = p[:, 0].sum()
 print(f"windows per wave {p[:, 0].mean():.1f}; items per wave {p[:, 12].mean():.2f}; second arrivals per window {p[:, 10].sum() / win:.2f}")
 print(f"wave lifetime cycles mean {p[:, 15].mean():.0f} max {p[:, 15].max():.0f} min {p[:, 15].min():.0f}; in window loops {p[:, 9].mean():.0f}; "
       f"setup per item {p[:, 8].sum() / p[:, 12].sum():.0f}; item end (drain, cold pass, result) {p[:, 13].sum() / p[:, 12].sum():.0f}")
-names = {1: "wait for the window's runs", 2: "marks phase 1 (stage, atomics issued)", 3: "wait for the last window's tf/fn word",
-         4: "C2 of the last window", 5: "all marks incl. C2 (t1..t4)", 6: "wipe, C1 (+ extra passes)", 7: "threshold, loads issued"}
+names = {1: "wait for the window's runs", 2: "marks phase 1 (stage, the group's atomics issued)", 3: "marks phase 2 (returned words -> second arrivals)",
+         4: "wipe", 5: "wait for the last window's tf/fn words", 6: "C2 of the last window's open passes", 7: "C1 of this window (+ passes beyond two)",
+         11: "threshold wait, loads issued"}
 for i, n in names.items():
     print(f"   {n:44s} {p[:, i].sum() / win:8.0f}")
+# where the spread of the waves' lifetimes comes from: between workgroups (CUs) or inside them; work (second arrivals) or place
+W = 12
+wg = p[: (WAVES // W) * W].reshape(-1, W, 16)
+life = wg[:, :, 15]
+print(f"lifetime: workgroup means min {life.mean(1).min():.0f} max {life.mean(1).max():.0f}; spread inside a workgroup (max - min) mean {np.mean(life.max(1) - life.min(1)):.0f}")
+print(f"correlation of a wave's lifetime with its second arrivals {np.corrcoef(p[:, 15], p[:, 10])[0, 1]:.2f}, with its time in the window loops {np.corrcoef(p[:, 15], p[:, 9])[0, 1]:.2f}")
+slot = life.mean(0)
+print("mean lifetime by wave slot of the workgroup:", " ".join(f"{x:.0f}" for x in slot))
+xcd = life.mean(1).reshape(-1, 8).mean(0) if life.shape[0] % 8 == 0 else None
+print("mean lifetime by workgroup number mod 8 (XCD):", None if xcd is None else " ".join(f"{x:.0f}" for x in xcd))

@@ -138,27 +138,28 @@ __device__ __forceinline__ void wn_load_theta(unsigned long long &dst, const uin
 #define WN_OPS4(b) WN_OPS2(b), "+v"(b[2]), "+v"(b[3])
 #define WN_OPS5(b) WN_OPS4(b), "+v"(b[4])
 #define WN_OPS8(b) WN_OPS5(b), "+v"(b[5]), "+v"(b[6]), "+v"(b[7])
+// (issue order at the end of a window w: P(w), the words of its two open passes Ga(w) and Gb(w), then R(w + 2): MT + 3 loads)
 template <int MT>
-__device__ __forceinline__ void wn_wait_runs(unsigned long long (&b)[MT]) {
+__device__ __forceinline__ void wn_wait_runs(unsigned long long (&b)[MT]) {  // R(w + 1): P, Ga, Gb, R(w + 2) behind it
     static_assert(MT == 2 || MT == 4 || MT == 5 || MT == 8, "operand lists");
-    if constexpr (MT == 2) asm volatile("s_waitcnt vmcnt(4)" : WN_OPS2(b));
-    if constexpr (MT == 4) asm volatile("s_waitcnt vmcnt(6)" : WN_OPS4(b));
-    if constexpr (MT == 5) asm volatile("s_waitcnt vmcnt(7)" : WN_OPS5(b));
-    if constexpr (MT == 8) asm volatile("s_waitcnt vmcnt(10)" : WN_OPS8(b));
+    if constexpr (MT == 2) asm volatile("s_waitcnt vmcnt(5)" : WN_OPS2(b));
+    if constexpr (MT == 4) asm volatile("s_waitcnt vmcnt(7)" : WN_OPS4(b));
+    if constexpr (MT == 5) asm volatile("s_waitcnt vmcnt(8)" : WN_OPS5(b));
+    if constexpr (MT == 8) asm volatile("s_waitcnt vmcnt(11)" : WN_OPS8(b));
 }
 template <int MT>
-__device__ __forceinline__ void wn_wait_word(uint32_t &g) {
-    if constexpr (MT == 2) asm volatile("s_waitcnt vmcnt(2)" : "+v"(g));
-    if constexpr (MT == 4) asm volatile("s_waitcnt vmcnt(4)" : "+v"(g));
-    if constexpr (MT == 5) asm volatile("s_waitcnt vmcnt(5)" : "+v"(g));
-    if constexpr (MT == 8) asm volatile("s_waitcnt vmcnt(8)" : "+v"(g));
+__device__ __forceinline__ void wn_wait_words(uint32_t &ga, uint32_t &gb) {  // Ga(w) and Gb(w): R(w + 2) behind them
+    if constexpr (MT == 2) asm volatile("s_waitcnt vmcnt(2)" : "+v"(ga), "+v"(gb));
+    if constexpr (MT == 4) asm volatile("s_waitcnt vmcnt(4)" : "+v"(ga), "+v"(gb));
+    if constexpr (MT == 5) asm volatile("s_waitcnt vmcnt(5)" : "+v"(ga), "+v"(gb));
+    if constexpr (MT == 8) asm volatile("s_waitcnt vmcnt(8)" : "+v"(ga), "+v"(gb));
 }
 template <int MT>
-__device__ __forceinline__ void wn_wait_theta(unsigned long long &p) {
-    if constexpr (MT == 2) asm volatile("s_waitcnt vmcnt(3)" : "+v"(p));
-    if constexpr (MT == 4) asm volatile("s_waitcnt vmcnt(5)" : "+v"(p));
-    if constexpr (MT == 5) asm volatile("s_waitcnt vmcnt(6)" : "+v"(p));
-    if constexpr (MT == 8) asm volatile("s_waitcnt vmcnt(9)" : "+v"(p));
+__device__ __forceinline__ void wn_wait_theta(unsigned long long &p) {  // P(w - 1): Ga, Gb (w - 1) and R(w + 1) behind it
+    if constexpr (MT == 2) asm volatile("s_waitcnt vmcnt(4)" : "+v"(p));
+    if constexpr (MT == 4) asm volatile("s_waitcnt vmcnt(6)" : "+v"(p));
+    if constexpr (MT == 5) asm volatile("s_waitcnt vmcnt(7)" : "+v"(p));
+    if constexpr (MT == 8) asm volatile("s_waitcnt vmcnt(10)" : "+v"(p));
 }
 __device__ __forceinline__ void wn_wait_all(uint32_t &g) { asm volatile("s_waitcnt vmcnt(0)" : "+v"(g)); }
 // the rare paths inside the loop (a run thicker than one load per lane) load by hand too, and wait for everything: a load the
@@ -175,12 +176,17 @@ __device__ __forceinline__ uint32_t wn_load_u16_now(const uint16_t *addr) {
 }
 // every load issued by hand has landed: their registers are the compiler's again (they stay allocated up to here)
 template <int MT>
-__device__ __forceinline__ void wn_drain(unsigned long long (&a)[MT], unsigned long long (&b)[MT], uint32_t &g, unsigned long long &p) {
-    if constexpr (MT == 2) asm volatile("s_waitcnt vmcnt(0)" : WN_OPS2(a), WN_OPS2(b), "+v"(g), "+v"(p));
-    if constexpr (MT == 4) asm volatile("s_waitcnt vmcnt(0)" : WN_OPS4(a), WN_OPS4(b), "+v"(g), "+v"(p));
-    if constexpr (MT == 5) asm volatile("s_waitcnt vmcnt(0)" : WN_OPS5(a), WN_OPS5(b), "+v"(g), "+v"(p));
-    if constexpr (MT == 8) asm volatile("s_waitcnt vmcnt(0)" : WN_OPS8(a), WN_OPS8(b), "+v"(g), "+v"(p));
+__device__ __forceinline__ void wn_drain(unsigned long long (&a)[MT], unsigned long long (&b)[MT], uint32_t &g, uint32_t &g2, unsigned long long &p) {
+    if constexpr (MT == 2) asm volatile("s_waitcnt vmcnt(0)" : WN_OPS2(a), WN_OPS2(b), "+v"(g), "+v"(g2), "+v"(p));
+    if constexpr (MT == 4) asm volatile("s_waitcnt vmcnt(0)" : WN_OPS4(a), WN_OPS4(b), "+v"(g), "+v"(g2), "+v"(p));
+    if constexpr (MT == 5) asm volatile("s_waitcnt vmcnt(0)" : WN_OPS5(a), WN_OPS5(b), "+v"(g), "+v"(g2), "+v"(p));
+    if constexpr (MT == 8) asm volatile("s_waitcnt vmcnt(0)" : WN_OPS8(a), WN_OPS8(b), "+v"(g), "+v"(g2), "+v"(p));
 }
+// an open pass of second arrivals: what C1 found for the lane's (entry, term), the word requested for it
+struct WnPend {
+    bool valid, found, task;
+    uint32_t x, te, p, w, gw;
+};
 
 template <int MT>
 __global__ void __launch_bounds__(wn_waves(MT) * 64, (wn_waves(MT) + 3) / 4) scan_win_kernel(DevIndex ix, DevBatch bt) {
@@ -344,7 +350,7 @@ __global__ void __launch_bounds__(wn_waves(MT) * 64, (wn_waves(MT) + 3) / 4) sca
                 wn_load_run(dst[t], lane8, a);
             }
         };
-        uint32_t d_gw = 0;
+        WnPend pa{}, pb{};  // the two open passes of the last window (entries 0 .. epp - 1 and epp .. 2 epp - 1)
         unsigned long long pgv = 0;  // the query's shared threshold, polled a window ahead
         uint32_t vzero = 0;
         asm volatile("" : "+v"(vzero));
@@ -354,12 +360,13 @@ __global__ void __launch_bounds__(wn_waves(MT) * 64, (wn_waves(MT) + 3) / 4) sca
         for (int t = 0; t < MT; ++t) bufa[t] = bufb[t] = 0;
         load_runs(bufa, 0u);
         wn_load_theta(pgv, vzero, &bt.theta[q]);
-        wn_load_word(d_gw, ix.post_tfn);
+        wn_load_word(pa.gw, ix.post_tfn);
+        wn_load_word(pb.gw, ix.post_tfn);
         load_runs(bufb, 1u);
         // (landed before the loop is entered: the compiler may move these registers on the way in -- a copy of a register whose
         // load is still in flight would copy what was there before.  One exposed round trip per item; inside the loop a buffer is
         // written by its loads and read by its marks only)
-        wn_drain<MT>(bufa, bufb, d_gw, pgv);
+        wn_drain<MT>(bufa, bufb, pa.gw, pb.gw, pgv);
 
         // ---- completion of the second arrivals in two halves: C1 (after a window's marks) finds the postings -- lane = (entry, term),
         // bisection of the term's staged run -- and requests their tf / fieldnorm words; C2 scores, sums and offers.  The first
@@ -368,9 +375,8 @@ __global__ void __launch_bounds__(wn_waves(MT) * 64, (wn_waves(MT) + 3) / 4) sca
         const uint32_t el = (lane * inv_m) >> 16, tl = m ? lane - el * m : 0u;  // the lane's entry of a pass and its term
         const uint32_t fbl = (uint32_t)__shfl((int)fb, (int)tl);
         const double s0l = __shfl(s0, (int)tl);
-        bool d_valid = false, d_found = false, d_task = false, notf = false;
-        uint32_t d_x = 0, d_te = 0, d_p = 0, d_w = 0;
-        auto c1 = [&](const uint32_t e0, const uint32_t nd, const uint32_t w) {
+        bool notf = false;
+        auto c1 = [&](WnPend &d, const uint32_t e0, const uint32_t nd, const uint32_t w) {
             const bool task = el < epp && e0 + el < nd;
             const uint32_t ent = S.list[task ? e0 + el : 0u];
             const uint32_t x = ent & 0xffffu;
@@ -407,37 +413,37 @@ __global__ void __launch_bounds__(wn_waves(MT) * 64, (wn_waves(MT) + 3) / 4) sca
                     base = lo;
                 }
             }
-            d_task = task;
-            d_found = found;
-            d_x = x;
-            d_te = ent >> 16;
-            d_p = plo + base;
-            d_w = w;
+            d.task = task;
+            d.found = found;
+            d.x = x;
+            d.te = ent >> 16;
+            d.p = plo + base;
+            d.w = w;
         };
         // the word of post_tfn that holds the posting C1 found (word 0 for the lanes that found none: the load is unconditional)
-        auto c1_request = [&]() { wn_load_word(d_gw, ix.post_tfn + (d_found ? 64ull * fbl + (d_p >> 1) : 0ull)); };
-        auto c2 = [&]() {
+        auto c1_request = [&](WnPend &d) { wn_load_word(d.gw, ix.post_tfn + (d.found ? 64ull * fbl + (d.p >> 1) : 0ull)); };
+        auto c2 = [&](const WnPend &d) {
             double c = 0.0;
-            if (d_found) {
-                const uint32_t ww = d_gw >> ((d_p & 1u) * 8u);
+            if (d.found) {
+                const uint32_t ww = d.gw >> ((d.p & 1u) * 8u);
                 const uint32_t tfv = ww & 0xffu, fn = (ww >> 16) & 0xffu;
                 notf = notf || tfv == 0u;  // (a term frequency above 255: the word holds zeros -- not this kernel's item)
                 const double tf = (double)tfv;
                 c = (tf * s0l) / (tf + S1[fn]);  // Cache::evaluate, bm25.rs:355-358
             }
             S.contrib[lane] = c;
-            const unsigned long long fm = __ballot(d_found);
+            const unsigned long long fm = __ballot(d.found);
             __builtin_amdgcn_wave_barrier();
             bool okd = false;
             double acc = 0.0;
-            if (d_task && tl == 0u) {
+            if (d.task && tl == 0u) {
                 const uint32_t my = (uint32_t)(fm >> lane) & ((1u << m) - 1u);
                 // the entry of the LAST term that holds the document completes it (one offer per document)
-                okd = (my >> (d_te + 1u)) == 0u && (my & (my - 1u)) != 0u;
+                okd = (my >> (d.te + 1u)) == 0u && (my & (my - 1u)) != 0u;
                 for (uint32_t t = 0; t < m; ++t) acc += S.contrib[lane + t];  // ascending key order; absent terms add 0.0
             }
             __builtin_amdgcn_wave_barrier();
-            offer(okd, acc, d_w << 16 | d_x);
+            offer(okd, acc, d.w << 16 | d.x);
         };
 
         // One window: `cur` holds its runs (requested two windows ago) and takes the runs of the window after next at the end.  Two
@@ -454,6 +460,9 @@ __global__ void __launch_bounds__(wn_waves(MT) * 64, (wn_waves(MT) + 3) / 4) sca
             wn_wait_runs<MT>(cur);
             PROF_T(t_1);
             PROF_ADD(1, t_0, t_1);
+#ifdef VBM25_PROFILE
+            unsigned long long t_p1 = t_1;
+#endif
 #pragma unroll
             for (int gq = 0; gq < 2; ++gq) {
                 uint32_t hb[5][4], ho[5][4];  // the bit of every posting of the group (0: not a posting of the run), the word that came back
@@ -500,6 +509,13 @@ __global__ void __launch_bounds__(wn_waves(MT) * 64, (wn_waves(MT) + 3) / 4) sca
                         }
                     }
                 }
+#ifdef VBM25_PROFILE
+                if (gq == 0) {
+                    const unsigned long long t_2 = __builtin_readcyclecounter();
+                    prof[2] += t_2 - t_1;
+                    t_p1 = t_2;
+                }
+#endif
                 if ((gq == 0 || MT > 5) && !(dbg & 128u)) {
 #pragma unroll
                     for (int u = 0; u < 5; ++u) {
@@ -523,7 +539,9 @@ __global__ void __launch_bounds__(wn_waves(MT) * 64, (wn_waves(MT) + 3) / 4) sca
             }
             __builtin_amdgcn_wave_barrier();
             PROF_T(t_4);
-            PROF_ADD(5, t_1, t_4);
+#ifdef VBM25_PROFILE
+            prof[3] += t_4 - t_p1;
+#endif
             // more second arrivals than the list holds: the lists are too dense here for this kernel
             if (nd > (uint32_t)WN_LIST) failed = true;
 #ifdef VBM25_PROFILE
@@ -537,23 +555,35 @@ __global__ void __launch_bounds__(wn_waves(MT) * 64, (wn_waves(MT) + 3) / 4) sca
 
             // ---- the last window's open pass of second arrivals: its tf / fieldnorm words were requested a whole window ago (between the
             // two phases of the marks, right behind the request, the wait for them was still exposed)
-            wn_wait_word<MT>(d_gw);
-            if (d_valid) c2();
-            d_valid = false;
-            // ---- this window's second arrivals: passes beyond the first at once (rare), the first one left open
-            d_found = false;
+            PROF_T(t_w0);
+            PROF_ADD(4, t_4, t_w0);
+            wn_wait_words<MT>(pa.gw, pb.gw);
+            PROF_T(t_w1);
+            PROF_ADD(5, t_w0, t_w1);
+            if (pa.valid) c2(pa);
+            if (pb.valid) c2(pb);
+            pa.valid = pb.valid = false;
+            PROF_T(t_w2);
+            PROF_ADD(6, t_w1, t_w2);
+            // ---- this window's second arrivals: passes beyond the second at once (rare), the first two left open
+            pa.found = pb.found = false;
             if (nd != 0u && !failed && !(dbg & 2u)) {
-                for (uint32_t e0 = ((nd - 1u) / epp) * epp; e0 != 0u; e0 -= epp) {
-                    c1(e0, nd, w);
-                    c1_request();
-                    wn_wait_all(d_gw);
-                    c2();
+                for (uint32_t e0 = ((nd - 1u) / epp) * epp; e0 >= 2u * epp; e0 -= epp) {
+                    c1(pb, e0, nd, w);
+                    c1_request(pb);
+                    wn_wait_all(pb.gw);
+                    c2(pb);
                 }
-                c1(0u, nd, w);
-                d_valid = true;
+                pb.found = false;
+                if (nd > epp) {
+                    c1(pb, epp, nd, w);
+                    pb.valid = true;
+                }
+                c1(pa, 0u, nd, w);
+                pa.valid = true;
             }
             PROF_T(t_5);
-            PROF_ADD(6, t_4, t_5);
+            PROF_ADD(7, t_w2, t_5);
             // ---- the shared threshold polled a window ago; then, in this order: the next poll P(w), the word of this window's open
             // pass G(w), the runs of the window after next R(w + 2)
             {
@@ -562,10 +592,11 @@ __global__ void __launch_bounds__(wn_waves(MT) * 64, (wn_waves(MT) + 3) / 4) sca
                 if (pg > th) th = pg;
             }
             wn_load_theta(pgv, vzero, &bt.theta[q]);
-            c1_request();
+            c1_request(pa);
+            c1_request(pb);
             load_runs(cur, w - w_lo + 2u);
             PROF_T(t_6);
-            PROF_ADD(7, t_5, t_6);
+            PROF_ADD(11, t_5, t_6);
             if (failed) return false;
             return true;
         };
@@ -575,10 +606,12 @@ __global__ void __launch_bounds__(wn_waves(MT) * 64, (wn_waves(MT) + 3) / 4) sca
             if (w + 1u < w_hi && !window(bufb, w + 1u)) break;
         }
         PROF_T(t_loop_end);
-        wn_drain<MT>(bufa, bufb, d_gw, pgv);
-        uint32_t next_draw = 0;
-        if (lane == 0) next_draw = atomicAdd(cold_args()->bt.work_ctr, 1u);  // (consumed at the item's very end)
-        if (d_valid && !failed) c2();
+        wn_drain<MT>(bufa, bufb, pa.gw, pb.gw, pgv);
+        // (a launch of no more items than waves: nobody draws -- thousands of waves finishing together would queue at the counter)
+        uint32_t next_draw = n_items;
+        if (lane == 0 && n_items > n_waves) next_draw = atomicAdd(cold_args()->bt.work_ctr, 1u);  // (consumed at the item's very end)
+        if (pa.valid && !failed) c2(pa);
+        if (pb.valid && !failed) c2(pb);
         failed = failed || __ballot(notf) != 0ull;
 
         // ---- cold pass (search.rs:203): the item's blocks whose upper bound reaches the threshold of now.  Their postings are scored

@@ -229,7 +229,8 @@ struct Tuning {
     int win_planes = 1;            // read at index creation: derive the window planes (post_id16, win_off)
     int win_guided = 0;            // scan_win_kernel's items of a query of decreasing length, handed out longest first (0: equal runs; measured
                                    // no better on C3 -- an item's setup costs more than the shorter tail saves)
-    uint32_t win_grid = 0;         // its persistent workgroups (0: three per CU)
+    uint32_t win_grid = 0;         // its persistent workgroups (0: one per CU)
+    int win_skew = 1;              // one item per wave: a query's three runs of windows sized for the three kinds of waves of a SIMD
     uint32_t generation = 0;       // bumped by every vbm25_tuning_set / reset: vbm25_search_batch's batch object is rebuilt when it is stale
 };
 static Tuning g_tune;
@@ -266,6 +267,7 @@ struct vbm25_batch {
     uint32_t fused_g = 0;         // items per query of the current queries on that route (0: general route)
     uint32_t arith_g = 0;         // general route without plan_kernel (every query sparse): items per query, made by the scan kernel itself
     uint32_t win_mt = 8;          // scan_win_kernel: the most indexed terms of a query of the current batch
+    bool win_skew = false;        // scan_win_kernel: one item per wave, a query's three runs sized for the three kinds of waves of a SIMD
     uint32_t q_stride = 0;        // != 0: every query of the current batch has this many terms
     bool order_useful = true;     // the current queries differ enough in length for the longest-first order to matter
     uint32_t win_g = 0;           // ... and scan_win_kernel's flavour of it (items = runs of 2^16-document windows, one result list each)
@@ -919,9 +921,33 @@ static int vbm25_batch_set_queries_impl(vbm25_batch *bt, const uint32_t *term_id
                 qs.resize(nq);
                 for (uint32_t q = 0; q < nq; ++q) qs[q] = q;
                 std::stable_sort(qs.begin(), qs.end(), [&](uint32_t a, uint32_t b) { return q_postings[a] > q_postings[b]; });
-                // (queries of about the same length: the order buys nothing and costs every work item a dependent load)
-                bt->order_useful = !win_g || !bt->tune.win_guided ? q_postings[qs[0]] * 4 > q_postings[qs[nq - 1]] * 5 : true;
-                if (win_g)  // (parts of decreasing length: every query's first part, then every query's second one, ...)
+
+                const uint32_t wpw = win_g ? scan_win_wg(range_mt) : 0u;
+                bt->win_skew = win_g == 3u && wpw == 12u && size_t(nq) * 3u <= scan_win_resident_waves(range_mt) && bt->tune.win_skew;
+                // (queries of about the same length: the longest-first order buys nothing and costs every work item a dependent load)
+                bt->order_useful = bt->win_skew || (!win_g || !bt->tune.win_guided ? q_postings[qs[0]] * 4 > q_postings[qs[nq - 1]] * 5 : true);
+                if (bt->win_skew) {
+                    // One item per wave, three per query: a SIMD's three waves do not run equally fast -- the workgroup's waves 0..3
+                    // (the first wave of every SIMD) lived 449 k cycles on C3, 4..7 497 k, 8..11 559 k, whatever priority they set
+                    // themselves -- and the launch ends with the slowest.  A workgroup takes four queries; a query's three runs of
+                    // windows, of lengths in the ratio of those speeds (win_cut, vbm25_batch_run), go to one wave of each kind.
+                    for (uint32_t d = 0; d < nq * 3u; ++d) ord[d] = UINT32_MAX;
+                    uint32_t qi = 0;
+                    for (uint32_t wgi = 0; qi < nq; ++wgi)
+                        for (uint32_t s4 = 0; s4 < 4u && qi < nq; ++s4, ++qi)
+                            for (uint32_t part = 0; part < 3u; ++part) ord[size_t(wgi) * 12u + part * 4u + s4] = qs[qi] * 3u + part;
+                    // (a last workgroup of fewer than four queries leaves holes: filled with the numbers not handed out)
+                    uint32_t hole = 0;
+                    std::vector<uint8_t> used(size_t(nq) * 3u, 0);
+                    for (uint32_t d = 0; d < nq * 3u; ++d)
+                        if (ord[d] != UINT32_MAX) used[ord[d]] = 1;
+                    for (uint32_t d = 0; d < nq * 3u; ++d)
+                        if (ord[d] == UINT32_MAX) {
+                            while (used[hole]) ++hole;
+                            ord[d] = hole;
+                            used[hole] = 1;
+                        }
+                } else if (win_g)  // (parts of decreasing length: every query's first part, then every query's second one, ...)
                     for (uint32_t part = 0; part < g; ++part)
                         for (uint32_t i = 0; i < nq; ++i) ord[size_t(part) * nq + i] = qs[i] * uint32_t(g) + part;
                 else
@@ -1164,7 +1190,13 @@ static int vbm25_batch_run_impl(vbm25_batch *bt, void *hip_stream) {
             // 63 windows an item can hold, or with more than 16 items per query.
             const uint32_t gq = bt->win_g, nwin = bt->index->n_win;
             std::memset(db.win_cut, 0, sizeof db.win_cut);
-            if (gq <= 16u && bt->tune.win_guided) {
+            if (bt->win_skew) {  // (the three kinds of waves: 57 / 51 / 45 of C3's 153 windows)
+                db.win_cut[0] = 0;
+                db.win_cut[1] = uint32_t(uint64_t(nwin) * 370u / 1000u);
+                db.win_cut[2] = uint32_t(uint64_t(nwin) * 704u / 1000u);
+                db.win_cut[3] = nwin;
+                if (db.win_cut[1] > 63u || db.win_cut[2] - db.win_cut[1] > 63u || nwin - db.win_cut[2] > 63u) std::memset(db.win_cut, 0, sizeof db.win_cut);
+            } else if (gq <= 16u && bt->tune.win_guided) {
                 const uint64_t total = uint64_t(gq) * (gq + 3u) / 2u;
                 uint64_t cum = 0;
                 bool fits = true;
@@ -1431,6 +1463,7 @@ int vbm25_tuning_set(const char *name, long long value) {
     else if (n == "win_planes") g_tune.win_planes = value != 0;
     else if (n == "win_guided") g_tune.win_guided = value != 0;
     else if (n == "win_grid") g_tune.win_grid = (uint32_t)std::max(0ll, value);
+    else if (n == "win_skew") g_tune.win_skew = value != 0;
     else return set_error(VBM25_ERR_INVALID, "unknown tuning switch %s", name);
     ++g_tune.generation;
     return VBM25_OK;
