@@ -490,7 +490,7 @@ def run(argv=None, scorer_factory=None, backend="nccl"):
         pcie_qps = n_pipe * nq_local / (time.perf_counter() - t0)
         del st
     results = [b.fetch() for b in batches]
-    for hits, n_hits in (results if "team_dbg" not in args.tune else []):  # (timing experiments switch parts of the kernel off)
+    for hits, n_hits in (results if "dbg" not in args.tune else []):  # (timing experiments switch parts of the kernel off)
         assert (n_hits == k).all() or args.workload in ("C1",), "missing hits"
         s = hits["score"]
         assert (s[:, :-1] >= s[:, 1:]).all()
@@ -502,7 +502,7 @@ def run(argv=None, scorer_factory=None, backend="nccl"):
     oix = None
     verified = None
     verified_sample = None
-    if on_gpu and world == 1 and not args.verify and not args.no_verify_sample and "team_dbg" not in args.tune:
+    if on_gpu and world == 1 and not args.verify and not args.no_verify_sample and "dbg" not in args.tune:
         # ties the number to parity: a sample of 64 queries of the first batch, bit-exact against the oracle's brute force
         # (outside the timed region; --verify checks every query of every batch)
         t0 = time.perf_counter()

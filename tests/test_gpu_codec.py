@@ -1,6 +1,7 @@
 """The HIP decoders fed every codec shape of compression.rs:65-136 through small hand-made indexes, against the oracle bit for
-bit -- through scan_range_kernel (default), scan_team_kernel (tuning team), scan_dense_kernel (every query declared dense) and
-the exhaustive scan_many_kernel (k = 300).  -m gpu only.
+bit -- through scan_range_kernel (plan-free and general route), scan_win_kernel (win_force: whatever the lists' lengths; it reads the
+window planes derived from the decoded blocks, and the blob in its cold pass), the one-launch route, scan_dense_kernel (every query
+declared dense) and the exhaustive scan_many_kernel (k = 300).  -m gpu only.
 
 * byte-packed TAIL blocks with document-id byte widths 3 and 4 (gaps >= 2^16 and >= 2^24; width 4 is raw absolute ids,
   bytepacking_u32_ordered.rs:200-214 -- its own branch in decode.h) and term-frequency byte widths 2 and 3;
@@ -33,8 +34,8 @@ def _index(n_docs, lists, seed=0):
 
 def _check_routes(tuning, gix, oix, terms, off, ks=(10, 128)):
     nq = len(off) - 1
-    routes = [("range", dict(team=0, fused=0)), ("team4", dict(team=1, team_size=4, fused=0)), ("team8", dict(team=1, team_size=8, fused=0)),
-              ("fused", dict(team=0, fused=1)), ("dense", dict(team=0, fused=0, dense_x1000=0))]
+    routes = [("range", dict(win=0, fused=0)), ("range-general", dict(win=0, fused=0, arith=0)), ("win", dict(win_force=1, fused=0)),
+              ("fused", dict(fused=1)), ("dense", dict(fused=0, dense_x1000=0))]
     for name, tune in routes:
         vb.reset_tuning()
         tuning(**tune)

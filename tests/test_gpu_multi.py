@@ -1,6 +1,6 @@
 """The N-GPU split behind the C ABI (vbm25_multi_*) on the one GPU of the test box: replicas made with
 hipMemcpyPeerAsync on device 0 itself, the batch sharded over them -- every record identical to the single-handle result.
-Also: the alternative scan kernel (scan_team_kernel, tuning team = 1) against the oracle.  -m gpu only."""
+Also: the pipelined host-buffer boundary (vbm25_stream_*).  -m gpu only."""
 import numpy as np
 import pytest
 
@@ -59,28 +59,6 @@ def test_multi_argument_errors():
         multi.search_batch(np.zeros(1, dtype=np.uint32), np.array([0, 1], dtype=np.uint32), 0)
     h, n = multi.search_batch(np.zeros(0, dtype=np.uint32), np.array([0], dtype=np.uint32), 10)  # no queries
     assert len(n) == 0
-
-
-@pytest.mark.parametrize("team_size", [4, 8])
-def test_team_kernel_matches_the_oracle(tuning, team_size):
-    """scan_team_kernel (tuning team = 1: the round-4 alternative to scan_range_kernel): bit-exact against the canonical
-    brute force on sparse queries of 1..16 terms, k up to 256, a corpus with tails and wide blocks."""
-    c, seg = _setup(300_000, 4000, seed=3)
-    oix = orc.OracleIndex.from_arrays(seg.meta(), seg.arrays())
-    gix = vb.GpuIndex(seg)
-    tuning(team=1, team_size=team_size, fused=0)
-    for nterms, k in ((1, 10), (2, 10), (5, 10), (8, 64), (16, 100), (5, 256)):
-        terms, off = make_queries(c, 96, nterms, seed=100 + nterms)
-        b = vb.Batch(gix, 96, len(terms), k)
-        b.set_queries(terms, off)
-        for _ in range(2):
-            b.run()
-            hits, nh = b.fetch()
-            ob, onb, _ = oix.search_batch(terms, off, k, mode="brute", threads=8)
-            assert np.array_equal(nh, onb)
-            for q in range(96):
-                assert_bit_exact(ob[q, :onb[q]], hits[q, :nh[q]], what=f"team {team_size} terms {nterms} k {k} q{q}")
-        assert b.debug_counts()[1] == 0
 
 
 def test_prefilter_by_over_fetch_matches_the_filtered_ranking():

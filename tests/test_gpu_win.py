@@ -56,7 +56,7 @@ def bench_queries(seg, vocab, nq, nterms, seed, zipf_s=0.0):
     return mq(seg, vocab, nq, nterms, seed=seed, zipf_s=zipf_s)
 
 
-@pytest.mark.parametrize("k,items", [(1, 0), (10, 0), (64, 0), (10, 192), (10, 400)])
+@pytest.mark.parametrize("k,items", [(1, 0), (10, 0), (64, 0), (100, 0), (256, 0), (10, 192), (10, 400), (200, 192)])
 def test_c3_shape_scaled_down_takes_the_window_kernel(tuning, k, items):
     """(items: work items of the batch -- 192 = one per query: all of its eleven windows in one item, the window loop's steady state)
     C3's shape (33 k vocabulary, 100 draws per document: about 190 postings per term and 2^16-document window) at 700 k documents:

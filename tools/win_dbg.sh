@@ -1,6 +1,6 @@
 # timing experiments on scan_win_kernel (wrong results by design): which part costs what
 R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/${1:-r5c}; mkdir -p $O; cd $R
-for t in ${TUNES:-team_dbg=0 team_dbg=1 team_dbg=3 team_dbg=7 win=0}; do
+for t in ${TUNES:-dbg=0 dbg=1 dbg=3 dbg=7 win=0}; do
   timeout 200 python bench.py --no-cpu-baseline --no-verify-sample --steps 100 --extra-budget-s 0 --tune $t 2>/dev/null | python -c "
 import json,sys
 d=json.loads(sys.stdin.read()); print('$t', 'kernel_ms', d['roofline']['kernel_ms'], 'step', d['ms_per_step'])"

@@ -1,6 +1,7 @@
 // device_types.h -- device-side views of the index and of one batch; constants of the kernels.
 // Part of libvbm25's single device translation unit: included by search.hip inside namespace vbm25, in
-// this order: device_types, decode, plan, topk_lds, block_fetch, topk_reg, scan_range, scan_dense, scan_many, merge.
+// this order: device_types, decode, plan, topk_lds, block_fetch, topk_reg, scan_range, scan_dense, scan_many, merge (scan_win.hip:
+// device_types, decode, topk_lds, block_fetch, topk_reg, scan_win).
 
 // ---------------------------------------------------------------------------
 // Device-side view of the index and of one batch
@@ -22,11 +23,6 @@ struct DevIndex {
     const uint8_t *post_fn;      // derived: fieldnorm of every posting, 128 bytes per block
     const uint32_t *post_rel16;  // derived: 64 words per block -- word l = (id[2l + 1] - min_doc) << 16 | (id[2l] - min_doc) of a
                                  // full bit-packed block that spans < 2^16 documents (rel16_block), undefined for the others
-    const uint2 *term_loc;       // derived: per term {first entry in blk_loc, log2 of the bucket width}
-    const uint32_t *blk_loc;     // derived: bucket locator -- entry b of a term = its first block whose last document is >= b << shift
-                                 // (term_first_block[t + 1] if none); (n_docs >> shift) + 2 entries per term, buckets of about one block span
-    const uint4 *blk_piv;        // derived: per block with a post_rel16 word its ids 15, 31, ..., 127 (relative, 16 bits each): the first
-                                 // level of scan_team_kernel's search for one document of the block
     const uint32_t *post_tfn;    // derived: 64 words per block -- word l = tf[2l] | tf[2l + 1] << 8 | fieldnorm[2l] << 16 |
                                  // fieldnorm[2l + 1] << 24 of a full block whose term frequencies are bit-packed in <= 7 bits
                                  // (tfn_block), undefined for the others
@@ -99,8 +95,7 @@ struct DevBatch {
     uint32_t win_cut[17];      // ... item `part` of a query = the windows [win_cut[part], win_cut[part + 1]) when win_g <= 16 and
                                // win_cut[win_g] != 0 (runs of decreasing length, handed out longest first: the last items drawn
                                // are the short ones); equal runs n_win part / win_g otherwise
-    uint32_t *team_cand;       // scan_team_kernel: TM_CAND candidate documents per wave of its grid
-    uint32_t team_dbg;         // development switch of scan_team_kernel (timing only, wrong results): 1 = candidates are not completed
+    uint32_t win_dbg;          // development switch of scan_win_kernel (timing experiments only, wrong results; scan_win.h)
     uint32_t *dbg;             // -DVBM25_CHECK builds: [0] first violated check (0: none), [1] value, [2] item, [3] thread
 };
 
@@ -147,3 +142,4 @@ constexpr int PLAN_BUCKETS = 512;      // of plan_kernel's sort of the items by 
 constexpr int CUR_HB = 256;            // score buckets of the per-query histogram of accepted documents
 constexpr int REG_K = 256;                // largest k whose running top-k lives in registers
 constexpr uint32_t NONE32 = 0xffffffffu;
+constexpr int KTH_LEVELS = 9;            // term_kth_ub: the 2^i-th largest block maximum of a term, i = 0..8

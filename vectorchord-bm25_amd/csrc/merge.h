@@ -64,7 +64,7 @@ __global__ void __launch_bounds__(64) merge_kernel(DevIndex ix, DevBatch bt) {
                     const bool hb = lane < nsv;
                     rtop.template offer<true>(hb, hb ? s_sv_score[lane] : 0.0, hb ? s_sv_doc[lane] : 0u, k, lane);
                 }
-                rtop.template offer<true>(has, sc, d, k, lane);  // (scan_team_kernel: a document may be in two waves' lists)
+                rtop.template offer<true>(has, sc, d, k, lane);  // (a document offered twice is kept once)
             }
             __builtin_amdgcn_wave_barrier();
         }

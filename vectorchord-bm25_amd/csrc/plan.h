@@ -11,7 +11,6 @@ struct PostFnArgs {
     const uint8_t *blob, *doc_fieldnorm;
     uint8_t *post_fn;
     uint32_t *post_rel16, *post_tfn;
-    uint4 *blk_piv;
     uint32_t *post_id16, *win_off;   // scan_win_kernel's planes (device_types.h); term_win says which terms have a table
     const uint32_t *term_win;
     uint32_t n_win;
@@ -50,13 +49,6 @@ __global__ void __launch_bounds__(256) post_fn_kernel(PostFnArgs a) {
     if (bad) atomicOr(a.error_flag, 1u);
     reinterpret_cast<uchar2 *>(a.post_fn + 128ull * j)[lane] = make_uchar2(f0, f1);
     a.post_rel16[64ull * j + lane] = rel16_block(m.x, m.y, m.w) ? (d1 - m.x) << 16 | (d0 - m.x) : 0u;
-    {   // every 16th id of the block (ids 15, 31, ..., 127 sit in lanes 7, 15, ..., 63)
-        const uint32_t pr = rel16_block(m.x, m.y, m.w) ? d1 - m.x : 0u;
-        uint32_t pv[8];
-#pragma unroll
-        for (int u = 0; u < 8; ++u) pv[u] = (uint32_t)__shfl((int)pr, 8 * u + 7);
-        if (lane == 0) a.blk_piv[j] = make_uint4(pv[0] | pv[1] << 16, pv[2] | pv[3] << 16, pv[4] | pv[5] << 16, pv[6] | pv[7] << 16);
-    }
 
     // The WAND pairs must bound every posting: Cache::evaluate of each posting against the block's
     // bound (blk_ub, margin included) and the token's (search.rs:363,377-380).
@@ -161,25 +153,6 @@ __global__ void __launch_bounds__(256) kth_pick_kernel(uint32_t n_terms, const u
     const uint32_t b0 = term_first_block[t], nb = term_first_block[t + 1] - b0, at = (1u << i) - 1u;
     kth[e] = at < nb ? sorted[b0 + at] : 0.0;
 }
-// bucket locator: entry b of term t = its first block whose last document is >= b << shift (term_first_block[t + 1] if none)
-__global__ void __launch_bounds__(256) loc_kernel(uint32_t n_terms, uint32_t n_docs, const uint32_t *term_first_block, const uint2 *term_loc,
-                                                  const uint32_t *blk_max_doc, uint32_t *blk_loc) {
-    const uint32_t t = blockIdx.x;
-    if (t >= n_terms) return;
-    const uint32_t b0 = term_first_block[t], b1 = term_first_block[t + 1];
-    const uint2 tl = term_loc[t];
-    const uint32_t n_buckets = (n_docs >> tl.y) + 2u;
-    for (uint32_t b = threadIdx.x; b < n_buckets; b += blockDim.x) {
-        const unsigned long long start = (unsigned long long)b << tl.y;
-        uint32_t lo = b0, hi = b1;
-        while (lo < hi) {
-            const uint32_t mid = (lo + hi) >> 1;
-            if ((unsigned long long)blk_max_doc[mid] < start) lo = mid + 1; else hi = mid;
-        }
-        blk_loc[tl.x + b] = lo;
-    }
-}
-
 // ---------------------------------------------------------------------------
 // Planner
 // ---------------------------------------------------------------------------

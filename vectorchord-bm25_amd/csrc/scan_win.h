@@ -1,5 +1,5 @@
 // scan_win.h -- scan_win_kernel: the document-WINDOW formulation of the sparse posting scan (queries of <= WN_T indexed terms
-// whose lists are of comparable length, k <= 64): the dominant kernel of C3.
+// whose lists are of comparable length; k <= 256 with at most five terms, k <= 64 with more): the dominant kernel of C3.
 // Part of libvbm25's device code: included inside namespace vbm25 after device_types, decode, topk_lds, block_fetch, topk_reg.
 //
 // Replaces the traversal of search.rs:149-280 (the WAND main loop) for these queries.  What the loop computes -- the k best sums of
@@ -188,7 +188,8 @@ struct WnPend {
     uint32_t x, te, p, w, gw;
 };
 
-template <int MT>
+// RK: rows of 64 entries of the wave's top-k in registers (k <= 64 RK)
+template <int MT, int RK>
 __global__ void __launch_bounds__(wn_waves(MT) * 64, (wn_waves(MT) + 3) / 4) scan_win_kernel(DevIndex ix, DevBatch bt) {
     constexpr int WN_WAVES = wn_waves(MT), WN_WG = WN_WAVES * 64;
     static_assert(sizeof(WinWave<MT>) == 512 * MT + 256 + 512, "wn_waves() knows the size");
@@ -203,7 +204,7 @@ __global__ void __launch_bounds__(wn_waves(MT) * 64, (wn_waves(MT) + 3) / 4) sca
     bmbase.mask = 0x1ffcu;
     asm volatile("" : "+v"(bmbase.mask));
     const uint32_t k = bt.k, g = bt.win_g, n_items = bt.nq * g, NWIN = ix.n_win;
-    const uint32_t dbg = bt.team_dbg;  // timing experiments (wrong results): 1 no cold pass, 2 no completion, 4 no second arrivals, 32 no marks, 64 no wipe
+    const uint32_t dbg = bt.win_dbg;  // timing experiments (wrong results): 1 no cold pass, 2 no completion, 4 no second arrivals, 32 no marks, 64 no wipe
     const uint16_t *ids16 = reinterpret_cast<const uint16_t *>(ix.post_id16);
     for (uint32_t i = threadIdx.x; i < 256u; i += WN_WG) S1[i] = ix.s1[i];
 #pragma unroll
@@ -324,7 +325,7 @@ __global__ void __launch_bounds__(wn_waves(MT) * 64, (wn_waves(MT) + 3) / 4) sca
             if (item + 1 == n_items) ca->bt.q_item_base[q + 1] = n_items;
         }
 
-        RegTopK<1> rtop;
+        RegTopK<RK> rtop;
         rtop.init();
         unsigned long long published = 0;
         auto offer = [&](bool has, double sc, uint32_t d) {
@@ -711,10 +712,12 @@ __global__ void __launch_bounds__(wn_waves(MT) * 64, (wn_waves(MT) + 3) / 4) sca
         const uint32_t nres = failed ? 0u : rtop.cnt;
         const KernArgsP ce = cold_args();
         const size_t list = (size_t)item * ce->bt.lpi;
-        if (lane < nres) {
-            ce->bt.res_score[list * k + lane] = rtop.score[0];
-            ce->bt.res_doc[list * k + lane] = rtop.doc[0];
-        }
+#pragma unroll
+        for (int r = 0; r < RK; ++r)
+            if (r * 64 + lane < nres) {
+                ce->bt.res_score[list * k + r * 64 + lane] = rtop.score[r];
+                ce->bt.res_doc[list * k + r * 64 + lane] = rtop.doc[r];
+            }
         if (lane == 0) {
             ce->bt.res_cnt[list] = nres;
             ce->bt.item_failed[item] = failed ? 0x101u : 0u;

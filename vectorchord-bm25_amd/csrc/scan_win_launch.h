@@ -2,5 +2,5 @@
 hipError_t scan_win_launch(const DevIndex &ix, const DevBatch &bt, uint32_t mt, uint32_t grid, hipStream_t st);
 uint32_t scan_win_resident_waves(uint32_t mt);  // persistent waves of a full grid (mt: as above)
 uint32_t scan_win_max_terms();       // indexed terms per query
-uint32_t scan_win_max_k();
+uint32_t scan_win_max_k(uint32_t mt);  // the largest k of a batch whose queries have at most mt indexed terms
 uint32_t scan_win_wg(uint32_t mt);              // waves (= work items in flight) per workgroup

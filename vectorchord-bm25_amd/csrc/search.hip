@@ -3,8 +3,9 @@
 // (bm25::search) for the sealed segment.  One translation unit; the kernels live in headers:
 //   plan.h         post_fn_kernel (index preparation: per-posting fieldnorm stream + validation of block
 //                  structure and WAND bounds) and plan_kernel (queries -> doc-range work items)
-//   scan_team.h    scan_team_kernel: sparse queries of <= 16 terms, k <= 256 (the dominant kernel: C3)
-//   scan_range.h   scan_range_kernel: the same queries on the one-launch route of vbm25_search_batch (C2) and behind the `team` switch
+//   scan_win.h     scan_win_kernel (its own translation unit, scan_win.hip): sparse queries of <= 8 terms of comparable length, k <= 64 --
+//                  the document-window formulation, the dominant kernel of C3
+//   scan_range.h   scan_range_kernel: every other sparse query of <= 16 terms, k <= 256; the one-launch route of vbm25_search_batch (C2)
 //   scan_dense.h   scan_dense_kernel: queries with many postings per document (Zipf head terms; C5), <= 16 terms, k <= 256
 //   scan_many.h    scan_many_kernel: up to 1024 terms, 256 < k <= 1024, items the others gave up (exhaustive)
 //   merge.h        merge_kernel: per-item top-k lists -> hits with payloads
@@ -61,7 +62,6 @@ int set_error(int code, const char *fmt, ...) {
 #include "topk_reg.h"
 #include "scan_range.h"
 #include "scan_win_launch.h"
-#include "scan_team.h"
 #include "scan_dense.h"
 #include "scan_many.h"
 #include "merge.h"
@@ -199,7 +199,7 @@ struct vbm25_index {
     std::vector<uint32_t> term_df_host;  // host copy for query routing
     vbm25_batch *scratch = nullptr;      // batch object re-used by vbm25_search_batch
     DeviceBuffer term_wand_tf, term_wand_fn, term_df, term_first_block, term_s0, blk_min_doc, blk_max_doc, blk_meta, blk_ub, blob,
-        post_fn, post_rel16, post_tfn, doc_payload, s1, term_idf, fn_len, term_kth_ub, blk_piv, term_loc, blk_loc, post_id16, win_off, term_win;
+        post_fn, post_rel16, post_tfn, doc_payload, s1, term_idf, fn_len, term_kth_ub, post_id16, win_off, term_win;
     std::vector<uint32_t> term_win_host;  // host copy of term_win (query routing); empty: the index has no window planes
     uint32_t n_win = 0;
     double k1 = 1.2;
@@ -217,10 +217,7 @@ struct Tuning {
     uint32_t dense_items = D_TARGET_ITEMS;
     uint32_t range_items = R_TARGET_ITEMS, range_min_chunk = R_MIN_CHUNK_POSTINGS;
     uint32_t range_grid = R_GRID, dense_grid = D_GRID;
-    int team = 0;                  // 1: sparse queries on the general route take scan_team_kernel (the round-4 alternative) instead of scan_range_kernel
-    uint32_t team_size = 4;        // waves per team: 4 (four workgroups per CU) or 8 (two)
-    uint32_t team_items = 2048;    // work items of a batch on that route
-    uint32_t team_dbg = 0;         // timing experiments only
+    uint32_t dbg = 0;              // timing experiments of scan_win_kernel only (wrong results)
     uint32_t fused_items = 128;    // the one-launch route takes batches of up to this many work items
     int arith = 1;                 // batches of sparse queries beyond that: work items made by the scan kernel (no plan_kernel)
     int win = 1;                   // batches of sparse queries of <= 8 comparable terms, k <= 64: scan_win_kernel (the window formulation)
@@ -245,7 +242,7 @@ struct vbm25_batch {
     int device = 0;  // the index's device ordinal: the batch can be destroyed after its index
     uint32_t max_queries = 0, max_terms = 0, k = 0, nq = 0, max_items = 0;
     DeviceBuffer term_ids, q_off, items, n_items, q_item_base, theta, res_score, res_doc, res_cnt,
-        hits, n_hits, error_flag, prof, q_dense, item_failed, item_order, work_ctr, hist, fused_state, dbg, team_cand, fail_any, q_failed, theta_last;
+        hits, n_hits, error_flag, prof, q_dense, item_failed, item_order, work_ctr, hist, fused_state, dbg, fail_any, q_failed, theta_last;
     bool bigk = false;            // k > 1024: exhaustive path, one query at a time
     DeviceBuffer bk_acc, bk_keys, bk_iota, bk_docs, bk_tmp;
     size_t bk_tmp_bytes = 0;
@@ -303,7 +300,7 @@ DeviceBuffer vbm25_index::*const INDEX_BUFFERS[] = {
     &vbm25_index::term_wand_tf, &vbm25_index::term_wand_fn, &vbm25_index::term_df, &vbm25_index::term_first_block, &vbm25_index::term_s0,
     &vbm25_index::blk_min_doc, &vbm25_index::blk_max_doc, &vbm25_index::blk_meta, &vbm25_index::blk_ub, &vbm25_index::blob,
     &vbm25_index::post_fn, &vbm25_index::post_rel16, &vbm25_index::post_tfn, &vbm25_index::doc_payload, &vbm25_index::s1,
-    &vbm25_index::term_idf, &vbm25_index::fn_len, &vbm25_index::term_kth_ub, &vbm25_index::blk_piv, &vbm25_index::term_loc, &vbm25_index::blk_loc,
+    &vbm25_index::term_idf, &vbm25_index::fn_len, &vbm25_index::term_kth_ub,
     &vbm25_index::post_id16, &vbm25_index::win_off, &vbm25_index::term_win};
 
 void fill_dev(vbm25_index *ix) {
@@ -323,9 +320,6 @@ void fill_dev(vbm25_index *ix) {
     ix->dev.post_fn = ix->post_fn.as<uint8_t>();
     ix->dev.post_rel16 = ix->post_rel16.as<uint32_t>();
     ix->dev.post_tfn = ix->post_tfn.as<uint32_t>();
-    ix->dev.blk_piv = ix->blk_piv.as<uint4>();
-    ix->dev.term_loc = ix->term_loc.as<uint2>();
-    ix->dev.blk_loc = ix->blk_loc.as<uint32_t>();
     ix->dev.doc_payload = ix->doc_payload.as<uint16_t>();
     ix->dev.s1 = ix->s1.as<double>();
     ix->dev.term_kth_ub = ix->term_kth_ub.as<double>();  // (NULL when the block maxima are not attained)
@@ -404,7 +398,7 @@ static int index_create_common(const RawSegment &r, int device, vbm25_index **ou
     const bool has_wand = r.blk_wand_fn && r.blk_wand_tf;
 
     // per-term s0 = idf (k1 + 1), idf (vbm25_evaluate_batch) -- host libm log, bm25.rs:285-289,348 -- and the s1 table of
-    // bm25.rs:349-352; the bucket locator's geometry
+    // bm25.rs:349-352
     std::vector<double> s0(r.n_terms), idf(r.n_terms);
     for (uint32_t t = 0; t < r.n_terms; ++t) {
         s0[t] = bm25_s0(r.n_docs, r.term_df_host[t], r.k1);
@@ -412,18 +406,6 @@ static int index_create_common(const RawSegment &r, int device, vbm25_index **ou
     }
     double s1[256];
     bm25_tables(r.n_docs, r.sum_len, r.k1, r.b, s1);
-    std::vector<uint32_t> loc_off(2ull * r.n_terms);
-    uint64_t n_loc = 0;
-    for (uint32_t t = 0; t < r.n_terms; ++t) {  // buckets of about one block span
-        const uint64_t nb = std::max<uint32_t>(r.term_first_block_host[t + 1] - r.term_first_block_host[t], 1u);
-        uint32_t sh = 8;
-        while (sh < 31 && (uint64_t(r.n_docs) >> sh) > nb) ++sh;
-        loc_off[2ull * t] = uint32_t(n_loc);
-        loc_off[2ull * t + 1] = sh;
-        n_loc += (r.n_docs >> sh) + 2u;
-        if (n_loc > 0xfffffff0ull) return set_error(VBM25_ERR_UNSUPPORTED, "block locator exceeds 2^32 entries");
-    }
-
     // scan_win_kernel's planes: the low 16 bits of every id in posting order, and for every term with at least a posting per four
     // windows the table of its n_win + 1 window offsets (a rarer term's table would be larger than its list)
     const bool win_planes = tuning_snapshot().win_planes != 0 && r.n_blocks != 0;
@@ -474,9 +456,6 @@ static int index_create_common(const RawSegment &r, int device, vbm25_index **ou
         (rc = ix->post_tfn.alloc(256ull * r.n_blocks + 1024)) ||  // (slack: scan_win_kernel's cold pass reads whole runs)
         (win_planes && ((rc = ix->post_id16.alloc(256ull * r.n_blocks + 1024)) || (rc = ix->win_off.alloc(4ull * n_woff)) ||
                         (rc = ix->term_win.upload(term_win.data(), 4ull * r.n_terms)))) ||
-        (rc = ix->blk_piv.alloc(16ull * r.n_blocks)) ||
-        (rc = ix->term_loc.upload(loc_off.data(), 4ull * loc_off.size())) ||
-        (rc = ix->blk_loc.alloc(4ull * n_loc)) ||
         (rc = put(ix->doc_payload, r.doc_payload, 6ull * r.n_docs)) ||
         (rc = ix->s1.upload(s1, sizeof s1)) || (rc = err.alloc(4)))
         return rc;
@@ -485,7 +464,7 @@ static int index_create_common(const RawSegment &r, int device, vbm25_index **ou
     if (r.blob_bytes) HIP_TRY(hipMemcpy(ix->blob.p, r.blob, r.blob_bytes, kind));
     if (r.n_blocks) {
         if (has_wand && ((rc = t_raw.alloc(8ull * r.n_blocks)) || (rc = t_sorted.alloc(8ull * r.n_blocks)) ||
-                         (rc = ix->term_kth_ub.alloc(8ull * TM_KTH * r.n_terms))))
+                         (rc = ix->term_kth_ub.alloc(8ull * KTH_LEVELS * r.n_terms))))
             return rc;
         DeriveArgs da{};
         da.n_blocks = r.n_blocks;
@@ -520,12 +499,9 @@ static int index_create_common(const RawSegment &r, int device, vbm25_index **ou
             if ((rc = t_tmp.alloc(tb))) return rc;
             HIP_TRY(hipcub::DeviceSegmentedRadixSort::SortKeysDescending(t_tmp.p, tb, t_raw.as<double>(), t_sorted.as<double>(), (int)r.n_blocks,
                                                                         (int)r.n_terms, seg, seg + 1));
-            kth_pick_kernel<<<(r.n_terms * TM_KTH + 255) / 256, 256>>>(r.n_terms, seg, t_sorted.as<double>(), ix->term_kth_ub.as<double>());
+            kth_pick_kernel<<<(r.n_terms * KTH_LEVELS + 255) / 256, 256>>>(r.n_terms, seg, t_sorted.as<double>(), ix->term_kth_ub.as<double>());
             HIP_TRY(hipGetLastError());
         }
-        loc_kernel<<<r.n_terms, 256>>>(r.n_terms, r.n_docs, ix->term_first_block.as<uint32_t>(), ix->term_loc.as<uint2>(),
-                                       ix->blk_max_doc.as<uint32_t>(), ix->blk_loc.as<uint32_t>());
-        HIP_TRY(hipGetLastError());
         const uint32_t grid = (r.n_blocks + 3) / 4;
         PostFnArgs pa{};
         pa.n_blocks = r.n_blocks;
@@ -537,7 +513,6 @@ static int index_create_common(const RawSegment &r, int device, vbm25_index **ou
         pa.post_fn = ix->post_fn.as<uint8_t>();
         pa.post_rel16 = ix->post_rel16.as<uint32_t>();
         pa.post_tfn = ix->post_tfn.as<uint32_t>();
-        pa.blk_piv = ix->blk_piv.as<uint4>();
         pa.post_id16 = ix->post_id16.as<uint32_t>();
         pa.win_off = ix->win_off.as<uint32_t>();
         pa.term_win = ix->term_win.as<uint32_t>();
@@ -584,7 +559,7 @@ static int index_create_common(const RawSegment &r, int device, vbm25_index **ou
     ix->dev.blk_ub_attained = has_wand && !(flag & 4u) ? 1u : 0u;
     for (const DeviceBuffer *b : {&ix->term_df, &ix->term_first_block, &ix->term_s0, &ix->blk_min_doc,
                                   &ix->blk_max_doc, &ix->blk_meta, &ix->blk_ub, &ix->blob, &ix->post_fn,
-                                  &ix->post_rel16, &ix->post_tfn, &ix->blk_piv, &ix->term_loc, &ix->blk_loc, &ix->term_kth_ub, &ix->doc_payload, &ix->s1,
+                                  &ix->post_rel16, &ix->post_tfn, &ix->term_kth_ub, &ix->doc_payload, &ix->s1,
                                   &ix->post_id16, &ix->win_off, &ix->term_win})
         ix->device_bytes += b->bytes;
     *out = ix.release();
@@ -706,11 +681,11 @@ static int vbm25_batch_create_impl(vbm25_index *ix, uint32_t max_queries, uint32
     bt->use_range = k <= (uint32_t)REG_K;
     bt->lpi = bt->use_range ? (uint32_t)RNW : 1u;
     bt->use_dense = bt->use_range && k <= (uint32_t)D_KMAX && bt->tune.dense != 0;
-    bt->target_items = bt->use_range ? std::max(256u, bt->tune.team ? bt->tune.team_items : bt->tune.range_items) : TARGET_ITEMS;
+    bt->target_items = bt->use_range ? std::max(256u, bt->tune.range_items) : TARGET_ITEMS;
     bt->min_chunk = bt->use_range ? std::max(128u, bt->tune.range_min_chunk) : MIN_CHUNK_POSTINGS;
     bt->max_items = max_queries + bt->target_items + (bt->use_dense ? std::max(256u, bt->tune.dense_items) : 0u);
     // scan_win_kernel's items are one wave's work each (a few per query): room for them
-    if (bt->use_range && k <= scan_win_max_k() && bt->tune.win && !ix->term_win_host.empty())
+    if (bt->use_range && k <= scan_win_max_k(1) && bt->tune.win && !ix->term_win_host.empty())
         bt->max_items = std::max(bt->max_items, std::max(8192u, 8u * max_queries));
     int rc = 0;
     if (k > 1024) {  // exhaustive path: query buffers, results and an accumulator per document
@@ -758,8 +733,6 @@ static int vbm25_batch_create_impl(vbm25_index *ix, uint32_t max_queries, uint32
     HIP_TRY(hipMemset(bt->hist.p, 0, 4ull * CUR_HB * max_queries));
     HIP_TRY(hipMemset(bt->item_failed.p, 0, 4ull * bt->max_items));
     HIP_TRY(hipMemset(bt->res_cnt.p, 0, 4ull * bt->max_items * bt->lpi));
-    if (bt->use_range && bt->tune.team)  // one candidate list per wave of scan_team_kernel's grid (1024 x 4 or 512 x 8 waves)
-        if (int rc2 = bt->team_cand.alloc(4ull * TM_CAND * 4096)) return rc2;
     if (int rc2 = bt->dbg.alloc(64)) return rc2;
     HIP_TRY(hipMemset(bt->dbg.p, 0, 64));
 #ifdef VBM25_PROFILE
@@ -866,7 +839,7 @@ static int vbm25_batch_set_queries_impl(vbm25_batch *bt, const uint32_t *term_id
             // per 2^16-document window (32 .. 232 postings on average: one 8-byte load per lane holds a run)
             uint32_t win_g = 0;
             const vbm25_index *ixh = bt->index;
-            if (bt->tune.win && bt->k <= scan_win_max_k() && !ixh->term_win_host.empty() && !bt->tune.team) {
+            if (bt->tune.win && bt->k <= scan_win_max_k(range_mt) && !ixh->term_win_host.empty()) {
                 const double wins = std::max(1.0, double(ixh->n_docs) / 65536.0);
                 double e_max = 1.0;
                 bool ok = true;
@@ -907,7 +880,7 @@ static int vbm25_batch_set_queries_impl(vbm25_batch *bt, const uint32_t *term_id
             if (bt->tune.fused && nq * g <= bt->tune.fused_items) {
                 bt->fused_g = uint32_t(g);
                 bt->fused_pinned = fast && nq <= 8 && !bt->timing;
-            } else if (win_g || (bt->tune.arith && !bt->tune.team)) {
+            } else if (win_g || bt->tune.arith) {
                 if (win_g) {
                     bt->win_g = win_g;
                     g = win_g;
@@ -1023,7 +996,7 @@ static int vbm25_batch_set_queries_impl(vbm25_batch *bt, const uint32_t *term_id
             if (c > bt->index->n_docs) c = bt->index->n_docs;
             items += c;
         }
-        bt->range_grid = uint32_t(std::min<unsigned long long>(std::max<unsigned long long>(items, 1), bt->tune.team ? 1024u : std::max(1u, bt->tune.range_grid)));
+        bt->range_grid = uint32_t(std::min<unsigned long long>(std::max<unsigned long long>(items, 1), std::max(1u, bt->tune.range_grid)));
         bt->dense_grid = uint32_t(std::min<unsigned long long>(std::max<unsigned long long>(items, 1), std::max(1u, bt->tune.dense_grid)));
 #ifdef VBM25_PROFILE
         bt->range_grid = std::min<uint32_t>(bt->range_grid, R_GRID);  // (the phase counters are sized for R_GRID workgroups)
@@ -1094,8 +1067,7 @@ static int vbm25_batch_run_impl(vbm25_batch *bt, void *hip_stream) {
     db.ne_on = bt->tune.ne ? 1u : 0u;
     db.ne_ratio = std::max(1u, bt->tune.ne_ratio);
     db.dense_on = bt->use_dense ? 1u : 0u;
-    db.team_dbg = bt->tune.team_dbg;
-    db.team_cand = bt->team_cand.as<uint32_t>();
+    db.win_dbg = bt->tune.dbg;
     db.fail_any = bt->fail_any.as<uint32_t>();
     db.q_failed = bt->q_failed.as<uint32_t>();
     db.theta_last = bt->theta_last.as<unsigned long long>();
@@ -1168,7 +1140,7 @@ static int vbm25_batch_run_impl(vbm25_batch *bt, void *hip_stream) {
         bt->state_clean = true;
         return VBM25_OK;
     }
-    if (bt->win_g && bt->k <= scan_win_max_k()) {
+    if (bt->win_g && bt->k <= scan_win_max_k(bt->win_mt)) {
         // Every query sparse, <= 8 terms of comparable length: scan_win_kernel (its waves make their work items themselves), then as
         // on the route below: scan_many_kernel leaves at once unless an item was given up, merge_kernel merges and cleans.
         const bool clean = bt->state_clean;
@@ -1220,9 +1192,15 @@ static int vbm25_batch_run_impl(vbm25_batch *bt, void *hip_stream) {
         const uint32_t wmt = bt->range_rt == 8 ? bt->win_mt : 8u, wpw = scan_win_wg(wmt);
         const uint32_t wgrid = std::min<uint32_t>((bt->nq * bt->win_g + wpw - 1u) / wpw, bt->tune.win_grid ? bt->tune.win_grid : scan_win_resident_waves(wmt) / wpw);
         HIP_TRY(scan_win_launch(ix, db, wmt, wgrid, st));
-        scan_many_kernel<64><<<64, WG, 0, st>>>(ix, db);
-        if (bt->timing) (void)hipEventRecord(e1, st);
-        merge_kernel<64><<<bt->nq, 64, 0, st>>>(ix, db);
+        (void)dispatch_k(bt->k, [&](auto kmax) {
+            constexpr int KM = decltype(kmax)::value;
+            if constexpr (KM <= REG_K) {
+                scan_many_kernel<KM><<<64, WG, 0, st>>>(ix, db);
+                if (bt->timing) (void)hipEventRecord(e1, st);
+                merge_kernel<KM><<<bt->nq, 64, 0, st>>>(ix, db);
+            }
+            return int(VBM25_OK);
+        });
         HIP_TRY(hipGetLastError());
         bt->state_clean = true;
         return VBM25_OK;
@@ -1272,10 +1250,7 @@ static int vbm25_batch_run_impl(vbm25_batch *bt, void *hip_stream) {
     const int rc = dispatch_k(bt->k, [&](auto kmax) {
         constexpr int KM = decltype(kmax)::value;
         if constexpr (KM <= REG_K) {
-            if (range && bt->range_rt && bt->tune.team) {  // persistent teams of waves; items are handed out through bt.work_ctr
-                if (bt->tune.team_size == 8) scan_team_kernel<KM, 8><<<std::min(bt->range_grid, 512u), 512, 0, st>>>(ix, db);
-                else scan_team_kernel<KM, 4><<<std::min(bt->range_grid, 1024u), 256, 0, st>>>(ix, db);
-            } else if (range) {  // persistent 8-wave workgroups
+            if (range) {  // persistent 8-wave workgroups
                 if (bt->range_rt == 8) scan_range_kernel<KM, 8><<<bt->range_grid, RWG, 0, st>>>(ix, db);
                 else if (bt->range_rt == 16) scan_range_kernel<KM, 16><<<bt->range_grid, RWG, 0, st>>>(ix, db);
             }
@@ -1435,8 +1410,8 @@ int vbm25_evaluate_batch(vbm25_index *ix, const uint32_t *q_terms, uint32_t n_q,
 }
 
 // tuning / test aid (not declared in include/vbm25.h): process-wide switches, read when a batch object is created.
-// Names: dense_x1000, dense, ne, fused, ne_ratio, dense_items, range_items, range_min_chunk, range_grid, dense_grid, team,
-// team_size, team_items.
+// Names: dense_x1000, dense, ne, fused, ne_ratio, dense_items, range_items, range_min_chunk, range_grid, dense_grid, fused_items, arith,
+// win, win_force, win_items, win_planes, win_guided, win_grid, win_skew, dbg.
 int vbm25_tuning_set(const char *name, long long value) {
     if (!name) return set_error(VBM25_ERR_INVALID, "NULL argument");
     std::lock_guard<std::mutex> guard(g_tune_mutex);
@@ -1451,10 +1426,7 @@ int vbm25_tuning_set(const char *name, long long value) {
     else if (n == "range_min_chunk") g_tune.range_min_chunk = (uint32_t)std::max(128ll, value);
     else if (n == "range_grid") g_tune.range_grid = (uint32_t)std::max(1ll, value);
     else if (n == "dense_grid") g_tune.dense_grid = (uint32_t)std::max(1ll, value);
-    else if (n == "team") g_tune.team = value != 0;
-    else if (n == "team_size") g_tune.team_size = value == 8 ? 8u : 4u;
-    else if (n == "team_items") g_tune.team_items = (uint32_t)std::max(256ll, value);
-    else if (n == "team_dbg") g_tune.team_dbg = (uint32_t)value;
+    else if (n == "dbg") g_tune.dbg = (uint32_t)value;
     else if (n == "fused_items") g_tune.fused_items = (uint32_t)std::max(0ll, value);
     else if (n == "arith") g_tune.arith = value != 0;
     else if (n == "win") g_tune.win = value != 0;

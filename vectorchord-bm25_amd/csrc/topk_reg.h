@@ -25,7 +25,7 @@ struct RegTopK {
         kth_d = 0;
     }
     // offer one candidate per lane (`has` marks validity); all 64 lanes call.  DEDUP: a candidate that is already in the
-    // list -- same document, same score bits (scan_team_kernel may score a document twice) -- is dropped.
+    // list -- same document, same score bits (a document that reaches the merge in two lists) -- is dropped.
     template <bool DEDUP = false>
     __device__ __forceinline__ void offer(bool has, double sc, uint32_t d, uint32_t k, uint32_t lane) {
         for (;;) {
