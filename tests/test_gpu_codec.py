@@ -5,7 +5,10 @@ declared dense) and the exhaustive scan_many_kernel (k = 300).  -m gpu only.
 
 * byte-packed TAIL blocks with document-id byte widths 3 and 4 (gaps >= 2^16 and >= 2^24; width 4 is raw absolute ids,
   bytepacking_u32_ordered.rs:200-214 -- its own branch in decode.h) and term-frequency byte widths 2 and 3;
-* full bit-packed blocks of EVERY document-id width 1..25 and tf width 1..17 (bitpacking_u32_ordered.rs:222-237)."""
+* full bit-packed blocks of EVERY document-id width 1..25 and tf width 1..17 (bitpacking_u32_ordered.rs:222-237);
+* widths 26, 27 and 28 on an index of 2^28 documents (a gap of w bits needs that many documents; 29..31 would need the
+  per-document arrays of 2^29..2^31 documents -- 5 to 21 GB on the host alone -- and stay with the decode unit tests of the
+  oracle and of index creation, which decodes every block of every index it is given)."""
 import numpy as np
 import pytest
 
@@ -116,3 +119,24 @@ def test_every_bit_width_of_full_blocks(tuning, seed):
     terms += list(range(nterm))        # all 26: beyond 16 terms -> scan_many_kernel in every route
     off.append(len(terms))
     _check_routes(tuning, gix, oix, np.array(terms, dtype=np.uint32), np.array(off, dtype=np.uint32), ks=(10,))
+
+
+def test_bit_widths_26_to_28_of_full_blocks(tuning):
+    n_docs = (1 << 28) + 200_000
+    rng = np.random.default_rng(7)
+    lists = []
+    for w in (26, 27, 28):  # 128 postings, ONE gap with bit w - 1 set
+        gaps = rng.integers(1, 400, 128)
+        gaps[0] = 0
+        gaps[rng.integers(1, 128)] = rng.integers(1 << (w - 1), (1 << w) - 60_000)
+        docs = rng.integers(0, 1000) + np.cumsum(gaps)
+        lists.append((docs, rng.integers(1, 4, 128)))
+    mix = np.unique(np.concatenate([d[::7] for d, _ in lists] + [rng.integers(0, n_docs, 300)]))
+    lists.append((mix, rng.integers(1, 4, len(mix))))
+    seg, a, gix, oix = _index(n_docs, lists, 3)
+    first = a["term_first_block"]
+    for i, w in enumerate((26, 27, 28)):
+        assert a["blk_meta_doc"][first[i]] == w, (w, a["blk_meta_doc"][first[i]])
+    terms = np.array([0, 0, 3, 1, 1, 3, 2, 2, 3, 0, 1, 2, 3], dtype=np.uint32)
+    off = np.array([0, 1, 3, 4, 6, 7, 9, 13], dtype=np.uint32)
+    _check_routes(tuning, gix, oix, terms, off, ks=(10,))

@@ -455,15 +455,19 @@ def test_c3_full_size_full_batch_parity():
     import time
     sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
     from bench import make_queries as bench_queries, usable_cpus
-    seg = vb.Segment.synth(10_000_000, 30000, mean_len=100, len_mode=1, seed=20260925, threads=usable_cpus())
-    gix = vb.GpuIndex(seg)
-    terms, off = bench_queries(seg, 30000, 1024, 5, seed=1, zipf_s=0.0)
+    # (the bench's own corpus: generated, flushed and indexed ON THE DEVICE -- the oracle gets the segment's download)
+    dseg = vb.DeviceSegment.synth(10_000_000, 30000, mean_len=100, len_mode=1, seed=20260925, device=0)
+    gix = vb.GpuIndex(dseg)
+    terms, off = bench_queries(dseg, 30000, 1024, 5, seed=1, zipf_s=0.0)
+    seg = dseg.download()
     b = vb.Batch(gix, 1024, len(terms), 10)  # (the bench's own object and call sequence)
+    b.set_queries(terms, off)
+    assert b.debug_route() == 3, "the bench line would not be scan_win_kernel's"
     b.set_queries(terms, off)
     b.run()
     hits, nh = b.fetch()
     items, failed = b.debug_counts()
-    assert failed == 0, f"{failed} of {items} work items fell back to scan_many_kernel: the bench line would not be scan_range_kernel's"
+    assert failed == 0, f"{failed} of {items} work items fell back to scan_many_kernel: the bench line would not be scan_win_kernel's"
     assert (nh == 10).all()
     h1, n1 = vb.search_batch(gix, terms, off, 10)
     assert h1.tobytes() == hits.tobytes() and np.array_equal(n1, nh)

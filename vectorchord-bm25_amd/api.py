@@ -406,19 +406,22 @@ class Stream:
         return int(lib().vbm25_stream_in_flight(self.h))
 
 
-def search_batch_filtered(index, term_ids, q_off, k, keep, overfetch=2):
+def search_batch_filtered(index, term_ids, q_off, k, keep, overfetch=2, return_truncated=False):
     """`prefilter = on` (default.rs:120-128, fetcher.rs:180-216: a candidate enters Results only if filter(payload) holds -- a heap
     visibility check the GPU cannot make) as the shim runs it: OVER-FETCH and filter on the host.  The GPU returns overfetch * k
     hits per query; the host keeps those `keep(hits) -> bool array` accepts; a query left with fewer than k accepted hits although
     the GPU delivered a full list is asked again, four times deeper, until k survive or its matches are exhausted (bm25.limit's
     maximum, 65535, bounds the depth as it bounds the reference's k).  Exact: the accepted hits are the first k accepted of the
     unfiltered ranking, which is what the reference's filtered search returns (ties aside).  Returns (hits[nq, k], n_hits[nq],
-    rounds)."""
+    rounds); with `return_truncated=True` a fourth value: per query, True when the depth reached bm25.limit's maximum with fewer than
+    k accepted hits although the GPU's list was full -- the answer may then miss accepted documents beyond rank 65535 (the
+    reference's k is bounded the same way)."""
     term_ids = np.ascontiguousarray(term_ids, dtype=np.uint32)
     q_off = np.ascontiguousarray(q_off, dtype=np.uint32)
     nq = len(q_off) - 1
     out = np.zeros((nq, max(k, 1)), dtype=HIT_DTYPE)
     n_out = np.zeros(nq, dtype=np.uint32)
+    truncated = np.zeros(nq, dtype=bool)
     todo = np.arange(nq)
     depth = min(65535, max(k, int(k * overfetch)))
     rounds = 0
@@ -434,10 +437,13 @@ def search_batch_filtered(index, term_ids, q_off, k, keep, overfetch=2):
             if len(ok) >= k or n_hits[i] < depth or depth == 65535:  # enough, or the query has no more matches to offer
                 n_out[q] = min(k, len(ok))
                 out[q, :n_out[q]] = ok[:k]
+                truncated[q] = len(ok) < k and n_hits[i] == depth and depth == 65535
             else:
                 again.append(q)
         todo = np.array(again, dtype=np.int64)
         depth = min(65535, depth * 4)
+    if return_truncated:
+        return out, n_out, rounds, truncated
     return out, n_out, rounds
 
 

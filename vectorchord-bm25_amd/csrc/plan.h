@@ -19,6 +19,7 @@ struct PostFnArgs {
     const uint32_t *term_first_block, *term_wand_tf;
     const uint8_t *term_wand_fn;
     const double *term_s0, *s1, *blk_ub;
+    const double *blk_raw;  // the block maxima without the margin (NULL: no block WAND pairs): what "attained" is tested against
 };
 __global__ void __launch_bounds__(256) post_fn_kernel(PostFnArgs a) {
     const uint32_t lane = threadIdx.x & 63;
@@ -93,17 +94,21 @@ __global__ void __launch_bounds__(256) post_fn_kernel(PostFnArgs a) {
     // tfn_block blocks only; scan_win_kernel reads it for every posting -- tails included -- and takes a zero term frequency for
     // "wider than a byte")
     a.post_tfn[64ull * j + lane] = t0 <= 255u && t1 <= 255u ? t0 | t1 << 8 | (uint32_t)f0 << 16 | (uint32_t)f1 << 24 : 0u;
+    // (attained: the very score the k-th largest maxima are taken from -- blk_raw, no margin: compared after the margin two scores
+    // an ulp apart could round to the same value and a bound one ulp above every posting would pass)
+    const bool braw_ok = a.blk_raw != nullptr;
+    const double braw = braw_ok ? a.blk_raw[j] : 0.0;
     bool loose = false, attained = false;  // attained: the block's bound is the score of one of its postings (flag 4 if not: no error,
                                            // but the k-th largest block maxima are then no lower bound of anything)
     if (i0 < n) {
         const double tf = (double)t0, p = (tf * s0) / (tf + a.s1[f0]);
         loose |= p > bub || p > tub;
-        attained |= p * (1.0 + 1e-12) == bub;
+        attained |= braw_ok && p == braw;
     }
     if (i1 < n) {
         const double tf = (double)t1, p = (tf * s0) / (tf + a.s1[f1]);
         loose |= p > bub || p > tub;
-        attained |= p * (1.0 + 1e-12) == bub;
+        attained |= braw_ok && p == braw;
     }
     if (loose) atomicOr(a.error_flag, 2u);
     if (!__ballot(attained) && lane == 0) atomicOr(a.error_flag, 4u);

@@ -26,8 +26,11 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <condition_variable>
+#include <functional>
 #include <memory>
 #include <mutex>
+#include <thread>
 #include <string>
 #include <vector>
 
@@ -525,6 +528,7 @@ static int index_create_common(const RawSegment &r, int device, vbm25_index **ou
         pa.term_s0 = ix->term_s0.as<double>();
         pa.s1 = ix->s1.as<double>();
         pa.blk_ub = ix->blk_ub.as<double>();
+        pa.blk_raw = has_wand ? t_raw.as<double>() : nullptr;
         post_fn_kernel<<<grid, 256>>>(pa);
         HIP_TRY(hipGetLastError());
     }
@@ -1679,11 +1683,78 @@ int vbm25_stream_in_flight(const vbm25_stream *s) { return s ? int(s->in_flight)
 // ---------------------------------------------------------------------------
 }  // extern "C"
 
+// One host thread per device (round 5): a shard's set_queries -- validation, routing, staging in pinned memory: 80 us per 1024
+// queries -- and the enqueue of its scan were done for all the devices by the caller's thread, one after the other; at eight devices
+// that was 0.78 ms of host time per step against 0.28 ms of device time (profiles/r5_multi_enqueue.txt).  The workers live as long
+// as the vbm25_multi; a call hands every worker its part and waits for all of them.
+struct MultiWorker {
+    std::thread th;
+    std::mutex m;
+    std::condition_variable cv;
+    std::function<int()> job;  // (empty: none)
+    bool quit = false, done = true;
+    int rc = 0;
+    char err[sizeof g_error] = "";
+    void loop() {
+        std::unique_lock<std::mutex> lk(m);
+        for (;;) {
+            cv.wait(lk, [&] { return quit || job; });
+            if (quit) return;
+            std::function<int()> f = std::move(job);
+            job = nullptr;
+            lk.unlock();
+            const int r = f();
+            lk.lock();
+            rc = r;
+            if (r) std::memcpy(err, g_error, sizeof err);
+            done = true;
+            cv.notify_all();
+        }
+    }
+};
 struct vbm25_multi {
     std::vector<vbm25_index *> replicas;  // [0] is the one uploaded from the host
     vbm25_multi_batch *scratch = nullptr;  // batch object re-used by vbm25_multi_search_batch
+    std::vector<std::unique_ptr<MultiWorker>> workers;  // one per replica beyond the first (the caller's thread takes part 0)
     ~vbm25_multi() {
+        for (auto &w : workers) {
+            {
+                std::lock_guard<std::mutex> g(w->m);
+                w->quit = true;
+            }
+            w->cv.notify_all();
+            if (w->th.joinable()) w->th.join();
+        }
         for (vbm25_index *ix : replicas) vbm25_index_destroy(ix);
+    }
+    // fn(i) for every part i, concurrently; the first error (by part number) is the call's
+    int each_part(size_t n, const std::function<int(size_t)> &fn) {
+        while (workers.size() + 1 < n) {
+            workers.emplace_back(new MultiWorker);
+            MultiWorker *w = workers.back().get();
+            w->th = std::thread([w] { w->loop(); });
+        }
+        for (size_t i = 1; i < n; ++i) {
+            MultiWorker *w = workers[i - 1].get();
+            std::lock_guard<std::mutex> g(w->m);
+            w->done = false;
+            w->job = [&fn, i] { return fn(i); };
+            w->cv.notify_all();
+        }
+        int rc = n ? fn(0) : 0;
+        char err[sizeof g_error];
+        std::memcpy(err, g_error, sizeof err);
+        for (size_t i = 1; i < n; ++i) {
+            MultiWorker *w = workers[i - 1].get();
+            std::unique_lock<std::mutex> lk(w->m);
+            w->cv.wait(lk, [&] { return w->done; });
+            if (w->rc && !rc) {
+                rc = w->rc;
+                std::memcpy(err, w->err, sizeof err);
+            }
+        }
+        if (rc) std::memcpy(g_error, err, sizeof err);
+        return rc;
     }
 };
 struct vbm25_multi_batch {
@@ -1691,7 +1762,8 @@ struct vbm25_multi_batch {
     uint32_t max_queries = 0, max_terms = 0, k = 0, nq = 0;
     std::vector<vbm25_batch *> parts;      // one per replica
     std::vector<uint32_t> lo;              // shard bounds: replica i has the queries [lo[i], lo[i + 1])
-    std::vector<uint32_t> off_scratch;
+    std::vector<std::vector<uint32_t>> off_parts;  // per part: its queries' offsets rebased to 0
+    uint32_t tune_generation = 0;          // of the tuning switches its parts copied (vbm25_multi_search_batch rebuilds a stale one)
     ~vbm25_multi_batch() {
         for (vbm25_batch *b : parts) vbm25_batch_destroy(b);
     }
@@ -1777,6 +1849,7 @@ int multi_batch_create_impl(vbm25_multi *m, uint32_t max_queries, uint32_t max_t
         mb->parts.push_back(b);
     }
     mb->lo.assign(n + 1, 0);
+    mb->tune_generation = tuning_snapshot().generation;
     *out = mb.release();
     return VBM25_OK;
 }
@@ -1791,37 +1864,42 @@ int multi_batch_set_queries_impl(vbm25_multi_batch *mb, const uint32_t *term_ids
         const uint32_t base = nq / n, rem = nq % n;
         mb->lo[i] = i * base + std::min(i, rem);
     }
-    for (uint32_t i = 0; i < n; ++i) {
+    for (uint32_t i = 0; i < n; ++i)
+        if (q_off[mb->lo[i + 1]] < q_off[mb->lo[i]]) return set_error(VBM25_ERR_INVALID, "q_off not monotone");
+    mb->off_parts.resize(n);
+    // every shard by its device's own host thread: validation, routing and staging of the shards run side by side
+    return mb->multi->each_part(n, [&](size_t i) -> int {
         const uint32_t a = mb->lo[i], b = mb->lo[i + 1];
-        if (q_off[b] < q_off[a]) return set_error(VBM25_ERR_INVALID, "q_off not monotone");
-        mb->off_scratch.resize(size_t(b - a) + 1);
-        for (uint32_t q = a; q <= b; ++q) mb->off_scratch[q - a] = q_off[q] - q_off[a];
+        std::vector<uint32_t> &off = mb->off_parts[i];
+        off.resize(size_t(b - a) + 1);
+        for (uint32_t q = a; q <= b; ++q) off[q - a] = q_off[q] - q_off[a];
         // staged in the part's pinned memory, copied on its own stream: the devices' uploads overlap
-        if (int rc = vbm25_batch_set_queries_impl(mb->parts[i], term_ids ? term_ids + q_off[a] : nullptr, mb->off_scratch.data(), b - a, true))
-            return rc;
-    }
-    return VBM25_OK;
+        return vbm25_batch_set_queries_impl(mb->parts[i], term_ids ? term_ids + q_off[a] : nullptr, off.data(), b - a, true);
+    });
 }
 
 int multi_batch_run_impl(vbm25_multi_batch *mb) {
     if (!mb) return set_error(VBM25_ERR_INVALID, "batch is NULL");
-    for (size_t i = 0; i < mb->parts.size(); ++i) {  // every device on its own stream: the shards run concurrently
+    // every device on its own stream, enqueued by its own host thread: the shards run concurrently
+    return mb->multi->each_part(mb->parts.size(), [&](size_t i) -> int {
         vbm25_batch *b = mb->parts[i];
-        if (!b->nq) continue;
+        if (!b->nq) return VBM25_OK;
         if (int rc = vbm25_batch_run_impl(b, b->bigk ? nullptr : b->lat_stream)) return rc;
-        if (int rc = vbm25_batch_enqueue_download(b)) return rc;  // the shard's records to pinned host memory, behind its scan
-    }
-    return VBM25_OK;
+        return vbm25_batch_enqueue_download(b);  // the shard's records to pinned host memory, behind its scan
+    });
 }
 
 int multi_batch_fetch_impl(vbm25_multi_batch *mb, vbm25_hit *hits, uint32_t *n_hits) {
     if (!mb || (!hits && mb->nq) || (!n_hits && mb->nq)) return set_error(VBM25_ERR_INVALID, "NULL argument");
-    for (size_t i = 0; i < mb->parts.size(); ++i) {
+    // every part is drained -- by its device's own host thread -- whatever another one returns: no stream is left with a download
+    // pending that the next fetch would take for its own; the first error (by part number) is the call's
+    return mb->multi->each_part(mb->parts.size(), [&](size_t i) -> int {
         vbm25_batch *b = mb->parts[i];
-        if (!b->nq) continue;
-        if (int rc = vbm25_batch_finish_download(b, hits + size_t(mb->lo[i]) * mb->k, n_hits + mb->lo[i])) return rc;
-    }
-    return VBM25_OK;
+        if (!b->nq) return VBM25_OK;
+        const int rc = vbm25_batch_finish_download(b, hits + size_t(mb->lo[i]) * mb->k, n_hits + mb->lo[i]);
+        b->download_enqueued = false;
+        return rc;
+    });
 }
 
 }  // namespace
@@ -1862,7 +1940,7 @@ int vbm25_multi_search_batch(vbm25_multi *m, const uint32_t *term_ids, const uin
         if (nq == 0) return k ? VBM25_OK : set_error(VBM25_ERR_INVALID, "number of needed rows is set to 0");
         vbm25_multi_batch *mb = m->scratch;
         const uint32_t n_terms = q_off[nq] ? q_off[nq] : 1;
-        if (!mb || mb->k != k || mb->max_queries < nq || mb->max_terms < n_terms) {
+        if (!mb || mb->k != k || mb->max_queries < nq || mb->max_terms < n_terms || mb->tune_generation != tuning_snapshot().generation) {
             if (mb) vbm25_multi_batch_destroy(mb);
             m->scratch = nullptr;
             if (int rc = multi_batch_create_impl(m, std::max(nq, 16u), std::max(n_terms, 256u), k, &mb)) return rc;

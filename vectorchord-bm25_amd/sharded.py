@@ -53,7 +53,10 @@ class RootGather:
     """The gather of the per-rank hit records to rank `dst` (north_star: "top-k gather") with every buffer made ONCE: the
     padded send buffer, the flat receive buffer whose per-rank slices are the gather list, and -- only when the shards differ
     in size -- the compacted output.  Calling it moves the records and allocates nothing (the round-3 version built a list
-    of tensors and a torch.cat per step inside the measured loop)."""
+    of tensors and a torch.cat per step inside the measured loop).
+
+    The tensor a call returns is this object's own receive / output buffer: it is valid until the NEXT call, which overwrites it
+    (clone it to keep it)."""
 
     def __init__(self, n_queries: int, k: int, device, dst: int = 0, group=None):
         import torch
