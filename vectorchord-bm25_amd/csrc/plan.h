@@ -49,7 +49,7 @@ __global__ void __launch_bounds__(256) post_fn_kernel(PostFnArgs a) {
     if (i1 == n - 1) bad |= d1 != m.y;
     if (bad) atomicOr(a.error_flag, 1u);
     reinterpret_cast<uchar2 *>(a.post_fn + 128ull * j)[lane] = make_uchar2(f0, f1);
-    a.post_rel16[64ull * j + lane] = rel16_block(m.x, m.y, m.w) ? (d1 - m.x) << 16 | (d0 - m.x) : 0u;
+    if (a.post_rel16) a.post_rel16[64ull * j + lane] = rel16_block(m.x, m.y, m.w) ? (d1 - m.x) << 16 | (d0 - m.x) : 0u;
 
     // The WAND pairs must bound every posting: Cache::evaluate of each posting against the block's
     // bound (blk_ub, margin included) and the token's (search.rs:363,377-380).

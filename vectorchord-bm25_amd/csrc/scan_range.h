@@ -396,7 +396,8 @@ __global__ void __launch_bounds__(RWG, KMAX > 64 ? VBM25_RWPS_BIGK : VBM25_RWPS)
             }
             // bit 8 of the last word: every block of the tile has its post_rel16 word (the workers then skip the per-block tests:
             // S1 is bound by its scalar instructions -- one issue slot per SIMD every fourth cycle -- before its vector ones)
-            const bool all_rel16 = !__ballot(in_tile && !rel16_block(meta.x, meta.y, meta.w));
+            // (an index made without the plane -- the `rel16_plane` switch of index creation -- has none: every block is decoded)
+            const bool all_rel16 = ix.post_rel16 != nullptr && !__ballot(in_tile && !rel16_block(meta.x, meta.y, meta.w));
             if (lane == 0) S.hdr[buf] = make_uint4(p_tlo, thi, (uint32_t)__popcll(mask), p_ne | (all_rel16 ? 0x100u : 0u));
             p_tlo = thi;
         };
@@ -633,6 +634,8 @@ __global__ void __launch_bounds__(RWG, KMAX > 64 ? VBM25_RWPS_BIGK : VBM25_RWPS)
         // the lane's post_rel16 words of its wave's blocks of a planned tile, loaded one tile ahead (right after the barrier
         // that publishes the plan) so that S1 does not start with a round trip to HBM
         uint32_t reln[RB];
+        const uint32_t *relp = ix.post_rel16 ? ix.post_rel16 : reinterpret_cast<const uint32_t *>(ix.blob);
+        const uint32_t relmul = ix.post_rel16 ? 64u : 0u;
         auto fetch_rel = [&](uint32_t b) {
             // branch-free (a branch per load made the compiler wait for every load at the join): entries beyond the plan
             // read the plan's last block, a plan of no blocks reads block 0; S1 masks those entries
@@ -646,7 +649,8 @@ __global__ void __launch_bounds__(RWG, KMAX > 64 ? VBM25_RWPS_BIGK : VBM25_RWPS)
                 blk[2 * i + 1] = two.z;
             }
 #pragma unroll
-            for (int i = 0; i < RB; ++i) reln[i] = ix.post_rel16[64ull * min(uni(blk[i]), bmax) + lane];  // (a plan of no blocks leaves its rows as they were: clamped)
+            for (int i = 0; i < RB; ++i)  // (a plan of no blocks leaves its rows as they were: clamped; no plane: the blob's first words, unused)
+                reln[i] = relp[(unsigned long long)relmul * min(uni(blk[i]), bmax) + lane];
         };
         fetch_rel(0);
 
@@ -701,7 +705,7 @@ __global__ void __launch_bounds__(RWG, KMAX > 64 ? VBM25_RWPS_BIGK : VBM25_RWPS)
                     for (uint32_t i = 0; i < nv; ++i) {
                         const uint4 cc = uni4(S.pm[buf][(wave - 1u) + (RNW - 1) * i]);
                         const uint32_t md = (cc.w >> 8) & 0xff;
-                        if (!rel16_block(cc.x, cc.y, cc.w)) {
+                        if (!ix.post_rel16 || !rel16_block(cc.x, cc.y, cc.w)) {
                             const uint32_t n = cc.w & 0xff;
                             uint32_t a0, a1;
                             decode_doc_ids(ix.blob + 8ull * cc.z, md, n, cc.x, lane, a0, a1);

@@ -227,6 +227,7 @@ struct Tuning {
     int win_force = 0;             // tests: that route whatever the lists' lengths
     uint32_t win_items = 0;        // work items of a batch on that route (0: twice the resident waves)
     int win_planes = 1;            // read at index creation: derive the window planes (post_id16, win_off)
+    int rel16_plane = 1;           // read at index creation: derive post_rel16 (0: the kernels decode the blob's delta streams themselves)
     int win_guided = 0;            // scan_win_kernel's items of a query of decreasing length, handed out longest first (0: equal runs; measured
                                    // no better on C3 -- an item's setup costs more than the shorter tail saves)
     uint32_t win_grid = 0;         // its persistent workgroups (0: one per CU)
@@ -411,7 +412,11 @@ static int index_create_common(const RawSegment &r, int device, vbm25_index **ou
     bm25_tables(r.n_docs, r.sum_len, r.k1, r.b, s1);
     // scan_win_kernel's planes: the low 16 bits of every id in posting order, and for every term with at least a posting per four
     // windows the table of its n_win + 1 window offsets (a rarer term's table would be larger than its list)
-    const bool win_planes = tuning_snapshot().win_planes != 0 && r.n_blocks != 0;
+    const Tuning tune_now = tuning_snapshot();
+    const bool win_planes = tune_now.win_planes != 0 && r.n_blocks != 0;
+    // (`rel16_plane` = 0: no post_rel16 -- scan_range_kernel and scan_dense_kernel unpack the delta streams of the blob in the
+    // kernel: 256 bytes per block less in HBM, more instructions per block; DESIGN.md section 1 has both measured)
+    const bool rel16_plane = tune_now.rel16_plane != 0;
     const uint32_t n_win = uint32_t((uint64_t(r.n_docs) + 65535u) >> 16);
     std::vector<uint32_t> term_win(win_planes ? r.n_terms : 0u, UINT32_MAX);
     uint64_t n_woff = 0;
@@ -455,7 +460,7 @@ static int index_create_common(const RawSegment &r, int device, vbm25_index **ou
         (rc = ix->blk_ub.alloc(8ull * r.n_blocks)) ||
         (rc = ix->blob.alloc(blob_alloc)) ||
         (rc = ix->post_fn.alloc(128ull * r.n_blocks)) ||
-        (rc = ix->post_rel16.alloc(256ull * r.n_blocks)) ||
+        (rel16_plane && (rc = ix->post_rel16.alloc(256ull * r.n_blocks))) ||
         (rc = ix->post_tfn.alloc(256ull * r.n_blocks + 1024)) ||  // (slack: scan_win_kernel's cold pass reads whole runs)
         (win_planes && ((rc = ix->post_id16.alloc(256ull * r.n_blocks + 1024)) || (rc = ix->win_off.alloc(4ull * n_woff)) ||
                         (rc = ix->term_win.upload(term_win.data(), 4ull * r.n_terms)))) ||
@@ -684,7 +689,8 @@ static int vbm25_batch_create_impl(vbm25_index *ix, uint32_t max_queries, uint32
     // whatever those two give up: scan_many_kernel; 256 < k <= 1024: scan_many_kernel (LDS top-k); above: the exhaustive path
     bt->use_range = k <= (uint32_t)REG_K;
     bt->lpi = bt->use_range ? (uint32_t)RNW : 1u;
-    bt->use_dense = bt->use_range && k <= (uint32_t)D_KMAX && bt->tune.dense != 0;
+    // (scan_dense_kernel reads post_rel16 unconditionally: an index made without the plane sends its dense queries to scan_many_kernel)
+    bt->use_dense = bt->use_range && k <= (uint32_t)D_KMAX && bt->tune.dense != 0 && ix->post_rel16.p != nullptr;
     bt->target_items = bt->use_range ? std::max(256u, bt->tune.range_items) : TARGET_ITEMS;
     bt->min_chunk = bt->use_range ? std::max(128u, bt->tune.range_min_chunk) : MIN_CHUNK_POSTINGS;
     bt->max_items = max_queries + bt->target_items + (bt->use_dense ? std::max(256u, bt->tune.dense_items) : 0u);
@@ -1438,6 +1444,7 @@ int vbm25_tuning_set(const char *name, long long value) {
     else if (n == "win_items") g_tune.win_items = (uint32_t)std::max(0ll, value);
     else if (n == "win_planes") g_tune.win_planes = value != 0;
     else if (n == "win_guided") g_tune.win_guided = value != 0;
+    else if (n == "rel16_plane") g_tune.rel16_plane = value != 0;
     else if (n == "win_grid") g_tune.win_grid = (uint32_t)std::max(0ll, value);
     else if (n == "win_skew") g_tune.win_skew = value != 0;
     else return set_error(VBM25_ERR_INVALID, "unknown tuning switch %s", name);
