@@ -1172,10 +1172,10 @@ static int vbm25_batch_run_impl(vbm25_batch *bt, void *hip_stream) {
             // 63 windows an item can hold, or with more than 16 items per query.
             const uint32_t gq = bt->win_g, nwin = bt->index->n_win;
             std::memset(db.win_cut, 0, sizeof db.win_cut);
-            if (bt->win_skew) {  // (the three kinds of waves: 57 / 51 / 45 of C3's 153 windows)
+            if (bt->win_skew) {  // (the three kinds of waves: 58 / 51 / 44 of C3's 153 windows)
                 db.win_cut[0] = 0;
-                db.win_cut[1] = uint32_t(uint64_t(nwin) * 370u / 1000u);
-                db.win_cut[2] = uint32_t(uint64_t(nwin) * 704u / 1000u);
+                db.win_cut[1] = uint32_t(uint64_t(nwin) * 383u / 1000u);
+                db.win_cut[2] = uint32_t(uint64_t(nwin) * 717u / 1000u);
                 db.win_cut[3] = nwin;
                 if (db.win_cut[1] > 63u || db.win_cut[2] - db.win_cut[1] > 63u || nwin - db.win_cut[2] > 63u) std::memset(db.win_cut, 0, sizeof db.win_cut);
             } else if (gq <= 16u && bt->tune.win_guided) {
