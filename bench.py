@@ -32,6 +32,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBPS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+C5_CPU_NEED_S = 90.0    # extra.c5.cpu_baseline: download of the 50 M-document segment + the sample (measured: see DESIGN.md)
 
 WORKLOADS = {
     # name: (n_docs, vocab, mean_len, len_mode, zipf_s, queries/GPU, terms/query, k)
@@ -97,10 +98,11 @@ def committed_traffic(sha16, workload):
         return None
 
 
-def extra_workload(vb, name, budget_s, sha16):
+def extra_workload(vb, name, budget_s, sha16, with_cpu=True):
     """The other single-GPU configurations of BASELINE.json inside the same driver-timed run, under a wall-clock budget:
     C2 (single 3-term query, 1 M documents: C-ABI latencies) and C5 (50 M documents / 100 k Zipf vocabulary / 10-term / top-100:
-    scan_dense_kernel against the roofline).  Fewer steps than a dedicated run and no CPU baseline."""
+    scan_dense_kernel against the roofline, then -- budget permitting -- the CPU Block-WAND restatement on a sample of the
+    same batch).  Fewer steps than a dedicated run."""
     import ctypes as C
     t_start = time.perf_counter()
     n_docs, vocab, mean_len, len_mode, zipf_s, nq, nterms, k = WORKLOADS[name]
@@ -167,6 +169,20 @@ def extra_workload(vb, name, budget_s, sha16):
                     "roofline": {"bound": "hbm", "kernel": "scan_dense_kernel", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBPS,
                                  "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": committed_traffic(sha16, name),
                                  "algorithmic_bytes_per_launch": int(a), "kernel_ms": round(kernel_ms, 3), "launches_timed": n_launch}})
+        left = budget_s - (time.perf_counter() - t_start)
+        if not with_cpu:
+            pass
+        elif left < C5_CPU_NEED_S:
+            out["cpu_baseline"] = {"skipped": f"{C5_CPU_NEED_S:.0f} s needed, {max(0.0, left):.0f} s of --extra-budget-s left"}
+        else:  # the segment comes down from HBM for the checker; 12 s of CPU work on the first queries of batch 0
+            t_cpu = time.perf_counter()
+            del batches
+            oix = oracle_index(seg)
+            t_prep = time.perf_counter() - t_cpu
+            out["cpu_baseline"] = cpu_baseline(oix, shards[0][0], shards[0][1], k, budget_s=12.0)
+            out["cpu_baseline"]["prepare_s"] = round(t_prep, 1)
+            out["cpu_baseline"]["seconds"] = round(time.perf_counter() - t_cpu, 1)
+            del oix
     out["seconds"] = round(time.perf_counter() - t_start, 1)
     return out
 
@@ -254,6 +270,9 @@ def run(argv=None, scorer_factory=None, backend="nccl"):
                     help="check every query of every batch bit-exact against the oracle (outside the timed region)")
     ap.add_argument("--build-threads", type=int, default=0)
     ap.add_argument("--cache", default="", help="segment file: load if present, else build and save")
+    ap.add_argument("--no-host-buffer", action="store_true",
+                    help="skip the host-buffer (vbm25_stream_*) figures: profiler runs, whose per-kernel averages the overlapped "
+                         "launches of three batches in flight would distort")
     ap.add_argument("--extra-budget-s", type=float, default=240.0,
                     help="wall-clock budget for the C2 / C5 lines appended as `extra` (N = 1 only; 0 switches them off)")
     ap.add_argument("--tune", default="", help="development aid: library test switches, name=value[,name=value...] (vbm25_tuning_set)")
@@ -469,13 +488,15 @@ def run(argv=None, scorer_factory=None, backend="nccl"):
         # the boundary as the reference's caller sees it -- host buffers in, host buffers out (search.rs:28-36 returns a Vec):
         # (1) one batch at a time: upload, scan, download, each waited for; (2) PIPELINED (vbm25_stream_*: three batches in
         # flight on their own streams with pinned staging -- upload n + 1 and download n - 1 overlap scan n)
+    if on_gpu and not args.no_host_buffer:
         t0 = time.perf_counter()
         for _ in range(5):
             batches[0].set_queries(*shards[0])
             batches[0].run(stream_ptr)
             batches[0].fetch()
         pcie_sync_qps = 5 * nq_local / (time.perf_counter() - t0)
-        depth, n_pipe = 3, max(20, min(args.steps, 200))
+        # (400 batches whatever --steps says: filling and draining the pipeline costs about two steps)
+        depth, n_pipe = 3, 400 if nq_local * nterms <= 8192 else 20
         st = vb.Stream(gix, depth, nq_local, max(len(t) for t, _ in shards), k)
         outs = [(np.zeros((nq_local, k), dtype=vb.HIT_DTYPE), np.zeros(nq_local, dtype=np.uint32)) for _ in range(depth)]
         for phase in ("warm", "timed"):
@@ -627,7 +648,8 @@ def run(argv=None, scorer_factory=None, backend="nccl"):
             del batches, results, gix, oix, seg
             t_extra = time.perf_counter()
             extra = {"c2": extra_workload(vb, "C2", args.extra_budget_s, sha16)}
-            extra["c5"] = extra_workload(vb, "C5", args.extra_budget_s - (time.perf_counter() - t_extra), sha16)
+            extra["c5"] = extra_workload(vb, "C5", args.extra_budget_s - (time.perf_counter() - t_extra), sha16,
+                                         with_cpu=not args.no_cpu_baseline)
             out["extra"] = extra
         result_line = json.dumps(out)
     if use_dist:

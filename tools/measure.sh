@@ -20,8 +20,8 @@ for step in "$@"; do case $step in
   c3full) seg C3; timeout 900 python bench.py $TUNE_ARG > $O/bench_c3_full.json 2> $O/bench_c3_full.err; show $O/bench_c3_full.json;;
   c5) seg C5; timeout 900 python bench.py --workload C5 --no-cpu-baseline --steps 10 --warmup 2 $TUNE_ARG > $O/bench_c5.json 2> $O/bench_c5.err; show $O/bench_c5.json;;
   c2) seg C2; timeout 600 python bench.py --workload C2 --no-cpu-baseline --steps 200 $TUNE_ARG > $O/bench_c2.json 2> $O/bench_c2.err; show $O/bench_c2.json;;
-  c3stats) seg C3; (cd /tmp; export TMPDIR=/tmp; timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats -- python $R/bench.py --steps 20 --warmup 3 --no-cpu-baseline --no-verify-sample --extra-budget-s 0 $TUNE_ARG > $O/stats.log 2>&1); f=$(find $O/stats -name "*kernel_stats.csv" | head -1); [ -n "$f" ] && cp $f $O/c3_kernel_stats.csv && head -8 $O/c3_kernel_stats.csv; find $O/stats -name "*.csv" -size +5M -delete;;
-  c3pmc) seg C3; B="python $R/bench.py --steps 20 --warmup 3 --no-cpu-baseline --no-verify-sample --extra-budget-s 0 $TUNE_ARG"
+  c3stats) seg C3; (cd /tmp; export TMPDIR=/tmp; timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats -- python $R/bench.py --steps 20 --warmup 3 --no-cpu-baseline --no-verify-sample --no-host-buffer --extra-budget-s 0 $TUNE_ARG > $O/stats.log 2>&1); f=$(find $O/stats -name "*kernel_stats.csv" | head -1); [ -n "$f" ] && cp $f $O/c3_kernel_stats.csv && head -8 $O/c3_kernel_stats.csv; find $O/stats -name "*.csv" -size +5M -delete;;
+  c3pmc) seg C3; B="python $R/bench.py --steps 20 --warmup 3 --no-cpu-baseline --no-verify-sample --no-host-buffer --extra-budget-s 0 $TUNE_ARG"
      (cd /tmp; export TMPDIR=/tmp
       timeout 300 rocprofv3 --kernel-trace --pmc SQ_WAVE_CYCLES SQ_BUSY_CU_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_WAIT_INST_LDS SQ_ACTIVE_INST_ANY SQ_INSTS_VALU SQ_INSTS_SALU --output-format csv -d $O/pmc_sq1 -- $B > $O/pmc_sq1.log 2>&1
       timeout 300 rocprofv3 --kernel-trace --pmc SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_VMEM_RD SQ_INSTS_SMEM SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_IFETCH --output-format csv -d $O/pmc_sq2 -- $B > $O/pmc_sq2.log 2>&1
@@ -30,8 +30,8 @@ for step in "$@"; do case $step in
      python tools/pmc_summary.py ${KERNEL:-scan_range_kernel} sq1=$O/pmc_sq1 sq2=$O/pmc_sq2 fetch=$O/pmc_fetch write=$O/pmc_write > $O/pmc_summary.csv 2> $O/pmc_summary.err; cat $O/pmc_summary.csv
      python tools/pmc_traffic.py C3 ${KERNEL:-scan_range_kernel} $O/pmc_fetch $O/pmc_write > $O/pmc_traffic_c3.json; cat $O/pmc_traffic_c3.json
      find $O -name "*.csv" -size +5M -delete;;
-  c5stats) (cd /tmp; export TMPDIR=/tmp; timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats5 -- python $R/bench.py --workload C5 --steps 5 --warmup 1 --no-cpu-baseline --extra-budget-s 0 $TUNE_ARG > $O/stats5.log 2>&1); f=$(find $O/stats5 -name "*kernel_stats.csv" | head -1); [ -n "$f" ] && cp $f $O/c5_kernel_stats.csv && head -8 $O/c5_kernel_stats.csv; find $O/stats5 -name "*.csv" -size +5M -delete;;
-  c5pmc) B="python $R/bench.py --workload C5 --steps 3 --warmup 1 --no-cpu-baseline --extra-budget-s 0 $TUNE_ARG"
+  c5stats) (cd /tmp; export TMPDIR=/tmp; timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats5 -- python $R/bench.py --workload C5 --steps 5 --warmup 1 --no-cpu-baseline --no-verify-sample --no-host-buffer --extra-budget-s 0 $TUNE_ARG > $O/stats5.log 2>&1); f=$(find $O/stats5 -name "*kernel_stats.csv" | head -1); [ -n "$f" ] && cp $f $O/c5_kernel_stats.csv && head -8 $O/c5_kernel_stats.csv; find $O/stats5 -name "*.csv" -size +5M -delete;;
+  c5pmc) B="python $R/bench.py --workload C5 --steps 3 --warmup 1 --no-cpu-baseline --no-verify-sample --no-host-buffer --extra-budget-s 0 $TUNE_ARG"
      (cd /tmp; export TMPDIR=/tmp
       timeout 400 rocprofv3 --kernel-trace --pmc SQ_WAVE_CYCLES SQ_BUSY_CU_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_WAIT_INST_LDS SQ_ACTIVE_INST_ANY SQ_INSTS_VALU SQ_INSTS_SALU --output-format csv -d $O/pmc5_sq1 -- $B > $O/pmc5_sq1.log 2>&1
       timeout 400 rocprofv3 --kernel-trace --pmc GRBM_GUI_ACTIVE FETCH_SIZE --output-format csv -d $O/pmc5_fetch -- $B > $O/pmc5_fetch.log 2>&1
