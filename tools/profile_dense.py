@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Phase timers of scan_dense_kernel (libvbm25_prof.so, built with -DVBM25_PROFILE).
-usage: profile_dense.py <n_docs> <vocab> <nq> <nterms> <k> [cache]"""
+usage: profile_dense.py C5 | <n_docs> <vocab> <nq> <nterms> <k> [cache]"""
 import ctypes as C
 import os
 import sys
@@ -14,11 +14,17 @@ from vectorchord_bm25_amd import _lib
 
 _lib._SO = os.environ.get("VBM25_LIBRARY") or os.path.join(ROOT, "vectorchord-bm25_amd", "csrc", "libvbm25_prof.so")
 _lib._lib = None
-from bench import make_queries, usable_cpus
+from bench import WORKLOADS, make_queries, usable_cpus
 
-n_docs, vocab, nq, nterms, k = (int(x) for x in sys.argv[1:6])
-cache = sys.argv[6] if len(sys.argv) > 6 else ""
-if cache and os.path.exists(cache):
+if sys.argv[1] in WORKLOADS:
+    n_docs, vocab, _, _, _, nq, nterms, k = WORKLOADS[sys.argv[1]]
+    cache = "device"
+else:
+    n_docs, vocab, nq, nterms, k = (int(x) for x in sys.argv[1:6])
+    cache = sys.argv[6] if len(sys.argv) > 6 else ""
+if cache == "device":
+    seg = vb.DeviceSegment.synth(n_docs, vocab, mean_len=100, len_mode=1, zipf_s=1.0, seed=20260925, device=0)
+elif cache and os.path.exists(cache):
     seg = vb.Segment.load(cache)
 else:
     seg = vb.Segment.synth(n_docs, vocab, mean_len=100, len_mode=1, zipf_s=1.0, seed=20260925, threads=usable_cpus())
@@ -48,7 +54,7 @@ print(f"tasks fetched {int(p[:, :, 13].sum())} skipped {int(p[:, :, 14].sum())};
 print(f"wave lifetime cycles mean {p[:, :, 15].mean():.0f} max {p[:, :, 15].max():.0f} min {p[:, :, 15].min():.0f}; in window loops mean {p[:, :, 9].mean():.0f}; item setup {p[:, :, 8].sum() / max(1, p[:, :, 12].sum()):.0f} per item")
 if os.environ.get("PD_SUB"):
     print(f"run_group per window per wave: entry read {p[:, :, 10].sum() / win / 8:.0f}  fetch wait {p[:, :, 11].sum() / win / 8:.0f}  accumulate {p[:, :, 14].sum() / win / 8:.0f}")
-names = {1: "P0 enumerate (2 barriers)", 2: "P1 essential tasks", 3: "P2 non-essential phases", 4: "barrier before P3", 5: "P3 scan + barrier",
+names = {1: "P0 enumerate + task list (1 barrier)", 2: "P1 essential tasks", 3: "P2 non-essential phases", 4: "barrier before P3", 5: "P3 scan, wipe (no barrier)",
          6: "flush: filter", 7: "flush: exact re-scoring"}
 for w in ("all", 0, 7):
     sel = p if w == "all" else p[:, w:w + 1, :]

@@ -8,24 +8,33 @@
 // whole rest of a window).  A window is
 //
 //   P0  enumerate: the blocks of every term that start below the window's end (one lane per block: 16-byte
-//       metadata + block upper bound), laid out as TASKS in descending order of the terms' token upper bounds.
-//   P1  ESSENTIAL terms (search.rs:153-169: the MaxScore split on token upper bounds against the threshold):
-//       every task fetched -- the lane's words of post_rel16 and post_tfn: two ids, two term frequencies, two
-//       fieldnorms (blocks without plane words: generic decode of the blob) -- and an UPPER BOUND of each posting's
-//       score (f32 rounded up, scaled to an integer, + 1) added to its document's accumulator, in any order:
-//       no barrier between terms, all eight waves busy, groups of four blocks per wave, the next group issued
-//       before the current one is added up.
-//   P2  NON-ESSENTIAL terms, one phase per term in descending order of upper bound.  A block is fetched only
-//       if some document of its span can still reach the threshold: max accumulator over the span + the bounds
-//       of the terms not yet complete, with the block's own upper bound for its term (search.rs:177-203: the
-//       block-max test).  Every other block is SKIPPED: no id, tf or fieldnorm byte of it is read.
-//   P3  candidates: documents whose accumulated bound reaches the threshold go to the item's candidate buffer
-//       (document, bound) and -- by the LOWER bound of their score that the accumulator also implies -- into the
-//       query's 256-bucket histogram (bt.hist, shared by all items of the query, as in scan_range.h): k documents
-//       in buckets >= b put the final k-th score at or above the lower edge of b.  The threshold therefore rises
-//       from approximate sums alone, across items, without any exact score.  Accumulators wiped in the same pass.
+//       metadata + block upper bound, requested a window ahead), written as TASKS straight into the window's task
+//       list: a term takes its place with one LDS atomic -- from the bottom of the list upwards, the HEAD terms (below)
+//       from the top downwards -- so nobody waits for the other terms' counts.  Wave 0 polls the threshold and takes
+//       the MaxScore split the NEXT window is laid out for.  One barrier.
+//   P1  every term but the heads (search.rs:153-169: the essential terms of the MaxScore split on token upper bounds,
+//       and the non-essential ones that are not dense): every task fetched -- the lane's words of post_rel16 and
+//       post_tfn: two ids, two term frequencies, two fieldnorms (blocks without plane words: generic decode of the
+//       blob) -- and an UPPER BOUND of each posting's score (f32 rounded up, scaled to an integer, + 1) added to its
+//       document's accumulator, in any order: no barrier between terms, all eight waves busy, groups of four blocks
+//       per wave, the next group issued before the current one is added up.
+//   P2  the HEAD terms (non-essential and df >= N / 2), after a barrier.  A block is fetched only if some document
+//       of its span can still reach the threshold: max accumulator over the span + the bounds of the other heads +
+//       the block's own upper bound (search.rs:177-203: the block-max test).  Every other block is SKIPPED: no id,
+//       tf or fieldnorm byte of it is read.  The test stands on its own for ANY set of tested terms, so the split a
+//       window is laid out for may be one window old (the threshold only rises: the set only grows).
+//   P3  after a barrier (every sum of the window complete): candidates -- documents whose accumulated bound reaches
+//       the threshold go to the wave's candidate buffer (document, bound) and -- by the LOWER bound of their score
+//       that the accumulator also implies -- into the query's 256-bucket histogram (bt.hist, shared by all items of
+//       the query, as in scan_range.h): k documents in buckets >= b put the final k-th score at or above the lower
+//       edge of b.  The threshold therefore rises from approximate sums alone, across items, without any exact
+//       score.  Accumulators wiped in the same pass; no barrier behind it (nobody adds to them before the next
+//       window's P0 barrier).
+// Three barriers per window (two when no term is a head); rounds 2-4 took six (two in P0, one behind P3, two around
+// a flush).
 //
-// FLUSH (buffer half full after dropping the entries the threshold has overtaken; always at the item's end):
+// FLUSH (some wave's buffer half full: every wave, before the next window's P3; a wave alone when a bucket no longer
+// fits; always at the item's end), after dropping the entries the threshold has overtaken:
 // the surviving candidates are re-scored EXACTLY -- block located by interpolation + gallop + bisection of
 // blk_max_doc, block upper bounds first (search.rs:177-203), then the block decoded by the wave and the one
 // posting's f64 Cache::evaluate (bm25.rs:355-358) taken, sum in ascending key order (evaluate.rs:43-72) -> the
@@ -73,13 +82,17 @@ struct DenseLds {
     float s1f[256];           // rounded down
     double t_s0[D_T], t_ub[D_T], t_cum[D_T + 1];
     float t_s0i[D_T];         // scale x s0, rounded up, x (1 + 2^-19)
-    uint32_t t_cur[D_T], t_end[D_T], t_b0[D_T], t_cnt[D_T], t_base[D_T];
+    uint32_t t_cur[D_T], t_end[D_T], t_b0[D_T];
     uint8_t t_rank[D_T], t_ord[D_T];
     uint8_t t_cls[D_T];       // document-frequency class: 2 = df >= N / 2, 1 = df >= N / 8, 0 = rarer
     uint32_t t_rem[D_T];      // non-essential term: scaled bounds of the OTHER terms that are incomplete during its phase
     double scale, hscale;
     unsigned long long theta; // bits of a lower bound of the query's k-th best score
-    uint32_t cover, cflag, item, m, fail, p_ne, h_ne, resolved, ntask, wmax;
+    uint32_t item, m, fail, p_ne, h_ne, resolved, wmax;
+    // by window parity: tasks of the window laid out so far from the bottom of the task list (nlo: every term but the heads) and
+    // from its top (nhi: the head terms), and "some wave's candidate buffer is half full" (cfl, raised in P3, acted on by
+    // everybody after the next window's barrier).  The entry of the other parity is zeroed while this one is in use.
+    uint32_t nlo[2], nhi[2], cfl[2];
     uint32_t scratch[64];
 };
 
@@ -117,11 +130,10 @@ __global__ void __launch_bounds__(DWG, KMAX > 128 ? 2 : 4) scan_dense_kernel(Dev
         __syncthreads();  // previous item fully done with LDS
         if (tid == 0) {
             S.item = atomicAdd(&cold_args()->bt.work_ctr[1], 1u);
-            S.cover = 0;
-            S.cflag = 0;
             S.fail = 0;
-            S.ntask = 0;
             S.resolved = 0;
+            S.h_ne = 0;
+            S.nlo[0] = S.nlo[1] = S.nhi[0] = S.nhi[1] = S.cfl[0] = S.cfl[1] = 0;
         }
         __syncthreads();
         const uint32_t item = uni(S.item);
@@ -228,7 +240,11 @@ __global__ void __launch_bounds__(DWG, KMAX > 128 ? 2 : 4) scan_dense_kernel(Dev
                 S.t_ord[rank] = (uint8_t)lane;
             }
             double cum = 0.0;
-            if (lane == 0) S.t_cum[0] = 0.0;
+            {   // (a zero made here: the compiler otherwise keeps a 64-bit zero from kernel entry on -- in scratch memory)
+                int z = 0;
+                asm volatile("" : "+v"(z));
+                if (lane == 0) S.t_cum[0] = __hiloint2double(z, z);
+            }
             for (uint32_t pp = 0; pp < m; ++pp) {
                 const uint32_t owner = (uint32_t)__ffsll((long long)__ballot(act && rank == pp)) - 1u;
                 cum += readlane_f64(tub, owner);
@@ -417,26 +433,35 @@ __global__ void __launch_bounds__(DWG, KMAX > 128 ? 2 : 4) scan_dense_kernel(Dev
             };
             uint32_t base = wave;
             if (base >= cnt) return;
+#ifdef VBM25_PROFILE_SUB  // P1 taken apart (slots 10, 11, 14): entries + issue, wait for the words, adds
+#define SUB_ISSUE(G) { PROF_T(s_a); grp_issue(G); PROF_T(s_b); PROF_ADD(10, s_a, s_b); }
+#define SUB_FINISH(G) { PROF_T(s_a); asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); PROF_T(s_b); grp_finish(G, wlo, wspan); PROF_T(s_c); PROF_ADD(11, s_a, s_b); PROF_ADD(14, s_b, s_c); }
+#else
+#define SUB_ISSUE(G) grp_issue(G)
+#define SUB_FINISH(G) grp_finish(G, wlo, wspan)
+#endif
             entries(g0, base);
-            grp_issue(g0);
+            SUB_ISSUE(g0);
             for (;;) {
                 base += DNW * D_UN;
                 const bool more1 = base < cnt;
                 if (more1) {
                     entries(g1, base);
-                    grp_issue(g1);
+                    SUB_ISSUE(g1);
                 }
-                grp_finish(g0, wlo, wspan);
+                SUB_FINISH(g0);
                 if (!more1) break;
                 base += DNW * D_UN;
                 const bool more0 = base < cnt;
                 if (more0) {
                     entries(g0, base);
-                    grp_issue(g0);
+                    SUB_ISSUE(g0);
                 }
-                grp_finish(g1, wlo, wspan);
+                SUB_FINISH(g1);
                 if (!more0) break;
             }
+#undef SUB_ISSUE
+#undef SUB_FINISH
         };
         // non-essential tasks [first, first + cnt) of one term, a contiguous share per wave: one lane per task tests
         // whether any document of the block's span can still reach the threshold (largest accumulator of the
@@ -459,7 +484,9 @@ __global__ void __launch_bounds__(DWG, KMAX > 128 ? 2 : 4) scan_dense_kernel(Dev
             }
             unsigned long long mask = __ballot(alive);
 #ifdef VBM25_PROFILE
+#ifndef VBM25_PROFILE_SUB
             prof[14] += (uint32_t)__popcll(__ballot(o0 + lane < share && o < cnt)) - (uint32_t)__popcll(mask);
+#endif
 #endif
             while (mask) {
                 Grp g;
@@ -493,7 +520,9 @@ __global__ void __launch_bounds__(DWG, KMAX > 128 ? 2 : 4) scan_dense_kernel(Dev
             cand = cand && bound * (1.0 + 1e-12) >= thd;
             if (!__ballot(cand)) return;
 #ifdef VBM25_PROFILE
+#ifndef VBM25_PROFILE_SUB
             prof[11] += (unsigned long long)__popcll(__ballot(cand));
+#endif
 #endif
             // pass 2: the exact score, terms in ascending key order (evaluate.rs:43-72)
             uint32_t *scr = S.scr[wave];
@@ -582,7 +611,7 @@ __global__ void __launch_bounds__(DWG, KMAX > 128 ? 2 : 4) scan_dense_kernel(Dev
         const uint32_t wmax = uni(S.wmax);
         uint32_t W = theta_now() == 0ull ? (uint32_t)D_W0 : wmax;
         bool failed = false;
-        uint32_t ocur[2] = {0, 0}, oend[2] = {0, 0};
+        uint32_t ocur[2] = {0, 0}, oend[2] = {0, 0}, orank[2] = {0, 0};
         bool odense[2] = {false, false};
 #pragma unroll
         for (int s = 0; s < 2; ++s) {
@@ -590,6 +619,7 @@ __global__ void __launch_bounds__(DWG, KMAX > 128 ? 2 : 4) scan_dense_kernel(Dev
             if (t < m) {
                 ocur[s] = uni(S.t_cur[t]);
                 oend[s] = uni(S.t_end[t]);
+                orank[s] = uni((uint32_t)S.t_rank[t]);
                 odense[s] = uni((uint32_t)S.t_cls[t]) == 2u;
             }
         }
@@ -615,18 +645,25 @@ __global__ void __launch_bounds__(DWG, KMAX > 128 ? 2 : 4) scan_dense_kernel(Dev
         PROF_T(t_loop);
         PROF_ADD(8, t_item, t_loop);
         enum_request();
-        for (uint32_t wlo = lo; wlo < hi;) {
+        // h_lay: the number of head terms the task list of this window is laid out for = the split wave 0 took in the PREVIOUS
+        // window (0 in an item's first).  Any set of terms may be tested block by block -- the test stands on its own (accumulated
+        // sums + the bounds of the other tested terms + the block's bound against a lower bound of the final threshold); the
+        // MaxScore split only says for which terms the test pays.  The threshold only rises, so the heads only grow: the bounds
+        // t_rem and the floor of the bucket maxima, which follow the NEWEST split, cover the laid-out set.
+        uint32_t h_lay = 0;
+        for (uint32_t wlo = lo, par = 0; wlo < hi; par ^= 1u) {
             const uint32_t whi = hi - wlo > W ? wlo + W : hi;
             const uint32_t wspan = whi - wlo;
             PROF_T(t_a);
 
-            // ---- P0: the window's blocks = the blocks that start below its end
-            uint32_t ecnt[2] = {0, 0}, ecur[2] = {0, 0};
+            // ---- P0: the window's blocks = the blocks that start below its end, written to the task list straight away: every
+            // term takes its place with one LDS atomic -- from the bottom of the list upwards, the head terms from the top
+            // downwards -- so that nobody has to know the other terms' counts: ONE barrier.
 #pragma unroll
             for (int s = 0; s < 2; ++s) {
                 const uint32_t t = wave + DNW * s;
                 if (t < m) {
-                    ecur[s] = ocur[s];
+                    const uint32_t ecur = ocur[s];
                     uint32_t cnt = 0, fin = 0;
 #pragma unroll
                     for (int ch = 0; ch < 2; ++ch) {
@@ -643,12 +680,29 @@ __global__ void __launch_bounds__(DWG, KMAX > 128 ? 2 : 4) scan_dense_kernel(Dev
                         cnt += (uint32_t)__popcll(__ballot(in));
                         fin += (uint32_t)__popcll(__ballot(in && em[s][ch].y < whi));
                     }
-                    ecnt[s] = cnt;
                     ocur[s] += fin;  // blocks that end below the window's end are done
+                    const bool head = orank[s] < h_lay;
+                    uint32_t taken = 0;
                     if (lane == 0) {
-                        S.t_cnt[t] = cnt;
-                        if (cnt >= (uint32_t)D_SEG) S.fail = 1;  // (128 enumerated: more may follow)
-                        if (atomicAdd(&S.ntask, cnt) + cnt > (uint32_t)D_TCAP) S.fail = 1;
+                        taken = head ? atomicAdd(&S.nhi[par], cnt) : atomicAdd(&S.nlo[par], cnt);
+                        if (cnt >= (uint32_t)D_SEG || taken + cnt > (uint32_t)D_TCAP) S.fail = 1;  // (128 enumerated: more may follow)
+                    }
+                    taken = (uint32_t)__builtin_amdgcn_readfirstlane((int)taken);
+                    if (taken + cnt <= (uint32_t)D_TCAP) {  // (the two ends meeting in the middle: seen after the barrier)
+                        const uint32_t at = head ? (uint32_t)D_TCAP - taken - cnt : taken;
+                        uint32_t fl = lane, tb = t;
+                        asm volatile("" : "+v"(fl), "+s"(tb));  // (as sl in the item setup: nothing of this block hoisted to kernel entry)
+#pragma unroll
+                        for (int ch = 0; ch < 2; ++ch) {
+                            const uint32_t i = 64u * ch + fl;
+                            if (i < cnt) {
+                                VCHK(at + i < (uint32_t)D_TCAP, 1, at + i);
+                                S.tmeta[at + i] = em[s][ch];
+                                S.tblk[at + i] = ecur + i;
+                                S.tub[at + i] = __double2uint_ru(eub[s][ch] * scale) + 1u;
+                                S.tterm[at + i] = (uint8_t)tb;
+                            }
+                        }
                     }
                 }
             }
@@ -660,14 +714,14 @@ __global__ void __launch_bounds__(DWG, KMAX > 128 ? 2 : 4) scan_dense_kernel(Dev
                 // lowest positions) are tested block by block in one phase after everything else; the other
                 // non-essential terms are fetched with the essential ones: a phase per term would fetch 23 % of the
                 // blocks of a Zipf(1) query instead of 39 % (oracle/dense_model.inc) but costs a barrier and a
-                // memory round trip per term.  Lane p = position p.
+                // memory round trip per term.  Lane p = position p.  The NEXT window's list is laid out for this split.
                 const double thd = __longlong_as_double((long long)S.theta);
                 const bool below = lane < m && S.t_cum[lane + 1u] < thd;  // a prefix of the lanes (t_cum ascends)
                 uint32_t pn = (uint32_t)__popcll(__ballot(below));
                 if (!cold_args()->bt.ne_on && pn < m) pn = 0;
                 const bool head = lane < pn && pn < m && S.t_cls[S.t_ord[lane]] == 2;
                 const unsigned long long hm = __ballot(head);
-                const uint32_t h = (uint32_t)__ffsll((long long)~hm) - 1u;  // heads below the first other term
+                const uint32_t h = max((uint32_t)__ffsll((long long)~hm) - 1u, h_lay);  // heads below the first other term
                 if (lane < h) {
                     // bounds of the other heads (the subtraction's rounding is far below one unit; + 2 covers it and
                     // the ceiling)
@@ -677,67 +731,37 @@ __global__ void __launch_bounds__(DWG, KMAX > 128 ? 2 : 4) scan_dense_kernel(Dev
                 if (lane == 0) {
                     S.p_ne = pn;
                     S.h_ne = h;
+                    S.nlo[par ^ 1u] = 0;  // the next window's counters (last read after the previous window's barrier)
+                    S.nhi[par ^ 1u] = 0;
+                    S.cfl[par] = 0;       // raised in this window's P3, read after the next window's barrier
                 }
             }
-            lds_barrier();  // counts of every term known
-            {
-                const uint32_t cu = lane < m ? S.t_cnt[lane] : 0u, ru = lane < m ? (uint32_t)S.t_rank[lane] : 0u;
-#pragma unroll
-                for (int s = 0; s < 2; ++s) {
-                    const uint32_t t = wave + DNW * s;
-                    if (t < m) {
-                        const uint32_t rt = (uint32_t)__builtin_amdgcn_readlane((int)ru, (int)t);
-                        // tasks in descending rank order: the terms of higher rank come first
-                        const uint32_t before = (uint32_t)__builtin_amdgcn_readlane((int)wave_incl_scan_u32(lane < m && ru > rt ? cu : 0u), 63);
-                        if (lane == 0) S.t_base[t] = before;
-                        if (!uni(S.fail)) {
-                            uint32_t fl = lane, tb = t;
-                            asm volatile("" : "+v"(fl), "+s"(tb));  // (as sl in the item setup: nothing of this block hoisted to kernel entry)
-#pragma unroll
-                            for (int ch = 0; ch < 2; ++ch) {
-                                const uint32_t i = 64u * ch + fl;
-                                if (i < ecnt[s]) {
-                                    VCHK(before + i < (uint32_t)D_TCAP, 1, before + i);
-                                    S.tmeta[before + i] = em[s][ch];
-                                    S.tblk[before + i] = ecur[s] + i;
-                                    S.tub[before + i] = __double2uint_ru(eub[s][ch] * scale) + 1u;
-                                    S.tterm[before + i] = (uint8_t)tb;
-                                }
-                            }
-                        }
-                    }
-                }
-            }
-            lds_barrier();  // tasks, split and threshold visible
-            if (uni(S.fail)) {
-                failed = true;
+            lds_barrier();  // tasks, counts, split and threshold visible
+            const uint32_t cnt1 = uni(S.nlo[par]), cnth = uni(S.nhi[par]);
+            if (uni(S.fail) || cnt1 + cnth > (uint32_t)D_TCAP || uni(S.resolved) > D_MAX_RESOLVED) {
+                failed = true;  // (too many re-scorings: the sums cannot tell masses of equal scores apart -- exhaustive kernel)
                 break;
             }
-            const uint32_t p_ne = uni(S.p_ne), h_ne = uni(S.h_ne);
-            if (tid == 0) S.ntask = 0;  // (read by nobody until the next window's counts)
-            if (p_ne >= m) break;  // no document can reach the threshold any more (search.rs:153-169 with every term)
+            if (uni(S.p_ne) >= m) break;  // no document can reach the threshold any more (search.rs:153-169 with every term)
+            const uint32_t h_new = uni(S.h_ne);
+            bool flush_due = uni(S.cfl[par ^ 1u]) != 0;  // some wave's buffer was half full after the last window: everybody re-scores before P3
             const uint32_t theta_i = theta_fix(theta_now());
             {   // rem + tub of any head block <= scale x (sum of the head terms' bounds) + a few units of rounding (t_rem, tub above)
-                const uint32_t heads = __double2uint_ru(S.t_cum[h_ne] * scale) + 8u;
+                const uint32_t heads = __double2uint_ru(S.t_cum[h_new] * scale) + 8u;
                 bmax_floor = theta_i > heads ? theta_i - heads : 0u;
             }
             PROF_T(t_b);
             PROF_ADD(1, t_a, t_b);
 
-            // ---- P1: every term but the heads = the ranks >= h_ne = the first tasks
-            uint32_t cnt1, cnt_all;
-            {
-                const uint32_t cu = lane < m ? S.t_cnt[lane] : 0u, ru = lane < m ? (uint32_t)S.t_rank[lane] : 0u;
-                cnt1 = (uint32_t)__builtin_amdgcn_readlane((int)wave_incl_scan_u32(lane < m && ru >= h_ne ? cu : 0u), 63);
-                cnt_all = (uint32_t)__builtin_amdgcn_readlane((int)wave_incl_scan_u32(cu), 63);
-            }
+            // ---- P1: every term but the heads = the tasks at the bottom of the list
             run_all(cnt1, wlo, wspan);
             PROF_T(t_c);
             PROF_ADD(2, t_b, t_c);
-            // ---- P2: the head terms, every block tested
-            if (cnt_all > cnt1) {
+            if (whi < hi) enum_request();  // the next window's metadata: in flight during P2 and P3
+            // ---- P2: the head terms (the tasks at the top of the list), every block tested
+            if (cnth) {
                 lds_barrier();
-                run_tested(cnt1, cnt_all - cnt1, theta_i, wlo, wspan);
+                run_tested((uint32_t)D_TCAP - cnth, cnth, theta_i, wlo, wspan);
             }
             PROF_T(t_d);
             PROF_ADD(3, t_c, t_d);
@@ -747,12 +771,13 @@ __global__ void __launch_bounds__(DWG, KMAX > 128 ? 2 : 4) scan_dense_kernel(Dev
 #ifdef VBM25_PROFILE
             prof[0] += 1;
 #endif
-            if (whi < hi) enum_request();  // the next window's metadata: in flight during P3
 
             // ---- P3: candidates -> the wave's buffer + the query's histogram; wipe.  Wave w owns the documents
             // [2048 w, 2048 (w + 1)) of the window = the buckets 32 w .. 32 w + 31: candidates only where the bucket
-            // maximum reaches the threshold.
+            // maximum reaches the threshold.  No barrier behind it: nobody adds to these accumulators before the next window's.
             for (;;) {
+                if (flush_due) flush();  // (the one call in the loop: all waves together, or this wave alone with a full buffer)
+                flush_due = true;
                 PROF_T(t_f);
                 constexpr uint32_t BPW = D_W / 64 / DNW;  // buckets per wave
                 const double inv = (1.0 / scale) * (1.0 - 1.0 / 131072.0) * S.hscale;  // accumulator -> bucket of the score's lower bound
@@ -781,46 +806,31 @@ __global__ void __launch_bounds__(DWG, KMAX > 128 ? 2 : 4) scan_dense_kernel(Dev
                     }
                     cn += c;
 #ifdef VBM25_PROFILE
+#ifndef VBM25_PROFILE_SUB
                     prof[10] += c;
 #endif
+#endif
                 }
+                PROF_T(t_g);
+                PROF_ADD(5, t_f, t_g);
                 if (left == 0u) {  // wipe the wave's accumulators and its bucket maxima
 #pragma unroll
                     for (int x = 0; x < (int)(BPW * 32 / 256); ++x)
                         *reinterpret_cast<uint4 *>(&S.acc[wave * BPW * 32u + 256u * x + 4u * lane]) = make_uint4(0, 0, 0, 0);
                     if (lane < BPW) S.bmax[wave * BPW + lane] = 0u;
-                } else {
-                    for (uint32_t bk = 0; bk < BPW; ++bk)
-                        if (!((left >> bk) & 1u)) {
-                            if (lane < 32u) S.acc[(wave * BPW + bk) * 32u + lane] = 0u;
-                            if (lane == 0) S.bmax[wave * BPW + bk] = 0u;
-                        }
-                    if (lane == 0) S.cover = 1;
+                    break;
                 }
-                if (cn >= (uint32_t)D_WCB / 2 && lane == 0) S.cflag = 1;
-                lds_barrier();
-                PROF_T(t_g);
-                PROF_ADD(5, t_f, t_g);
-                const bool over = uni(S.cover) != 0;
-                if (over || uni(S.cflag)) {
-                    flush();
-                    lds_barrier();  // everybody has read the flags (and counted its re-scorings)
-                    if (tid == 0) {
-                        S.cover = 0;
-                        S.cflag = 0;
+                for (uint32_t bk = 0; bk < BPW; ++bk)  // the buffer is full: the buckets taken are wiped, the wave re-scores, the rest follows
+                    if (!((left >> bk) & 1u)) {
+                        if (lane < 32u) S.acc[(wave * BPW + bk) * 32u + lane] = 0u;
+                        if (lane == 0) S.bmax[wave * BPW + bk] = 0u;
                     }
-                    const bool too_many = uni(S.resolved) > D_MAX_RESOLVED;
-                    lds_barrier();
-                    if (too_many) {  // the sums cannot tell masses of equal scores apart: exhaustive kernel
-                        failed = true;
-                        break;
-                    }
-                }
-                if (!over) break;
+                __builtin_amdgcn_wave_barrier();
             }
-            if (failed) break;
+            if (cn >= (uint32_t)D_WCB / 2 && lane == 0) S.cfl[par] = 1;
             wlo = whi;
             W = min(2u * W, wmax);
+            h_lay = h_new;
         }
         if (!failed) flush();
 #ifdef VBM25_PROFILE
