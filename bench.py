@@ -1,23 +1,31 @@
 #!/usr/bin/env python3
 """bench.py -- queries/sec of the batched BM25 top-k path on MI355X.
 
-A "step" is one pass of the hot path (plan -> posting scan -> merge) over one batch of synthetic queries
-already resident in HBM.  Default workload = BASELINE.json configs[2] ("C3"): 10M docs / 30k vocab, 1024
-five-term queries, top-10, one MI355X.  --workload C5 is configs[4] (50M docs / 100k vocab Zipf(1) /
-10-term / top-100), C2 the single 3-term query on 1M docs (adds host-inclusive latencies), C1 the plumbing
-case.
+A "step" is one pass of the hot path (posting scan -> merge; the general route adds plan_kernel) over one batch of synthetic
+queries already resident in HBM.  Default workload = BASELINE.json configs[2] ("C3"): 10M docs / 30k vocab, 1024 five-term
+queries, top-10, one MI355X.  --workload C5 is configs[4] (50M docs / 100k vocab Zipf(1) / 10-term / top-100), C2 the single
+3-term query on 1M docs (adds host-inclusive latencies), C1 the plumbing case.
 
-The timed loop ROTATES through --batches (default 4) different query batches of the workload's shape, every
-one resident in HBM before the clock starts: four C3 batches touch 1.9 GB of postings, far more than the 256 MiB
-Infinity Cache, so a step's reads come from HBM and not from the previous step's leftovers.
+Order of a run (single process, --gpus 1):
+  1. corpus generated, flushed and indexed on the device; --batches (default 4) query batches made and handed over;
+  2. the HOST-BUFFER figures, before the timed region (config.host_buffer_*): 400 batches through vbm25_stream_* (three in
+     flight, pinned staging: queries up, records down every step), then 20 batches one at a time;
+  3. W untimed warm-up steps, then EXACTLY K timed steps rotating through the batches, bracketed by synchronisations; kernel
+     durations by HIP events on the launch stream (roofline.kernel_ms);
+  4. outside the timed region: 64 queries of batch 0 checked bit-exact against the oracle (config.verified_sample; --verify:
+     every query of every batch), the CPU baseline (oracle's Block-WAND, T = 1 and T = usable cores), and -- C3 only, under
+     --extra-budget-s -- C2 and C5 in the same process (`extra`, C5 with its own CPU baseline).
+The rotation is there so that a step's reads come from HBM and not from the previous step's leftovers; profiles/r5_warmup.txt
+shows the kernel's duration does not depend on it (1, 4 or 16 batches: the same), and why step 2 comes first.
 
-With --gpus N (launched by torch.distributed.run, one rank per GPU) the run is BASELINE.json configs[3]
-("C4"): rank 0 makes the N x 1024 queries of every batch, broadcasts the two descriptor arrays (RCCL), every
-rank keeps its contiguous shard, searches it against its replica of the index, and the hit records are
-gathered to rank 0 on a second stream while the next step's scan is already running.  The broadcast is paid
-once (scatter_ms); the gather is inside every step (gather_ms, of which gather_exposed_ms is not hidden).
+--gpus N WITHOUT torch.distributed's environment drives N devices from this one process through vbm25_multi_* (one host thread
+per device).  Launched by torch.distributed.run (one rank per GPU) the run is BASELINE.json configs[3] ("C4"): rank 0 makes the
+N x 1024 queries of every batch, broadcasts the two descriptor arrays (RCCL), every rank keeps its contiguous shard, searches it
+against its replica of the index, and the hit records are gathered to rank 0 on a second stream while the next step's scan is
+already running.  The broadcast is paid once (scatter_ms); the gather is inside every step (gather_ms, of which
+gather_exposed_ms is not hidden).
 
-Prints ONE JSON line (rank 0).  See DESIGN.md "Measurement".
+Prints ONE JSON line (rank 0).  See DESIGN.md section 3.
 """
 import argparse
 import json

@@ -10,4 +10,5 @@ bash tools/measure.sh $SUB c3full c3stats c3pmc
 timeout 300 python bench.py --steps 20 --warmup 5 --no-cpu-baseline --extra-budget-s 0 > $O/bench_c3_driver_flags.json 2> $O/bench_c3_driver_flags.err
 timeout 300 python bench.py --k 100 --steps 100 --no-cpu-baseline --extra-budget-s 0 > $O/bench_c3_k100.json 2> $O/bench_c3_k100.err
 timeout 300 python tools/profile_win.py C3 > $O/c3_phase_timers.txt 2>&1; head -30 $O/c3_phase_timers.txt
+timeout 300 python tools/profile_dense.py C5 > $O/c5_phase_timers.txt 2>&1; head -12 $O/c5_phase_timers.txt
 bash tools/measure.sh $SUB c5stats c5pmc

@@ -17,6 +17,7 @@ names = {
     "pmc_summary.csv": f"{tag}_c3_pmc_scan_win_kernel.csv",
     "c3_phase_timers.txt": f"{tag}_c3_phase_timers.txt",
     "c5_kernel_stats.csv": f"{tag}_c5_kernel_stats.csv",
+    "c5_phase_timers.txt": f"{tag}_c5_phase_timers.txt",
     "pmc5_summary.csv": f"{tag}_c5_pmc_scan_dense_kernel.csv",
 }
 for a, b in names.items():

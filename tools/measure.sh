@@ -27,8 +27,8 @@ for step in "$@"; do case $step in
       timeout 300 rocprofv3 --kernel-trace --pmc SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_VMEM_RD SQ_INSTS_SMEM SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_IFETCH --output-format csv -d $O/pmc_sq2 -- $B > $O/pmc_sq2.log 2>&1
       timeout 300 rocprofv3 --kernel-trace --pmc GRBM_GUI_ACTIVE FETCH_SIZE --output-format csv -d $O/pmc_fetch -- $B > $O/pmc_fetch.log 2>&1
       timeout 300 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $O/pmc_write -- $B > $O/pmc_write.log 2>&1)
-     python tools/pmc_summary.py ${KERNEL:-scan_range_kernel} sq1=$O/pmc_sq1 sq2=$O/pmc_sq2 fetch=$O/pmc_fetch write=$O/pmc_write > $O/pmc_summary.csv 2> $O/pmc_summary.err; cat $O/pmc_summary.csv
-     python tools/pmc_traffic.py C3 ${KERNEL:-scan_range_kernel} $O/pmc_fetch $O/pmc_write > $O/pmc_traffic_c3.json; cat $O/pmc_traffic_c3.json
+     python tools/pmc_summary.py ${KERNEL:-scan_win_kernel} sq1=$O/pmc_sq1 sq2=$O/pmc_sq2 fetch=$O/pmc_fetch write=$O/pmc_write > $O/pmc_summary.csv 2> $O/pmc_summary.err; cat $O/pmc_summary.csv
+     python tools/pmc_traffic.py C3 ${KERNEL:-scan_win_kernel} $O/pmc_fetch $O/pmc_write > $O/pmc_traffic_c3.json; cat $O/pmc_traffic_c3.json
      find $O -name "*.csv" -size +5M -delete;;
   c5stats) (cd /tmp; export TMPDIR=/tmp; timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats5 -- python $R/bench.py --workload C5 --steps 5 --warmup 1 --no-cpu-baseline --no-verify-sample --no-host-buffer --extra-budget-s 0 $TUNE_ARG > $O/stats5.log 2>&1); f=$(find $O/stats5 -name "*kernel_stats.csv" | head -1); [ -n "$f" ] && cp $f $O/c5_kernel_stats.csv && head -8 $O/c5_kernel_stats.csv; find $O/stats5 -name "*.csv" -size +5M -delete;;
   c5pmc) B="python $R/bench.py --workload C5 --steps 3 --warmup 1 --no-cpu-baseline --no-verify-sample --no-host-buffer --extra-budget-s 0 $TUNE_ARG"

@@ -12,7 +12,7 @@
 //     8-byte load per lane (four postings) and four LDS atomics.
 //   * A WAVE owns its work item (a run of windows of one query) and everything it touches: an exact filter of 2^16 bits, the staged
 //     ids of the current window, a list of second arrivals, its top-k in registers.  There is no workgroup barrier anywhere; a
-//     workgroup is four independent waves.  The next window's runs are in flight while this one is marked.
+//     workgroup is up to twelve independent waves (wn_waves).  The runs of the next two windows are in flight while this one is marked.
 //   * A mark that finds its bit set is a SECOND ARRIVAL: the document has postings in two of the query's lists.  After the window's
 //     marks every (second arrival, term) pair is one lane: bisection of the term's staged run, the posting's tf / fieldnorm from
 //     ONE word of post_tfn, Cache::evaluate; the entry of the LAST term that holds the document sums the row in ascending key
@@ -25,13 +25,18 @@
 //     64-bit atomicMax word polled once per window.  Filtering on score < threshold is exact (a lower bound of the final k-th
 //     score; ties are kept).
 //
-// The window loop holds no vector memory operation under a branch: the compiler's count of the loads in flight stays exact, and
-// the runs of the next window, the boundaries after them, the shared threshold and the tf / fieldnorm words of the last window's
-// second arrivals are all in flight while a window is marked.
+// The window loop's loads are HAND-ISSUED (inline-asm global_load_* + s_waitcnt vmcnt(n), the wn_load_* / wn_wait_* helpers below) in
+// a fixed order per window -- the shared threshold, the tf / fieldnorm words of the two open completion passes, the runs of the
+// next-but-one window -- so that every wait names exactly the loads it needs.  Left to the compiler the loop waited for everything
+// at its header and after every branch that held a load.  Two rules keep this safe; tools/check_inflight.py (a CPU test) checks
+// them on the ISA: (1) the loads are unconditional -- the kernel is a template over the run loads per window MT, dummies below
+// the query's term count -- and no compiler-generated instruction touches a register while a hand-issued load into it is in
+// flight; (2) an asm load that takes its address from an SGPR pair starts with s_nop 4: the compiler does not pad the hazard between
+// a VALU write of an SGPR (v_readlane, an SGPR restored from its spill lane) and a VMEM read of it inside an asm statement.
 //
 // Results: one list per item at res_*[item] (bt.lpi == 1 on this route); merge_kernel merges a query's lists.  An item with a
-// window that collects more than WN_LIST second arrivals, a run thicker than one load per lane (WN_SLOT postings) or a term
-// frequency above 255 in a second arrival is handed to scan_many_kernel (item_failed).
+// window that collects more than WN_LIST second arrivals or a term frequency above 255 in a second arrival is handed to
+// scan_many_kernel (item_failed).  A run thicker than one load per lane (WN_SLOT postings) takes a chunk loop on the spot.
 
 constexpr int WN_T = 8;               // indexed terms per query
 // Independent waves per workgroup: ONE workgroup per CU holds all the LDS its waves need (three workgroups of four waves, 3 x 54 KB,
@@ -46,7 +51,7 @@ constexpr int wn_waves(int mt) {
 }
 constexpr int WN_BM_WORDS = 2048;     // 2^16 bits
 constexpr int WN_SLOT = 256;          // staged ids per term: what one 8-byte load per lane covers
-constexpr int WN_LIST = 64;           // second arrivals per window (the LDS is handed out in 512-byte granules: 106 per workgroup, three workgroups per CU)
+constexpr int WN_LIST = 64;           // second arrivals per window
 constexpr uint32_t WN_GRID = 256;     // persistent workgroups: one per CU
 
 // A wave's filter lives in its own array, 8 KB-aligned: the address of a posting's word is `base | offset` -- one v_and_or_b32 --
