@@ -629,7 +629,7 @@ def run(argv=None, scorer_factory=None, backend="nccl"):
                        "gather_exposed_ms": round(gather_exposed_ms, 4),
                        "route": route,
                        "host_buffer_inclusive_qps_per_gpu": None if pcie_qps is None else round(pcie_qps, 1),
-                       "host_buffer_inclusive": "vbm25_stream_*: three batches in flight, pinned staging (queries up, 24-byte records down every step)",
+                       "host_buffer_inclusive": "vbm25_stream_*: three batches in flight on their own streams; queries uploaded from pinned staging, counts and 24-byte records written to pinned memory by merge_kernel, every step",
                        "host_buffer_one_batch_at_a_time_qps_per_gpu": None if pcie_sync_qps is None else round(pcie_sync_qps, 1)},
         }
         if verified:

@@ -284,6 +284,9 @@ struct vbm25_batch {
     hipStream_t lat_stream = nullptr;
     hipStream_t last_stream = nullptr;  // the stream of the last run: what fetch waits for (not the whole device)
     bool download_enqueued = false;     // the last run's records are already on their way to pin_out (vbm25_multi_batch_run)
+    // vbm25_stream_*: merge_kernel writes counts and records straight into the pinned output buffer (posted writes over PCIe, no
+    // download command on the step: only the 4-byte flag is copied); results_pinned_now: the last run did so
+    bool pinned_results = false, results_pinned_now = false;
     uint8_t *pin_in = nullptr, *pin_out = nullptr;
     size_t pin_in_bytes = 0, pin_out_bytes = 0, pin_nt = 0, pin_order_bytes = 0;
     ~vbm25_batch() {
@@ -1023,6 +1026,7 @@ static int vbm25_batch_run_impl(vbm25_batch *bt, void *hip_stream) {
     hipStream_t st = static_cast<hipStream_t>(hip_stream);
     bt->last_stream = st;
     bt->download_enqueued = false;
+    bt->results_pinned_now = false;
     if (bt->index->n_docs == 0) {  // empty sealed segment: no hits (the growing segment is the shim's, search.rs:83-135)
         HIP_TRY(hipMemsetAsync(bt->n_hits.p, 0, 4ull * bt->nq, st));
         return VBM25_OK;
@@ -1063,6 +1067,13 @@ static int vbm25_batch_run_impl(vbm25_batch *bt, void *hip_stream) {
     db.res_cnt = bt->res_cnt.as<uint32_t>();
     db.hits = bt->hits.as<vbm25_hit>();
     db.n_hits = bt->n_hits.as<uint32_t>();
+    bt->results_pinned_now = false;
+    if (bt->pinned_results && !bt->bigk && !bt->fused_g && bt->lat_stream && bt->pin_out) {
+        const size_t nc = (4ull * bt->nq + 7) & ~size_t(7);  // (set_queries sized pin_out for 8 + nc + the records)
+        db.n_hits = reinterpret_cast<uint32_t *>(bt->pin_out + 8);
+        db.hits = reinterpret_cast<vbm25_hit *>(bt->pin_out + 8 + nc);
+        bt->results_pinned_now = true;
+    }
     db.error_flag = bt->error_flag.as<uint32_t>();
     db.q_dense = bt->q_dense.as<uint8_t>();
     db.item_failed = bt->item_failed.as<uint32_t>();
@@ -1294,7 +1305,8 @@ static int vbm25_batch_fetch_impl(vbm25_batch *bt, vbm25_hit *hits, uint32_t *n_
         return VBM25_OK;
     }
     if (fast && bt->lat_stream) {  // flag, counts and hits come down asynchronously; one synchronisation
-        const size_t nh = sizeof(vbm25_hit) * size_t(bt->nq) * bt->k, nc = 4ull * bt->nq;
+        const size_t nh = sizeof(vbm25_hit) * size_t(bt->nq) * bt->k;
+        const size_t nc = bt->results_pinned_now ? (4ull * bt->nq + 7) & ~size_t(7) : 4ull * bt->nq;  // (the kernel's records are 8-byte aligned)
         if (!bt->download_enqueued)
             if (int rc = vbm25_batch_enqueue_download(bt)) return rc;
         bt->download_enqueued = false;
@@ -1341,7 +1353,7 @@ static int vbm25_batch_enqueue_download(vbm25_batch *bt) {
         HIP_TRY(hipHostMalloc(reinterpret_cast<void **>(&bt->pin_out), bt->pin_out_bytes, hipHostMallocDefault));
     }
     HIP_TRY(hipMemcpyAsync(bt->pin_out, bt->error_flag.p, 4, hipMemcpyDeviceToHost, bt->lat_stream));
-    if (bt->nq) {
+    if (bt->nq && !bt->results_pinned_now) {
         HIP_TRY(hipMemcpyAsync(bt->pin_out + 8, bt->n_hits.p, nc, hipMemcpyDeviceToHost, bt->lat_stream));
         HIP_TRY(hipMemcpyAsync(bt->pin_out + 8 + nc, bt->hits.p, nh, hipMemcpyDeviceToHost, bt->lat_stream));
     }
@@ -1557,6 +1569,7 @@ static int vbm25_search_batch_impl(vbm25_index *ix, const uint32_t *term_ids, co
         if (bt) vbm25_batch_destroy(bt);
         ix->scratch = nullptr;
         if (int rc = vbm25_batch_create(ix, std::max(nq, 16u), std::max(n_terms, 256u), k, &bt)) return rc;
+        bt->pinned_results = true;  // (host buffers in, host buffers out: nobody reads this batch's records on the device)
         ix->scratch = bt;
     }
     const bool fast = !bt->bigk;
@@ -1618,8 +1631,12 @@ static int vbm25_batch_finish_download(vbm25_batch *bt, vbm25_hit *hits, uint32_
 
 // ---------------------------------------------------------------------------
 // The pipelined boundary (include/vbm25.h): a ring of batch objects, each with its own stream and pinned staging.  submit =
-// set_queries (staged) + run + download, all enqueued on the slot's stream; collect = the oldest slot's stream synchronisation
-// and one copy out of its pinned buffer.
+// set_queries (staged) + run, enqueued on the slot's stream; merge_kernel writes the counts and the 24-byte records straight into
+// the slot's pinned output buffer (pinned_results: posted writes over PCIe -- no download command on the step, only the 4-byte
+// flag is copied); collect = the oldest slot's stream synchronisation and one copy out of its pinned buffer.  The kernels of
+// neighbouring batches are launched into each other's tails: on C3 a pipelined step is SHORTER than a step of a loop over resident
+// batches on one stream (0.21 against 0.235 ms, profiles/r5_stream_host_time.txt).  With the records downloaded by copy
+// commands (three per batch) the same ring took 0.25 ms.
 // ---------------------------------------------------------------------------
 }  // extern "C"
 struct vbm25_stream {
@@ -1638,6 +1655,7 @@ static int stream_create_impl(vbm25_index *ix, uint32_t depth, uint32_t max_quer
     for (uint32_t i = 0; i < depth; ++i) {
         vbm25_batch *b = nullptr;
         if (int rc = vbm25_batch_create(ix, max_queries, std::max(max_total_terms, 1u), k, &b)) return rc;
+        b->pinned_results = true;
         s->slots.push_back(b);
     }
     *out = s.release();
@@ -1853,6 +1871,7 @@ int multi_batch_create_impl(vbm25_multi *m, uint32_t max_queries, uint32_t max_t
     for (vbm25_index *ix : m->replicas) {
         vbm25_batch *b = nullptr;
         if (int rc = vbm25_batch_create(ix, per, std::max(max_total_terms, 1u), k, &b)) return rc;
+        b->pinned_results = true;
         mb->parts.push_back(b);
     }
     mb->lo.assign(n + 1, 0);
