@@ -209,7 +209,11 @@ __global__ void __launch_bounds__(wn_waves(MT) * 64, (wn_waves(MT) + 3) / 4) sca
     bmbase.mask = 0x1ffcu;
     asm volatile("" : "+v"(bmbase.mask));
     const uint32_t k = bt.k, g = bt.win_g, n_items = bt.nq * g, NWIN = ix.n_win;
+#ifdef VBM25_DEV
     const uint32_t dbg = bt.win_dbg;  // timing experiments (wrong results): 1 no cold pass, 2 no completion, 4 no second arrivals, 32 no marks, 64 no wipe
+#else
+    constexpr uint32_t dbg = 0;       // (the product has no switch that changes results: the experiments need make libvbm25_dev.so)
+#endif
     const uint16_t *ids16 = reinterpret_cast<const uint16_t *>(ix.post_id16);
     for (uint32_t i = threadIdx.x; i < 256u; i += WN_WG) S1[i] = ix.s1[i];
 #pragma unroll

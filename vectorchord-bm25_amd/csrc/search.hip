@@ -1448,7 +1448,9 @@ int vbm25_tuning_set(const char *name, long long value) {
     else if (n == "range_min_chunk") g_tune.range_min_chunk = (uint32_t)std::max(128ll, value);
     else if (n == "range_grid") g_tune.range_grid = (uint32_t)std::max(1ll, value);
     else if (n == "dense_grid") g_tune.dense_grid = (uint32_t)std::max(1ll, value);
-    else if (n == "dbg") g_tune.dbg = (uint32_t)value;
+#ifdef VBM25_DEV
+    else if (n == "dbg") g_tune.dbg = (uint32_t)value;  // (scan_win_kernel's timing experiments: development build only)
+#endif
     else if (n == "fused_items") g_tune.fused_items = (uint32_t)std::max(0ll, value);
     else if (n == "arith") g_tune.arith = value != 0;
     else if (n == "win") g_tune.win = value != 0;
