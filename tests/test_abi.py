@@ -75,3 +75,19 @@ def test_intern_and_query():
     assert q.keys == [vb.intern(b"10"), vb.intern(b"9")]  # bytewise order: "10" < "9"
     with pytest.raises(ValueError):
         vb.Query([vb.intern(b"9"), vb.intern(b"10")])
+
+
+def test_tuning_switches_of_the_product_library():
+    """vbm25_tuning_set (exported, not in the header) knows the routing / geometry switches and refuses everything else --
+    in particular `dbg`, the development switch that turns parts of scan_win_kernel off (wrong results by design): it exists
+    only in libvbm25_dev.so.  Host-only: no device is touched."""
+    import vectorchord_bm25_amd as vb
+
+    try:
+        for name in ("win", "win_items", "win_skew", "win_planes", "rel16_plane", "arith", "fused", "dense_x1000"):
+            vb.set_tuning(name, 1)
+        for name in ("dbg", "team", "team_dbg", "no_such_switch"):
+            with pytest.raises(RuntimeError, match="unknown tuning switch"):
+                vb.set_tuning(name, 1)
+    finally:
+        vb.reset_tuning()
