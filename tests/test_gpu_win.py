@@ -77,12 +77,38 @@ def test_same_records_as_the_range_kernel(tuning):
     assert h_win.tobytes() == h_rng.tobytes() and np.array_equal(n_win, n_rng)
 
 
-@pytest.mark.parametrize("nterms", [1, 2, 3, 8])
+@pytest.mark.parametrize("nterms", [1, 2, 3, 4, 5, 6, 7, 8])
 def test_term_counts(tuning, nterms):
+    """every query of the batch has the same number of indexed terms: the instantiation compiled for exactly that many (2 .. 8; a
+    single term: the two-load kernel with a dummy)"""
     seg, gix, oix = synth_pair(300_000, 33_000, seed=5)
     terms, off = bench_queries(seg, 33_000, 64, nterms, seed=nterms)
     tuning(fused=0)
     check(gix, oix, terms, off, 10)
+
+
+@pytest.mark.parametrize("nterms,k", [(3, 100), (4, 200), (2, 256)])
+def test_term_counts_with_more_register_rows(tuning, nterms, k):
+    seg, gix, oix = synth_pair(300_000, 33_000, seed=5)
+    terms, off = bench_queries(seg, 33_000, 64, nterms, seed=10 + nterms)
+    tuning(fused=0)
+    check(gix, oix, terms, off, k)
+
+
+@pytest.mark.parametrize("k", [10, 100])
+def test_mixed_term_counts_in_one_batch(tuning, k):
+    """queries of one to five terms in one batch, and one whose last token the index does not know: the kernel compiled for the most
+    terms, the shorter queries load dummies"""
+    seg, gix, oix = synth_pair(300_000, 33_000, seed=5)
+    rows = []
+    for nterms in (5, 2, 3, 1, 4, 5, 3):
+        t, o = bench_queries(seg, 33_000, 12, nterms, seed=20 + nterms)
+        rows += [t[o[q]:o[q + 1]] for q in range(12)]
+    rows.append(np.r_[rows[0][:3], [0xfffffff0]].astype(np.uint32))  # (an id beyond the vocabulary: ignored, search.rs:59-61)
+    terms = np.concatenate(rows).astype(np.uint32)
+    off = np.r_[0, np.cumsum([len(r) for r in rows])].astype(np.uint32)
+    tuning(fused=0)
+    check(gix, oix, terms, off, k)
 
 
 def test_thick_runs_are_chunked_and_searched_in_memory(tuning):

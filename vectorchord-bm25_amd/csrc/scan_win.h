@@ -133,37 +133,54 @@ __device__ __forceinline__ void wn_load_word(uint32_t &dst, const uint32_t *addr
 __device__ __forceinline__ void wn_load_theta(unsigned long long &dst, const uint32_t vzero, const unsigned long long *sbase) {
     asm volatile("s_nop 4\n\tglobal_load_dwordx2 %0, %1, %2 sc1" : "=v"(dst) : "v"(vzero), "s"(sbase));  // (sc1: an agent-scope load, as __hip_atomic_load makes it)
 }
-// The kernel is compiled for MT run loads per window (MT = the most indexed terms of a query of the batch: 2, 4, 5 or 8; a query of
+// The kernel is compiled for MT run loads per window (FULL: every query of the batch has exactly MT = 2 .. 8 indexed terms; otherwise
+// MT = the most indexed terms of a query of the batch rounded up to 2, 4, 5 or 8, and a query of
 // fewer terms loads the plane's first bytes for the others -- every load of the loop is unconditional: a conditional one made the
 // compiler COPY the arriving registers, i.e. read them before their loads had landed).  R(w + 1) complete: the MT + 2 loads issued
 // after it -- P(w), G(w), R(w + 2) -- may still be in flight; G(w): the MT of R(w + 2) behind it; P(w - 1): G(w - 1) and R(w + 1).
 #define WN_STR2(x) #x
 #define WN_STR(x) WN_STR2(x)
-#define WN_OPS2(b) "+v"(b[0]), "+v"(b[1])
-#define WN_OPS4(b) WN_OPS2(b), "+v"(b[2]), "+v"(b[3])
+#define WN_OPS1(b) "+v"(b[0])
+#define WN_OPS2(b) WN_OPS1(b), "+v"(b[1])
+#define WN_OPS3(b) WN_OPS2(b), "+v"(b[2])
+#define WN_OPS4(b) WN_OPS3(b), "+v"(b[3])
 #define WN_OPS5(b) WN_OPS4(b), "+v"(b[4])
-#define WN_OPS8(b) WN_OPS5(b), "+v"(b[5]), "+v"(b[6]), "+v"(b[7])
+#define WN_OPS6(b) WN_OPS5(b), "+v"(b[5])
+#define WN_OPS7(b) WN_OPS6(b), "+v"(b[6])
+#define WN_OPS8(b) WN_OPS7(b), "+v"(b[7])
 // (issue order at the end of a window w: P(w), the words of its two open passes Ga(w) and Gb(w), then R(w + 2): MT + 3 loads)
 template <int MT>
-__device__ __forceinline__ void wn_wait_runs(unsigned long long (&b)[MT]) {  // R(w + 1): P, Ga, Gb, R(w + 2) behind it
-    static_assert(MT == 2 || MT == 4 || MT == 5 || MT == 8, "operand lists");
+__device__ __forceinline__ void wn_wait_runs(unsigned long long (&b)[MT]) {  // R(w + 1): P, Ga, Gb, R(w + 2) behind it: vmcnt(MT + 3)
+    static_assert(MT >= 1 && MT <= 8, "operand lists");
+    if constexpr (MT == 1) asm volatile("s_waitcnt vmcnt(4)" : WN_OPS1(b));
     if constexpr (MT == 2) asm volatile("s_waitcnt vmcnt(5)" : WN_OPS2(b));
+    if constexpr (MT == 3) asm volatile("s_waitcnt vmcnt(6)" : WN_OPS3(b));
     if constexpr (MT == 4) asm volatile("s_waitcnt vmcnt(7)" : WN_OPS4(b));
     if constexpr (MT == 5) asm volatile("s_waitcnt vmcnt(8)" : WN_OPS5(b));
+    if constexpr (MT == 6) asm volatile("s_waitcnt vmcnt(9)" : WN_OPS6(b));
+    if constexpr (MT == 7) asm volatile("s_waitcnt vmcnt(10)" : WN_OPS7(b));
     if constexpr (MT == 8) asm volatile("s_waitcnt vmcnt(11)" : WN_OPS8(b));
 }
 template <int MT>
-__device__ __forceinline__ void wn_wait_words(uint32_t &ga, uint32_t &gb) {  // Ga(w) and Gb(w): R(w + 2) behind them
+__device__ __forceinline__ void wn_wait_words(uint32_t &ga, uint32_t &gb) {  // Ga(w) and Gb(w): R(w + 2) behind them: vmcnt(MT)
+    if constexpr (MT == 1) asm volatile("s_waitcnt vmcnt(1)" : "+v"(ga), "+v"(gb));
     if constexpr (MT == 2) asm volatile("s_waitcnt vmcnt(2)" : "+v"(ga), "+v"(gb));
+    if constexpr (MT == 3) asm volatile("s_waitcnt vmcnt(3)" : "+v"(ga), "+v"(gb));
     if constexpr (MT == 4) asm volatile("s_waitcnt vmcnt(4)" : "+v"(ga), "+v"(gb));
     if constexpr (MT == 5) asm volatile("s_waitcnt vmcnt(5)" : "+v"(ga), "+v"(gb));
+    if constexpr (MT == 6) asm volatile("s_waitcnt vmcnt(6)" : "+v"(ga), "+v"(gb));
+    if constexpr (MT == 7) asm volatile("s_waitcnt vmcnt(7)" : "+v"(ga), "+v"(gb));
     if constexpr (MT == 8) asm volatile("s_waitcnt vmcnt(8)" : "+v"(ga), "+v"(gb));
 }
 template <int MT>
-__device__ __forceinline__ void wn_wait_theta(unsigned long long &p) {  // P(w - 1): Ga, Gb (w - 1) and R(w + 1) behind it
+__device__ __forceinline__ void wn_wait_theta(unsigned long long &p) {  // P(w - 1): Ga, Gb (w - 1) and R(w + 1) behind it: vmcnt(MT + 2)
+    if constexpr (MT == 1) asm volatile("s_waitcnt vmcnt(3)" : "+v"(p));
     if constexpr (MT == 2) asm volatile("s_waitcnt vmcnt(4)" : "+v"(p));
+    if constexpr (MT == 3) asm volatile("s_waitcnt vmcnt(5)" : "+v"(p));
     if constexpr (MT == 4) asm volatile("s_waitcnt vmcnt(6)" : "+v"(p));
     if constexpr (MT == 5) asm volatile("s_waitcnt vmcnt(7)" : "+v"(p));
+    if constexpr (MT == 6) asm volatile("s_waitcnt vmcnt(8)" : "+v"(p));
+    if constexpr (MT == 7) asm volatile("s_waitcnt vmcnt(9)" : "+v"(p));
     if constexpr (MT == 8) asm volatile("s_waitcnt vmcnt(10)" : "+v"(p));
 }
 __device__ __forceinline__ void wn_wait_all(uint32_t &g) { asm volatile("s_waitcnt vmcnt(0)" : "+v"(g)); }
@@ -182,9 +199,13 @@ __device__ __forceinline__ uint32_t wn_load_u16_now(const uint16_t *addr) {
 // every load issued by hand has landed: their registers are the compiler's again (they stay allocated up to here)
 template <int MT>
 __device__ __forceinline__ void wn_drain(unsigned long long (&a)[MT], unsigned long long (&b)[MT], uint32_t &g, uint32_t &g2, unsigned long long &p) {
+    if constexpr (MT == 1) asm volatile("s_waitcnt vmcnt(0)" : WN_OPS1(a), WN_OPS1(b), "+v"(g), "+v"(g2), "+v"(p));
     if constexpr (MT == 2) asm volatile("s_waitcnt vmcnt(0)" : WN_OPS2(a), WN_OPS2(b), "+v"(g), "+v"(g2), "+v"(p));
+    if constexpr (MT == 3) asm volatile("s_waitcnt vmcnt(0)" : WN_OPS3(a), WN_OPS3(b), "+v"(g), "+v"(g2), "+v"(p));
     if constexpr (MT == 4) asm volatile("s_waitcnt vmcnt(0)" : WN_OPS4(a), WN_OPS4(b), "+v"(g), "+v"(g2), "+v"(p));
     if constexpr (MT == 5) asm volatile("s_waitcnt vmcnt(0)" : WN_OPS5(a), WN_OPS5(b), "+v"(g), "+v"(g2), "+v"(p));
+    if constexpr (MT == 6) asm volatile("s_waitcnt vmcnt(0)" : WN_OPS6(a), WN_OPS6(b), "+v"(g), "+v"(g2), "+v"(p));
+    if constexpr (MT == 7) asm volatile("s_waitcnt vmcnt(0)" : WN_OPS7(a), WN_OPS7(b), "+v"(g), "+v"(g2), "+v"(p));
     if constexpr (MT == 8) asm volatile("s_waitcnt vmcnt(0)" : WN_OPS8(a), WN_OPS8(b), "+v"(g), "+v"(g2), "+v"(p));
 }
 // an open pass of second arrivals: what C1 found for the lane's (entry, term), the word requested for it
@@ -194,7 +215,9 @@ struct WnPend {
 };
 
 // RK: rows of 64 entries of the wave's top-k in registers (k <= 64 RK)
-template <int MT, int RK>
+// FULL: every query of the batch has exactly MT indexed terms (the host's promise; a query that breaks it is given up): the
+// per-term tests of the window loop are decided at compile time
+template <int MT, int RK, bool FULL>
 __global__ void __launch_bounds__(wn_waves(MT) * 64, (wn_waves(MT) + 3) / 4) scan_win_kernel(DevIndex ix, DevBatch bt) {
     constexpr int WN_WAVES = wn_waves(MT), WN_WG = WN_WAVES * 64;
     static_assert(sizeof(WinWave<MT>) == 512 * MT + 256 + 512, "wn_waves() knows the size");
@@ -290,8 +313,9 @@ __global__ void __launch_bounds__(wn_waves(MT) * 64, (wn_waves(MT) + 3) / 4) sca
             }
         }
         // (the host routes only queries of <= WN_T indexed terms that all have a table this way)
-        bool failed = m > (uint32_t)MT || __ballot(act && wb == NONE32) != 0ull;
+        bool failed = m > (uint32_t)MT || (FULL && m != (uint32_t)MT) || __ballot(act && wb == NONE32) != 0ull;
         if (failed) m = 0;
+        const uint32_t mm = FULL ? (uint32_t)MT : m;  // (FULL and failed: the loads below are safe for any term; the first window gives the item up)
         const uint32_t wbs = act && !failed ? wb : 0u;  // (lanes without a term read the first table: every load below is unconditional)
         // the term's postings as bytes (lane = term), and per term the numbers of its postings below the item's window boundaries
         // (lane i = boundary w_lo + i; the host cuts items of at most 63 windows): no boundary is loaded inside the window loop
@@ -381,8 +405,8 @@ __global__ void __launch_bounds__(wn_waves(MT) * 64, (wn_waves(MT) + 3) / 4) sca
         // ---- completion of the second arrivals in two halves: C1 (after a window's marks) finds the postings -- lane = (entry, term),
         // bisection of the term's staged run -- and requests their tf / fieldnorm words; C2 scores, sums and offers.  The first
         // pass of a window is finished only after the NEXT window's marks: the round trip to HBM hides behind them.
-        const uint32_t inv_m = m ? (65536u + m - 1u) / m : 0u, epp = m ? 64u / m : 0u;
-        const uint32_t el = (lane * inv_m) >> 16, tl = m ? lane - el * m : 0u;  // the lane's entry of a pass and its term
+        const uint32_t inv_m = mm ? (65536u + mm - 1u) / mm : 0u, epp = mm ? 64u / mm : 0u;
+        const uint32_t el = (lane * inv_m) >> 16, tl = mm ? lane - el * mm : 0u;  // the lane's entry of a pass and its term
         const uint32_t fbl = (uint32_t)__shfl((int)fb, (int)tl);
         const double s0l = __shfl(s0, (int)tl);
         bool notf = false;
@@ -447,10 +471,10 @@ __global__ void __launch_bounds__(wn_waves(MT) * 64, (wn_waves(MT) + 3) / 4) sca
             bool okd = false;
             double acc = 0.0;
             if (d.task && tl == 0u) {
-                const uint32_t my = (uint32_t)(fm >> lane) & ((1u << m) - 1u);
+                const uint32_t my = (uint32_t)(fm >> lane) & ((1u << mm) - 1u);
                 // the entry of the LAST term that holds the document completes it (one offer per document)
                 okd = (my >> (d.te + 1u)) == 0u && (my & (my - 1u)) != 0u;
-                for (uint32_t t = 0; t < m; ++t) acc += S.contrib[lane + t];  // ascending key order; absent terms add 0.0
+                for (uint32_t t = 0; t < mm; ++t) acc += S.contrib[lane + t];  // ascending key order; absent terms add 0.0
             }
             __builtin_amdgcn_wave_barrier();
             offer(okd, acc, d.w << 16 | d.x);
@@ -482,7 +506,7 @@ __global__ void __launch_bounds__(wn_waves(MT) * 64, (wn_waves(MT) + 3) / 4) sca
                         const int t = 5 * gq + u;
 #pragma unroll
                         for (int j = 0; j < 4; ++j) hb[u][j] = ho[u][j] = 0;
-                        if (t < MT && (uint32_t)t < m) {
+                        if (t < MT && (uint32_t)t < mm) {
                             const uint32_t o_lo = (uint32_t)__builtin_amdgcn_readlane((int)wo[t < MT ? t : 0], (int)(w - w_lo));
                             const uint32_t o_hi = (uint32_t)__builtin_amdgcn_readlane((int)wo[t < MT ? t : 0], (int)(w - w_lo + 1u));
                             const uint32_t n = o_hi - o_lo, o_al = o_lo & ~3u, r0 = o_al + 4u * lane - o_lo;
@@ -530,7 +554,7 @@ __global__ void __launch_bounds__(wn_waves(MT) * 64, (wn_waves(MT) + 3) / 4) sca
 #pragma unroll
                     for (int u = 0; u < 5; ++u) {
                         const int t = 5 * gq + u;
-                        if (t >= 1 && t < MT && (uint32_t)t < m) {
+                        if (t >= 1 && t < MT && (uint32_t)t < mm) {
                             const unsigned long long cv = cur[t < MT ? t : 0];
 #pragma unroll
                             for (int j = 0; j < 4; ++j) {
@@ -635,7 +659,7 @@ __global__ void __launch_bounds__(wn_waves(MT) * 64, (wn_waves(MT) + 3) / 4) sca
             for (int t = 0; t < MT; ++t) {
                 const uint32_t pS = (uint32_t)__builtin_amdgcn_readlane((int)wS, t), pE = (uint32_t)__builtin_amdgcn_readlane((int)wE, t);
                 const uint32_t fbt = (uint32_t)__builtin_amdgcn_readlane((int)fb, t);
-                const bool in = (uint32_t)t < m && pE != pS && (pS >> 7) + lane <= ((pE - 1u) >> 7);
+                const bool in = (uint32_t)t < mm && pE != pS && (pS >> 7) + lane <= ((pE - 1u) >> 7);
                 double ub = 0.0;
                 if (in) ub = ix.blk_ub[fbt + (pS >> 7) + lane];
                 const unsigned long long hm = __ballot(in && (unsigned long long)__double_as_longlong(ub) >= th);
@@ -644,7 +668,7 @@ __global__ void __launch_bounds__(wn_waves(MT) * 64, (wn_waves(MT) + 3) / 4) sca
                     hm0h = (uint32_t)(hm >> 32);
                 }
             }
-            for (uint32_t t = 0; t < m; ++t) {
+            for (uint32_t t = 0; t < mm; ++t) {
                 const uint32_t pS = (uint32_t)__builtin_amdgcn_readlane((int)wS, (int)t), pE = (uint32_t)__builtin_amdgcn_readlane((int)wE, (int)t);
                 if (pE == pS) continue;
                 const uint32_t fbt = (uint32_t)__builtin_amdgcn_readlane((int)fb, (int)t);
@@ -679,7 +703,7 @@ __global__ void __launch_bounds__(wn_waves(MT) * 64, (wn_waves(MT) + 3) / 4) sca
                             bool cand = 2u * lane + j < n && wd >= w_lo && wd < w_hi && (unsigned long long)__double_as_longlong(sc) >= th &&
                                         (rtop.cnt < k || better(sc, d, rtop.kth_s, rtop.kth_d));
                             if (!__ballot(cand)) continue;
-                            for (uint32_t t2 = 0; t2 < m; ++t2) {  // ... unless another list of the query holds the document
+                            for (uint32_t t2 = 0; t2 < mm; ++t2) {  // ... unless another list of the query holds the document
                                 if (t2 == t) continue;
                                 const uint32_t wb2 = (uint32_t)__builtin_amdgcn_readlane((int)wb, (int)t2);
                                 const uint16_t *run = ids16 + 128ull * (uint32_t)__builtin_amdgcn_readlane((int)fb, (int)t2);

@@ -14,26 +14,41 @@ namespace vbm25 {
 #include "scan_win.h"
 #include "scan_win_launch.h"
 
-// mt: the most indexed terms of a query of the batch -- the kernel is compiled for 2, 4, 5 and 8 run loads per window; k: the top-k
-// lives in 1, 2 or 4 register rows of 64 entries (the eight-load kernel has registers for one row only: scan_win_max_k)
-template <int MT>
+// mt: the most indexed terms of a query of the batch; k: the top-k lives in 1, 2 or 4 register rows of 64 entries (beyond five run
+// loads the kernel has registers for one row only: scan_win_max_k)
+template <int MT, bool FULL>
 static void launch_mt(const DevIndex &ix, const DevBatch &bt, uint32_t grid, hipStream_t st) {
     // (grid: workgroups; a workgroup is wn_waves(MT) independent waves)
-    if (bt.k <= 64u) scan_win_kernel<MT, 1><<<grid, wn_waves(MT) * 64, 0, st>>>(ix, bt);
+    if (bt.k <= 64u) scan_win_kernel<MT, 1, FULL><<<grid, wn_waves(MT) * 64, 0, st>>>(ix, bt);
     else if constexpr (MT <= 5) {
-        if (bt.k <= 128u) scan_win_kernel<MT, 2><<<grid, wn_waves(MT) * 64, 0, st>>>(ix, bt);
-        else scan_win_kernel<MT, 4><<<grid, wn_waves(MT) * 64, 0, st>>>(ix, bt);
+        if (bt.k <= 128u) scan_win_kernel<MT, 2, FULL><<<grid, wn_waves(MT) * 64, 0, st>>>(ix, bt);
+        else scan_win_kernel<MT, 4, FULL><<<grid, wn_waves(MT) * 64, 0, st>>>(ix, bt);
     }
 }
-hipError_t scan_win_launch(const DevIndex &ix, const DevBatch &bt, uint32_t mt, uint32_t grid, hipStream_t st) {
-    if (bt.k > scan_win_max_k(mt)) return hipErrorInvalidValue;
-    if (mt <= 2) launch_mt<2>(ix, bt, grid, st);
-    else if (mt <= 4) launch_mt<4>(ix, bt, grid, st);
-    else if (mt <= 5) launch_mt<5>(ix, bt, grid, st);
-    else launch_mt<8>(ix, bt, grid, st);
+// full: every query of the batch has exactly mt indexed terms -- the kernel compiled for exactly mt terms (2 .. 8); otherwise the one
+// for the next of 2, 4, 5, 8 (shorter queries load dummies)
+hipError_t scan_win_launch(const DevIndex &ix, const DevBatch &bt, uint32_t mt, bool full, uint32_t grid, hipStream_t st) {
+    if (bt.k > scan_win_max_k(mt) || mt == 0 || mt > (uint32_t)WN_T) return hipErrorInvalidValue;
+    // (one term: the two-load kernel with a dummy -- compiled for a single run load the compiler copies the buffer's registers
+    // across the loop while their loads are in flight; tools/check_inflight.py finds it)
+    if (full && mt >= 2) {
+        switch (mt) {
+            case 2: launch_mt<2, true>(ix, bt, grid, st); break;
+            case 3: launch_mt<3, true>(ix, bt, grid, st); break;
+            case 4: launch_mt<4, true>(ix, bt, grid, st); break;
+            case 5: launch_mt<5, true>(ix, bt, grid, st); break;
+            case 6: launch_mt<6, true>(ix, bt, grid, st); break;
+            case 7: launch_mt<7, true>(ix, bt, grid, st); break;
+            default: launch_mt<8, true>(ix, bt, grid, st); break;
+        }
+    } else if (mt <= 2) launch_mt<2, false>(ix, bt, grid, st);
+    else if (mt <= 4) launch_mt<4, false>(ix, bt, grid, st);
+    else if (mt <= 5) launch_mt<5, false>(ix, bt, grid, st);
+    else launch_mt<8, false>(ix, bt, grid, st);
     return hipGetLastError();
 }
-static uint32_t waves_of(uint32_t mt) { return uint32_t(mt <= 2 ? wn_waves(2) : mt <= 4 ? wn_waves(4) : mt <= 5 ? wn_waves(5) : wn_waves(8)); }
+static_assert(wn_waves(1) == wn_waves(8), "the host sizes grids and items with one number of waves per workgroup, whatever the term count");
+static uint32_t waves_of(uint32_t) { return uint32_t(wn_waves(8)); }
 uint32_t scan_win_resident_waves(uint32_t mt) { return WN_GRID * waves_of(mt); }
 uint32_t scan_win_max_terms() { return WN_T; }
 uint32_t scan_win_max_k(uint32_t mt) { return mt <= 5 ? 256u : 64u; }
