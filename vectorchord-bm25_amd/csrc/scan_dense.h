@@ -401,11 +401,18 @@ __global__ void __launch_bounds__(DWG, KMAX > 128 ? 2 : 4) scan_dense_kernel(Dev
             }
         };
         auto grp_finish = [&](const Grp &g, uint32_t wlo, uint32_t wspan) __attribute__((always_inline)) {
+            if (g.fastm == (1u << D_UN) - 1u) {  // a full group of plane blocks (the common case): one straight-line block
 #pragma unroll
-            for (int i = 0; i < D_UN; ++i)
-                if ((g.fastm >> i) & 1u)
+                for (int i = 0; i < D_UN; ++i)
                     add_pair(g.s0i[i], g.mind[i] + (g.r[i].rel & 0xffffu), g.mind[i] + (g.r[i].rel >> 16), g.r[i].tfn & 0xffu,
                              (g.r[i].tfn >> 8) & 0xffu, g.r[i].tfn >> 16, true, true, wlo, wspan);
+            } else {
+#pragma unroll
+                for (int i = 0; i < D_UN; ++i)
+                    if ((g.fastm >> i) & 1u)
+                        add_pair(g.s0i[i], g.mind[i] + (g.r[i].rel & 0xffffu), g.mind[i] + (g.r[i].rel >> 16), g.r[i].tfn & 0xffu,
+                                 (g.r[i].tfn >> 8) & 0xffu, g.r[i].tfn >> 16, true, true, wlo, wspan);
+            }
             uint32_t slow = g.slowm;
             while (slow) {
                 const uint32_t i = (uint32_t)__ffs((int)slow) - 1u;

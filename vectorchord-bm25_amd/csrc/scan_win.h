@@ -133,8 +133,7 @@ __device__ __forceinline__ void wn_load_word(uint32_t &dst, const uint32_t *addr
 __device__ __forceinline__ void wn_load_theta(unsigned long long &dst, const uint32_t vzero, const unsigned long long *sbase) {
     asm volatile("s_nop 4\n\tglobal_load_dwordx2 %0, %1, %2 sc1" : "=v"(dst) : "v"(vzero), "s"(sbase));  // (sc1: an agent-scope load, as __hip_atomic_load makes it)
 }
-// The kernel is compiled for MT run loads per window (FULL: every query of the batch has exactly MT = 2 .. 8 indexed terms; otherwise
-// MT = the most indexed terms of a query of the batch rounded up to 2, 4, 5 or 8, and a query of
+// The kernel is compiled for MT run loads per window (MT = the most indexed terms of a query of the batch, 2 .. 8; a query of
 // fewer terms loads the plane's first bytes for the others -- every load of the loop is unconditional: a conditional one made the
 // compiler COPY the arriving registers, i.e. read them before their loads had landed).  R(w + 1) complete: the MT + 2 loads issued
 // after it -- P(w), G(w), R(w + 2) -- may still be in flight; G(w): the MT of R(w + 2) behind it; P(w - 1): G(w - 1) and R(w + 1).
@@ -215,9 +214,10 @@ struct WnPend {
 };
 
 // RK: rows of 64 entries of the wave's top-k in registers (k <= 64 RK)
-// FULL: every query of the batch has exactly MT indexed terms (the host's promise; a query that breaks it is given up): the
-// per-term tests of the window loop are decided at compile time
-template <int MT, int RK, bool FULL>
+// MT: the most indexed terms of a query of the batch (2 .. 8).  A query of fewer terms gets NULL terms for the rest -- the window table
+// at the start of win_off, all zeros: runs without postings -- so that the per-term tests of the window loop are decided at compile
+// time and the terms' marks are one straight-line block (with the number of terms a run-time value: 0.215 instead of 0.199 ms on C3)
+template <int MT, int RK>
 __global__ void __launch_bounds__(wn_waves(MT) * 64, (wn_waves(MT) + 3) / 4) scan_win_kernel(DevIndex ix, DevBatch bt) {
     constexpr int WN_WAVES = wn_waves(MT), WN_WG = WN_WAVES * 64;
     static_assert(sizeof(WinWave<MT>) == 512 * MT + 256 + 512, "wn_waves() knows the size");
@@ -313,10 +313,10 @@ __global__ void __launch_bounds__(wn_waves(MT) * 64, (wn_waves(MT) + 3) / 4) sca
             }
         }
         // (the host routes only queries of <= WN_T indexed terms that all have a table this way)
-        bool failed = m > (uint32_t)MT || (FULL && m != (uint32_t)MT) || __ballot(act && wb == NONE32) != 0ull;
+        bool failed = m > (uint32_t)MT || __ballot(act && wb == NONE32) != 0ull;
         if (failed) m = 0;
-        const uint32_t mm = FULL ? (uint32_t)MT : m;  // (FULL and failed: the loads below are safe for any term; the first window gives the item up)
-        const uint32_t wbs = act && !failed ? wb : 0u;  // (lanes without a term read the first table: every load below is unconditional)
+        constexpr uint32_t mm = (uint32_t)MT;  // (terms beyond the query's own, and every term of an item given up here: the null table)
+        const uint32_t wbs = act && !failed ? wb : 0u;  // (lanes without a term: the null table at win_off[0 ..]; every load below is unconditional)
         // the term's postings as bytes (lane = term), and per term the numbers of its postings below the item's window boundaries
         // (lane i = boundary w_lo + i; the host cuts items of at most 63 windows): no boundary is loaded inside the window loop
         const unsigned long long pbase = (unsigned long long)ids16 + (act && !failed ? 256ull * fb : 0ull);
@@ -705,7 +705,7 @@ __global__ void __launch_bounds__(wn_waves(MT) * 64, (wn_waves(MT) + 3) / 4) sca
                             if (!__ballot(cand)) continue;
                             for (uint32_t t2 = 0; t2 < mm; ++t2) {  // ... unless another list of the query holds the document
                                 if (t2 == t) continue;
-                                const uint32_t wb2 = (uint32_t)__builtin_amdgcn_readlane((int)wb, (int)t2);
+                                const uint32_t wb2 = (uint32_t)__builtin_amdgcn_readlane((int)wbs, (int)t2);
                                 const uint16_t *run = ids16 + 128ull * (uint32_t)__builtin_amdgcn_readlane((int)fb, (int)t2);
                                 uint32_t lo = 0, hi = 0;
                                 if (cand) {

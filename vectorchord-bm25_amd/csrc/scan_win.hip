@@ -16,35 +16,30 @@ namespace vbm25 {
 
 // mt: the most indexed terms of a query of the batch; k: the top-k lives in 1, 2 or 4 register rows of 64 entries (beyond five run
 // loads the kernel has registers for one row only: scan_win_max_k)
-template <int MT, bool FULL>
+template <int MT>
 static void launch_mt(const DevIndex &ix, const DevBatch &bt, uint32_t grid, hipStream_t st) {
     // (grid: workgroups; a workgroup is wn_waves(MT) independent waves)
-    if (bt.k <= 64u) scan_win_kernel<MT, 1, FULL><<<grid, wn_waves(MT) * 64, 0, st>>>(ix, bt);
+    if (bt.k <= 64u) scan_win_kernel<MT, 1><<<grid, wn_waves(MT) * 64, 0, st>>>(ix, bt);
     else if constexpr (MT <= 5) {
-        if (bt.k <= 128u) scan_win_kernel<MT, 2, FULL><<<grid, wn_waves(MT) * 64, 0, st>>>(ix, bt);
-        else scan_win_kernel<MT, 4, FULL><<<grid, wn_waves(MT) * 64, 0, st>>>(ix, bt);
+        if (bt.k <= 128u) scan_win_kernel<MT, 2><<<grid, wn_waves(MT) * 64, 0, st>>>(ix, bt);
+        else scan_win_kernel<MT, 4><<<grid, wn_waves(MT) * 64, 0, st>>>(ix, bt);
     }
 }
-// full: every query of the batch has exactly mt indexed terms -- the kernel compiled for exactly mt terms (2 .. 8); otherwise the one
-// for the next of 2, 4, 5, 8 (shorter queries load dummies)
-hipError_t scan_win_launch(const DevIndex &ix, const DevBatch &bt, uint32_t mt, bool full, uint32_t grid, hipStream_t st) {
+// mt: the most indexed terms of a query of the batch: the kernel compiled for exactly that many run loads per window (2 .. 8; shorter
+// queries get null terms.  One term: the two-load kernel -- compiled for a single run load the compiler copies the buffer's
+// registers across the loop while their loads are in flight; tools/check_inflight.py finds it)
+hipError_t scan_win_launch(const DevIndex &ix, const DevBatch &bt, uint32_t mt, uint32_t grid, hipStream_t st) {
     if (bt.k > scan_win_max_k(mt) || mt == 0 || mt > (uint32_t)WN_T) return hipErrorInvalidValue;
-    // (one term: the two-load kernel with a dummy -- compiled for a single run load the compiler copies the buffer's registers
-    // across the loop while their loads are in flight; tools/check_inflight.py finds it)
-    if (full && mt >= 2) {
-        switch (mt) {
-            case 2: launch_mt<2, true>(ix, bt, grid, st); break;
-            case 3: launch_mt<3, true>(ix, bt, grid, st); break;
-            case 4: launch_mt<4, true>(ix, bt, grid, st); break;
-            case 5: launch_mt<5, true>(ix, bt, grid, st); break;
-            case 6: launch_mt<6, true>(ix, bt, grid, st); break;
-            case 7: launch_mt<7, true>(ix, bt, grid, st); break;
-            default: launch_mt<8, true>(ix, bt, grid, st); break;
-        }
-    } else if (mt <= 2) launch_mt<2, false>(ix, bt, grid, st);
-    else if (mt <= 4) launch_mt<4, false>(ix, bt, grid, st);
-    else if (mt <= 5) launch_mt<5, false>(ix, bt, grid, st);
-    else launch_mt<8, false>(ix, bt, grid, st);
+    switch (mt) {
+        case 1:
+        case 2: launch_mt<2>(ix, bt, grid, st); break;
+        case 3: launch_mt<3>(ix, bt, grid, st); break;
+        case 4: launch_mt<4>(ix, bt, grid, st); break;
+        case 5: launch_mt<5>(ix, bt, grid, st); break;
+        case 6: launch_mt<6>(ix, bt, grid, st); break;
+        case 7: launch_mt<7>(ix, bt, grid, st); break;
+        default: launch_mt<8>(ix, bt, grid, st); break;
+    }
     return hipGetLastError();
 }
 static_assert(wn_waves(1) == wn_waves(8), "the host sizes grids and items with one number of waves per workgroup, whatever the term count");

@@ -268,7 +268,6 @@ struct vbm25_batch {
     uint32_t fused_g = 0;         // items per query of the current queries on that route (0: general route)
     uint32_t arith_g = 0;         // general route without plan_kernel (every query sparse): items per query, made by the scan kernel itself
     uint32_t win_mt = 8;          // scan_win_kernel: the most indexed terms of a query of the current batch
-    bool win_full = false;        // ... and every query of it has exactly that many (scan_win_kernel<.., FULL>)
     bool win_skew = false;        // scan_win_kernel: one item per wave, a query's three runs sized for the three kinds of waves of a SIMD
     uint32_t q_stride = 0;        // != 0: every query of the current batch has this many terms
     bool order_useful = true;     // the current queries differ enough in length for the longest-first order to matter
@@ -423,7 +422,7 @@ static int index_create_common(const RawSegment &r, int device, vbm25_index **ou
     const bool rel16_plane = tune_now.rel16_plane != 0;
     const uint32_t n_win = uint32_t((uint64_t(r.n_docs) + 65535u) >> 16);
     std::vector<uint32_t> term_win(win_planes ? r.n_terms : 0u, UINT32_MAX);
-    uint64_t n_woff = 0;
+    uint64_t n_woff = n_win + 2u;  // (entries 0 .. n_win + 1: the NULL table -- a term without postings, what a query's missing terms read)
     if (win_planes)
         for (uint32_t t = 0; t < r.n_terms; ++t) {
             if (uint64_t(r.term_df_host[t]) * 4u < n_win || n_woff + n_win + 1u > 0xfffffff0ull) continue;
@@ -783,7 +782,7 @@ static int vbm25_batch_set_queries_impl(vbm25_batch *bt, const uint32_t *term_id
     if (nq > bt->max_queries) return set_error(VBM25_ERR_INVALID, "%u queries exceed the batch capacity %u", nq, bt->max_queries);
     if (q_off[0] != 0) return set_error(VBM25_ERR_INVALID, "q_off[0] must be 0");
     bool many = false, has_dense = false;
-    uint32_t n_dense = 0, range_mt = 0, range_min = UINT32_MAX;
+    uint32_t n_dense = 0, range_mt = 0;
     // Routing: scan_range_kernel is built for sparse queries; a query with many postings per document (Zipf head terms)
     // takes the dense-window kernel, one with more than 16 indexed terms scan_many_kernel.  (The scratch vectors were
     // sized when the batch was created: nothing is allocated here.)
@@ -811,7 +810,6 @@ static int vbm25_batch_set_queries_impl(vbm25_batch *bt, const uint32_t *term_id
             many |= valid > 16u;
             has_dense |= bt->use_dense && dense[q] && valid <= (uint32_t)D_T;
             if (!dense[q] && valid <= 16u) range_mt = std::max(range_mt, valid);
-            range_min = std::min(range_min, valid);
         } else {
             many = true;
         }
@@ -983,7 +981,6 @@ static int vbm25_batch_set_queries_impl(vbm25_batch *bt, const uint32_t *term_id
     bt->has_dense = has_dense;
     bt->range_rt = !bt->use_range || range_mt == 0 ? 0u : (range_mt <= 8u ? 8u : 16u);
     bt->win_mt = range_mt;
-    bt->win_full = nq != 0 && range_min == range_mt;  // every query has the same number of indexed terms: the kernel compiled for exactly that many
     bt->q_stride = 0;
     if (nq && q_off[1] != 0) {
         bt->q_stride = q_off[1];
@@ -1215,7 +1212,7 @@ static int vbm25_batch_run_impl(vbm25_batch *bt, void *hip_stream) {
         if (int rc = take_events()) return rc;
         const uint32_t wmt = bt->range_rt == 8 ? bt->win_mt : 8u, wpw = scan_win_wg(wmt);
         const uint32_t wgrid = std::min<uint32_t>((bt->nq * bt->win_g + wpw - 1u) / wpw, bt->tune.win_grid ? bt->tune.win_grid : scan_win_resident_waves(wmt) / wpw);
-        HIP_TRY(scan_win_launch(ix, db, wmt, bt->range_rt == 8 && bt->win_full, wgrid, st));
+        HIP_TRY(scan_win_launch(ix, db, wmt, wgrid, st));
         (void)dispatch_k(bt->k, [&](auto kmax) {
             constexpr int KM = decltype(kmax)::value;
             if constexpr (KM <= REG_K) {
