@@ -522,6 +522,24 @@ def run(argv=None, scorer_factory=None, backend="nccl"):
     if on_gpu:
         route = {0: "general (plan_kernel)", 1: "one launch", 2: "plan-free scan_range_kernel", 3: "scan_win_kernel", 4: "exhaustive"}.get(
             batches[0].debug_route(), "?")
+    multi_stream_qps = None
+    if on_gpu and world == 1 and not use_dist and not args.no_host_buffer and args.workload in ("C3", "C1"):
+        # the same resident batches with ONE STREAM PER BATCH OBJECT instead of one stream for all (outside the timed region; the
+        # timed loop above stays on one stream so that a kernel's duration means something): the next batch's scan starts in the
+        # tail of this one's -- what the pipelined host-buffer figure above has and the one-stream loop does not
+        streams = [torch.cuda.Stream() for _ in range(nb)]
+        n3 = max(40, min(4 * args.steps, 400))
+        for i in range(2 * nb):
+            batches[i % nb].run(streams[i % nb].cuda_stream)
+        sync()
+        t0 = time.perf_counter()
+        for i in range(n3):
+            batches[i % nb].run(streams[i % nb].cuda_stream)
+        sync()
+        multi_stream_qps = n3 * nq_local / (time.perf_counter() - t0)
+        for i in range(nb):  # (a batch's consecutive runs stay on one stream: back to the launch stream through a synchronisation)
+            batches[i].run(stream_ptr)
+        sync()
     results = [b.fetch() for b in batches]
     for hits, n_hits in (results if "dbg" not in args.tune else []):  # (timing experiments switch parts of the kernel off)
         assert (n_hits == k).all() or args.workload in ("C1",), "missing hits"
@@ -630,7 +648,8 @@ def run(argv=None, scorer_factory=None, backend="nccl"):
                        "route": route,
                        "host_buffer_inclusive_qps_per_gpu": None if pcie_qps is None else round(pcie_qps, 1),
                        "host_buffer_inclusive": "vbm25_stream_*: three batches in flight on their own streams; queries uploaded from pinned staging, counts and 24-byte records written to pinned memory by merge_kernel, every step",
-                       "host_buffer_one_batch_at_a_time_qps_per_gpu": None if pcie_sync_qps is None else round(pcie_sync_qps, 1)},
+                       "host_buffer_one_batch_at_a_time_qps_per_gpu": None if pcie_sync_qps is None else round(pcie_sync_qps, 1),
+                       "resident_one_stream_per_batch_qps_per_gpu": None if multi_stream_qps is None else round(multi_stream_qps, 1)},
         }
         if verified:
             out["config"]["verified_bit_exact_vs_oracle"] = verified
