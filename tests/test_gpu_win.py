@@ -141,3 +141,53 @@ def test_index_without_window_planes_takes_the_range_kernel(tuning):
     tuning(win_planes=1)
     terms, off = bench_queries(seg, 33_000, 200, 5, seed=2)
     check(gix, oix, terms, off, 10, expect_route=2)
+
+
+@pytest.mark.parametrize("force", [1, 0])
+def test_random_shapes_through_the_window_kernel(tuning, force):
+    """The differential rule of the reference's fuzz test (tests/fuzz:217-303: random corpus, random queries, compare with an exact
+    scorer) on the window kernel: sixteen random shapes -- 3 k .. 400 k documents, vocabularies from 50 to 40 k tokens (runs from
+    empty to thousands of postings per window), uniform and Zipf tokens, one to eight terms with unknown tokens among them, one to
+    ninety queries, k from 1 to 256 -- with win_force so that every sparse batch takes it whatever its density (force = 1), and with the library's own routing (force = 0).  Items the kernel
+    gives up go to scan_many_kernel; the records are the oracle's either way."""
+    rng = np.random.default_rng(20260927 + force)
+    if force:
+        tuning(win_force=1, fused=0, dense_x1000=10 ** 9)
+    else:  # (the library's own routing: window, range, dense or many-term kernels as the shapes fall)
+        tuning(fused=0)
+    for case in range(16):
+        n_docs = int(rng.choice([3000, 20_000, 66_000, 150_000, 400_000]))
+        vocab = int(rng.choice([50, 400, 3000, 40_000]))
+        if n_docs * 30 // vocab > 600_000:  # (keep the oracle's brute force in seconds)
+            vocab *= 10
+        zipf = None if rng.random() < 0.6 else 1.0
+        c = make_corpus(n_docs, vocab, seed=100 + case, length=str(rng.choice(["fixed", "lognormal", "mixed"])), mean_len=int(rng.choice([12, 30, 60])), zipf=zipf)
+        seg = vb.Segment.build(1.2, 0.75, c["doc_len"], c["doc_payload"], c["term_key"], c["term_start"], c["post_doc"], c["post_tf"])
+        gix, oix = vb.GpuIndex(seg), orc.OracleIndex.from_arrays(seg.meta(), seg.arrays())
+        nterms = int(rng.integers(1, 9))
+        nq = int(rng.integers(1, 91))
+        k = int(rng.choice([1, 3, 10, 64, 65, 128, 256]))
+        if nterms > 5:
+            k = min(k, 64)  # (beyond five terms the window kernel keeps one register row: larger k takes another route)
+        terms, off = make_queries(c, nq, nterms, seed=case, zipf=zipf)
+        b = vb.Batch(gix, nq, max(1, len(terms)), k)
+        b.set_queries(terms, off)
+        route = b.debug_route()
+        b.run()
+        hits, nh = b.fetch()
+        ob, onb, _ = oix.search_batch(terms, off, k, mode="brute", threads=8)
+        assert np.array_equal(nh, onb), (case, route, n_docs, vocab, nterms, nq, k)
+        for q in range(nq):
+            assert_bit_exact(ob[q, :onb[q]], hits[q, :nh[q]], what=f"case {case} (route {route}, {n_docs} docs, vocab {vocab}, {nterms} terms, k {k}) q{q}")
+        assert route in (3, 0, 2), route
+
+
+@pytest.mark.parametrize("nq", [1, 2, 3, 5, 7, 13, 22])
+def test_three_parts_per_query_with_any_number_of_queries(tuning, nq):
+    """An index of exactly three windows: three parts per query, the layout of the skewed parts (a workgroup takes four queries, part
+    k goes to the wave slots 4 k .. 4 k + 3).  Query counts that are not multiples of four: the left-over queries' items follow in
+    plain order (the fuzz test above found them written beyond the end of the host's order array)."""
+    seg, gix, oix = synth_pair(150_000, 12_000, mean_len=40, seed=3)
+    terms, off = bench_queries(seg, 12_000, nq, 3, seed=nq)
+    tuning(fused=0)
+    check(gix, oix, terms, off, 10)

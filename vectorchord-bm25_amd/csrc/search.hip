@@ -917,22 +917,14 @@ static int vbm25_batch_set_queries_impl(vbm25_batch *bt, const uint32_t *term_id
                     // (the first wave of every SIMD) lived 449 k cycles on C3, 4..7 497 k, 8..11 559 k, whatever priority they set
                     // themselves -- and the launch ends with the slowest.  A workgroup takes four queries; a query's three runs of
                     // windows, of lengths in the ratio of those speeds (win_cut, vbm25_batch_run), go to one wave of each kind.
-                    for (uint32_t d = 0; d < nq * 3u; ++d) ord[d] = UINT32_MAX;
-                    uint32_t qi = 0;
-                    for (uint32_t wgi = 0; qi < nq; ++wgi)
-                        for (uint32_t s4 = 0; s4 < 4u && qi < nq; ++s4, ++qi)
-                            for (uint32_t part = 0; part < 3u; ++part) ord[size_t(wgi) * 12u + part * 4u + s4] = qs[qi] * 3u + part;
-                    // (a last workgroup of fewer than four queries leaves holes: filled with the numbers not handed out)
-                    uint32_t hole = 0;
-                    std::vector<uint8_t> used(size_t(nq) * 3u, 0);
-                    for (uint32_t d = 0; d < nq * 3u; ++d)
-                        if (ord[d] != UINT32_MAX) used[ord[d]] = 1;
-                    for (uint32_t d = 0; d < nq * 3u; ++d)
-                        if (ord[d] == UINT32_MAX) {
-                            while (used[hole]) ++hole;
-                            ord[d] = hole;
-                            used[hole] = 1;
-                        }
+                    // (nq mod 4 queries are left over: their items follow in plain order -- written to a partial last workgroup's
+                    // slots they would land beyond the end of the array)
+                    const uint32_t full = nq / 4u;
+                    for (uint32_t wgi = 0; wgi < full; ++wgi)
+                        for (uint32_t s4 = 0; s4 < 4u; ++s4)
+                            for (uint32_t part = 0; part < 3u; ++part) ord[size_t(wgi) * 12u + part * 4u + s4] = qs[wgi * 4u + s4] * 3u + part;
+                    for (uint32_t qi = full * 4u; qi < nq; ++qi)
+                        for (uint32_t part = 0; part < 3u; ++part) ord[size_t(qi) * 3u + part] = qs[qi] * 3u + part;
                 } else if (win_g)  // (parts of decreasing length: every query's first part, then every query's second one, ...)
                     for (uint32_t part = 0; part < g; ++part)
                         for (uint32_t i = 0; i < nq; ++i) ord[size_t(part) * nq + i] = qs[i] * uint32_t(g) + part;
