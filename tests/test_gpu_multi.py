@@ -112,3 +112,43 @@ def test_pipelined_boundary_returns_the_single_batch_records():
     assert len(got) == len(want)
     for (h, n), (hw, nw) in zip(got, want):
         assert np.array_equal(n, nw) and h.tobytes() == hw.tobytes()
+
+
+@pytest.mark.parametrize("k", [10, 100])
+def test_pipelined_boundary_random_batches_against_the_oracle(k):
+    """forty batches of random size (1 .. 300 queries: the one-launch route of a handful of queries and the three-launch routes share a
+    ring), random term counts (0 .. 7, unknown tokens among them), through a ring of three slots: every batch's records equal the
+    oracle's brute force"""
+    import orc
+    from parity import assert_bit_exact
+    seg = vb.Segment.synth(300_000, 33_000, mean_len=100, len_mode=1, seed=21)
+    gix = vb.GpuIndex(seg)
+    oix = orc.OracleIndex.from_arrays(seg.meta(), seg.arrays())
+    rng = np.random.default_rng(k)
+    batches = []
+    for i in range(40):
+        nq = int(rng.choice([1, 2, 5, 8, 9, 33, 100, 300]))
+        rows = []
+        for q in range(nq):
+            nt = int(rng.integers(0, 8))
+            ids = seg.token_terms(rng.choice(33_000, nt, replace=False).astype(np.uint32)) if nt else np.zeros(0, dtype=np.uint32)
+            if nt and rng.random() < 0.2:
+                ids = np.r_[ids[:-1], [0xfffffff0]].astype(np.uint32)  # (a token the index does not know)
+            rows.append(np.sort(ids).astype(np.uint32))
+        terms = np.concatenate(rows).astype(np.uint32) if rows else np.zeros(0, dtype=np.uint32)
+        off = np.r_[0, np.cumsum([len(r) for r in rows])].astype(np.uint32)
+        batches.append((terms, off))
+    st = vb.Stream(gix, 3, 300, 300 * 8, k)
+    got = []
+    for t, o in batches:
+        if st.in_flight == 3:
+            got.append(st.collect())
+        st.submit(t, o)
+    while st.in_flight:
+        got.append(st.collect())
+    assert len(got) == len(batches)
+    for i, ((t, o), (hits, nh)) in enumerate(zip(batches, got)):
+        ob, onb, _ = oix.search_batch(t, o, k, mode="brute", threads=8)
+        assert np.array_equal(nh, onb), i
+        for q in range(len(o) - 1):
+            assert_bit_exact(ob[q, :onb[q]], hits[q, :nh[q]], what=f"batch {i} q{q}")
