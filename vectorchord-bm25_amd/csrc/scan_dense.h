@@ -67,7 +67,9 @@ constexpr int D_UN = D_UN_V;                  // tasks per wave in flight
 constexpr uint32_t D_MAX_RESOLVED = 16384;  // exact re-scorings per item; beyond (masses of equal scores): scan_many_kernel
 constexpr uint32_t D_SPAN_TEST = 512;    // widest block span the skip test reads (8 accumulators per lane)
 constexpr uint32_t D_GRID = 512;         // persistent workgroups: 256 CUs x 2
-constexpr uint32_t D_TARGET_ITEMS = 4096;
+constexpr uint32_t D_TARGET_ITEMS = 12288;   // items of a batch of dense queries: the launch ends with its slowest workgroup, and an item's setup is 24 k cycles of
+                                           // the 20 M an item of C5 takes at 4096 -- C5: 4096 items 72.9 ms, 8192 69.9, 12288 69.7, 24576 70.9 (search.hip caps a
+                                           // query's share where the corpus is small)
 
 struct DenseLds {
     uint32_t acc[D_W / 2];    // 16-bit fixed point, two documents per word: scale x (upper bound of the document's score) < 2^16

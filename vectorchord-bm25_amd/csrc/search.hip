@@ -984,6 +984,12 @@ static int vbm25_batch_set_queries_impl(vbm25_batch *bt, const uint32_t *term_id
         // number of items (equal document counts)
         const uint32_t dense_target = std::max(256u, bt->tune.dense_items);
         bt->dense_c = has_dense ? std::max(1u, (dense_target + n_dense / 2) / std::max(n_dense, 1u)) : 0u;
+        if (has_dense) {
+            // (a few dense queries on a small corpus: no finer than 4096 items in all -- what the rounds before used -- or one item per
+            // 2^16 documents, whichever is more: below that an item is all setup)
+            const uint32_t floor_c = std::max(std::max(1u, 4096u / std::max(n_dense, 1u)), bt->index->n_docs >> 16);
+            if (bt->tune.dense_items == D_TARGET_ITEMS) bt->dense_c = std::min(bt->dense_c, floor_c);
+        }
         unsigned long long sparse_postings = 0;
         for (uint32_t q = 0; q < nq; ++q)
             if (!(bt->dense_c && dense[q])) sparse_postings += q_postings[q];
