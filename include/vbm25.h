@@ -285,9 +285,10 @@ int vbm25_batch_kernel_ms(vbm25_batch *, double *avg_ms, uint32_t *n_launches);
 
 /* The same boundary PIPELINED (the caller hands over host buffers and gets host buffers back, as bm25::search
  * returns a Vec, search.rs:28-36): up to `depth` batches are in flight at once, each on its own stream with its
- * own pinned staging -- the upload of batch n + 1 and the download of batch n - 1 overlap the scan of batch n, and
- * the host never waits for the device between a submit and the matching collect.
- *   vbm25_stream_submit   copies the queries into pinned memory and enqueues upload, scan and download; returns at
+ * own pinned staging -- the upload of batch n + 1 and the records of batch n - 1 (written straight into pinned memory
+ * by the last kernel of its scan) overlap the scan of batch n, and the host never waits for the device between a
+ * submit and the matching collect.  One host thread drives a stream object (two threads: two objects).
+ *   vbm25_stream_submit   copies the queries into pinned memory and enqueues upload and scan; returns at
  *                         once.  VBM25_ERR_INVALID when `depth` batches are already in flight (collect first).
  *   vbm25_stream_collect  waits for the OLDEST batch in flight and writes its records (nq x k hits, nq counts, in
  *                         submission order -- first in, first out); *nq_out = its number of queries.
