@@ -247,10 +247,10 @@ __global__ void __launch_bounds__(wn_waves(MT) * 64, (wn_waves(MT) + 3) / 4) sca
     const unsigned long long prof_t0 = __builtin_readcyclecounter();
 #endif
 
-    // Items come from one counter; the next one is drawn at the END of the item before (the round trip hides behind the cold pass).
-    // The first one too: thousands of waves queueing at that address at kernel start costs them up to tens of microseconds -- and
-    // is worth it (measured: 0.377 ms when every wave starts on its own number, 0.342 ms through the counter): the queue staggers
-    // the waves, and waves in lockstep meet at the same pipes at the same time.
+    // A wave's FIRST item is its own number (thousands of waves drawing from one counter at kernel start queued at that address for
+    // up to 33 us of a 270 us launch); further items -- only when the launch has more items than waves -- come from the counter, drawn
+    // at the END of the item before (the round trip hides behind the cold pass).  (The development switch 8 draws the first one from
+    // the counter too.)
     const uint32_t n_waves = gridDim.x * (uint32_t)WN_WAVES;
     uint32_t drawn = blockIdx.x * (uint32_t)WN_WAVES + uni(threadIdx.x >> 6);
     if (dbg & 8u) {
