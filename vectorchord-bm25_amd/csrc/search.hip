@@ -3,15 +3,15 @@
 // (bm25::search) for the sealed segment.  One translation unit; the kernels live in headers:
 //   plan.h         post_fn_kernel (index preparation: per-posting fieldnorm stream + validation of block
 //                  structure and WAND bounds) and plan_kernel (queries -> doc-range work items)
-//   scan_win.h     scan_win_kernel (its own translation unit, scan_win.hip): sparse queries of <= 8 terms of comparable length, k <= 64 --
-//                  the document-window formulation, the dominant kernel of C3
+//   scan_win.h     scan_win_kernel (its own translation unit, scan_win.hip): sparse queries of <= 8 terms of comparable length, k <= 256
+//                  (k <= 64 beyond five terms) -- the document-window formulation, the dominant kernel of C3
 //   scan_range.h   scan_range_kernel: every other sparse query of <= 16 terms, k <= 256; the one-launch route of vbm25_search_batch (C2)
 //   scan_dense.h   scan_dense_kernel: queries with many postings per document (Zipf head terms; C5), <= 16 terms, k <= 256
 //   scan_many.h    scan_many_kernel: up to 1024 terms, 256 < k <= 1024, items the others gave up (exhaustive)
 //   merge.h        merge_kernel: per-item top-k lists -> hits with payloads
 //   decode.h / block_fetch.h / topk_lds.h / topk_reg.h / device_types.h   shared pieces
-// This file: error text, host objects (index, batch) and the C ABI of include/vbm25.h.  DESIGN.md has
-// the full story.
+// This file: error text, host objects (index, batch, the pipelined ring vbm25_stream, the multi-device handle with its host
+// threads), routing, and the C ABI of include/vbm25.h.  DESIGN.md has the full story.
 //
 // Result order is canonical: score descending, ties by ascending doc id.  All f64 arithmetic is IEEE
 // (compiled with -ffp-contract=off, no fast-math): results are bit-identical to the CPU oracle's
