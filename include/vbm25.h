@@ -275,7 +275,9 @@ int vbm25_batch_set_queries(vbm25_batch *, const uint32_t *term_ids, const uint3
                             uint32_t nq);
 int vbm25_batch_run(vbm25_batch *, void *hip_stream);
 int vbm25_batch_fetch(vbm25_batch *, vbm25_hit *hits, uint32_t *n_hits);
-/* Device address of the nq x k vbm25_hit array / the nq counts (valid after run). */
+/* Device address of the nq x k vbm25_hit array / the nq counts (valid after run; a batch object whose device
+ * addresses were asked for leaves complete records there after EVERY run -- without this call a run may leave a
+ * query to vbm25_batch_fetch, which then repeats the scan for it before it returns). */
 int vbm25_batch_device_results(vbm25_batch *, void **hits, void **n_hits);
 /* When enabled, run() brackets the posting-scan kernel with HIP events on the
  * launch stream; kernel_ms() synchronises and returns the average duration of
@@ -351,8 +353,10 @@ int vbm25_index_create_from_device(const vbm25_device_segment *, vbm25_index **o
  * shard on its own stream, and the 24-byte hit records go from every device
  * straight into the caller's host arrays in query order (the caller is the
  * host: a device-side gather would only add a hop).  Same results, record for
- * record, as vbm25_search_batch on one device.  One host thread drives all
- * devices; a handle may be used from one thread at a time.
+ * record, as vbm25_search_batch on one device.  Every device has its own host
+ * thread inside the library (they belong to the vbm25_multi); a handle may be
+ * used from one thread at a time, and calls on DIFFERENT vbm25_multi_batch
+ * objects of one vbm25_multi from several threads are serialised by the library.
  * ---------------------------------------------------------------------- */
 typedef struct vbm25_multi vbm25_multi;
 typedef struct vbm25_multi_batch vbm25_multi_batch;

@@ -61,6 +61,52 @@ def test_multi_argument_errors():
     assert len(n) == 0
 
 
+@pytest.mark.parametrize("nq", [9, 11, 33, 101])
+def test_odd_query_counts_do_not_write_past_the_callers_counts(nq):
+    """The kernels' records sit 8-byte aligned behind the counts in the pinned buffer; the copy into the caller's n_hits must be
+    exactly 4 nq bytes (round-5 advisor: the aligned size was copied, four bytes too many for an odd nq).  n_hits is handed over as
+    the first nq words of a longer array whose tail is a guard pattern: vbm25_search_batch (general route: more than 8 queries),
+    vbm25_stream_collect and vbm25_multi_batch_fetch with odd shards on the general route (nq >= 18 over two replicas)."""
+    import ctypes as C
+    c, seg = _setup(150_000, 3000, seed=4)
+    gix = vb.GpuIndex(seg)
+    terms, off = make_queries(c, nq, 4, seed=9)
+    L = vb.lib()
+    GUARD = 0xA5A5A5A5
+
+    def guarded():
+        hits = np.zeros((nq, 10), dtype=vb.HIT_DTYPE)
+        cnt = np.full(nq + 4, GUARD, dtype=np.uint32)
+        return hits, cnt
+
+    want_h, want_n = vb.search_batch(gix, terms, off, 10)
+    hits, cnt = guarded()
+    vb.api.check(L.vbm25_search_batch(gix.h, terms.ctypes.data_as(C.c_void_p), off.ctypes.data_as(C.c_void_p), nq, 10,
+                                  hits.ctypes.data_as(C.c_void_p), cnt.ctypes.data_as(C.c_void_p)))
+    assert np.all(cnt[nq:] == GUARD), "vbm25_search_batch wrote past n_hits[nq]"
+    assert np.array_equal(cnt[:nq], want_n) and hits.tobytes() == want_h.tobytes()
+
+    st = vb.Stream(gix, 2, nq, len(terms), 10)
+    st.submit(terms, off)
+    hits, cnt = guarded()
+    got = C.c_uint32()
+    vb.api.check(L.vbm25_stream_collect(st.h, hits.ctypes.data, cnt.ctypes.data, C.byref(got)))
+    st._nq.pop(0)
+    assert got.value == nq and np.all(cnt[nq:] == GUARD), "vbm25_stream_collect wrote past n_hits[nq]"
+    assert np.array_equal(cnt[:nq], want_n) and hits.tobytes() == want_h.tobytes()
+
+    for n_rep in (2, 3):
+        multi = vb.MultiIndex(seg, [0] * n_rep)
+        mb = vb.MultiBatch(multi, nq, len(terms), 10)
+        mb.set_queries(terms, off)
+        for _ in range(3):  # (a stale count of a neighbouring shard would show on a repeated run)
+            mb.run()
+            hits, cnt = guarded()
+            vb.api.check(L.vbm25_multi_batch_fetch(mb.h, hits.ctypes.data_as(C.c_void_p), cnt.ctypes.data_as(C.c_void_p)))
+            assert np.all(cnt[nq:] == GUARD), "vbm25_multi_batch_fetch wrote past n_hits[nq]"
+            assert np.array_equal(cnt[:nq], want_n) and hits.tobytes() == want_h.tobytes()
+
+
 def test_prefilter_by_over_fetch_matches_the_filtered_ranking():
     """prefilter = on (default.rs:120-128): the shim's over-fetch loop (vb.search_batch_filtered) against the oracle's full ranking
     with the same filter applied: the first k accepted hits, for filters that keep half, a tenth and one in 300 of the documents
@@ -106,7 +152,7 @@ def test_pipelined_boundary_returns_the_single_batch_records():
     assert st.in_flight == 3
     with pytest.raises(vb.Vbm25Error):
         st.submit(*batches[0])
-    st._nq.pop()  # (the refused submit was never in flight)
+    assert len(st._nq) == 3  # (the refused submit never entered the wrapper's bookkeeping: api.py appends only after the library accepted it)
     while st.in_flight:
         got.append(st.collect())
     assert len(got) == len(want)

@@ -29,6 +29,10 @@ def check(gix, oix, terms, off, k, expect_route=3, wand=False, expect_failed=0):
     items, failed = b.debug_counts()
     if expect_failed is not None:
         assert failed == expect_failed, f"{failed} of {items} items went to scan_many_kernel"
+    # the one-launch form (the kernel merges: no scan_many_kernel / merge_kernel behind it) serves every run that gives no item up
+    # and has no more items than resident waves; a run that gave one up was repeated with the two kernels behind the scan
+    if expect_route == 3 and failed:
+        assert b.debug_win_launches() == 3, "an item was given up, but the batch was not re-run with scan_many_kernel"
     ob, onb, _ = oix.search_batch(terms, off, k, mode="brute", threads=8)
     assert np.array_equal(nh, onb)
     for q in range(len(off) - 1):
@@ -87,7 +91,7 @@ def test_term_counts(tuning, nterms):
     check(gix, oix, terms, off, 10)
 
 
-@pytest.mark.parametrize("nterms,k", [(3, 100), (4, 200), (2, 256)])
+@pytest.mark.parametrize("nterms,k", [(3, 100), (4, 200), (2, 256), (6, 100), (7, 200), (8, 256)])  # (six to eight terms with k > 64: round 6)
 def test_term_counts_with_more_register_rows(tuning, nterms, k):
     seg, gix, oix = synth_pair(300_000, 33_000, seed=5)
     terms, off = bench_queries(seg, 33_000, 64, nterms, seed=10 + nterms)
@@ -109,6 +113,48 @@ def test_mixed_term_counts_in_one_batch(tuning, k):
     off = np.r_[0, np.cumsum([len(r) for r in rows])].astype(np.uint32)
     tuning(fused=0)
     check(gix, oix, terms, off, k)
+
+
+def test_one_launch_merge_and_its_fallback(tuning):
+    """Round 6: scan_win_kernel merges a query's lists itself (the wave that finishes the query's last item) -- one launch per batch.
+    C3's shape: one launch, no item given up, records equal the three-launch form's byte for byte.  Thick lists (win_force): windows
+    with more second arrivals than the list holds give their item up, the query's count comes back NONE32 on the device and fetch
+    re-runs the batch with scan_many_kernel and merge_kernel -- the caller sees the oracle's records either way."""
+    seg, gix, oix = synth_pair(700_000, 33_000, seed=7)
+    terms, off = bench_queries(seg, 33_000, 256, 5, seed=3)
+    tuning(fused=0)
+    b, hits, nh = run_batch(gix, terms, off, 10)
+    assert b.debug_win_launches() == 1 and b.debug_counts()[1] == 0
+    tuning(fused=0, win_fuse=0)
+    b3, hits3, nh3 = run_batch(gix, terms, off, 10)
+    assert b3.debug_win_launches() == 3
+    assert hits.tobytes() == hits3.tobytes() and np.array_equal(nh, nh3)
+    ob, onb, _ = oix.search_batch(terms, off, 10, mode="brute", threads=8)
+    assert np.array_equal(nh, onb)
+    for q in range(len(off) - 1):
+        assert_bit_exact(ob[q, :onb[q]], hits[q, :nh[q]], what=f"q{q} vs brute")
+    # the fallback
+    c = make_corpus(200_000, 3000, seed=2, length="lognormal", mean_len=60)
+    seg2 = vb.Segment.build(1.2, 0.75, c["doc_len"], c["doc_payload"], c["term_key"], c["term_start"], c["post_doc"], c["post_tf"])
+    gix2, oix2 = vb.GpuIndex(seg2), orc.OracleIndex.from_arrays(seg2.meta(), seg2.arrays())
+    terms2, off2 = make_queries(c, 48, 4, seed=9)
+    tuning(win_force=1, fused=0, win_fuse=1)
+    b = vb.Batch(gix2, 48, len(terms2), 10)
+    b.set_queries(terms2, off2)
+    assert b.debug_route() == 3
+    b.run()
+    assert b.debug_win_launches() == 1
+    hits2, nh2 = b.fetch()
+    items, failed = b.debug_counts()
+    assert failed > 0 and b.debug_win_launches() == 3, "this shape is expected to give items up (more second arrivals than the list holds)"
+    ob, onb, _ = oix2.search_batch(terms2, off2, 10, mode="brute", threads=8)
+    assert np.array_equal(nh2, onb)
+    for q in range(48):
+        assert_bit_exact(ob[q, :onb[q]], hits2[q, :nh2[q]], what=f"fallback q{q}")
+    b.run()  # (the query set stays on the three-launch form)
+    assert b.debug_win_launches() == 3
+    h3, n3 = b.fetch()
+    assert h3.tobytes() == hits2.tobytes()
 
 
 def test_thick_runs_are_chunked_and_searched_in_memory(tuning):

@@ -340,6 +340,14 @@ class Batch:
         f.argtypes = [C.c_void_p]
         return int(f(self.h))
 
+    def debug_win_launches(self):
+        """test aid: 1 = the last run's scan_win_kernel merged in the kernel (one launch), 3 = scan_win_kernel + scan_many_kernel +
+        merge_kernel (also the re-run after a one-launch run that gave an item up), 0 = another route"""
+        f = lib().vbm25_batch_debug_win_launches
+        f.restype = C.c_int
+        f.argtypes = [C.c_void_p]
+        return int(f(self.h))
+
     def debug_theta(self, nq):
         """test aid: the thresholds (as float64 scores) the last run ended with; None if the library lacks the entry"""
         f = getattr(lib(), "vbm25_batch_debug_theta", None)
@@ -384,8 +392,8 @@ class Stream:
     def submit(self, term_ids, q_off):
         term_ids = np.ascontiguousarray(term_ids, dtype=np.uint32)
         q_off = np.ascontiguousarray(q_off, dtype=np.uint32)
-        self._nq.append(len(q_off) - 1)
         check(lib().vbm25_stream_submit(self.h, term_ids.ctypes.data if len(term_ids) else None, q_off.ctypes.data, len(q_off) - 1))
+        self._nq.append(len(q_off) - 1)  # (only a batch the library accepted is in the ring)
 
     def collect_raw(self):
         """collect without this object's bookkeeping (tests: the library's own error on an empty ring)"""
@@ -394,10 +402,15 @@ class Stream:
 
     def collect(self, out=None):
         """The oldest batch in flight: (hits [nq, k], n_hits [nq]).  `out` = (hits, n_hits) arrays to write into."""
-        nq = self._nq.pop(0)
+        if not self._nq:
+            self.collect_raw()  # (the library's own error for an empty ring)
+        nq = self._nq[0]
         hits, n_hits = out if out is not None else (np.zeros((nq, self.k), dtype=HIT_DTYPE), np.zeros(nq, dtype=np.uint32))
+        if hits.size < nq * self.k or n_hits.size < nq:
+            raise ValueError(f"collect: the output arrays hold {hits.size} records / {n_hits.size} counts, the batch needs {nq * self.k} / {nq}")
         got = C.c_uint32()
         check(lib().vbm25_stream_collect(self.h, hits.ctypes.data, n_hits.ctypes.data, C.byref(got)))
+        self._nq.pop(0)  # (popped only after the library handed the batch over: an error leaves the bookkeeping in step with the ring)
         assert got.value == nq
         return hits, n_hits
 

@@ -95,6 +95,8 @@ struct DevBatch {
     uint32_t win_cut[17];      // ... item `part` of a query = the windows [win_cut[part], win_cut[part + 1]) when win_g <= 16 and
                                // win_cut[win_g] != 0 (runs of decreasing length, handed out longest first: the last items drawn
                                // are the short ones); equal runs n_win part / win_g otherwise
+    uint32_t win_fuse;         // scan_win_kernel merges a query's lists itself (the wave that finishes the query's last item) and leaves the
+                               // per-launch state zero: no scan_many_kernel, no merge_kernel behind it (a query with an item given up gets n_hits = NONE32)
     uint32_t win_dbg;          // development switch of scan_win_kernel (timing experiments only, wrong results; scan_win.h)
     uint32_t *dbg;             // -DVBM25_CHECK builds: [0] first violated check (0: none), [1] value, [2] item, [3] thread
 };

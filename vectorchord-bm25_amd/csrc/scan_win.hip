@@ -19,11 +19,9 @@ namespace vbm25 {
 template <int MT>
 static void launch_mt(const DevIndex &ix, const DevBatch &bt, uint32_t grid, hipStream_t st) {
     // (grid: workgroups; a workgroup is wn_waves(MT) independent waves)
-    if (bt.k <= 64u) scan_win_kernel<MT, 1><<<grid, wn_waves(MT) * 64, 0, st>>>(ix, bt);
-    else if constexpr (MT <= 5) {
-        if (bt.k <= 128u) scan_win_kernel<MT, 2><<<grid, wn_waves(MT) * 64, 0, st>>>(ix, bt);
-        else scan_win_kernel<MT, 4><<<grid, wn_waves(MT) * 64, 0, st>>>(ix, bt);
-    }
+    if (bt.k <= 64u) scan_win_kernel<MT, 1><<<grid, wn_waves(MT, 1) * 64, 0, st>>>(ix, bt);
+    else if (bt.k <= 128u) scan_win_kernel<MT, 2><<<grid, wn_waves(MT, 2) * 64, 0, st>>>(ix, bt);
+    else scan_win_kernel<MT, 4><<<grid, wn_waves(MT, 4) * 64, 0, st>>>(ix, bt);
 }
 // mt: the most indexed terms of a query of the batch: the kernel compiled for exactly that many run loads per window (2 .. 8; shorter
 // queries get null terms.  One term: the two-load kernel -- compiled for a single run load the compiler copies the buffer's
@@ -42,10 +40,23 @@ hipError_t scan_win_launch(const DevIndex &ix, const DevBatch &bt, uint32_t mt, 
     }
     return hipGetLastError();
 }
-static_assert(wn_waves(1) == wn_waves(8), "the host sizes grids and items with one number of waves per workgroup, whatever the term count");
-static uint32_t waves_of(uint32_t) { return uint32_t(wn_waves(8)); }
-uint32_t scan_win_resident_waves(uint32_t mt) { return WN_GRID * waves_of(mt); }
+// (the waves of a workgroup depend on the instantiation: the run loads mt the kernel is compiled for and the register rows of its top-k)
+static uint32_t waves_of(uint32_t mt, uint32_t k) {
+    const int rk = k <= 64u ? 1 : k <= 128u ? 2 : 4;
+    switch (mt) {
+        case 0:
+        case 1:
+        case 2: return uint32_t(wn_waves(2, rk));
+        case 3: return uint32_t(wn_waves(3, rk));
+        case 4: return uint32_t(wn_waves(4, rk));
+        case 5: return uint32_t(wn_waves(5, rk));
+        case 6: return uint32_t(wn_waves(6, rk));
+        case 7: return uint32_t(wn_waves(7, rk));
+        default: return uint32_t(wn_waves(8, rk));
+    }
+}
+uint32_t scan_win_resident_waves(uint32_t mt, uint32_t k) { return WN_GRID * waves_of(mt, k); }
 uint32_t scan_win_max_terms() { return WN_T; }
-uint32_t scan_win_max_k(uint32_t mt) { return mt <= 5 ? 256u : 64u; }
-uint32_t scan_win_wg(uint32_t mt) { return waves_of(mt); }
+uint32_t scan_win_max_k(uint32_t) { return 256u; }  // (round 6: four register rows of the top-k with any number of run loads)
+uint32_t scan_win_wg(uint32_t mt, uint32_t k) { return waves_of(mt, k); }
 }  // namespace vbm25

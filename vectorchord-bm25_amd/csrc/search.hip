@@ -231,6 +231,7 @@ struct Tuning {
     int win_guided = 0;            // scan_win_kernel's items of a query of decreasing length, handed out longest first (0: equal runs; measured
                                    // no better on C3 -- an item's setup costs more than the shorter tail saves)
     uint32_t win_grid = 0;         // its persistent workgroups (0: one per CU)
+    int win_fuse = 1;              // scan_win_kernel merges the queries' lists itself: the batched route is one launch (0: scan_many_kernel and merge_kernel behind it)
     int win_skew = 1;              // one item per wave: a query's three runs of windows sized for the three kinds of waves of a SIMD
     uint32_t generation = 0;       // bumped by every vbm25_tuning_set / reset: vbm25_search_batch's batch object is rebuilt when it is stale
 };
@@ -272,6 +273,10 @@ struct vbm25_batch {
     uint32_t q_stride = 0;        // != 0: every query of the current batch has this many terms
     bool order_useful = true;     // the current queries differ enough in length for the longest-first order to matter
     uint32_t win_g = 0;           // ... and scan_win_kernel's flavour of it (items = runs of 2^16-document windows, one result list each)
+    uint32_t win_len = 0;         // ... a query's runs: win_len windows each and a shorter rest (0: equal runs)
+    bool device_consumer = false; // vbm25_batch_device_results was called: every run leaves complete records on the device
+    bool win_nofuse = false;      // the last run's in-kernel merge marked a query (an item was given up): this query set runs with scan_many_kernel and merge_kernel
+    bool win_fused_run = false;   // the last run was a one-launch run of scan_win_kernel (a count of NONE32 means: re-run, see vbm25_batch_fetch_impl)
     bool need_many = true;        // the current queries have items for scan_many_kernel (more than 16 terms, 256 < k, dense without the dense kernel)
     bool fused_pinned = false;    // ... with queries and hits in pinned host memory (vbm25_search_batch, <= 8 queries); else device buffers
     bool state_clean = false;     // threshold / histogram / counters are zero (the fused route leaves them so; the general one does not)
@@ -828,6 +833,8 @@ static int vbm25_batch_set_queries_impl(vbm25_batch *bt, const uint32_t *term_id
     bt->fused_g = 0;
     bt->arith_g = 0;
     bt->win_g = 0;
+    bt->win_len = 0;
+    bt->win_nofuse = false;
     bt->need_many = many || !bt->use_range;
     bt->fused_pinned = false;
     if (bt->use_range && nq && !many && !has_dense && range_mt != 0) {  // every query sparse, <= 16 indexed terms: the one-launch route
@@ -883,11 +890,19 @@ static int vbm25_batch_set_queries_impl(vbm25_batch *bt, const uint32_t *term_id
                 if (ok) {
                     // items: one per resident wave (an item's setup is a chain of six round trips to memory: on C3 3072 items of 51
                     // windows take 0.270 ms, 6144 of 25 windows 0.287 ms)
-                    const uint32_t target = bt->tune.win_items ? bt->tune.win_items : scan_win_resident_waves(range_mt);
+                    // ... of as many windows as give every resident wave the same share of the batch's windows: L = ceil(nq n_win / waves).
+                    // A query is cut into runs of L windows and a shorter rest (win_cut, vbm25_batch_run): with 14 waves per workgroup C3's
+                    // 1024 queries x 153 windows are 3072 runs of 44 and 1024 of 21 for 3584 waves -- the short ones go last, two to a wave.
+                    const uint32_t target = bt->tune.win_items ? bt->tune.win_items : scan_win_resident_waves(range_mt, bt->k);
                     const uint32_t g_min = (ixh->n_win + 62u) / 63u;  // (an item holds at most 63 windows)
-                    uint32_t gw = std::max(std::max(1u, (target + nq / 2) / nq), g_min);
+                    const uint64_t all_win = uint64_t(nq) * ixh->n_win;
+                    const uint32_t len = uint32_t(std::min<uint64_t>(63u, std::max<uint64_t>(1u, (all_win + target - 1u) / target)));
+                    uint32_t gw = std::max((ixh->n_win + len - 1u) / len, g_min);
                     gw = std::min(std::min(gw, ixh->n_win), bt->max_items / nq);
-                    if (gw >= g_min && gw >= 1u) win_g = gw;
+                    if (gw >= g_min && gw >= 1u) {
+                        win_g = gw;
+                        bt->win_len = (ixh->n_win + gw - 1u) / gw > len ? 0u : len;  // (0: equal runs -- the item limit cut the number of runs)
+                    }
                 }
             }
             if (bt->tune.fused && nq * g <= bt->tune.fused_items) {
@@ -908,10 +923,12 @@ static int vbm25_batch_set_queries_impl(vbm25_batch *bt, const uint32_t *term_id
                 for (uint32_t q = 0; q < nq; ++q) qs[q] = q;
                 std::stable_sort(qs.begin(), qs.end(), [&](uint32_t a, uint32_t b) { return q_postings[a] > q_postings[b]; });
 
-                const uint32_t wpw = win_g ? scan_win_wg(range_mt) : 0u;
-                bt->win_skew = win_g == 3u && wpw == 12u && size_t(nq) * 3u <= scan_win_resident_waves(range_mt) && bt->tune.win_skew;
-                // (queries of about the same length: the longest-first order buys nothing and costs every work item a dependent load)
-                bt->order_useful = bt->win_skew || (!win_g || !bt->tune.win_guided ? q_postings[qs[0]] * 4 > q_postings[qs[nq - 1]] * 5 : true);
+                const uint32_t wpw = win_g ? scan_win_wg(range_mt, bt->k) : 0u;
+                bt->win_skew = win_g == 3u && wpw == 12u && size_t(nq) * 3u <= scan_win_resident_waves(range_mt, bt->k) && bt->tune.win_skew;
+                // (queries of about the same length: the longest-first order buys nothing and costs every work item a dependent load --
+                // unless there are more items than waves: then the queries' short last runs must be the ones drawn late)
+                bt->order_useful = bt->win_skew || (!win_g || !bt->tune.win_guided ? q_postings[qs[0]] * 4 > q_postings[qs[nq - 1]] * 5 : true) ||
+                                   (win_g && size_t(nq) * win_g > scan_win_resident_waves(range_mt, bt->k));
                 if (bt->win_skew) {
                     // One item per wave, three per query: a SIMD's three waves do not run equally fast -- the workgroup's waves 0..3
                     // (the first wave of every SIMD) lived 449 k cycles on C3, 4..7 497 k, 8..11 559 k, whatever priority they set
@@ -1023,6 +1040,7 @@ static int vbm25_batch_run_impl(vbm25_batch *bt, void *hip_stream) {
     if (int rc = use_device(bt->index->device)) return rc;
     hipStream_t st = static_cast<hipStream_t>(hip_stream);
     bt->last_stream = st;
+    bt->win_fused_run = false;
     bt->download_enqueued = false;
     bt->results_pinned_now = false;
     if (bt->index->n_docs == 0) {  // empty sealed segment: no hits (the growing segment is the shim's, search.rs:83-135)
@@ -1187,17 +1205,10 @@ static int vbm25_batch_run_impl(vbm25_batch *bt, void *hip_stream) {
                 db.win_cut[2] = uint32_t(uint64_t(nwin) * 717u / 1000u);
                 db.win_cut[3] = nwin;
                 if (db.win_cut[1] > 63u || db.win_cut[2] - db.win_cut[1] > 63u || nwin - db.win_cut[2] > 63u) std::memset(db.win_cut, 0, sizeof db.win_cut);
-            } else if (gq <= 16u && bt->tune.win_guided) {
-                const uint64_t total = uint64_t(gq) * (gq + 3u) / 2u;
-                uint64_t cum = 0;
-                bool fits = true;
-                for (uint32_t p = 0; p < gq; ++p) {
-                    db.win_cut[p] = uint32_t(uint64_t(nwin) * cum / total);
-                    cum += gq + 1u - p;
-                }
+            } else if (gq <= 16u && bt->win_len && uint64_t(bt->win_len) * (gq - 1u) < nwin) {
+                // runs of win_len windows and a shorter rest (set_queries: every resident wave the same share of the windows)
+                for (uint32_t p = 0; p < gq; ++p) db.win_cut[p] = bt->win_len * p;
                 db.win_cut[gq] = nwin;
-                for (uint32_t p = 0; p < gq; ++p) fits = fits && db.win_cut[p + 1] - db.win_cut[p] <= 63u;
-                if (!fits) std::memset(db.win_cut, 0, sizeof db.win_cut);
             }
         }
         db.lpi = 1;
@@ -1208,9 +1219,19 @@ static int vbm25_batch_run_impl(vbm25_batch *bt, void *hip_stream) {
         db.order_on = bt->order_useful ? 1u : 0u;
         db.q_stride = bt->q_stride;
         if (int rc = take_events()) return rc;
-        const uint32_t wmt = bt->range_rt == 8 ? bt->win_mt : 8u, wpw = scan_win_wg(wmt);
-        const uint32_t wgrid = std::min<uint32_t>((bt->nq * bt->win_g + wpw - 1u) / wpw, bt->tune.win_grid ? bt->tune.win_grid : scan_win_resident_waves(wmt) / wpw);
+        const uint32_t wmt = bt->range_rt == 8 ? bt->win_mt : 8u, wpw = scan_win_wg(wmt, bt->k);
+        const uint32_t wgrid = std::min<uint32_t>((bt->nq * bt->win_g + wpw - 1u) / wpw, bt->tune.win_grid ? bt->tune.win_grid : scan_win_resident_waves(wmt, bt->k) / wpw);
+        // One launch (round 6): the wave that finishes a query's last item merges the query's lists, writes its records and leaves
+        // the per-launch state zero.  A query with an item the kernel gave up comes back with the count NONE32: whoever hands the
+        // records to the caller (vbm25_batch_fetch_impl) re-runs the batch with scan_many_kernel and merge_kernel behind the scan.
+        // (only when every wave has at most one item: the kernel's merge sits behind its item loop)
+        const bool fuse = bt->tune.win_fuse && !bt->win_nofuse && !bt->device_consumer && uint64_t(bt->nq) * bt->win_g <= scan_win_resident_waves(wmt, bt->k) && !bt->tune.win_grid;
+        db.win_fuse = fuse ? 1u : 0u;
+        bt->win_fused_run = fuse;
         HIP_TRY(scan_win_launch(ix, db, wmt, wgrid, st));
+        if (fuse) {
+            if (bt->timing) (void)hipEventRecord(e1, st);
+        } else
         (void)dispatch_k(bt->k, [&](auto kmax) {
             constexpr int KM = decltype(kmax)::value;
             if constexpr (KM <= REG_K) {
@@ -1289,7 +1310,24 @@ static int vbm25_batch_run_impl(vbm25_batch *bt, void *hip_stream) {
 }
 
 static int vbm25_batch_enqueue_download(vbm25_batch *bt);
-static int vbm25_batch_fetch_impl(vbm25_batch *bt, vbm25_hit *hits, uint32_t *n_hits, bool fast = false) {
+static int vbm25_batch_fetch_impl(vbm25_batch *bt, vbm25_hit *hits, uint32_t *n_hits, bool fast = false);
+// After a one-launch run of scan_win_kernel (win_fuse): a count of NONE32 marks a query with an item the kernel gave up (more second
+// arrivals in a window than its list holds, a term frequency above 255).  The batch is run again with scan_many_kernel and
+// merge_kernel behind the scan -- on the same stream, before any record reaches the caller -- and this query set stays on that route.
+static bool win_marked(const vbm25_batch *bt, const uint32_t *cnt) {
+    if (!bt->win_fused_run) return false;
+    for (uint32_t q = 0; q < bt->nq; ++q)
+        if (cnt[q] == UINT32_MAX) return true;
+    return false;
+}
+static int win_rerun_and_fetch(vbm25_batch *bt, vbm25_hit *hits, uint32_t *n_hits, bool fast) {
+    bt->win_nofuse = true;
+    bt->state_clean = false;  // (the one-launch run left fail_any set)
+    bt->download_enqueued = false;
+    if (int rc = vbm25_batch_run_impl(bt, bt->last_stream)) return rc;
+    return vbm25_batch_fetch_impl(bt, hits, n_hits, fast);
+}
+static int vbm25_batch_fetch_impl(vbm25_batch *bt, vbm25_hit *hits, uint32_t *n_hits, bool fast) {
     if (!bt || (!hits && bt->nq) || (!n_hits && bt->nq)) return set_error(VBM25_ERR_INVALID, "NULL argument");
     if (int rc = use_device(bt->index->device)) return rc;
     if (fast && bt->lat_stream && bt->fused_g && bt->fused_pinned) {  // the kernel wrote counts and hits into the pinned buffer: one synchronisation
@@ -1316,7 +1354,10 @@ static int vbm25_batch_fetch_impl(vbm25_batch *bt, vbm25_hit *hits, uint32_t *n_
             return set_error(VBM25_ERR_DEVICE, "device-side planner overflow (flag %u)", flag);
         }
         if (bt->nq) {
-            std::memcpy(n_hits, bt->pin_out + 8, nc);
+            if (win_marked(bt, reinterpret_cast<const uint32_t *>(bt->pin_out + 8))) return win_rerun_and_fetch(bt, hits, n_hits, fast);
+            // (nc is the 8-byte aligned OFFSET of the records; the caller's n_hits holds exactly nq counts: copying nc bytes wrote four
+            // bytes past it for an odd nq -- into the next shard's first count on the multi-device route)
+            std::memcpy(n_hits, bt->pin_out + 8, 4ull * bt->nq);
             std::memcpy(hits, bt->pin_out + 8 + nc, nh);
         }
         return VBM25_OK;
@@ -1335,6 +1376,7 @@ static int vbm25_batch_fetch_impl(vbm25_batch *bt, vbm25_hit *hits, uint32_t *n_
         HIP_TRY(hipStreamSynchronize(st));
         return set_error(VBM25_ERR_DEVICE, "device-side planner overflow (flag %u)", flag);
     }
+    if (bt->nq && win_marked(bt, n_hits)) return win_rerun_and_fetch(bt, hits, n_hits, fast);
     return VBM25_OK;
 }
 
@@ -1363,6 +1405,9 @@ int vbm25_batch_device_results(vbm25_batch *bt, void **hits, void **n_hits) {
     if (!bt) return set_error(VBM25_ERR_INVALID, "batch is NULL");
     if (hits) *hits = bt->hits.p;
     if (n_hits) *n_hits = bt->n_hits.p;
+    // (whoever reads the records on the device gets them complete after every run: the one-launch form of scan_win_kernel, which
+    // leaves a query whose item it gave up to vbm25_batch_fetch, is not used for this batch object any more)
+    bt->device_consumer = true;
     return VBM25_OK;
 }
 
@@ -1459,6 +1504,7 @@ int vbm25_tuning_set(const char *name, long long value) {
     else if (n == "rel16_plane") g_tune.rel16_plane = value != 0;
     else if (n == "win_grid") g_tune.win_grid = (uint32_t)std::max(0ll, value);
     else if (n == "win_skew") g_tune.win_skew = value != 0;
+    else if (n == "win_fuse") g_tune.win_fuse = value != 0;
     else return set_error(VBM25_ERR_INVALID, "unknown tuning switch %s", name);
     ++g_tune.generation;
     return VBM25_OK;
@@ -1497,6 +1543,13 @@ int vbm25_batch_debug_counts(vbm25_batch *bt, uint32_t *n_items, uint32_t *n_fai
 int vbm25_batch_debug_route(vbm25_batch *bt) {
     if (!bt) return -1;
     return bt->bigk ? 4 : bt->fused_g ? 1 : bt->win_g ? 3 : bt->arith_g ? 2 : 0;
+}
+
+// test aid (not declared in include/vbm25.h): launches of the last run's scan -- 1: scan_win_kernel merged the queries' lists itself
+// (win_fuse), 3: scan_win_kernel, scan_many_kernel, merge_kernel (also after a one-launch run that marked a query), 0: another route
+int vbm25_batch_debug_win_launches(vbm25_batch *bt) {
+    if (!bt || !bt->win_g) return 0;
+    return bt->win_fused_run ? 1 : 3;
 }
 
 // -DVBM25_CHECK builds (not declared in include/vbm25.h): the first violated assertion of the scan kernels, then reset.
@@ -1728,7 +1781,14 @@ struct MultiWorker {
             std::function<int()> f = std::move(job);
             job = nullptr;
             lk.unlock();
-            const int r = f();
+            int r;
+            try {  // (an exception on a worker thread would be std::terminate: it becomes the part's error code)
+                r = f();
+            } catch (const std::bad_alloc &) {
+                r = set_error(VBM25_ERR_NOMEM, "out of host memory in a device worker");
+            } catch (const std::exception &e) {
+                r = set_error(VBM25_ERR_DEVICE, "exception in a device worker: %s", e.what());
+            }
             lk.lock();
             rc = r;
             if (r) std::memcpy(err, g_error, sizeof err);
@@ -1753,7 +1813,11 @@ struct vbm25_multi {
         for (vbm25_index *ix : replicas) vbm25_index_destroy(ix);
     }
     // fn(i) for every part i, concurrently; the first error (by part number) is the call's
+    // The workers and their one job slot belong to the vbm25_multi: calls on different vbm25_multi_batch objects of one vbm25_multi from
+    // several threads are serialised here (vbm25.h says so).
+    std::mutex call_m;
     int each_part(size_t n, const std::function<int(size_t)> &fn) {
+        std::lock_guard<std::mutex> call_guard(call_m);
         while (workers.size() + 1 < n) {
             workers.emplace_back(new MultiWorker);
             MultiWorker *w = workers.back().get();
@@ -1766,7 +1830,14 @@ struct vbm25_multi {
             w->job = [&fn, i] { return fn(i); };
             w->cv.notify_all();
         }
-        int rc = n ? fn(0) : 0;
+        int rc = 0;
+        try {  // (the workers hold a reference to fn: they are always waited for, whatever part 0 does)
+            rc = n ? fn(0) : 0;
+        } catch (const std::bad_alloc &) {
+            rc = set_error(VBM25_ERR_NOMEM, "out of host memory");
+        } catch (const std::exception &e) {
+            rc = set_error(VBM25_ERR_DEVICE, "exception in part 0: %s", e.what());
+        }
         char err[sizeof g_error];
         std::memcpy(err, g_error, sizeof err);
         for (size_t i = 1; i < n; ++i) {

@@ -95,7 +95,9 @@ __device__ __forceinline__ void lds_barrier() {
 #ifdef VBM25_PROFILE
 #define PROF_T(var) const unsigned long long var = __builtin_readcyclecounter()
 #define PROF_ADD(slot, a, b) prof[slot] += (b) - (a)
+#define PROF_MARK(var) var = __builtin_readcyclecounter()
 #else
 #define PROF_T(var)
+#define PROF_MARK(var)
 #define PROF_ADD(slot, a, b)
 #endif
