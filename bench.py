@@ -48,6 +48,9 @@ WORKLOADS = {
     "C2": (1_000_000, 30_000, 100, 1, 0.0, 1, 3, 10),
     "C3": (10_000_000, 30_000, 100, 1, 0.0, 1024, 5, 10),
     "C5": (50_000_000, 100_000, 100, 1, 1.0, 1024, 10, 100),
+    # not a BASELINE.json configuration: C3's shape over a Zipf(1) vocabulary -- "the realistic middle" the round-5 review asked for
+    # (a batch of mixed sparse and dense queries on the general route; tools/measure.sh c3z, profiles/r6_c3z_*)
+    "C3z": (10_000_000, 30_000, 100, 1, 1.0, 1024, 5, 10),
 }
 METRIC = "queries/sec top-10 BM25, 10M synthetic docs; achieved HBM GB/s vs peak"
 
@@ -114,7 +117,7 @@ def extra_workload(vb, name, budget_s, sha16, with_cpu=True):
     import ctypes as C
     t_start = time.perf_counter()
     n_docs, vocab, mean_len, len_mode, zipf_s, nq, nterms, k = WORKLOADS[name]
-    need = {"C2": 10.0, "C5": 60.0}[name]  # generation + index + queries + steps on the round-4 box
+    need = {"C2": 10.0, "C5": 60.0, "C3z": 30.0}[name]  # generation + index + queries + steps on the round-4 box
     if budget_s < need:
         return {"skipped": f"{need:.0f} s needed, {max(0.0, budget_s):.0f} s of --extra-budget-s left"}
     seg = vb.DeviceSegment.synth(n_docs, vocab, mean_len=mean_len, len_mode=len_mode, zipf_s=zipf_s, seed=20260925, device=0)
@@ -454,6 +457,7 @@ def run(argv=None, scorer_factory=None, backend="nccl"):
     # about 30 launches of this 0.23 ms kernel (profiles/r5_warmup.txt) -- more than --warmup 5 of such steps covers; with
     # these 400 batches in front, the K timed steps below see the sustained rate whatever W is.
     pcie_qps = pcie_sync_qps = None
+    pre_timed_batches = 0  # (launches of the hot path in front of the W warm-up steps: reported in config.pre_timed_batches)
     if on_gpu and not args.no_host_buffer:
         # (400 batches whatever --steps says: filling and draining the pipeline costs about two steps)
         depth, n_pipe = 3, 400 if nq_local * nterms <= 8192 else 20
@@ -469,6 +473,7 @@ def run(argv=None, scorer_factory=None, backend="nccl"):
             while st.in_flight:
                 st.collect(outs[0])
         pcie_qps = n_pipe * nq_local / (time.perf_counter() - t0)
+        pre_timed_batches = n_pipe + 2 * depth + 20
         del st
         t0 = time.perf_counter()
         for _ in range(20):
@@ -623,7 +628,8 @@ def run(argv=None, scorer_factory=None, backend="nccl"):
     sha16 = lib_sha16(vb) if on_gpu else None
     if rank == 0:
         ms_per_step = 1e3 * elapsed / args.steps
-        dense = zipf_s > 0
+        routes = batches[0].debug_routes() if on_gpu and hasattr(batches[0], "debug_routes") else None
+        dense = zipf_s > 0 if routes is None else routes[1] > routes[0]  # (the roofline line names the kernel most of the queries go to)
         out = {
             "metric": METRIC,
             "value": round(n_total * args.steps / elapsed, 1),
@@ -635,6 +641,9 @@ def run(argv=None, scorer_factory=None, backend="nccl"):
             "config": {"workload": f"{args.workload if world == 1 else 'C4'}: {n_docs} docs / {vocab} vocab / "
                                    f"{nq_local} x {nterms}-term queries per GPU / top-{k}",
                        "batches_rotated": nb,
+                       # (the host-buffer figures run BEFORE the warm-up steps so that the chip's clocks have settled whatever W is: the
+                       # timed steps see this many launches of the hot path in front of them besides `warmup`; 0 with --no-host-buffer)
+                       "pre_timed_batches": pre_timed_batches,
                        "doc_length": "lognormal(ln 80, 0.6) clamp [8,2000]" if len_mode == 1 else f"fixed {mean_len}",
                        "token_distribution": f"zipf({zipf_s})" if zipf_s > 0 else "uniform",
                        "k1": 1.2, "b": 0.75, "index_hbm_bytes": gix.device_bytes if on_gpu else None,
@@ -646,6 +655,11 @@ def run(argv=None, scorer_factory=None, backend="nccl"):
                        "scatter_ms": round(scatter_ms, 3), "gather_ms": round(gather_ms, 4),
                        "gather_exposed_ms": round(gather_exposed_ms, 4),
                        "route": route,
+                       "routes": None if routes is None else {
+                           "queries_sparse": routes[0], "queries_dense": routes[1],
+                           "general_route_items_scan_range_kernel": routes[3], "general_route_items_scan_dense_kernel": routes[4],
+                           "general_route_items_scan_many_kernel": routes[5],
+                           "note": "batch 0; kernel_ms brackets every posting-scan kernel of a step (scan_range + scan_dense + scan_many on the general route)"},
                        "host_buffer_inclusive_qps_per_gpu": None if pcie_qps is None else round(pcie_qps, 1),
                        "host_buffer_inclusive": "vbm25_stream_*: three batches in flight on their own streams; queries uploaded from pinned staging, counts and 24-byte records written to pinned memory by merge_kernel, every step",
                        "host_buffer_one_batch_at_a_time_qps_per_gpu": None if pcie_sync_qps is None else round(pcie_sync_qps, 1),

@@ -491,6 +491,45 @@ def test_c3_full_size_full_batch_parity():
         assert np.array_equal(h2[f], hits[sample][f]), f
 
 
+def test_c3z_full_size_full_batch_parity():
+    """C3's shape over a Zipf(1) vocabulary at full size (bench.py --workload C3z: 10 M documents, 30 k tokens, 1024 five-term queries
+    whose tokens follow the same law, top-10) -- a batch of dense and sparse queries on the general route (plan_kernel; scan_dense_kernel
+    for the queries with a head term, scan_range_kernel for the others): ALL 1024 queries bit-exact against the oracle's brute force,
+    no work item served by the fallback kernel, a sample against the faithful Block-WAND restatement."""
+    import sys
+    import time
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    from bench import WORKLOADS, make_queries as bench_queries, usable_cpus
+    n_docs, vocab, mean_len, len_mode, zipf_s, nq, nterms, k = WORKLOADS["C3z"]
+    dseg = vb.DeviceSegment.synth(n_docs, vocab, mean_len=mean_len, len_mode=len_mode, zipf_s=zipf_s, seed=20260925, device=0)
+    gix = vb.GpuIndex(dseg)
+    terms, off = bench_queries(dseg, vocab, nq, nterms, seed=1, zipf_s=zipf_s)
+    b = vb.Batch(gix, nq, len(terms), k)
+    b.set_queries(terms, off)
+    assert b.debug_route() == 0, "a batch with dense queries takes the general route"
+    b.run()
+    hits, nh = b.fetch()
+    items, failed = b.debug_counts()
+    assert failed == 0, f"{failed} of {items} work items fell back to scan_many_kernel"
+    r = b.debug_routes()
+    assert r[0] + r[1] == nq and r[1] > 0 and r[3] + r[4] == items and r[4] > 0, r
+    assert (nh == k).all()
+    seg = dseg.download()
+    oix = orc.OracleIndex.from_arrays(seg.meta(), seg.arrays())
+    t0 = time.perf_counter()
+    ob, onb, _ = oix.search_batch(terms, off, k, mode="brute", threads=usable_cpus())
+    assert time.perf_counter() - t0 < 300.0, "the full-batch check must stay affordable"
+    assert np.array_equal(nh, onb)
+    for q in range(nq):
+        assert_bit_exact(ob[q, :onb[q]], hits[q, :nh[q]], what=f"C3z q{q} vs brute")
+    sample = list(range(0, nq, 64))
+    st = np.concatenate([terms[off[q]:off[q + 1]] for q in sample])
+    so = (np.arange(len(sample) + 1) * nterms).astype(np.uint32)
+    ow, onw, _ = oix.search_batch(st, so, k, mode="wand", threads=usable_cpus())
+    for i, q in enumerate(sample):
+        assert_same_ranking(ow[i, :onw[i]], hits[q, :nh[q]], ref_ext=oix.search_brute(st[so[i]:so[i + 1]], 300), what=f"C3z q{q} vs wand")
+
+
 @pytest.mark.parametrize("n_docs,vocab,nq,nterms,k", [(300_000, 20_000, 96, 10, 100), (1_000_000, 50_000, 64, 6, 10)])
 def test_maxscore_split_zipf(tuning, n_docs, vocab, nq, nterms, k):
     """Zipf(1) queries through scan_range_kernel's MaxScore split (tuning(dense_x1000=...) declares nothing dense:

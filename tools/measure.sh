@@ -19,6 +19,8 @@ for step in "$@"; do case $step in
   c3quick) seg C3; timeout 600 python bench.py --no-cpu-baseline --no-verify-sample --steps 100 --extra-budget-s 0 $TUNE_ARG > $O/bench_c3q.json 2> $O/bench_c3q.err; show $O/bench_c3q.json;;
   c3full) seg C3; timeout 900 python bench.py $TUNE_ARG > $O/bench_c3_full.json 2> $O/bench_c3_full.err; show $O/bench_c3_full.json;;
   c5) seg C5; timeout 900 python bench.py --workload C5 --no-cpu-baseline --steps 10 --warmup 2 $TUNE_ARG > $O/bench_c5.json 2> $O/bench_c5.err; show $O/bench_c5.json;;
+  c3z) timeout 900 python bench.py --workload C3z --steps 20 --warmup 3 --extra-budget-s 0 --no-host-buffer $TUNE_ARG > $O/bench_c3z.json 2> $O/bench_c3z.err; show $O/bench_c3z.json
+     (cd /tmp; export TMPDIR=/tmp; timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats3z -- python $R/bench.py --workload C3z --steps 10 --warmup 2 --no-cpu-baseline --no-verify-sample --no-host-buffer --extra-budget-s 0 $TUNE_ARG > $O/stats3z.log 2>&1); f=$(find $O/stats3z -name "*kernel_stats.csv" | head -1); [ -n "$f" ] && cp $f $O/c3z_kernel_stats.csv && head -8 $O/c3z_kernel_stats.csv; find $O/stats3z -name "*.csv" -size +5M -delete;;
   c2) seg C2; timeout 600 python bench.py --workload C2 --no-cpu-baseline --steps 200 $TUNE_ARG > $O/bench_c2.json 2> $O/bench_c2.err; show $O/bench_c2.json;;
   c3stats) seg C3; (cd /tmp; export TMPDIR=/tmp; timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats -- python $R/bench.py --steps 200 --warmup 5 --no-cpu-baseline --no-verify-sample --no-host-buffer --extra-budget-s 0 $TUNE_ARG > $O/stats.log 2>&1); f=$(find $O/stats -name "*kernel_stats.csv" | head -1); [ -n "$f" ] && cp $f $O/c3_kernel_stats.csv && head -8 $O/c3_kernel_stats.csv; find $O/stats -name "*.csv" -size +5M -delete;;
   c3pmc) seg C3; B="python $R/bench.py --steps 20 --warmup 3 --no-cpu-baseline --no-verify-sample --no-host-buffer --extra-budget-s 0 $TUNE_ARG"

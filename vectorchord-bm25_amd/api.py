@@ -340,6 +340,16 @@ class Batch:
         f.argtypes = [C.c_void_p]
         return int(f(self.h))
 
+    def debug_routes(self):
+        """bench / test aid: (queries classed sparse, dense, many-term by the host; work items of the last run on the general route
+        that went to the sparse, the dense and the many-term kernel)"""
+        f = lib().vbm25_batch_debug_routes
+        f.restype = C.c_int
+        f.argtypes = [C.c_void_p, C.c_void_p]
+        out = (C.c_uint32 * 6)()
+        check(f(self.h, out))
+        return tuple(int(x) for x in out)
+
     def debug_win_launches(self):
         """test aid: 1 = the last run's scan_win_kernel merged in the kernel (one launch), 3 = scan_win_kernel + scan_many_kernel +
         merge_kernel (also the re-run after a one-launch run that gave an item up), 0 = another route"""

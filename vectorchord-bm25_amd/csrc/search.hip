@@ -232,6 +232,7 @@ struct Tuning {
                                    // no better on C3 -- an item's setup costs more than the shorter tail saves)
     uint32_t win_grid = 0;         // its persistent workgroups (0: one per CU)
     int win_fuse = 1;              // scan_win_kernel merges the queries' lists itself: the batched route is one launch (0: scan_many_kernel and merge_kernel behind it)
+    int win_cut1 = 392, win_cut2 = 730;  // ... where a query's three runs are cut, in thousandths of its windows (round 6, tools/skew_sweep.sh: 59 / 52 / 42 of C3's 153)
     int win_skew = 1;              // one item per wave: a query's three runs of windows sized for the three kinds of waves of a SIMD
     uint32_t generation = 0;       // bumped by every vbm25_tuning_set / reset: vbm25_search_batch's batch object is rebuilt when it is stale
 };
@@ -274,6 +275,8 @@ struct vbm25_batch {
     bool order_useful = true;     // the current queries differ enough in length for the longest-first order to matter
     uint32_t win_g = 0;           // ... and scan_win_kernel's flavour of it (items = runs of 2^16-document windows, one result list each)
     uint32_t win_len = 0;         // ... a query's runs: win_len windows each and a shorter rest (0: equal runs)
+    DeviceBuffer qin;             // the staged descriptors on the device, one block: term ids | offsets | dense flags (padded to 8) | item order
+    bool qin_live = false;        // ... hold the current queries (set by upload_staged; a plain set_queries fills the separate buffers)
     bool device_consumer = false; // vbm25_batch_device_results was called: every run leaves complete records on the device
     bool win_nofuse = false;      // the last run's in-kernel merge marked a query (an item was given up): this query set runs with scan_many_kernel and merge_kernel
     bool win_fused_run = false;   // the last run was a one-launch run of scan_win_kernel (a count of NONE32 means: re-run, see vbm25_batch_fetch_impl)
@@ -428,12 +431,27 @@ static int index_create_common(const RawSegment &r, int device, vbm25_index **ou
     const uint32_t n_win = uint32_t((uint64_t(r.n_docs) + 65535u) >> 16);
     std::vector<uint32_t> term_win(win_planes ? r.n_terms : 0u, UINT32_MAX);
     uint64_t n_woff = n_win + 2u;  // (entries 0 .. n_win + 1: the NULL table -- a term without postings, what a query's missing terms read)
-    if (win_planes)
-        for (uint32_t t = 0; t < r.n_terms; ++t) {
-            if (uint64_t(r.term_df_host[t]) * 4u < n_win || n_woff + n_win + 1u > 0xfffffff0ull) continue;
+    if (win_planes) {
+        // BUDGET (round-5 advisor): a table is n_win + 1 words whatever the term's length -- up to four words per posting at the
+        // threshold -- so on a corpus of thousands of windows and hundreds of thousands of qualifying terms the tables would take
+        // gigabytes nobody asked for.  They get at most a quarter of what post_id16 takes (64 bytes per block; never less than 4 MiB), the
+        // longest lists first: the routing sends a query through the window kernel only when EVERY term has a table, and the terms it
+        // wants there are the long ones (32 .. 232 postings per window).
+        const uint64_t budget_words = std::max<uint64_t>(1ull << 20, 16ull * r.n_blocks);
+        std::vector<uint32_t> cand;
+        for (uint32_t t = 0; t < r.n_terms; ++t)
+            if (uint64_t(r.term_df_host[t]) * 4u >= n_win) cand.push_back(t);
+        if (uint64_t(cand.size()) * (n_win + 1u) > budget_words) {
+            std::stable_sort(cand.begin(), cand.end(), [&](uint32_t a, uint32_t b) { return r.term_df_host[a] > r.term_df_host[b]; });
+            cand.resize(size_t(budget_words / (n_win + 1u)));
+            std::sort(cand.begin(), cand.end());  // (tables in term order, as without a budget)
+        }
+        for (uint32_t t : cand) {
+            if (n_woff + n_win + 1u > 0xfffffff0ull) break;
             term_win[t] = uint32_t(n_woff);
             n_woff += n_win + 1u;
         }
+    }
     // the raw per-block arrays the derivation reads: used where they are (device segment) or uploaded for its duration
     DeviceBuffer t_n, t_wfn, t_wtf, t_md, t_mt, t_off8, t_fieldnorm, t_raw, t_sorted, t_tmp, err;
     const uint8_t *p_n = r.blk_n, *p_wfn = r.blk_wand_fn, *p_md = r.blk_meta_doc, *p_mt = r.blk_meta_tf, *p_fieldnorm = r.doc_fieldnorm;
@@ -734,6 +752,7 @@ static int vbm25_batch_create_impl(vbm25_index *ix, uint32_t max_queries, uint32
         (rc = bt->hits.alloc(sizeof(vbm25_hit) * size_t(max_queries) * k)) ||
         (rc = bt->n_hits.alloc(4ull * max_queries)) || (rc = bt->error_flag.alloc(4)) ||
         (rc = bt->q_dense.alloc(max_queries)) ||
+        (rc = bt->qin.alloc(4ull * max_total_terms + 4ull * (max_queries + 1) + max_queries + 8 + 4ull * bt->max_items + 64)) ||
         (rc = bt->item_failed.alloc(4ull * bt->max_items)) || (rc = bt->item_order.alloc(4ull * bt->max_items)) || (rc = bt->work_ctr.alloc(8)) ||
         (rc = bt->hist.alloc(4ull * CUR_HB * max_queries)) || (rc = bt->fused_state.alloc(4ull * (max_queries + 1))) ||
         (rc = bt->fail_any.alloc(4)) || (rc = bt->q_failed.alloc(4ull * max_queries)) || (rc = bt->theta_last.alloc(8ull * max_queries)))
@@ -769,14 +788,15 @@ void vbm25_batch_destroy(vbm25_batch *bt) {
 }
 
 // queries staged in the pinned buffer (term ids | offsets | dense flags) -> device, on the batch's own stream
+// The staged descriptors -- term ids, offsets, dense flags, the host's item order -- lie in ONE pinned block and go to ONE device
+// block with one copy command (round 6: they were four commands into four buffers, 15 .. 25 us of a device's 100 us of host time per
+// step on the multi-device route; vbm25_batch_run_impl points the kernels at the block's parts).
 static int upload_staged(vbm25_batch *bt) {
-    const size_t nt = bt->pin_nt, no = 4ull * (bt->nq + 1);
-    if (nt) HIP_TRY(hipMemcpyAsync(bt->term_ids.p, bt->pin_in, nt, hipMemcpyHostToDevice, bt->lat_stream));
-    HIP_TRY(hipMemcpyAsync(bt->q_off.p, bt->pin_in + nt, no, hipMemcpyHostToDevice, bt->lat_stream));
-    if (bt->nq) HIP_TRY(hipMemcpyAsync(bt->q_dense.p, bt->pin_in + nt + no, bt->nq, hipMemcpyHostToDevice, bt->lat_stream));
-    if (bt->pin_order_bytes)  // the host's item order of the routes without plan_kernel
-        HIP_TRY(hipMemcpyAsync(bt->item_order.p, bt->pin_in + nt + no + ((size_t(bt->nq) + 7) & ~size_t(7)), bt->pin_order_bytes,
-                               hipMemcpyHostToDevice, bt->lat_stream));
+    const size_t nt = bt->pin_nt, no = 4ull * (bt->nq + 1), nd8 = (size_t(bt->nq) + 7) & ~size_t(7);
+    const size_t total = nt + no + nd8 + bt->pin_order_bytes;
+    if (total > bt->qin.bytes) return set_error(VBM25_ERR_INVALID, "internal error: staged descriptors exceed the device block");
+    HIP_TRY(hipMemcpyAsync(bt->qin.p, bt->pin_in, total, hipMemcpyHostToDevice, bt->lat_stream));
+    bt->qin_live = true;
     return VBM25_OK;
 }
 
@@ -983,6 +1003,7 @@ static int vbm25_batch_set_queries_impl(vbm25_batch *bt, const uint32_t *term_id
         if (!(bt->fused_g && bt->fused_pinned))
             if (int rc = upload_staged(bt)) return rc;
     } else {
+        bt->qin_live = false;
         if (q_off[nq]) HIP_TRY(hipMemcpy(bt->term_ids.p, term_ids, 4ull * q_off[nq], hipMemcpyHostToDevice));
         HIP_TRY(hipMemcpy(bt->q_off.p, q_off, 4ull * (nq + 1), hipMemcpyHostToDevice));
         if (nq) HIP_TRY(hipMemcpy(bt->q_dense.p, dense, nq, hipMemcpyHostToDevice));
@@ -1092,8 +1113,17 @@ static int vbm25_batch_run_impl(vbm25_batch *bt, void *hip_stream) {
     }
     db.error_flag = bt->error_flag.as<uint32_t>();
     db.q_dense = bt->q_dense.as<uint8_t>();
+    if (bt->qin_live) {  // the staged descriptors: one device block (upload_staged)
+        uint8_t *qp = bt->qin.as<uint8_t>();
+        const size_t nt = bt->pin_nt, no = 4ull * (bt->nq + 1), nd8 = (size_t(bt->nq) + 7) & ~size_t(7);
+        db.term_ids = reinterpret_cast<const uint32_t *>(qp);
+        db.q_off = reinterpret_cast<const uint32_t *>(qp + nt);
+        db.q_dense = qp + nt + no;
+    }
     db.item_failed = bt->item_failed.as<uint32_t>();
     db.item_order = bt->item_order.as<uint32_t>();
+    if (bt->qin_live && bt->pin_order_bytes)  // (the host's item order of the routes without plan_kernel, which writes its own into item_order)
+        db.item_order = reinterpret_cast<uint32_t *>(bt->qin.as<uint8_t>() + bt->pin_nt + 4ull * (bt->nq + 1) + ((size_t(bt->nq) + 7) & ~size_t(7)));
     db.prof = bt->prof.as<unsigned long long>();
     db.hist = bt->hist.as<uint32_t>();
     db.work_ctr = bt->work_ctr.as<uint32_t>();
@@ -1199,10 +1229,10 @@ static int vbm25_batch_run_impl(vbm25_batch *bt, void *hip_stream) {
             // 63 windows an item can hold, or with more than 16 items per query.
             const uint32_t gq = bt->win_g, nwin = bt->index->n_win;
             std::memset(db.win_cut, 0, sizeof db.win_cut);
-            if (bt->win_skew) {  // (the three kinds of waves: 58 / 51 / 44 of C3's 153 windows)
+            if (bt->win_skew) {  // (the three kinds of waves: 59 / 52 / 42 of C3's 153 windows: the third wave of a SIMD takes 1.5 times the first one's time per window)
                 db.win_cut[0] = 0;
-                db.win_cut[1] = uint32_t(uint64_t(nwin) * 383u / 1000u);
-                db.win_cut[2] = uint32_t(uint64_t(nwin) * 717u / 1000u);
+                db.win_cut[1] = uint32_t(uint64_t(nwin) * uint32_t(bt->tune.win_cut1) / 1000u);
+                db.win_cut[2] = uint32_t(uint64_t(nwin) * uint32_t(bt->tune.win_cut2) / 1000u);
                 db.win_cut[3] = nwin;
                 if (db.win_cut[1] > 63u || db.win_cut[2] - db.win_cut[1] > 63u || nwin - db.win_cut[2] > 63u) std::memset(db.win_cut, 0, sizeof db.win_cut);
             } else if (gq <= 16u && bt->win_len && uint64_t(bt->win_len) * (gq - 1u) < nwin) {
@@ -1504,6 +1534,8 @@ int vbm25_tuning_set(const char *name, long long value) {
     else if (n == "rel16_plane") g_tune.rel16_plane = value != 0;
     else if (n == "win_grid") g_tune.win_grid = (uint32_t)std::max(0ll, value);
     else if (n == "win_skew") g_tune.win_skew = value != 0;
+    else if (n == "win_cut1") g_tune.win_cut1 = int(std::min<long long>(std::max<long long>(value, 1), 998));
+    else if (n == "win_cut2") g_tune.win_cut2 = int(std::min<long long>(std::max<long long>(value, 2), 999));
     else if (n == "win_fuse") g_tune.win_fuse = value != 0;
     else return set_error(VBM25_ERR_INVALID, "unknown tuning switch %s", name);
     ++g_tune.generation;
@@ -1543,6 +1575,31 @@ int vbm25_batch_debug_counts(vbm25_batch *bt, uint32_t *n_items, uint32_t *n_fai
 int vbm25_batch_debug_route(vbm25_batch *bt) {
     if (!bt) return -1;
     return bt->bigk ? 4 : bt->fused_g ? 1 : bt->win_g ? 3 : bt->arith_g ? 2 : 0;
+}
+
+// test / bench aid (not declared in include/vbm25.h): which kernel the current queries' work goes to.  out[0..2] = queries the host
+// classed sparse (scan_win_kernel / scan_range_kernel), dense (scan_dense_kernel: postings >= 0.1 n_docs), many-term (> 16 indexed
+// terms: scan_many_kernel); out[3..5] = work items of the last run on the general route by the same classes (0 on the routes whose
+// kernels make their items themselves: all of them are the sparse kernel's)
+int vbm25_batch_debug_routes(vbm25_batch *bt, uint32_t *out6) {
+    if (!bt || !out6) return set_error(VBM25_ERR_INVALID, "NULL argument");
+    for (int i = 0; i < 6; ++i) out6[i] = 0;
+    if (bt->bigk) return VBM25_OK;
+    if (int rc = use_device(bt->index->device)) return rc;
+    HIP_TRY(hipStreamSynchronize(bt->last_stream));
+    for (uint32_t q = 0; q < bt->nq; ++q) out6[bt->h_dense[q] ? 1 : 0]++;
+    if (!bt->fused_g && !bt->win_g && !bt->arith_g) {
+        uint32_t n = 0;
+        HIP_TRY(hipMemcpy(&n, bt->n_items.p, 4, hipMemcpyDeviceToHost));
+        n = std::min(n, bt->max_items);
+        std::vector<Item> items(n);
+        if (n) HIP_TRY(hipMemcpy(items.data(), bt->items.p, sizeof(Item) * size_t(n), hipMemcpyDeviceToHost));
+        for (const Item &it : items) {
+            const uint32_t m = it.m & ~ITEM_DENSE;
+            out6[3 + (m > 16u ? 2 : (it.m & ITEM_DENSE) ? 1 : 0)]++;
+        }
+    }
+    return VBM25_OK;
 }
 
 // test aid (not declared in include/vbm25.h): launches of the last run's scan -- 1: scan_win_kernel merged the queries' lists itself
