@@ -518,6 +518,13 @@ def run(argv=None, scorer_factory=None, backend="nccl"):
             gather_exposed_ms = 1e3 * (time.perf_counter() - t_scan_done) / args.steps if t_scan_done else 0.0
         else:
             gather_ms = gather_exposed_ms = 1e3 * gather_cpu_s[0] / args.steps
+        # every rank's own figures, so that a scaling line can be read: which device was slow, and whether the time went into its
+        # scan (kernel_ms), into the step loop around it (ms_per_step) or into a gather that nothing hid (gather_exposed_ms)
+        mine = torch.tensor([1e3 * elapsed / args.steps, kernel_ms, gather_ms, gather_exposed_ms], dtype=torch.float64, device=dev)
+        every = [torch.zeros_like(mine) for _ in range(world)]
+        dist.all_gather(every, mine)
+        per_rank = {name: [round(float(t[i].item()), 4) for t in every]
+                    for i, name in enumerate(("ms_per_step", "kernel_ms", "gather_ms", "gather_exposed_ms"))}
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
@@ -654,6 +661,7 @@ def run(argv=None, scorer_factory=None, backend="nccl"):
                        "build_s": round(t_build, 2), "upload_s": round(t_upload, 2),
                        "scatter_ms": round(scatter_ms, 3), "gather_ms": round(gather_ms, 4),
                        "gather_exposed_ms": round(gather_exposed_ms, 4),
+                       "per_rank": per_rank if use_dist else None,
                        "route": route,
                        "routes": None if routes is None else {
                            "queries_sparse": routes[0], "queries_dense": routes[1],

@@ -122,6 +122,11 @@ def test_bench_step_two_ranks_gloo():
     assert d["config"]["verified_bit_exact_vs_oracle"]["queries"] == 128
     assert d["config"]["batches_rotated"] == 2
     assert d["config"]["workload"].startswith("C4")
+    # every rank's own figures (what makes a scaling line readable): one value per rank, the slowest rank's step is the line's
+    pr = d["config"]["per_rank"]
+    assert sorted(pr) == ["gather_exposed_ms", "gather_ms", "kernel_ms", "ms_per_step"] and all(len(v) == 2 for v in pr.values())
+    assert max(pr["ms_per_step"]) <= d["ms_per_step"] * 1.0001 + 1e-3 and min(pr["ms_per_step"]) > 0
+    assert pr["gather_ms"][0] > 0 and pr["kernel_ms"] == [0.0, 0.0]  # (no GPU here: nothing timed by HIP events)
     assert "roofline" not in d and "cpu_baseline" not in d  # nothing measured on a GPU here
 
 

@@ -19,6 +19,13 @@ names = {
     "c5_kernel_stats.csv": f"{tag}_c5_kernel_stats.csv",
     "c5_phase_timers.txt": f"{tag}_c5_phase_timers.txt",
     "pmc5_summary.csv": f"{tag}_c5_pmc_scan_dense_kernel.csv",
+    "c3_win_ablation_raw.txt": f"{tag}_c3_win_ablation_raw.txt",
+    "bench_c3z.json": f"{tag}_c3z_bench.json",
+    "c3z_kernel_stats.csv": f"{tag}_c3z_kernel_stats.csv",
+    "mixed_batch.txt": f"{tag}_mixed_batch.txt",
+    "multi_enqueue.txt": f"{tag}_multi_enqueue.txt",
+    "stream_host_time.txt": f"{tag}_stream_host_time.txt",
+    "index_planes.txt": f"{tag}_index_planes.txt",
 }
 for a, b in names.items():
     if os.path.exists(os.path.join(src, a)):
