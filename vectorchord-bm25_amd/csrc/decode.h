@@ -64,13 +64,17 @@ __device__ __forceinline__ void decode_doc_ids(const uint8_t *__restrict__ p, ui
         d1 = v1;
         return;
     }
-    uint32_t x = v0 + v1;  // inclusive scan of the per-lane sums
-    const uint32_t own = x;
-#pragma unroll
-    for (int o = 1; o < 64; o <<= 1) {
-        uint32_t y = __shfl_up(x, o);
-        if ((int)lane >= o) x += y;
-    }
+    // inclusive scan of the per-lane sums over the wave: DPP row shifts and row broadcasts (round 6: six __shfl_up were six dependent
+    // round trips through the LDS crossbar per decoded block -- the in-kernel decode of an index without post_rel16, the cold pass
+    // of scan_win_kernel and the slow tasks of scan_dense_kernel all come through here).  All 64 lanes are active at every call site.
+    const uint32_t own = v0 + v1;
+    uint32_t x = own;
+    x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x111, 0xf, 0xf, false);  // row_shr:1
+    x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x112, 0xf, 0xf, false);  // row_shr:2
+    x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x114, 0xf, 0xf, false);  // row_shr:4
+    x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x118, 0xf, 0xf, false);  // row_shr:8
+    x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x142, 0xa, 0xf, false);  // row_bcast:15
+    x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x143, 0xc, 0xf, false);  // row_bcast:31
     d0 = min_doc + (x - own) + v0;
     d1 = d0 + v1;
 }

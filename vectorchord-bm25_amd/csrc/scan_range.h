@@ -37,6 +37,9 @@
 #define VBM25_RNW 8
 #define VBM25_RB 8
 #define VBM25_RWPS 4
+#ifndef VBM25_DECODE_GROUP
+#define VBM25_DECODE_GROUP 4  // blocks whose raw words are in flight together when the index has no post_rel16 plane
+#endif
 #define VBM25_RLIST 128
 #endif
 constexpr int RNW = VBM25_RNW;       // waves per workgroup: planner + 7 workers (16 waves x 4 blocks measured 13 % slower)
@@ -700,9 +703,48 @@ __global__ void __launch_bounds__(RWG, KMAX > 64 ? VBM25_RWPS_BIGK : VBM25_RWPS)
                     d0[i] = c[i].x + (reln[i] & 0xffffu);
                     d1[i] = c[i].x + (reln[i] >> 16);
                 }
+                // An index WITHOUT the post_rel16 plane (the reference's blocks decoded in the kernel, compression.rs:65-92,
+                // bitpacking_u32_ordered.rs:222-237): the bit-packed blocks of the wave -- every block but a term's tail -- in groups of
+                // four: the groups' words are requested together (two 8-byte loads per lane and block: the lane's two fields and
+                // what they may straddle into), then extracted and prefix-summed with DPP shifts.  (Round 5 decoded block after
+                // block: a round trip to memory and six through the LDS crossbar each -- 0.75 ms on C3.)
+                uint32_t bp_done = 0;  // entries decoded here
+                if (!ix.post_rel16) {
+                    constexpr int DG = VBM25_DECODE_GROUP < RB ? VBM25_DECODE_GROUP : RB;
+#pragma unroll
+                    for (int g4 = 0; g4 < RB; g4 += DG) {
+                        uint32_t w0[DG], w1[DG], w2[DG], w3[DG], wid[DG], mind[DG];
+#pragma unroll
+                        for (int u = 0; u < DG; ++u) {
+                            const int i = g4 + u;
+                            const uint4 cc = uni4(S.pm[buf][(wave - 1u) + (RNW - 1) * ((uint32_t)i < nv ? (uint32_t)i : 0u)]);
+                            const uint32_t md = (cc.w >> 8) & 0xff, n = cc.w & 0xff;
+                            const bool bp = (uint32_t)i < nv && (md >> 7) == 0 && (md & 127u) < 32u && (md & 127u) != 0 && n == 128u;
+                            wid[u] = bp ? md & 127u : 0u;  // (0: not decoded here)
+                            mind[u] = cc.x;
+                            bp_done |= bp ? 1u << i : 0u;
+                            // (an entry that is not decoded here reads its own body's first words, or entry 0's: any valid address)
+                            pair_fetch(ix.blob + 8ull * cc.z, bp ? wid[u] : 1u, lane, w0[u], w1[u], w2[u], w3[u]);
+                        }
+#pragma unroll
+                        for (int u = 0; u < DG; ++u) {
+                            const int i = g4 + u;
+                            uint32_t v0, v1;
+                            pair_extract(wid[u] ? wid[u] : 1u, lane, w0[u], w1[u], w2[u], w3[u], v0, v1);
+                            const uint32_t own = v0 + v1;
+                            const uint32_t incl = wave_incl_scan_u32(own);
+                            const uint32_t a0 = mind[u] + (incl - own) + v0;
+                            if (wid[u]) {
+                                d0[i] = a0;
+                                d1[i] = a0 + v1;
+                            }
+                        }
+                    }
+                }
                 if (!allfast) {  // wide, raw (width 32) or byte-packed tail blocks: generic, synchronous decode from the blob
 #pragma nounroll
                     for (uint32_t i = 0; i < nv; ++i) {
+                        if ((bp_done >> i) & 1u) continue;
                         const uint4 cc = uni4(S.pm[buf][(wave - 1u) + (RNW - 1) * i]);
                         const uint32_t md = (cc.w >> 8) & 0xff;
                         if (!ix.post_rel16 || !rel16_block(cc.x, cc.y, cc.w)) {
