@@ -218,8 +218,9 @@ __device__ __forceinline__ double wave_shl1_f64(double v) {  // lane l gets lane
 }
 // an open pass of second arrivals: what C1 found for the lane's (entry, term), the word requested for it
 struct WnPend {
-    bool valid, found, task, claimed;
+    bool valid, found, task;
     uint32_t x, p, w, gw;
+    uint32_t cw;  // the filter word the claim got back (looked at a window later: nobody waits for the atomic where it is issued)
 };
 
 // The query's hits from the lists of its items (merge.h's job, done here by the wave that finishes the query's LAST item: round 6 --
@@ -535,7 +536,8 @@ __global__ void __launch_bounds__(wn_waves(MT, RK) * 64, (wn_waves(MT, RK) + 3) 
             bool task, found, more;
             uint32_t x, base, plo, len, slen;
         };
-        auto c1_search = [&](const uint32_t e0, const uint32_t nd) -> C1S {
+        // (`hook(step)` runs between the search's round trips to the LDS: the merged block hands the steps of C2's f64 divide in)
+        auto c1_search = [&](const uint32_t e0, const uint32_t nd, auto &&hook) -> C1S {
             C1S r;
             const bool task = el < epp && e0 + el < nd;
             const uint32_t ent = S.list[task ? e0 + el : 0u];
@@ -549,15 +551,22 @@ __global__ void __launch_bounds__(wn_waves(MT, RK) * 64, (wn_waves(MT, RK) + 3) 
             uint32_t base = 0;  // the last posting of the run whose id is <= x
             const uint32_t slen = min(len, (uint32_t)WN_SLOT - (plo - pal));  // the staged part of the run
             uint32_t n2 = task ? slen : 0u;
-#pragma unroll
-            for (int it = 0; it < 8; ++it) {
-                const uint32_t half = n2 >> 1;
-                if ((uint32_t)sb[base + half] <= x) base += half;
-                n2 -= half;
-            }
-            r.found = task && len != 0u && (uint32_t)sb[base] == x;
+#define WN_BISECT_STEP(IT)                                              \
+    {                                                                   \
+        const uint32_t half = n2 >> 1;                                  \
+        const uint32_t probe = sb[base + half];                         \
+        hook(std::integral_constant<int, IT>());                        \
+        if (probe <= x) base += half;                                   \
+        n2 -= half;                                                     \
+    }
+            WN_BISECT_STEP(0) WN_BISECT_STEP(1) WN_BISECT_STEP(2) WN_BISECT_STEP(3) WN_BISECT_STEP(4) WN_BISECT_STEP(5) WN_BISECT_STEP(6) WN_BISECT_STEP(7)
+#undef WN_BISECT_STEP
+            // (both reads unconditional: a read under a lane condition is a branch, and a branch ends the block the scheduler works in)
+            uint32_t v_at = sb[base], v_last = sb[slen ? slen - 1u : 0u];
+            asm volatile("" : "+v"(v_at), "+v"(v_last));  // (opaque: the compiler sinks a load whose only use is conditional into the condition)
+            r.found = task && len != 0u && v_at == x;
             // a run thicker than its stage row and a document beyond the staged part: the rest of the run, in memory
-            r.more = task && !r.found && slen < len && (uint32_t)sb[slen - 1u] < x;
+            r.more = task && !r.found && slen < len && v_last < x;
             r.task = task;
             r.x = x;
             r.base = base;
@@ -590,20 +599,20 @@ __global__ void __launch_bounds__(wn_waves(MT, RK) * 64, (wn_waves(MT, RK) + 3) 
                 }
             }
             // the document is offered by the first of its entries that claims it: the bit goes, whoever saw it there owns the document
-            bool claimed = false;
+            uint32_t cw = 0;
             if (r.task && tl == 0u) {
                 const uint32_t bit = 1u << (x & 31u);
-                claimed = (__hip_atomic_fetch_and((wn_lds_u32 *)(((x >> 3) & bmbase.mask) | bmbase.base), ~bit, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) & bit) != 0u;
+                cw = __hip_atomic_fetch_and((wn_lds_u32 *)(((x >> 3) & bmbase.mask) | bmbase.base), ~bit, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
             }
             d.task = r.task;
             d.found = found;
-            d.claimed = claimed;
+            d.cw = cw;
             d.x = x;
             d.p = r.plo + base;
             d.w = w;
         };
         auto c1 = [&](WnPend &d, const uint32_t e0, const uint32_t nd, const uint32_t w) {
-            const C1S r = c1_search(e0, nd);
+            const C1S r = c1_search(e0, nd, [](auto) {});
             c1_finish(d, r, w);
         };
         // the word of post_tfn that holds the posting C1 found (word 0 for the lanes that found none: the load is unconditional)
@@ -615,13 +624,15 @@ __global__ void __launch_bounds__(wn_waves(MT, RK) * 64, (wn_waves(MT, RK) + 3) 
             uint32_t doc;
         };
         auto c2_calc = [&](const WnPend &d) -> C2R {
-            double c = 0.0;
-            if (d.found) {
+            // (every lane computes -- no branch around the divide, so that it can be scheduled into the search's waits; a lane that found
+            // nothing divides by S1[..] + 0 > 0 and drops the result)
+            double c;
+            {
                 const uint32_t ww = d.gw >> ((d.p & 1u) * 8u);
-                const uint32_t tfv = ww & 0xffu, fn = (ww >> 16) & 0xffu;
-                notf = notf || tfv == 0u;  // (a term frequency above 255: the word holds zeros -- not this kernel's item)
+                const uint32_t tfv = d.found ? ww & 0xffu : 0u, fn = (ww >> 16) & 0xffu;
+                notf = notf || (d.found && tfv == 0u);  // (a term frequency above 255: the word holds zeros -- not this kernel's item)
                 const double tf = (double)tfv;
-                c = (tf * s0l) / (tf + S1[fn]);  // Cache::evaluate, bm25.rs:355-358
+                c = (tf * s0l) / (tf + S1[fn]);  // Cache::evaluate, bm25.rs:355-358 (tf = 0: + 0.0)
             }
             const unsigned long long fm = __ballot(d.found);
             C2R r;
@@ -640,13 +651,64 @@ __global__ void __launch_bounds__(wn_waves(MT, RK) * 64, (wn_waves(MT, RK) + 3) 
             if (d.task && tl == 0u) {
                 const uint32_t my = (uint32_t)(fm >> lane) & ((1u << mm) - 1u);
                 // the entry that claimed the document completes it (one offer per document) -- if two lists hold it
-                r.okd = d.claimed && (my & (my - 1u)) != 0u;
+                r.okd = ((d.cw >> (d.x & 31u)) & 1u) != 0u && (my & (my - 1u)) != 0u;
             }
             return r;
         };
         auto c2 = [&](const WnPend &d) {
             const C2R r = c2_calc(d);
             offer(r.okd, r.acc, r.doc);
+        };
+        // C2 with its divide taken apart (the merged block): what LLVM makes of an f64 `/` -- div_scale, rcp, two Newton steps,
+        // div_fmas, div_fixup: the correctly rounded quotient, bit for bit what `/` gives -- as eight steps that the search's hook runs
+        // one per round trip to the LDS
+        struct C2Div {
+            double num, den, sc0, rcp, f0, f1, f2, sc1, f3, mul, f4, q;
+            bool vcc;
+        };
+        auto c2_div_begin = [&](const WnPend &d, C2Div &D) {
+            const uint32_t ww = d.gw >> ((d.p & 1u) * 8u);
+            const uint32_t tfv = d.found ? ww & 0xffu : 0u, fn = (ww >> 16) & 0xffu;
+            notf = notf || (d.found && tfv == 0u);
+            const double tf = (double)tfv;
+            D.num = tf * s0l;       // (a lane that found nothing: 0 / S1[..] = + 0.0)
+            D.den = tf + S1[fn];
+        };
+        auto c2_div_step = [&](C2Div &D, auto itc) {
+            constexpr int it = decltype(itc)::value;
+            if constexpr (it == 0) {
+                bool unused;
+                D.sc0 = __builtin_amdgcn_div_scale(D.num, D.den, false, &unused);
+                D.rcp = __builtin_amdgcn_rcp(D.sc0);
+            }
+            if constexpr (it == 1) D.f0 = __builtin_fma(-D.sc0, D.rcp, 1.0);
+            if constexpr (it == 2) D.f1 = __builtin_fma(D.rcp, D.f0, D.rcp);
+            if constexpr (it == 3) D.f2 = __builtin_fma(-D.sc0, D.f1, 1.0);
+            if constexpr (it == 4) {
+                D.sc1 = __builtin_amdgcn_div_scale(D.num, D.den, true, &D.vcc);
+                D.f3 = __builtin_fma(D.f1, D.f2, D.f1);
+            }
+            if constexpr (it == 5) D.mul = D.sc1 * D.f3;
+            if constexpr (it == 6) D.f4 = __builtin_fma(-D.sc0, D.mul, D.sc1);
+            if constexpr (it == 7) D.q = __builtin_amdgcn_div_fixup(__builtin_amdgcn_div_fmas(D.f4, D.f3, D.mul, D.vcc), D.den, D.num);
+        };
+        auto c2_sum = [&](const WnPend &d, const double c) -> C2R {
+            const unsigned long long fm = __ballot(d.found);
+            C2R r;
+            r.okd = false;
+            r.doc = d.w << 16 | d.x;
+            double sh = c;
+            r.acc = c;
+#pragma unroll
+            for (int t = 1; t < MT; ++t) {
+                sh = wave_shl1_f64(sh);
+                r.acc += sh;  // absent terms add 0.0
+            }
+            if (d.task && tl == 0u) {
+                const uint32_t my = (uint32_t)(fm >> lane) & ((1u << mm) - 1u);
+                r.okd = ((d.cw >> (d.x & 31u)) & 1u) != 0u && (my & (my - 1u)) != 0u;
+            }
+            return r;
         };
 
         // One window: `cur` holds its runs (requested two windows ago) and takes the runs of the window after next at the end.  Two
@@ -793,8 +855,10 @@ __global__ void __launch_bounds__(wn_waves(MT, RK) * 64, (wn_waves(MT, RK) + 3) 
             // with the other's instructions.  Both run unconditionally: an invalid pass has found nothing, an empty list gives no task.
             {
                 const uint32_t nd1 = !failed && !(dbg & 2u) ? nd : 0u;
-                const C2R ra = c2_calc(pa);
-                const C1S sa = c1_search(0u, nd1);
+                C2Div dv;
+                c2_div_begin(pa, dv);
+                const C1S sa = c1_search(0u, nd1, [&](auto itc) { c2_div_step(dv, itc); });
+                const C2R ra = c2_sum(pa, dv.q);
                 offer(ra.okd, ra.acc, ra.doc);
                 if (pb.valid) c2(pb);
                 pb.valid = false;
