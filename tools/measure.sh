@@ -36,9 +36,10 @@ for step in "$@"; do case $step in
   c5pmc) B="python $R/bench.py --workload C5 --steps 3 --warmup 1 --no-cpu-baseline --no-verify-sample --no-host-buffer --extra-budget-s 0 $TUNE_ARG"
      (cd /tmp; export TMPDIR=/tmp
       timeout 400 rocprofv3 --kernel-trace --pmc SQ_WAVE_CYCLES SQ_BUSY_CU_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_WAIT_INST_LDS SQ_ACTIVE_INST_ANY SQ_INSTS_VALU SQ_INSTS_SALU --output-format csv -d $O/pmc5_sq1 -- $B > $O/pmc5_sq1.log 2>&1
+      timeout 400 rocprofv3 --kernel-trace --pmc SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_VMEM_RD SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS --output-format csv -d $O/pmc5_sq2 -- $B > $O/pmc5_sq2.log 2>&1
       timeout 400 rocprofv3 --kernel-trace --pmc GRBM_GUI_ACTIVE FETCH_SIZE --output-format csv -d $O/pmc5_fetch -- $B > $O/pmc5_fetch.log 2>&1
       timeout 400 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $O/pmc5_write -- $B > $O/pmc5_write.log 2>&1)
-     python tools/pmc_summary.py scan_dense_kernel sq1=$O/pmc5_sq1 fetch=$O/pmc5_fetch write=$O/pmc5_write > $O/pmc5_summary.csv 2> $O/pmc5_summary.err; cat $O/pmc5_summary.csv
+     python tools/pmc_summary.py scan_dense_kernel sq1=$O/pmc5_sq1 sq2=$O/pmc5_sq2 fetch=$O/pmc5_fetch write=$O/pmc5_write > $O/pmc5_summary.csv 2> $O/pmc5_summary.err; cat $O/pmc5_summary.csv
      python tools/pmc_traffic.py C5 scan_dense_kernel $O/pmc5_fetch $O/pmc5_write > $O/pmc_traffic_c5.json; cat $O/pmc_traffic_c5.json
      find $O -name "*.csv" -size +5M -delete;;
   ubenchpmc) bash tools/ubench/pmc.sh > $O/mark_ceiling_pmc.txt 2>&1; tail -40 $O/mark_ceiling_pmc.txt;;
