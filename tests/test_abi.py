@@ -84,7 +84,7 @@ def test_tuning_switches_of_the_product_library():
     import vectorchord_bm25_amd as vb
 
     try:
-        for name in ("win", "win_items", "win_skew", "win_planes", "rel16_plane", "arith", "fused", "dense_x1000"):
+        for name in ("win", "win_items", "win_skew", "win_planes", "rel16_plane", "id16_plane", "arith", "fused", "dense_x1000"):
             vb.set_tuning(name, 1)
         for name in ("dbg", "team", "team_dbg", "no_such_switch"):
             with pytest.raises(RuntimeError, match="unknown tuning switch"):

@@ -1,7 +1,9 @@
 """The HIP decoders fed every codec shape of compression.rs:65-136 through small hand-made indexes, against the oracle bit for
 bit -- through scan_range_kernel (plan-free and general route), scan_win_kernel (win_force: whatever the lists' lengths; it reads the
 window planes derived from the decoded blocks, and the blob in its cold pass), the one-launch route, scan_dense_kernel (every query
-declared dense) and the exhaustive scan_many_kernel (k = 300).  -m gpu only.
+declared dense) and the exhaustive scan_many_kernel (k = 300); and through a SECOND index of the same segment made without the
+post_id16 and post_rel16 planes (tuning id16_plane = 0, rel16_plane = 0): scan_win_kernel behind decode_id16_kernel, which unpacks
+the batch's terms from the blob per launch, and scan_range_kernel's in-kernel decode.  -m gpu only.
 
 * byte-packed TAIL blocks with document-id byte widths 3 and 4 (gaps >= 2^16 and >= 2^24; width 4 is raw absolute ids,
   bytepacking_u32_ordered.rs:200-214 -- its own branch in decode.h) and term-frequency byte widths 2 and 3;
@@ -32,18 +34,27 @@ def _index(n_docs, lists, seed=0):
     doc_len = rng.integers(1, 3000, n_docs).astype(np.uint32)
     seg = vb.Segment.build(1.2, 0.75, doc_len, np.zeros((n_docs, 3), dtype=np.uint16), keys, term_start, post_doc, post_tf)
     a = seg.arrays()
-    return seg, a, vb.GpuIndex(seg), orc.OracleIndex.from_arrays(seg.meta(), a)
+    gix = vb.GpuIndex(seg)
+    vb.set_tuning("id16_plane", 0)  # (read at index creation)
+    vb.set_tuning("rel16_plane", 0)
+    try:
+        gix.no_planes = vb.GpuIndex(seg)
+    finally:
+        vb.reset_tuning()
+    assert gix.no_planes.device_bytes < gix.device_bytes
+    return seg, a, gix, orc.OracleIndex.from_arrays(seg.meta(), a)
 
 
 def _check_routes(tuning, gix, oix, terms, off, ks=(10, 128)):
     nq = len(off) - 1
     routes = [("range", dict(win=0, fused=0)), ("range-general", dict(win=0, fused=0, arith=0)), ("win", dict(win_force=1, fused=0)),
-              ("fused", dict(fused=1)), ("dense", dict(fused=0, dense_x1000=0))]
+              ("fused", dict(fused=1)), ("dense", dict(fused=0, dense_x1000=0)),
+              ("win-decode", dict(win_force=1, fused=0)), ("range-decode", dict(win=0, fused=0)), ("fused-decode", dict(fused=1))]
     for name, tune in routes:
         vb.reset_tuning()
         tuning(**tune)
         for k in ks:
-            b = vb.Batch(gix, nq, len(terms), k)
+            b = vb.Batch(gix.no_planes if name.endswith("-decode") else gix, nq, len(terms), k)
             b.set_queries(terms, off)
             b.run()
             hits, nh = b.fetch()

@@ -536,7 +536,7 @@ def set_tuning(name, value):
     """test / tuning aid (vbm25_tuning_set, not in include/vbm25.h): process-wide switch read when a Batch / GpuIndex
     scratch batch is created.  Names: dense_x1000, dense, ne, fused, ne_ratio, dense_items, range_items,
     range_min_chunk, range_grid, dense_grid, fused_items, arith, win, win_force, win_items, win_grid, win_skew, win_guided,
-    win_planes and rel16_plane (read at index creation).  No switch of the product library changes results (`dbg`, the
+    win_planes, rel16_plane and id16_plane (read at index creation).  No switch of the product library changes results (`dbg`, the
     timing experiments of scan_win_kernel, exists only in the development build libvbm25_dev.so)."""
     f = lib().vbm25_tuning_set
     f.restype = C.c_int

@@ -98,6 +98,9 @@ struct DevBatch {
     uint32_t win_fuse;         // scan_win_kernel merges a query's lists itself (the wave that finishes the query's last item) and leaves the
                                // per-launch state zero: no scan_many_kernel, no merge_kernel behind it (a query with an item given up gets n_hits = NONE32)
     uint32_t win_dbg;          // development switch of scan_win_kernel (timing experiments only, wrong results; scan_win.h)
+    const uint32_t *id16_fb;   // an index without the post_id16 plane (round 6): per term position of term_ids the first 256-byte block of that
+                               // term's low-16-bit ids in the batch's scratch plane, which decode_id16_kernel fills from the blob ahead of
+                               // scan_win_kernel (ix.post_id16 then points at the scratch plane); NULL: the index's own plane, at term_first_block
     uint32_t *dbg;             // -DVBM25_CHECK builds: [0] first violated check (0: none), [1] value, [2] item, [3] thread
 };
 

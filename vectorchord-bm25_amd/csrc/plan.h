@@ -63,8 +63,9 @@ __global__ void __launch_bounds__(256) post_fn_kernel(PostFnArgs a) {
     // 128 (j - first block) + i of its term: only a term's last block is short (flag 8 otherwise: the index then goes without
     // these planes).  Every boundary w << 16 lies between two consecutive postings of the term (or before its first / after its
     // last one): the later of the two writes entry w.
-    if (a.post_id16) {
-        a.post_id16[64ull * j + lane] = (d1 & 0xffffu) << 16 | (d0 & 0xffffu);
+    // (an index made without post_id16 keeps the tables: decode_id16_kernel makes the batch's terms' ids per launch)
+    if (a.post_id16) a.post_id16[64ull * j + lane] = (d1 & 0xffffu) << 16 | (d0 & 0xffffu);
+    if (a.win_off) {
         const uint32_t fb = a.term_first_block[lo], fe = a.term_first_block[lo + 1];
         if (j + 1 < fe && n != 128u) atomicOr(a.error_flag, 8u);
         const uint32_t wb = a.term_win[lo];

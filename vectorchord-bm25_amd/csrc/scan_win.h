@@ -402,18 +402,27 @@ __global__ void __launch_bounds__(wn_waves(MT, RK) * 64, (wn_waves(MT, RK) + 3) 
 
         // ---- item setup: lane t = term t of the query (ascending key order)
         uint32_t m = 0, term = NONE32;
+        uint32_t fbi = NONE32;  // the term's first block in the plane of ids: its own first block, or (an index without post_id16) its place in the batch's scratch plane
         {
             const KernArgsP ca = cold_args();
             // (the host sends queries of <= 64 terms this way; when they all have the same number of terms nobody waits for q_off)
             const uint32_t qs = ca->bt.q_stride;
             const uint32_t qb = qs ? qs * q : uni(ca->bt.q_off[q]), qe = qs ? qs * (q + 1u) : uni(ca->bt.q_off[q + 1]);
+            const uint32_t *idfb = ca->bt.id16_fb;
             const uint32_t tt = lane < qe - qb ? ca->bt.term_ids[qb + lane] : NONE32;
+            const uint32_t ti = idfb && lane < qe - qb ? idfb[qb + lane] : NONE32;
             const bool ok = tt < ix.n_terms;  // search.rs:59-61
             const unsigned long long okm = __ballot(ok);
-            if (ok) S.list[wn_mbcnt(okm)] = tt;
+            if (ok) {
+                S.list[wn_mbcnt(okm)] = tt;
+                if (wn_mbcnt(okm) < 32u) S.list[32u + wn_mbcnt(okm)] = ti;  // (queries of <= 64 terms come this way; the kernel takes the ones of <= 8)
+            }
             m = (uint32_t)__popcll(okm);
             __builtin_amdgcn_wave_barrier();
-            if (lane < min(m, (uint32_t)MT)) term = S.list[lane];
+            if (lane < min(m, (uint32_t)MT)) {
+                term = S.list[lane];
+                fbi = S.list[32u + lane];
+            }
             __builtin_amdgcn_wave_barrier();
         }
         const bool act = lane < min(m, (uint32_t)MT);
@@ -424,6 +433,7 @@ __global__ void __launch_bounds__(wn_waves(MT, RK) * 64, (wn_waves(MT, RK) + 3) 
             const double *kub = ca->ix.term_kth_ub;
             if (act) {
                 fb = ca->ix.term_first_block[term];
+                if (fbi == NONE32) fbi = fb;
                 s0 = ca->ix.term_s0[term];
                 wb = ca->ix.term_win[term];
                 if (kub) {  // (the smallest 2^i >= k: at least k documents of the term score that much)
@@ -440,7 +450,7 @@ __global__ void __launch_bounds__(wn_waves(MT, RK) * 64, (wn_waves(MT, RK) + 3) 
         const uint32_t wbs = act && !failed ? wb : 0u;  // (lanes without a term: the null table at win_off[0 ..]; every load below is unconditional)
         // the term's postings as bytes (lane = term), and per term the numbers of its postings below the item's window boundaries
         // (lane i = boundary w_lo + i; the host cuts items of at most 63 windows): no boundary is loaded inside the window loop
-        const unsigned long long pbase = (unsigned long long)ids16 + (act && !failed ? 256ull * fb : 0ull);
+        const unsigned long long pbase = (unsigned long long)ids16 + (act && !failed ? 256ull * fbi : 0ull);
         const uint32_t nw = w_hi - w_lo;
         failed = failed || nw > 63u;
         uint32_t wo[MT];
@@ -529,6 +539,7 @@ __global__ void __launch_bounds__(wn_waves(MT, RK) * 64, (wn_waves(MT, RK) + 3) 
         const uint32_t inv_m = mm ? (65536u + mm - 1u) / mm : 0u, epp = mm ? 64u / mm : 0u;
         const uint32_t el = (lane * inv_m) >> 16, tl = mm ? lane - el * mm : 0u;  // the lane's entry of a pass and its term
         const uint32_t fbl = (uint32_t)__shfl((int)fb, (int)tl);
+        const uint32_t fbil = (uint32_t)__shfl((int)fbi, (int)tl);  // (the same block unless the ids come from the batch's scratch plane)
         const double s0l = __shfl(s0, (int)tl);
         wB = (uint32_t)__shfl((int)wS, (int)tl);
         bool notf = false;
@@ -583,7 +594,7 @@ __global__ void __launch_bounds__(wn_waves(MT, RK) * 64, (wn_waves(MT, RK) + 3) 
             bool more = r.more;
             const uint32_t x = r.x;
             if (__ballot(more)) {
-                const uint16_t *gb = ids16 + 128ull * fbl + r.plo;
+                const uint16_t *gb = ids16 + 128ull * fbil + r.plo;
                 uint32_t lo = r.slen, hi = r.len;
                 while (__ballot(more && lo < hi)) {  // first posting of [slen, len) with id >= x
                     const uint32_t mid = (lo + hi) >> 1;
@@ -782,7 +793,7 @@ __global__ void __launch_bounds__(wn_waves(MT, RK) * 64, (wn_waves(MT, RK) + 3) 
                                 }
                             }
                             if (en[u] > (uint32_t)WN_SLOT) {  // a run that one load per lane does not hold: the rest, not staged (C1 reads it from memory)
-                                const uint16_t *rest = ids16 + 128ull * (uint32_t)__builtin_amdgcn_readlane((int)fb, t) + 4u * lane;
+                                const uint16_t *rest = ids16 + 128ull * (uint32_t)__builtin_amdgcn_readlane((int)fbi, t) + 4u * lane;
                                 const uint32_t n = o_hi - o_lo;
 #pragma nounroll
                                 for (uint32_t o = o_al + (uint32_t)WN_SLOT; o < o_hi; o += (uint32_t)WN_SLOT) {
@@ -992,7 +1003,7 @@ __global__ void __launch_bounds__(wn_waves(MT, RK) * 64, (wn_waves(MT, RK) + 3) 
                             for (uint32_t t2 = 0; t2 < mm; ++t2) {  // ... unless another list of the query holds the document
                                 if (t2 == t) continue;
                                 const uint32_t wb2 = (uint32_t)__builtin_amdgcn_readlane((int)wbs, (int)t2);
-                                const uint16_t *run = ids16 + 128ull * (uint32_t)__builtin_amdgcn_readlane((int)fb, (int)t2);
+                                const uint16_t *run = ids16 + 128ull * (uint32_t)__builtin_amdgcn_readlane((int)fbi, (int)t2);
                                 uint32_t lo = 0, hi = 0;
                                 if (cand) {
                                     lo = ix.win_off[wb2 + wd];

@@ -63,6 +63,7 @@ int set_error(int code, const char *fmt, ...) {
 #include "topk_lds.h"
 #include "block_fetch.h"
 #include "topk_reg.h"
+#include "decode_id16.h"
 #include "scan_range.h"
 #include "scan_win_launch.h"
 #include "scan_dense.h"
@@ -228,6 +229,8 @@ struct Tuning {
     uint32_t win_items = 0;        // work items of a batch on that route (0: twice the resident waves)
     int win_planes = 1;            // read at index creation: derive the window planes (post_id16, win_off)
     int rel16_plane = 1;           // read at index creation: derive post_rel16 (0: the kernels decode the blob's delta streams themselves)
+    int id16_plane = 1;            // read at index creation: derive post_id16 (0: the window tables only -- decode_id16_kernel unpacks the batch's
+                                   // terms from the blob into the batch's scratch plane ahead of every scan_win_kernel launch)
     int win_guided = 0;            // scan_win_kernel's items of a query of decreasing length, handed out longest first (0: equal runs; measured
                                    // no better on C3 -- an item's setup costs more than the shorter tail saves)
     uint32_t win_grid = 0;         // its persistent workgroups (0: one per CU)
@@ -275,6 +278,13 @@ struct vbm25_batch {
     bool order_useful = true;     // the current queries differ enough in length for the longest-first order to matter
     uint32_t win_g = 0;           // ... and scan_win_kernel's flavour of it (items = runs of 2^16-document windows, one result list each)
     uint32_t win_len = 0;         // ... a query's runs: win_len windows each and a shorter rest (0: equal runs)
+    // an index without the post_id16 plane: the batch's scratch plane (the low 16 bits of the ids of the current queries' terms, made by
+    // decode_id16_kernel ahead of every scan_win_kernel launch) and, per term position, the term's first 256-byte block in it
+    DeviceBuffer id16_tmp, id16_fb;
+    std::vector<uint32_t> h_id16_fb;
+    bool id16_decode = false;     // the current queries take scan_win_kernel through the scratch plane
+    uint32_t n_term_pos = 0;      // term positions of the current queries (q_off[nq])
+    size_t pin_id16_bytes = 0;    // ... and their h_id16_fb is staged behind the item order (upload_staged)
     DeviceBuffer qin;             // the staged descriptors on the device, one block: term ids | offsets | dense flags (padded to 8) | item order
     bool qin_live = false;        // ... hold the current queries (set by upload_staged; a plain set_queries fills the separate buffers)
     bool device_consumer = false; // vbm25_batch_device_results was called: every run leaves complete records on the device
@@ -428,6 +438,7 @@ static int index_create_common(const RawSegment &r, int device, vbm25_index **ou
     // (`rel16_plane` = 0: no post_rel16 -- scan_range_kernel and scan_dense_kernel unpack the delta streams of the blob in the
     // kernel: 256 bytes per block less in HBM, more instructions per block; DESIGN.md section 1 has both measured)
     const bool rel16_plane = tune_now.rel16_plane != 0;
+    const bool id16_plane = tune_now.id16_plane != 0;  // (0: the tables without the plane -- decode_id16.h)
     const uint32_t n_win = uint32_t((uint64_t(r.n_docs) + 65535u) >> 16);
     std::vector<uint32_t> term_win(win_planes ? r.n_terms : 0u, UINT32_MAX);
     uint64_t n_woff = n_win + 2u;  // (entries 0 .. n_win + 1: the NULL table -- a term without postings, what a query's missing terms read)
@@ -488,7 +499,7 @@ static int index_create_common(const RawSegment &r, int device, vbm25_index **ou
         (rc = ix->post_fn.alloc(128ull * r.n_blocks)) ||
         (rel16_plane && (rc = ix->post_rel16.alloc(256ull * r.n_blocks))) ||
         (rc = ix->post_tfn.alloc(256ull * r.n_blocks + 1024)) ||  // (slack: scan_win_kernel's cold pass reads whole runs)
-        (win_planes && ((rc = ix->post_id16.alloc(256ull * r.n_blocks + 1024)) || (rc = ix->win_off.alloc(4ull * n_woff)) ||
+        (win_planes && ((id16_plane && (rc = ix->post_id16.alloc(256ull * r.n_blocks + 1024))) || (rc = ix->win_off.alloc(4ull * n_woff)) ||
                         (rc = ix->term_win.upload(term_win.data(), 4ull * r.n_terms)))) ||
         (rc = put(ix->doc_payload, r.doc_payload, 6ull * r.n_docs)) ||
         (rc = ix->s1.upload(s1, sizeof s1)) || (rc = err.alloc(4)))
@@ -752,7 +763,8 @@ static int vbm25_batch_create_impl(vbm25_index *ix, uint32_t max_queries, uint32
         (rc = bt->hits.alloc(sizeof(vbm25_hit) * size_t(max_queries) * k)) ||
         (rc = bt->n_hits.alloc(4ull * max_queries)) || (rc = bt->error_flag.alloc(4)) ||
         (rc = bt->q_dense.alloc(max_queries)) ||
-        (rc = bt->qin.alloc(4ull * max_total_terms + 4ull * (max_queries + 1) + max_queries + 8 + 4ull * bt->max_items + 64)) ||
+        (rc = bt->qin.alloc(8ull * max_total_terms + 4ull * (max_queries + 1) + max_queries + 8 + 4ull * bt->max_items + 64)) ||
+        (rc = bt->id16_fb.alloc(4ull * max_total_terms)) ||
         (rc = bt->item_failed.alloc(4ull * bt->max_items)) || (rc = bt->item_order.alloc(4ull * bt->max_items)) || (rc = bt->work_ctr.alloc(8)) ||
         (rc = bt->hist.alloc(4ull * CUR_HB * max_queries)) || (rc = bt->fused_state.alloc(4ull * (max_queries + 1))) ||
         (rc = bt->fail_any.alloc(4)) || (rc = bt->q_failed.alloc(4ull * max_queries)) || (rc = bt->theta_last.alloc(8ull * max_queries)))
@@ -793,7 +805,7 @@ void vbm25_batch_destroy(vbm25_batch *bt) {
 // step on the multi-device route; vbm25_batch_run_impl points the kernels at the block's parts).
 static int upload_staged(vbm25_batch *bt) {
     const size_t nt = bt->pin_nt, no = 4ull * (bt->nq + 1), nd8 = (size_t(bt->nq) + 7) & ~size_t(7);
-    const size_t total = nt + no + nd8 + bt->pin_order_bytes;
+    const size_t total = nt + no + nd8 + bt->pin_order_bytes + bt->pin_id16_bytes;
     if (total > bt->qin.bytes) return set_error(VBM25_ERR_INVALID, "internal error: staged descriptors exceed the device block");
     HIP_TRY(hipMemcpyAsync(bt->qin.p, bt->pin_in, total, hipMemcpyHostToDevice, bt->lat_stream));
     bt->qin_live = true;
@@ -855,6 +867,9 @@ static int vbm25_batch_set_queries_impl(vbm25_batch *bt, const uint32_t *term_id
     bt->win_g = 0;
     bt->win_len = 0;
     bt->win_nofuse = false;
+    bt->id16_decode = false;
+    bt->pin_id16_bytes = 0;
+    bt->n_term_pos = q_off[nq];
     bt->need_many = many || !bt->use_range;
     bt->fused_pinned = false;
     if (bt->use_range && nq && !many && !has_dense && range_mt != 0) {  // every query sparse, <= 16 indexed terms: the one-launch route
@@ -932,6 +947,31 @@ static int vbm25_batch_set_queries_impl(vbm25_batch *bt, const uint32_t *term_id
                 if (win_g) {
                     bt->win_g = win_g;
                     g = win_g;
+                    if (!ixh->post_id16.p) {
+                        // An index without the post_id16 plane: every term position gets its blocks in the batch's scratch plane (a
+                        // term's blocks are full but its last: (df + 127) / 128 of them, post_fn_kernel's flag 8 saw to that), which
+                        // decode_id16_kernel fills ahead of the scan.  The plane grows with the largest batch it has held.
+                        std::vector<uint32_t> &fbv = bt->h_id16_fb;
+                        fbv.resize(q_off[nq]);
+                        uint64_t blocks = 2;  // (block 0: what the null terms' run loads read)
+                        for (uint32_t p = 0; p < q_off[nq]; ++p) {
+                            const uint32_t t = term_ids[p];
+                            fbv[p] = uint32_t(blocks);
+                            if (t < ixh->n_terms) blocks += (uint64_t(ixh->term_df_host[t]) + 127u) / 128u;
+                        }
+                        if (blocks > 0x00ffffffull) return set_error(VBM25_ERR_UNSUPPORTED, "the batch's terms exceed the scratch plane of an index without post_id16");
+                        const size_t need = 256ull * blocks + 1024;
+                        if (need > bt->id16_tmp.bytes) {
+                            if (bt->last_stream || bt->lat_stream) HIP_TRY(hipDeviceSynchronize());  // (a run still reading the old plane)
+                            if (bt->id16_tmp.p) HIP_TRY(hipFree(bt->id16_tmp.p));
+                            bt->id16_tmp.p = nullptr;
+                            bt->id16_tmp.bytes = 0;
+                            if (int rc = bt->id16_tmp.alloc(need + need / 4)) return rc;
+                            HIP_TRY(hipMemset(bt->id16_tmp.p, 0, bt->id16_tmp.bytes));
+                        }
+                        bt->id16_decode = true;
+                        if (!fast && q_off[nq]) HIP_TRY(hipMemcpy(bt->id16_fb.p, fbv.data(), 4ull * q_off[nq], hipMemcpyHostToDevice));
+                    }
                 } else
                 bt->arith_g = uint32_t(g);  // the general route, items made in the kernel: no plan_kernel, merge_kernel cleans
                 // ... handed out longest first, as plan_kernel would (the host has the posting counts): queries by
@@ -988,10 +1028,11 @@ static int vbm25_batch_set_queries_impl(vbm25_batch *bt, const uint32_t *term_id
         const size_t nt = 4ull * q_off[nq], no = 4ull * (nq + 1);
         const bool with_order = bt->arith_g || bt->win_g;
         const size_t nd8 = (size_t(nq) + 7) & ~size_t(7), nord = with_order ? 4ull * bt->h_order.size() : 0;
-        if (nt + no + nd8 + nord > bt->pin_in_bytes) {
+        const size_t nid = bt->id16_decode ? nt : 0;  // (the terms' blocks in the scratch plane of an index without post_id16)
+        if (nt + no + nd8 + nord + nid > bt->pin_in_bytes) {
             if (bt->pin_in) HIP_TRY(hipHostFree(bt->pin_in));
             bt->pin_in = nullptr;
-            bt->pin_in_bytes = 2 * (nt + no + nd8 + nord) + 256;
+            bt->pin_in_bytes = 2 * (nt + no + nd8 + nord + nid) + 256;
             HIP_TRY(hipHostMalloc(reinterpret_cast<void **>(&bt->pin_in), bt->pin_in_bytes, hipHostMallocDefault));
         }
         const size_t nh = sizeof(vbm25_hit) * size_t(nq) * bt->k, nc = (4ull * nq + 7) & ~size_t(7);
@@ -1006,8 +1047,10 @@ static int vbm25_batch_set_queries_impl(vbm25_batch *bt, const uint32_t *term_id
         std::memcpy(bt->pin_in + nt, q_off, no);
         if (nq) std::memcpy(bt->pin_in + nt + no, dense, nq);
         if (nord) std::memcpy(bt->pin_in + nt + no + nd8, bt->h_order.data(), nord);
+        if (nid) std::memcpy(bt->pin_in + nt + no + nd8 + nord, bt->h_id16_fb.data(), nid);
         bt->pin_nt = nt;
         bt->pin_order_bytes = nord;
+        bt->pin_id16_bytes = nid;
         if (!(bt->fused_g && bt->fused_pinned))
             if (int rc = upload_staged(bt)) return rc;
     } else {
@@ -1266,6 +1309,18 @@ static int vbm25_batch_run_impl(vbm25_batch *bt, void *hip_stream) {
         const bool fuse = bt->tune.win_fuse && !bt->win_nofuse && !bt->device_consumer && uint64_t(bt->nq) * bt->win_g <= scan_win_resident_waves(wmt, bt->k) && !bt->tune.win_grid;
         db.win_fuse = fuse ? 1u : 0u;
         bt->win_fused_run = fuse;
+        if (bt->id16_decode) {
+            // An index without the post_id16 plane: the ids of the batch's terms, unpacked from the blob into the batch's scratch
+            // plane (decode_id16.h) -- inside the timed region: kernel_ms is the decode and the scan.
+            db.id16_fb = bt->id16_fb.as<uint32_t>();
+            if (bt->qin_live && bt->pin_id16_bytes)
+                db.id16_fb = reinterpret_cast<const uint32_t *>(bt->qin.as<uint8_t>() + bt->pin_nt + 4ull * (bt->nq + 1) + ((size_t(bt->nq) + 7) & ~size_t(7)) + bt->pin_order_bytes);
+            const uint32_t n_pos = bt->n_term_pos;
+            if (n_pos) decode_id16_kernel<<<n_pos, DI_WAVES * 64, 0, st>>>(ix, db.term_ids, db.id16_fb, bt->id16_tmp.as<uint32_t>());
+            DevIndex ixw = ix;
+            ixw.post_id16 = bt->id16_tmp.as<uint32_t>();
+            HIP_TRY(scan_win_launch(ixw, db, wmt, wgrid, st));
+        } else
         HIP_TRY(scan_win_launch(ix, db, wmt, wgrid, st));
         if (fuse) {
             if (bt->timing) (void)hipEventRecord(e1, st);
@@ -1540,6 +1595,7 @@ int vbm25_tuning_set(const char *name, long long value) {
     else if (n == "win_planes") g_tune.win_planes = value != 0;
     else if (n == "win_guided") g_tune.win_guided = value != 0;
     else if (n == "rel16_plane") g_tune.rel16_plane = value != 0;
+    else if (n == "id16_plane") g_tune.id16_plane = value != 0;
     else if (n == "win_grid") g_tune.win_grid = (uint32_t)std::max(0ll, value);
     else if (n == "win_skew") g_tune.win_skew = value != 0;
     else if (n == "win_cut1") g_tune.win_cut1 = int(std::min<long long>(std::max<long long>(value, 1), 998));
