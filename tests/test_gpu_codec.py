@@ -31,7 +31,8 @@ def _index(n_docs, lists, seed=0):
     term_start = np.cumsum([0] + [len(d) for d, _ in lists]).astype(np.uint64)
     post_doc = np.concatenate([np.asarray(d, dtype=np.uint32) for d, _ in lists])
     post_tf = np.concatenate([np.asarray(t, dtype=np.uint32) for _, t in lists])
-    doc_len = rng.integers(1, 3000, n_docs).astype(np.uint32)
+    # (2^31 documents: drawn as 32-bit values, the 64-bit ones would be another 17 GB)
+    doc_len = rng.integers(1, 3000, n_docs, dtype=np.uint32) if n_docs > (1 << 29) else rng.integers(1, 3000, n_docs).astype(np.uint32)
     seg = vb.Segment.build(1.2, 0.75, doc_len, np.zeros((n_docs, 3), dtype=np.uint16), keys, term_start, post_doc, post_tf)
     a = seg.arrays()
     gix = vb.GpuIndex(seg)
@@ -147,6 +148,31 @@ def test_bit_widths_26_to_28_of_full_blocks(tuning):
     seg, a, gix, oix = _index(n_docs, lists, 3)
     first = a["term_first_block"]
     for i, w in enumerate((26, 27, 28)):
+        assert a["blk_meta_doc"][first[i]] == w, (w, a["blk_meta_doc"][first[i]])
+    terms = np.array([0, 0, 3, 1, 1, 3, 2, 2, 3, 0, 1, 2, 3], dtype=np.uint32)
+    off = np.array([0, 1, 3, 4, 6, 7, 9, 13], dtype=np.uint32)
+    _check_routes(tuning, gix, oix, terms, off, ks=(10,))
+
+
+def test_bit_widths_29_to_31_of_full_blocks(tuning):
+    """The widest delta fields of bitpacking_u32_ordered.rs:222-237 through every kernel: a gap with bit 30 set (width 31) needs more than
+    2^30 documents, so the index has 2^30 + 2^28 of them -- 5.4 GB of document lengths and 8 GB of payload on the host (the GPU box has
+    them; this test is -m gpu only), 20480 windows of 2^16 documents on the device."""
+    n_docs = (1 << 30) + (1 << 28)
+    rng = np.random.default_rng(11)
+    lists = []
+    for w in (29, 30, 31):  # 128 postings, ONE gap with bit w - 1 set
+        gaps = rng.integers(1, 400, 128)
+        gaps[0] = 0
+        gaps[rng.integers(1, 128)] = rng.integers(1 << (w - 1), min((1 << w), (1 << 30) + (1 << 27)) - 60_000)
+        docs = rng.integers(0, 1000) + np.cumsum(gaps)
+        assert docs[-1] < n_docs
+        lists.append((docs, rng.integers(1, 4, 128)))
+    mix = np.unique(np.concatenate([d[::7] for d, _ in lists] + [rng.integers(0, n_docs, 300)]))
+    lists.append((mix, rng.integers(1, 4, len(mix))))
+    seg, a, gix, oix = _index(n_docs, lists, 5)
+    first = a["term_first_block"]
+    for i, w in enumerate((29, 30, 31)):
         assert a["blk_meta_doc"][first[i]] == w, (w, a["blk_meta_doc"][first[i]])
     terms = np.array([0, 0, 3, 1, 1, 3, 2, 2, 3, 0, 1, 2, 3], dtype=np.uint32)
     off = np.array([0, 1, 3, 4, 6, 7, 9, 13], dtype=np.uint32)

@@ -723,8 +723,11 @@ __global__ void __launch_bounds__(RWG, KMAX > 64 ? VBM25_RWPS_BIGK : VBM25_RWPS)
                             wid[u] = bp ? md & 127u : 0u;  // (0: not decoded here)
                             mind[u] = cc.x;
                             bp_done |= bp ? 1u << i : 0u;
-                            // (an entry that is not decoded here reads its own body's first words, or entry 0's: any valid address)
-                            pair_fetch(ix.blob + 8ull * cc.z, bp ? wid[u] : 1u, lane, w0[u], w1[u], w2[u], w3[u]);
+                            // (an entry that is not decoded here reads its own body's first words; an entry BEYOND the wave's share of the
+                            // plan -- a wave without any block of a small tile has nv = 0: its "entry 0" is not an entry of this plan but
+                            // whatever the LDS holds there -- reads the blob's: found by the 2^30-document index of tests/test_gpu_codec.py,
+                            // where the stale offset pointed outside every allocation)
+                            pair_fetch(ix.blob + ((uint32_t)i < nv ? 8ull * cc.z : 0ull), bp ? wid[u] : 1u, lane, w0[u], w1[u], w2[u], w3[u]);
                         }
 #pragma unroll
                         for (int u = 0; u < DG; ++u) {
