@@ -189,6 +189,54 @@ def test_index_without_window_planes_takes_the_range_kernel(tuning):
     check(gix, oix, terms, off, 10, expect_route=2)
 
 
+def test_index_without_post_id16_takes_the_window_kernel_behind_the_decode(tuning):
+    """tuning id16_plane = 0 (and rel16_plane = 0: the blob, the tf / fieldnorm words and the window TABLES only): the batch's terms are
+    unpacked from the reference's bit-packed blocks into the batch's scratch plane by decode_id16_kernel ahead of every
+    scan_win_kernel launch (csrc/decode_id16.h).  Same route, no item given up, the records of the index with every plane -- also with
+    unknown tokens, queries of fewer terms, k = 100, a second query set on the same batch object (the scratch plane grows), and
+    through the pipelined boundary."""
+    seg = vb.Segment.synth(400_000, 33_000, mean_len=100, len_mode=1, seed=9)
+    gix_all = vb.GpuIndex(seg)
+    tuning(id16_plane=0, rel16_plane=0)
+    gix = vb.GpuIndex(seg)
+    tuning(id16_plane=1, rel16_plane=1, fused=0)  # (fused = 0: a handful of queries takes the batched route too)
+    assert gix.device_bytes <= gix_all.device_bytes - 2 * 256 * seg.meta()["n_blocks"]  # (two planes of 256 bytes per block less)
+    oix = orc.OracleIndex.from_arrays(seg.meta(), seg.arrays())
+    for nq, nterms, k in ((600, 5, 10), (90, 3, 100), (1, 2, 10)):
+        terms, off = bench_queries(seg, 33_000, nq, nterms, seed=nq)
+        if nq == 90:  # unknown tokens in a few queries, anywhere
+            terms = terms.copy()
+            terms[off[3]] = 0xfffffff0 - 1
+            terms[off[8] + 2] = 0xfffffff0
+            for q in (3, 8):
+                terms[off[q]:off[q + 1]] = np.sort(terms[off[q]:off[q + 1]])
+        hits, nh = check(gix, oix, terms, off, k)
+        _, h_all, n_all = run_batch(gix_all, terms, off, k)
+        assert hits.tobytes() == h_all.tobytes() and np.array_equal(nh, n_all)
+    # one batch object, query sets of growing size; then the ring of the pipelined boundary
+    b = vb.Batch(gix, 512, 4096, 10)
+    for nq in (3, 40, 512, 7):
+        terms, off = bench_queries(seg, 33_000, nq, 5, seed=100 + nq)
+        b.set_queries(terms, off)
+        assert b.debug_route() == 3
+        b.run()
+        hits, nh = b.fetch()
+        want, nw = vb.search_batch(gix_all, terms, off, 10)
+        assert hits.tobytes() == want.tobytes() and np.array_equal(nh, nw)
+    st = vb.Stream(gix, 3, 512, 4096, 10)
+    sets = [bench_queries(seg, 33_000, nq, 5, seed=200 + nq) for nq in (300, 5, 512, 64, 1)]
+    got = []
+    for t, o in sets:
+        if st.in_flight == 3:
+            got.append(st.collect())
+        st.submit(t, o)
+    while st.in_flight:
+        got.append(st.collect())
+    for (h, n), (t, o) in zip(got, sets):
+        want, nw = vb.search_batch(gix_all, t, o, 10)
+        assert h.tobytes() == want.tobytes() and np.array_equal(n, nw)
+
+
 @pytest.mark.parametrize("force", [1, 0])
 def test_random_shapes_through_the_window_kernel(tuning, force):
     """The differential rule of the reference's fuzz test (tests/fuzz:217-303: random corpus, random queries, compare with an exact
@@ -226,6 +274,18 @@ def test_random_shapes_through_the_window_kernel(tuning, force):
         for q in range(nq):
             assert_bit_exact(ob[q, :onb[q]], hits[q, :nh[q]], what=f"case {case} (route {route}, {n_docs} docs, vocab {vocab}, {nterms} terms, k {k}) q{q}")
         assert route in (3, 0, 2), route
+        # ... and through an index of the same segment without the post_id16 and post_rel16 planes (the scratch plane of decode_id16_kernel
+        # in front of the window kernel, scan_range_kernel's in-kernel decode): the same records
+        tuning(id16_plane=0, rel16_plane=0)
+        gix2 = vb.GpuIndex(seg)
+        tuning(id16_plane=1, rel16_plane=1)
+        b2 = vb.Batch(gix2, nq, max(1, len(terms)), k)
+        b2.set_queries(terms, off)
+        b2.run()
+        h2, n2 = b2.fetch()
+        assert np.array_equal(n2, nh), (case, route, b2.debug_route(), n_docs, vocab, nterms, nq, k)
+        for q in range(nq):  # (the rows behind a query's count are not part of the result)
+            assert h2[q, :nh[q]].tobytes() == hits[q, :nh[q]].tobytes(), (case, route, b2.debug_route(), n_docs, vocab, nterms, nq, k, q)
 
 
 @pytest.mark.parametrize("nq", [1, 2, 3, 5, 7, 13, 22])
