@@ -385,7 +385,18 @@ __global__ void __launch_bounds__(wn_waves(MT, RK) * 64, (wn_waves(MT, RK) + 3) 
         uint32_t w_lo, w_hi;
         {
             const KernArgsP ca = cold_args();
-            if (ca->bt.order_on) item = uni(ca->bt.item_order[item]);  // the host's order: longest items first
+            const uint32_t oo = ca->bt.order_on;
+            if (oo == 1u) item = uni(ca->bt.item_order[item]);  // the host's order: longest items first
+            else if (oo == 2u) {
+                // the skewed layout of a batch whose queries kept their order (C3), by arithmetic: a workgroup takes four queries, part k of
+                // them goes to the slots 4 k .. 4 k + 3 (search.hip, set_queries: the same formula fills item_order) -- one dependent
+                // round trip to memory less in every item's setup
+                const uint32_t full12 = (ca->bt.nq >> 2) * 12u;
+                if (item < full12) {
+                    const uint32_t wgi = item / 12u, r = item - wgi * 12u;
+                    item = (wgi * 4u + (r & 3u)) * 3u + (r >> 2);
+                }
+            }
         }
         PROF_T(t_item);
         const uint32_t q = item / g, part = item - q * g;
@@ -940,6 +951,16 @@ __global__ void __launch_bounds__(wn_waves(MT, RK) * 64, (wn_waves(MT, RK) + 3) 
             if (w + 1u < w_hi && !window(bufb, w + 1u)) break;
         }
         PROF_T(t_loop_end);
+        // (the cold pass's first look -- the upper bounds of every term's first 64 blocks of the item -- is requested here: its round trip
+        // to memory runs behind the drain of the loop's last loads and the two open passes' arithmetic)
+        double cold_ub[MT];
+#pragma unroll
+        for (int t = 0; t < MT; ++t) {
+            const uint32_t pS = (uint32_t)__builtin_amdgcn_readlane((int)wS, t), pE = (uint32_t)__builtin_amdgcn_readlane((int)wE, t);
+            const uint32_t fbt = (uint32_t)__builtin_amdgcn_readlane((int)fb, t);
+            const bool in = (uint32_t)t < mm && pE != pS && (pS >> 7) + lane <= ((pE - 1u) >> 7);
+            cold_ub[t] = in ? ix.blk_ub[fbt + (pS >> 7) + lane] : 0.0;
+        }
         wn_drain<MT>(bufa, bufb, pa.gw, pb.gw, pgv);
         // (a launch of no more items than waves: nobody draws -- thousands of waves finishing together would queue at the counter)
         uint32_t next_draw = n_items;
@@ -960,8 +981,7 @@ __global__ void __launch_bounds__(wn_waves(MT, RK) * 64, (wn_waves(MT, RK) + 3) 
                 const uint32_t pS = (uint32_t)__builtin_amdgcn_readlane((int)wS, t), pE = (uint32_t)__builtin_amdgcn_readlane((int)wE, t);
                 const uint32_t fbt = (uint32_t)__builtin_amdgcn_readlane((int)fb, t);
                 const bool in = (uint32_t)t < mm && pE != pS && (pS >> 7) + lane <= ((pE - 1u) >> 7);
-                double ub = 0.0;
-                if (in) ub = ix.blk_ub[fbt + (pS >> 7) + lane];
+                const double ub = cold_ub[t];  // (requested before the drain)
                 const unsigned long long hm = __ballot(in && (unsigned long long)__double_as_longlong(ub) >= th);
                 if (lane == (uint32_t)t) {
                     hm0l = (uint32_t)hm;

@@ -236,6 +236,7 @@ struct Tuning {
     uint32_t win_grid = 0;         // its persistent workgroups (0: one per CU)
     int win_fuse = 1;              // scan_win_kernel merges the queries' lists itself: the batched route is one launch (0: scan_many_kernel and merge_kernel behind it)
     int win_cut1 = 392, win_cut2 = 730;  // ... where a query's three runs are cut, in thousandths of its windows (round 6, tools/skew_sweep.sh: 59 / 52 / 42 of C3's 153)
+    int win_order_arith = 1;       // the skewed layout computed in the kernel when the queries keep their order (0: always the host's table)
     int win_skew = 1;              // one item per wave: a query's three runs of windows sized for the three kinds of waves of a SIMD
     uint32_t generation = 0;       // bumped by every vbm25_tuning_set / reset: vbm25_search_batch's batch object is rebuilt when it is stale
 };
@@ -275,6 +276,7 @@ struct vbm25_batch {
     uint32_t win_mt = 8;          // scan_win_kernel: the most indexed terms of a query of the current batch
     bool win_skew = false;        // scan_win_kernel: one item per wave, a query's three runs sized for the three kinds of waves of a SIMD
     uint32_t q_stride = 0;        // != 0: every query of the current batch has this many terms
+    bool order_identity = false;  // ... and their order in the host's item order is the caller's (no sort by length)
     bool order_useful = true;     // the current queries differ enough in length for the longest-first order to matter
     uint32_t win_g = 0;           // ... and scan_win_kernel's flavour of it (items = runs of 2^16-document windows, one result list each)
     uint32_t win_len = 0;         // ... a query's runs: win_len windows each and a shorter rest (0: equal runs)
@@ -988,6 +990,7 @@ static int vbm25_batch_set_queries_impl(vbm25_batch *bt, const uint32_t *term_id
                         lo = std::min(lo, q_postings[q]);
                         hi = std::max(hi, q_postings[q]);
                     }
+                    bt->order_identity = !(hi * 4 > lo * 5);  // (the queries keep their order: the skewed layout is arithmetic -- scan_win.h)
                     if (hi * 4 > lo * 5) std::stable_sort(qs.begin(), qs.end(), [&](uint32_t a, uint32_t b) { return q_postings[a] > q_postings[b]; });
                 }
 
@@ -1297,7 +1300,8 @@ static int vbm25_batch_run_impl(vbm25_batch *bt, void *hip_stream) {
         db.dense_on = 0;
         db.many_expected = 0;
         db.merge_clean = 1;
-        db.order_on = bt->order_useful ? 1u : 0u;
+        // (2: the skewed layout of queries in the caller's order is computed by the kernel itself, nobody loads item_order)
+        db.order_on = bt->order_useful ? (bt->win_skew && bt->order_identity && bt->tune.win_order_arith ? 2u : 1u) : 0u;
         db.q_stride = bt->q_stride;
         if (int rc = take_events()) return rc;
         const uint32_t wmt = bt->range_rt == 8 ? bt->win_mt : 8u, wpw = scan_win_wg(wmt, bt->k);
@@ -1596,6 +1600,7 @@ int vbm25_tuning_set(const char *name, long long value) {
     else if (n == "win_guided") g_tune.win_guided = value != 0;
     else if (n == "rel16_plane") g_tune.rel16_plane = value != 0;
     else if (n == "id16_plane") g_tune.id16_plane = value != 0;
+    else if (n == "win_order_arith") g_tune.win_order_arith = value != 0;
     else if (n == "win_grid") g_tune.win_grid = (uint32_t)std::max(0ll, value);
     else if (n == "win_skew") g_tune.win_skew = value != 0;
     else if (n == "win_cut1") g_tune.win_cut1 = int(std::min<long long>(std::max<long long>(value, 1), 998));
