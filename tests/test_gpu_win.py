@@ -169,6 +169,31 @@ def test_thick_runs_are_chunked_and_searched_in_memory(tuning):
     check(gix, oix, terms, off, 10, expect_failed=None)
 
 
+def test_runs_just_beyond_a_load_per_lane_in_a_batch_of_mixed_lengths(tuning):
+    """Runs of about 260 postings per window -- a few beyond the 256 one load per lane stages, so that second arrivals are looked up in
+    memory behind the staged part -- in a batch whose queries have two to five terms: the lanes of a shorter query's NULL terms take
+    part in that look-up's unconditional loads and must stay inside the plane (they did not for one commit of round 6: a memory fault on
+    C3's index with tools/mixed_batch.py, which no test of this file reached)."""
+    c = make_corpus(400_000, 15_000, seed=4, length="fixed", mean_len=60)
+    seg = vb.Segment.build(1.2, 0.75, c["doc_len"], c["doc_payload"], c["term_key"], c["term_start"], c["post_doc"], c["post_tf"])
+    gix, oix = vb.GpuIndex(seg), orc.OracleIndex.from_arrays(seg.meta(), seg.arrays())
+    rows = []
+    for nterms in (5, 2, 3, 4, 2, 5, 3):
+        t, o = make_queries(c, 40, nterms, seed=30 + nterms + len(rows))
+        rows += [t[o[q]:o[q + 1]] for q in range(40)]
+    rng = np.random.default_rng(1)
+    rows = [rows[i] for i in rng.permutation(len(rows))]
+    terms = np.concatenate(rows).astype(np.uint32)
+    off = np.r_[0, np.cumsum([len(r) for r in rows])].astype(np.uint32)
+    tuning(win_force=1, fused=0)
+    for k in (10, 100):
+        check(gix, oix, terms, off, k, expect_failed=None)
+    tuning(id16_plane=0, rel16_plane=0)
+    gix2 = vb.GpuIndex(seg)  # ... and behind decode_id16_kernel
+    tuning(id16_plane=1, rel16_plane=1)
+    check(gix2, oix, terms, off, 10, expect_failed=None)
+
+
 def test_small_corpora_tails_and_unknown_tokens(tuning):
     """1 k .. 70 k documents (one or two windows, the last one partial), byte-packed tail blocks only or mostly, query tokens the
     index does not know, k beyond the number of matching documents."""

@@ -454,6 +454,11 @@ __global__ void __launch_bounds__(wn_waves(MT, RK) * 64, (wn_waves(MT, RK) + 3) 
                 }
             }
         }
+        // (a lane without a term -- the null terms of a shorter query -- keeps block 0: every address built from it stays inside the plane;
+        // NONE32 there sent the unconditional loads of the rare search beyond the staged run to a wild address in batches of mixed lengths)
+#ifndef VBM25_EXPERIMENT_WILD_NULL_TERMS  // (tools/win_variant.sh: the regression test of this line must fail on that build)
+        if (!act) fbi = 0u;
+#endif
         // (the host routes only queries of <= WN_T indexed terms that all have a table this way)
         bool failed = m > (uint32_t)MT || __ballot(act && wb == NONE32) != 0ull;
         if (failed) m = 0;
