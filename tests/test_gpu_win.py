@@ -269,12 +269,13 @@ def test_random_shapes_through_the_window_kernel(tuning, force):
     empty to thousands of postings per window), uniform and Zipf tokens, one to eight terms with unknown tokens among them, one to
     ninety queries, k from 1 to 256 -- with win_force so that every sparse batch takes it whatever its density (force = 1), and with the library's own routing (force = 0).  Items the kernel
     gives up go to scan_many_kernel; the records are the oracle's either way."""
-    rng = np.random.default_rng(20260927 + force)
+    # (VBM25_FUZZ_SEED / VBM25_FUZZ_CASES: other shapes than the suite's fixed sixteen -- tools/fuzz_more.sh runs a few hundred on the GPU box)
+    rng = np.random.default_rng(int(os.environ.get("VBM25_FUZZ_SEED", 20260927)) + force)
     if force:
         tuning(win_force=1, fused=0, dense_x1000=10 ** 9)
     else:  # (the library's own routing: window, range, dense or many-term kernels as the shapes fall)
         tuning(fused=0)
-    for case in range(16):
+    for case in range(int(os.environ.get("VBM25_FUZZ_CASES", 16))):
         n_docs = int(rng.choice([3000, 20_000, 66_000, 150_000, 400_000]))
         vocab = int(rng.choice([50, 400, 3000, 40_000]))
         if n_docs * 30 // vocab > 600_000:  # (keep the oracle's brute force in seconds)
@@ -289,6 +290,10 @@ def test_random_shapes_through_the_window_kernel(tuning, force):
         if nterms > 5:
             k = min(k, 64)  # (beyond five terms the window kernel keeps one register row: larger k takes another route)
         terms, off = make_queries(c, nq, nterms, seed=case, zipf=zipf)
+        if rng.random() < 0.5 and nterms > 1:  # queries of different lengths in one batch: every one keeps a random prefix of its terms
+            rows = [terms[off[q]:off[q + 1]][:int(rng.integers(1, nterms + 1))] for q in range(nq)]
+            terms = np.concatenate(rows).astype(np.uint32)
+            off = np.r_[0, np.cumsum([len(r) for r in rows])].astype(np.uint32)
         b = vb.Batch(gix, nq, max(1, len(terms)), k)
         b.set_queries(terms, off)
         route = b.debug_route()
