@@ -327,3 +327,16 @@ def test_three_parts_per_query_with_any_number_of_queries(tuning, nq):
     terms, off = bench_queries(seg, 12_000, nq, 3, seed=nq)
     tuning(fused=0)
     check(gix, oix, terms, off, 10)
+
+
+@pytest.mark.parametrize("zipf_s", [0, 1])
+def test_unusual_batches_on_the_full_size_corpus(zipf_s):
+    """tools/stress_shapes.py: on the 10 M-document index of C3 (zipf_s = 0) and of its Zipf variant C3z (zipf_s = 1) -- batches of mixed
+    query lengths (1 .. 8 terms) at k = 10 / 64 / 100 / 256, through the index without post_id16 / post_rel16 too, unknown tokens and an
+    empty query, batches of 1 / 7 / 1023 / 3000 queries, k = 1000, nine to twelve terms, the pipelined ring -- a sample of every batch
+    against the oracle's brute force bit for bit, every batch run twice.  (A process of its own: a GPU fault aborts the process, and the
+    tool announces every step before it runs.)"""
+    import subprocess
+
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "stress_shapes.py"), str(zipf_s)], capture_output=True, text=True, timeout=1500)
+    assert r.returncode == 0 and "all shapes ok" in r.stdout, r.stdout[-3000:] + r.stderr[-3000:]
