@@ -287,8 +287,6 @@ def test_random_shapes_through_the_window_kernel(tuning, force):
         nterms = int(rng.integers(1, 9))
         nq = int(rng.integers(1, 91))
         k = int(rng.choice([1, 3, 10, 64, 65, 128, 256]))
-        if nterms > 5:
-            k = min(k, 64)  # (beyond five terms the window kernel keeps one register row: larger k takes another route)
         terms, off = make_queries(c, nq, nterms, seed=case, zipf=zipf)
         if rng.random() < 0.5 and nterms > 1:  # queries of different lengths in one batch: every one keeps a random prefix of its terms
             rows = [terms[off[q]:off[q + 1]][:int(rng.integers(1, nterms + 1))] for q in range(nq)]

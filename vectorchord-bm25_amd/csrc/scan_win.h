@@ -1,5 +1,5 @@
 // scan_win.h -- scan_win_kernel: the document-WINDOW formulation of the sparse posting scan (queries of <= WN_T indexed terms
-// whose lists are of comparable length; k <= 256 with at most five terms, k <= 64 with more): the dominant kernel of C3.
+// whose lists are of comparable length; k <= 256: one, two or four register rows of the top-k): the dominant kernel of C3.
 // Part of libvbm25's device code: included inside namespace vbm25 after device_types, decode, topk_lds, block_fetch, topk_reg.
 //
 // Replaces the traversal of search.rs:149-280 (the WAND main loop) for these queries.  What the loop computes -- the k best sums of
