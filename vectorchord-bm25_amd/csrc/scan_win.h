@@ -45,7 +45,7 @@ constexpr int WN_T = 8;               // indexed terms per query
 // were never resident together: the third one ran after the others).  As many waves as the LDS holds -- a wave's share grows with
 // the run loads MT it is compiled for -- and the registers allow: up to 12 waves have 168 VGPRs each, 13 to 16 have 128.
 // (round 6: the instantiations that fit 128 VGPRs -- at most five run loads with one register row of the top-k, at most four with two --
-// run FOUR waves on two of the CU's SIMDs: 14 per workgroup, which is what the LDS holds.)
+// COULD run four waves on two of the CU's SIMDs, 14 per workgroup; measured with -DVBM25_WIN_WAVES_MAX=13 / 14: slower)
 #ifndef VBM25_WIN_WAVES_MAX
 #define VBM25_WIN_WAVES_MAX 12
 #endif
